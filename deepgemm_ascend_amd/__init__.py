@@ -1,0 +1,32 @@
+"""deepgemm_ascend_amd -- MI355X-native drop-in for the DeepGEMM_Ascend hot path.
+
+Same entry-point names as the reference's ``deep_gemm_ascend`` package
+(/root/reference/deep_gemm_ascend/framework/deep_gemm_ascend/__init__.py:1-4) plus the fp8
+block-scaled operators.  Everything executes in libdga_hip.so (hand-written HIP for gfx950);
+importing the operators without that library raises ``DGALibraryError``.
+"""
+from ._lib import DGAError, DGALibraryError, Platform, Problem, Tiling, build, lib  # noqa: F401
+from .api import (  # noqa: F401
+    CONFIG_FIELDS,
+    bbit_params,
+    bench_params_fill,
+    gemm_fp8_fp8_bf16_nt,
+    get_bench_config,
+    get_best_config,
+    infer_dtype,
+    infer_shape,
+    m_grouped_gemm_fp8_fp8_bf16_nt_masked,
+    platform_ascend910b,
+    platform_mi355x,
+    run_mmad_bench,
+    run_mmad_custom,
+    run_mmad_rtc,
+    select_kernel,
+    tiling,
+    tiling_cache_clear,
+    tiling_cache_open,
+    tiling_cache_size,
+    workspace_bytes,
+)
+
+__all__ = [n for n in dir() if not n.startswith("_")]

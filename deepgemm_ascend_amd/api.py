@@ -1,0 +1,267 @@
+"""Host-side mirror of the reference's operator API, over the C ABI (no torch types cross it).
+
+Reference surface being mirrored (paths relative to /root/reference):
+  * ``deep_gemm_ascend.run_mmad_rtc(x, y, z)`` / ``run_mmad_bench(x, y, z, params)``
+    (deep_gemm_ascend/framework/deep_gemm_ascend/__init__.py:1-4,
+    framework/csrc/python_api.cpp:18-35): void return, output written in place into the
+    caller-allocated ``z``, current device stream.
+  * the aclnn operator ``CatlassDynamicMatmul(self, mat2) -> out`` hooks
+    (aclnn_catlass_dynamic_matmul/op_host/catlass_dynamic_matmul.cpp:16-80): infer_shape,
+    infer_dtype, tiling.
+  * new for the fp8 hot path (names from upstream DeepGEMM):
+    ``gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out)`` and
+    ``m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), out, masked_m, expected_m)``.
+
+PyTorch is used only for device memory and the current stream.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import DGAError, Platform, Problem, Tiling
+
+_FP8 = getattr(torch, "float8_e4m3fn", None)
+
+
+def _stream_ptr(t: torch.Tensor) -> int:
+    if t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    return 0
+
+
+def _require(cond: bool, msg: str):
+    # DGA_HOST_ASSERT analogue (csrc/utils/exception.hpp:26-33)
+    if not cond:
+        raise DGAError(-2, "host assert", msg)
+
+
+def _fp8_bytes(t: torch.Tensor) -> torch.Tensor:
+    if _FP8 is not None and t.dtype == _FP8:
+        return t.view(torch.uint8)
+    _require(t.dtype == torch.uint8, f"fp8 operand must be float8_e4m3fn or uint8 bytes, got {t.dtype}")
+    return t
+
+
+def _device_guard(*ts: torch.Tensor):
+    dev = ts[0].device
+    for t in ts:
+        _require(t.device == dev, "all tensors must live on one device")
+    _require(dev.type == "cuda", "tensors must be on a HIP device (there is no CPU path)")
+    return torch.cuda.device(dev)
+
+
+# ----------------------------------------------------------------------------- operator hooks
+
+def infer_shape(self_shape: Sequence[int], mat2_shape: Sequence[int]) -> Tuple[int, int]:
+    """InferShape hook (catlass_dynamic_matmul.cpp:16-35)."""
+    a = (ctypes.c_int64 * len(self_shape))(*self_shape)
+    b = (ctypes.c_int64 * len(mat2_shape))(*mat2_shape)
+    out = (ctypes.c_int64 * 2)()
+    _lib.check(_lib.lib().dga_infer_shape(a, len(self_shape), b, len(mat2_shape), out), "infer_shape")
+    return int(out[0]), int(out[1])
+
+
+def infer_dtype(self_dtype: int, mat2_dtype: int) -> int:
+    """InferDataType hook (catlass_dynamic_matmul.cpp:37-46)."""
+    out = ctypes.c_int(0)
+    _lib.check(_lib.lib().dga_infer_dtype(self_dtype, mat2_dtype, ctypes.byref(out)), "infer_dtype")
+    return out.value
+
+
+def _problem(m, n, k, groups=1, expected_m=0, dtype=_lib.DT_FP8_E4M3FN) -> Problem:
+    return Problem(m, n, k, groups, expected_m, _lib.LAYOUT_ROW_MAJOR, _lib.LAYOUT_COLUMN_MAJOR,
+                   _lib.LAYOUT_ROW_MAJOR, dtype)
+
+
+def tiling(m: int, n: int, k: int, groups: int = 1, expected_m: int = 0) -> Tiling:
+    """TilingFunc hook with the (m,n,k) cache (catlass_dynamic_matmul_tiling.cpp:77-122)."""
+    t = Tiling()
+    p = _problem(m, n, k, groups, expected_m)
+    _lib.check(_lib.lib().dga_tiling(ctypes.byref(p), ctypes.byref(t)), "tiling")
+    return t
+
+
+def select_kernel(m: int, n: int, k: int, platform: Optional[Platform] = None, groups: int = 1,
+                  expected_m: int = 0) -> Tiling:
+    """SelectKernel without the cache (select_kernel.cpp:333-369); platform None = MI355X."""
+    t = Tiling()
+    p = _problem(m, n, k, groups, expected_m)
+    pp = ctypes.byref(platform) if platform is not None else None
+    _lib.check(_lib.lib().dga_select_kernel(ctypes.byref(p), pp, ctypes.byref(t)), "select_kernel")
+    return t
+
+
+def platform_mi355x() -> Platform:
+    p = Platform()
+    _lib.lib().dga_platform_mi355x(ctypes.byref(p))
+    return p
+
+
+def platform_ascend910b(core_num: int = 24) -> Platform:
+    p = Platform()
+    _lib.lib().dga_platform_ascend910b(ctypes.byref(p), core_num)
+    return p
+
+
+def workspace_bytes(t: Tiling) -> int:
+    return int(_lib.lib().dga_workspace_bytes(ctypes.byref(t)))
+
+
+def tiling_cache_open(path: Optional[str]):
+    _lib.check(_lib.lib().dga_tiling_cache_open(path.encode() if path else None), "tiling_cache_open")
+
+
+def tiling_cache_clear():
+    _lib.lib().dga_tiling_cache_clear()
+
+
+def tiling_cache_size() -> int:
+    return int(_lib.lib().dga_tiling_cache_size())
+
+
+# ----------------------------------------------------------------------------- 28-int Config
+
+def get_best_config(batch: int, m: int, n: int, k: int) -> list:
+    out = (ctypes.c_uint32 * 28)()
+    _lib.check(_lib.lib().dga_get_best_config(batch, m, n, k, out), "get_best_config")
+    return list(out)
+
+
+def get_bench_config(m, n, k, m_sections, n_sections, m_sec_o_blocks, n_sec_o_blocks, k_o_iter_blocks,
+                     db_o_blocks) -> list:
+    out = (ctypes.c_uint32 * 28)()
+    _lib.check(_lib.lib().dga_get_bench_config(m, n, k, m_sections, n_sections, m_sec_o_blocks, n_sec_o_blocks,
+                                               k_o_iter_blocks, db_o_blocks, out), "get_bench_config")
+    return list(out)
+
+
+CONFIG_FIELDS = ("k_iters batch m n k m_sections n_sections m_blocks n_blocks k_blocks m_sc_blocks n_sc_blocks "
+                 "m_sec_o_blocks n_sec_o_blocks k_o_iter_blocks db_o_blocks m_o_fix n_o_fix k_o_fix db_o_num "
+                 "m_parts n_parts r_m_parts r_n_parts r_m_blocks r_n_blocks r_k_blocks r_db_num").split()
+
+
+def bbit_params(m, n, k, m_sections, n_sections, m_sec_o_blocks, n_sec_o_blocks, k_o_iter_blocks, db_o_blocks):
+    out = (ctypes.c_uint32 * 28)()
+    _lib.check(_lib.lib().dga_bbit_params(m, n, k, m_sections, n_sections, m_sec_o_blocks, n_sec_o_blocks,
+                                          k_o_iter_blocks, db_o_blocks, out), "bbit_params")
+    return list(out)
+
+
+def bench_params_fill(m: int, n: int, k: int, params6: Sequence[int]) -> list:
+    arr = (ctypes.c_int32 * 28)(*list(params6)[:6], *([0] * 22))
+    _lib.check(_lib.lib().dga_bench_params_fill(m, n, k, arr), "bench_params_fill")
+    return list(arr)
+
+
+# ----------------------------------------------------------------------------- the hot path
+
+def gemm_fp8_fp8_bf16_nt(lhs: Tuple[torch.Tensor, torch.Tensor], rhs: Tuple[torch.Tensor, torch.Tensor],
+                         out: torch.Tensor, tiling_: Optional[Tiling] = None, sync: bool = False) -> None:
+    """out[M,N] (bf16, written in place) = (A[M,K] fp8, sfa[M,ceil(K/128)]) x (B[N,K] fp8, sfb[ceil(N/128),ceil(K/128)])^T.
+
+    Asynchronous on the current stream (the reference syncs on every call, gemm.hpp:110;
+    pass sync=True for that behaviour)."""
+    a, sfa = lhs
+    b, sfb = rhs
+    a = _fp8_bytes(a); b = _fp8_bytes(b)
+    _require(a.dim() == 2 and b.dim() == 2 and out.dim() == 2, "rank must be 2")
+    m, k = a.shape
+    n, k2 = b.shape
+    _require(k == k2, "self dimk is not equal with mat2 dimk")
+    _require(tuple(out.shape) == (m, n), f"out must be [{m},{n}]")
+    _require(out.dtype == torch.bfloat16, "out must be bfloat16")
+    kb, nb = (k + 127) // 128, (n + 127) // 128
+    _require(sfa.dtype == torch.float32 and sfb.dtype == torch.float32, "scales must be float32")
+    _require(tuple(sfa.shape) == (m, kb), f"sfa must be [{m},{kb}]")
+    _require(tuple(sfb.shape) == (nb, kb), f"sfb must be [{nb},{kb}]")
+    for t in (a, b, sfa, sfb, out):
+        _require(t.is_contiguous(), "operands must be contiguous")
+    with _device_guard(a, b, sfa, sfb, out):
+        tp = ctypes.byref(tiling_) if tiling_ is not None else None
+        rc = _lib.lib().dga_gemm_fp8_fp8_bf16_nt(a.data_ptr(), sfa.data_ptr(), b.data_ptr(), sfb.data_ptr(),
+                                                 out.data_ptr(), m, n, k, tp, None, 0, _stream_ptr(out))
+        _lib.check(rc, "gemm_fp8_fp8_bf16_nt")
+        if sync:
+            torch.cuda.current_stream(out.device).synchronize()
+
+
+def m_grouped_gemm_fp8_fp8_bf16_nt_masked(lhs, rhs, out: torch.Tensor, masked_m: torch.Tensor, expected_m: int,
+                                          tiling_: Optional[Tiling] = None, sync: bool = False) -> None:
+    """Grouped masked-M GEMM: a [G,Mmax,K], sfa [G,Mmax,KB], b [G,N,K], sfb [G,NB,KB], out [G,Mmax,N] bf16;
+    only rows < masked_m[g] of out[g] are written (upstream DeepGEMM's convention)."""
+    a, sfa = lhs
+    b, sfb = rhs
+    a = _fp8_bytes(a); b = _fp8_bytes(b)
+    _require(a.dim() == 3 and b.dim() == 3 and out.dim() == 3, "rank must be 3")
+    g, mmax, k = a.shape
+    g2, n, k2 = b.shape
+    _require(g == g2 and k == k2, "group / k mismatch")
+    _require(tuple(out.shape) == (g, mmax, n) and out.dtype == torch.bfloat16, "out must be [G,Mmax,N] bfloat16")
+    kb, nb = (k + 127) // 128, (n + 127) // 128
+    _require(tuple(sfa.shape) == (g, mmax, kb) and sfa.dtype == torch.float32, f"sfa must be [{g},{mmax},{kb}] f32")
+    _require(tuple(sfb.shape) == (g, nb, kb) and sfb.dtype == torch.float32, f"sfb must be [{g},{nb},{kb}] f32")
+    _require(masked_m.dtype == torch.int32 and tuple(masked_m.shape) == (g,), "masked_m must be int32 [G]")
+    for t in (a, b, sfa, sfb, out, masked_m):
+        _require(t.is_contiguous(), "operands must be contiguous")
+    with _device_guard(a, b, sfa, sfb, out, masked_m):
+        tp = ctypes.byref(tiling_) if tiling_ is not None else None
+        rc = _lib.lib().dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked(
+            a.data_ptr(), sfa.data_ptr(), b.data_ptr(), sfb.data_ptr(), out.data_ptr(), masked_m.data_ptr(),
+            g, mmax, n, k, int(expected_m), tp, None, 0, _stream_ptr(out))
+        _lib.check(rc, "m_grouped_gemm_fp8_fp8_bf16_nt_masked")
+        if sync:
+            torch.cuda.current_stream(out.device).synchronize()
+
+
+# ----------------------------------------------------------------------------- the framework's 16-bit entry points
+
+def _dt16(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return _lib.DT_BF16
+    if t.dtype == torch.float16:
+        return _lib.DT_FP16
+    raise DGAError(-3, "dtype", f"expected bfloat16/float16, got {t.dtype}")
+
+
+def run_mmad_rtc(x: torch.Tensor, y: torch.Tensor, z: torch.Tensor) -> None:
+    """z[B,M,N] (f32, in place) = x[B,M,K] @ y[B,K,N]  (python_api.cpp:18, gemm.hpp:68-111). Synchronous, as the reference."""
+    _require(x.dim() == 3 and y.dim() == 3 and z.dim() == 3, "rank must be 3")
+    batch, m, k = x.shape
+    _, k2, n = y.shape
+    _require(k == k2 and y.shape[0] == batch and tuple(z.shape) == (batch, m, n), "shape mismatch")
+    _require(z.dtype == torch.float32 and x.dtype == y.dtype, "dtype mismatch")
+    for t in (x, y, z):
+        _require(t.is_contiguous(), "operands must be contiguous")
+    with _device_guard(x, y, z):
+        rc = _lib.lib().dga_run_mmad_rtc(x.data_ptr(), y.data_ptr(), z.data_ptr(), batch, m, n, k, _dt16(x),
+                                         _stream_ptr(z))
+        _lib.check(rc, "run_mmad_rtc")
+        torch.cuda.current_stream(z.device).synchronize()  # gemm.hpp:110
+
+
+def run_mmad_bench(x: torch.Tensor, y: torch.Tensor, z: torch.Tensor, params: torch.Tensor) -> None:
+    """z[M,N] (f32) = x[M,K] @ y[K,N]; params int32[28]: slots 0..5 knobs in, 6..27 written back
+    (python_api.cpp:23, gemm_bench.hpp:49-113)."""
+    _require(x.dim() == 2 and y.dim() == 2 and z.dim() == 2, "rank must be 2")
+    m, k = x.shape
+    k2, n = y.shape
+    _require(k == k2 and tuple(z.shape) == (m, n), "shape mismatch")
+    _require(params.dtype == torch.int32 and params.numel() == 28, "params must be int32[28]")
+    host = params.detach().cpu().tolist()          # the reference does 6 .item() syncs (gemm_bench.hpp:52-57)
+    filled = bench_params_fill(m, n, k, host[:6])
+    params.copy_(torch.tensor(filled, dtype=torch.int32))  # gemm_bench.hpp:79-81
+    with _device_guard(x, y, z):
+        arr = (ctypes.c_int32 * 28)(*filled)
+        rc = _lib.lib().dga_run_mmad_bench(x.data_ptr(), y.data_ptr(), z.data_ptr(), m, n, k, _dt16(x), arr,
+                                           _stream_ptr(z))
+        _lib.check(rc, "run_mmad_bench")
+        torch.cuda.current_stream(z.device).synchronize()
+
+
+def run_mmad_custom(x: torch.Tensor, y: torch.Tensor, z: torch.Tensor) -> None:
+    """The reference's static kernel returns immediately (include/impls/mmad.cpp:79): a no-op, kept for API parity."""
+    return None

@@ -1,0 +1,202 @@
+// Launch glue of the C ABI: argument checks, tiling lookup, kernel-variant dispatch.
+// Host counterpart of mmad_rtc (/root/reference/deep_gemm_ascend/framework/csrc/jit_kernels/impls/gemm.hpp:68-111):
+// shapes -> tiling -> launch on the caller's stream.  What the reference does with a cmake-subprocess
+// JIT and a blocking aclrtSynchronizeStream (gemm.hpp:103-110) is here an AOT template menu and an
+// asynchronous launch; ACL errors that the reference prints and ignores (utils/exception.hpp:35-43)
+// are returned as DGA_E_HIP.
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "dga_hip.h"
+#include "dga_internal.hpp"
+#include "gemm_fp8_kernel.hpp"
+
+namespace dga {
+
+__device__ uint8_t g_zero_chunk[256];
+
+static std::atomic<int> g_last_hip_error{0};
+int record_hip(hipError_t e)
+{
+    if (e != hipSuccess) {
+        g_last_hip_error.store(static_cast<int>(e));
+        return DGA_E_HIP;
+    }
+    return DGA_OK;
+}
+#define DGA_HIP_TRY(expr)                     \
+    do {                                      \
+        int _rc = dga::record_hip((expr));    \
+        if (_rc != DGA_OK) return _rc;        \
+    } while (0)
+
+static int zero_chunk_ptr(const uint8_t **out)
+{
+    // one address per device (the symbol lives in each device's copy of the code object)
+    static std::mutex mu;
+    static const uint8_t *cache[64] = {};
+    int dev = 0;
+    DGA_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 0 || dev >= 64) return DGA_E_HIP;
+    if (!cache[dev]) {
+        void *ptr = nullptr;
+        DGA_HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_zero_chunk)));
+        cache[dev] = static_cast<const uint8_t *>(ptr);
+    }
+    *out = cache[dev];
+    return DGA_OK;
+}
+
+template <class Cfg>
+static int launch_cfg(const GemmParams &p, hipStream_t stream)
+{
+    auto kfn = gemm_fp8_blockscaled_nt_kernel<Cfg>;
+    static std::once_flag once[64];
+    static hipError_t attr_err[64];
+    int dev = 0;
+    DGA_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return DGA_E_HIP;
+    std::call_once(once[dev], [&] {
+        attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    });
+    DGA_HIP_TRY(attr_err[dev]);
+    const unsigned grid = static_cast<unsigned>(p.groups) * p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p);
+    DGA_HIP_TRY(hipGetLastError());
+    return DGA_OK;
+}
+
+struct Variant {
+    int bm, bn, wm, wn;
+    int (*launch)(const GemmParams &, hipStream_t);
+    int lds;
+};
+
+#define DGA_VARIANT(BM, BN, WM, WN) \
+    Variant { BM, BN, WM, WN, &launch_cfg<GemmCfg<BM, BN, WM, WN>>, GemmCfg<BM, BN, WM, WN>::LDS_BYTES }
+
+static const Variant kVariants[] = {
+    DGA_VARIANT(256, 256, 4, 2), DGA_VARIANT(128, 256, 2, 2), DGA_VARIANT(256, 128, 4, 1),
+    DGA_VARIANT(128, 128, 2, 2), DGA_VARIANT(64, 256, 1, 4),  DGA_VARIANT(64, 128, 1, 4),
+    DGA_VARIANT(32, 256, 1, 4),  DGA_VARIANT(32, 128, 1, 4),  DGA_VARIANT(16, 256, 1, 4),
+    DGA_VARIANT(16, 128, 1, 4),
+};
+static constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+
+int variant_count() { return kNumVariants; }
+void variant_info(int i, int *bm, int *bn, int *wm, int *wn, int *lds)
+{
+    *bm = kVariants[i].bm; *bn = kVariants[i].bn; *wm = kVariants[i].wm; *wn = kVariants[i].wn;
+    *lds = kVariants[i].lds;
+}
+
+static const Variant *find_variant(int bm, int bn)
+{
+    for (int i = 0; i < kNumVariants; ++i)
+        if (kVariants[i].bm == bm && kVariants[i].bn == bn) return &kVariants[i];
+    return nullptr;
+}
+
+static int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, void *out,
+                   const int32_t *masked_m, int groups, int m, int n, int k, int expected_m,
+                   const dga_tiling_t *tiling, void *workspace, size_t workspace_bytes, hipStream_t stream)
+{
+    (void)workspace;
+    if (m < 0 || n < 0 || k < 0 || groups < 0) return DGA_E_SHAPE;
+    if (groups == 0 || m == 0 || n == 0) return DGA_OK;  // empty problem: nothing to write
+    if (!a || !b || !sfa || !sfb || !out) {
+        // k == 0 still reads nothing but must write zeros: pointers to out are required
+        if (!out || k != 0) return DGA_E_NULL;
+    }
+    dga_tiling_t local;
+    if (!tiling) {
+        dga_problem_t pr{};
+        pr.m = m; pr.n = n; pr.k = k; pr.groups = groups; pr.expected_m = expected_m;
+        pr.layoutTagA = DGA_LAYOUT_ROW_MAJOR; pr.layoutTagB = DGA_LAYOUT_COLUMN_MAJOR;
+        pr.layoutTagC = DGA_LAYOUT_ROW_MAJOR; pr.dtype = DGA_DT_FP8_E4M3FN;
+        int rc = dga_tiling(&pr, &local);
+        if (rc != DGA_OK) return rc;
+        tiling = &local;
+    }
+    if (dga_workspace_bytes(tiling) > workspace_bytes) return DGA_E_WORKSPACE;
+
+    GemmParams p{};
+    p.a = static_cast<const uint8_t *>(a);
+    p.sfa = sfa;
+    p.b = static_cast<const uint8_t *>(b);
+    p.sfb = sfb;
+    p.out = static_cast<uint16_t *>(out);
+    p.masked_m = masked_m;
+    p.m = m; p.n = n; p.k = k;
+    p.kb_n = (k + 127) / 128;
+    p.nb_n = (n + 127) / 128;
+    p.lda = k; p.ldb = k; p.ldc = n;
+    p.a_gs = static_cast<int64_t>(m) * k;
+    p.b_gs = static_cast<int64_t>(n) * k;
+    p.c_gs = static_cast<int64_t>(m) * n;
+    p.sfa_gs = static_cast<int64_t>(m) * p.kb_n;
+    p.sfb_gs = static_cast<int64_t>(p.nb_n) * p.kb_n;
+    p.groups = groups;
+    int rc = zero_chunk_ptr(&p.zeros);
+    if (rc != DGA_OK) return rc;
+
+    const bool fast_ok = (k % 16 == 0) && k > 0 && ((reinterpret_cast<uintptr_t>(a) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
+    if (!fast_ok) {
+        // K not a multiple of the 16-byte DMA chunk (or k == 0): element-wise kernel
+        dim3 grid((n + 15) / 16, (m + 15) / 16, groups);
+        hipLaunchKernelGGL(gemm_fp8_blockscaled_nt_generic_kernel, grid, dim3(256), 0, stream, p);
+        DGA_HIP_TRY(hipGetLastError());
+        return DGA_OK;
+    }
+    const Variant *v = find_variant(tiling->m1, tiling->n1);
+    if (!v) return DGA_E_TILING;
+    p.tiles_m = (m + v->bm - 1) / v->bm;
+    p.tiles_n = (n + v->bn - 1) / v->bn;
+    p.raster_group = tiling->swizzleOffset ? tiling->swizzleOffset : 1;
+    return v->launch(p, stream);
+}
+
+}  // namespace dga
+
+extern "C" {
+
+int dga_gemm_fp8_fp8_bf16_nt(const void *a, const float *sfa, const void *b, const float *sfb, void *out, int m,
+                             int n, int k, const dga_tiling_t *tiling, void *workspace, size_t workspace_bytes,
+                             void *stream)
+{
+    return dga::run_fp8(a, sfa, b, sfb, out, nullptr, 1, m, n, k, 0, tiling, workspace, workspace_bytes,
+                        static_cast<hipStream_t>(stream));
+}
+
+int dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked(const void *a, const float *sfa, const void *b, const float *sfb,
+                                              void *out, const int32_t *masked_m, int groups, int m_max, int n,
+                                              int k, int expected_m, const dga_tiling_t *tiling, void *workspace,
+                                              size_t workspace_bytes, void *stream)
+{
+    if (groups > 0 && m_max > 0 && !masked_m) return DGA_E_NULL;
+    return dga::run_fp8(a, sfa, b, sfb, out, masked_m, groups, m_max, n, k, expected_m, tiling, workspace,
+                        workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int dga_last_hip_error(void) { return dga::g_last_hip_error.load(); }
+
+int dga_device_platform(dga_platform_t *out)
+{
+    if (!out) return DGA_E_NULL;
+    dga_platform_mi355x(out);
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return DGA_E_HIP;
+    out->coreNum = static_cast<uint32_t>(prop.multiProcessorCount);
+    out->l1Size = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : out->l1Size;
+    out->waveSize = static_cast<uint32_t>(prop.warpSize);
+    return DGA_OK;
+}
+
+}  // extern "C"

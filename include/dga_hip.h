@@ -1,0 +1,187 @@
+/*
+ * dga_hip.h -- C ABI of libdga_hip.so: the MI355X (gfx950) drop-in for the
+ * DeepGEMM_Ascend hot path.  Plain pointers and sizes only; every entry point
+ * returns an int status (0 = DGA_OK, negative = error) and never throws.
+ * Device pointers are caller-owned; nothing here allocates device memory.
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *
+ * Each declaration cites the reference interface it replaces
+ * (paths relative to /root/reference).
+ */
+#ifndef DGA_HIP_H
+#define DGA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGA_ABI_VERSION 1
+
+/* ---- status codes (reference: DGA_HOST_ASSERT throws DGAException,
+ *      deep_gemm_ascend/framework/csrc/utils/exception.hpp:9-33; op hooks return
+ *      ge::GRAPH_FAILED, aclnn_catlass_dynamic_matmul/op_host/catlass_dynamic_matmul_tiling.cpp:86-100) */
+enum {
+    DGA_OK = 0,
+    DGA_E_NULL = -1,      /* required pointer is NULL */
+    DGA_E_SHAPE = -2,     /* rank / dimension mismatch (InferShape / TilingFunc checks) */
+    DGA_E_DTYPE = -3,     /* dtype mismatch (InferDataType) */
+    DGA_E_ALIGN = -4,     /* pointer / stride alignment the kernel cannot take */
+    DGA_E_HIP = -5,       /* a HIP runtime call failed (see dga_last_hip_error) */
+    DGA_E_TILING = -6,    /* tiling not supported by any compiled kernel variant */
+    DGA_E_WORKSPACE = -7, /* workspace too small */
+    DGA_E_IO = -8,        /* harness / cache file error */
+    DGA_E_RANGE = -9      /* masked_m / knob out of range */
+};
+
+/* dtypes (the values the aclnn op proto uses are ge::DataType; we keep our own small enum) */
+enum { DGA_DT_FP16 = 1, DGA_DT_BF16 = 2, DGA_DT_FP8_E4M3FN = 3, DGA_DT_FP32 = 4 };
+
+/* LayoutTag / PaddingTag: aclnn_catlass_dynamic_matmul/op_host/op_tiling/tiling_params.h:16-17 */
+enum { DGA_LAYOUT_ROW_MAJOR = 0, DGA_LAYOUT_COLUMN_MAJOR = 1 };
+enum { DGA_PADDING_NONE = 0, DGA_PADDING_ND = 1, DGA_PADDING_BLOCK_ND = 2, DGA_PADDING_NZ = 3 };
+
+/* kernelSerial menu, same numbering as the reference
+ * (op_kernel/kernel/kernel_utils.h:31-37, select_kernel.cpp:270-331):
+ *   0 Common, 1 Small, 2 PaddingCommon (never chosen on CDNA4), 4 StreamK/split-K. */
+enum { DGA_KERNEL_COMMON = 0, DGA_KERNEL_SMALL = 1, DGA_KERNEL_PADDING_COMMON = 2, DGA_KERNEL_STREAMK = 4 };
+
+/* Platform description: the CDNA4 retarget of PlatformInfo
+ * (op_tiling/platform_info.h:16-41; Python mirror get_best_config/tiling_calculator.py:25-30).
+ * The same struct carries the Ascend numbers when the reference's own arithmetic is
+ * replayed for parity (tests only). */
+typedef struct dga_platform_t {
+    uint32_t coreNum;   /* Ascend: AI cores (24/20).  MI355X: CUs (256) */
+    uint64_t ubSize;    /* Ascend UB 192 KiB.       MI355X: unused (0) */
+    uint64_t l1Size;    /* Ascend L1 512 KiB.       MI355X: LDS per CU (160 KiB) */
+    uint64_t l0ASize;   /* Ascend 64 KiB.           MI355X: VGPR bytes per SIMD lane-set usable for A fragments */
+    uint64_t l0BSize;
+    uint64_t l0CSize;   /* Ascend L0C 128 KiB.      MI355X: fp32 accumulator bytes per workgroup (8 waves x 128 regs x 64 lanes x 4) */
+    uint32_t xcdNum;    /* MI355X: 8 (Ascend: 1) */
+    uint32_t waveSize;  /* MI355X: 64 */
+} dga_platform_t;
+
+/* Host-side superset of the kernel tiling data: TilingParams
+ * (op_tiling/tiling_params.h:19-66) + CatlassDynamicMatmulTilingData
+ * (op_kernel/catlass_dynamic_matmul_tiling_data.h:19-33) + CDNA4 fields. */
+typedef struct dga_tiling_t {
+    uint64_t strideA, strideB, strideC;
+    uint32_t m, n, k;
+    uint16_t m1, n1, k1;         /* workgroup tile BM x BN x BK */
+    uint8_t swizzleOffset;       /* tile-rows rastered together (tiling_params.h:63) */
+    uint8_t swizzleDirection;    /* (m > n) ? 0 : 1 (tiling_params.h:64) */
+    uint16_t splitkFactor;
+    uint8_t layoutTagA, layoutTagB, layoutTagC;
+    uint8_t paddingTagA, paddingTagB, paddingTagC;
+    uint8_t kernelSerial;
+    uint8_t dispatchPolicyTag;
+    uint32_t blockDim;           /* workgroups launched (reference: uint8 AI-core count) */
+    /* CDNA4 */
+    uint8_t wavesM, wavesN;      /* wave grid inside the workgroup */
+    uint8_t stages;              /* LDS stages */
+    uint8_t reserved0;
+    uint32_t ldsBytes;
+    uint32_t groups;             /* 1 = dense */
+} dga_tiling_t;
+
+typedef struct dga_problem_t {
+    uint32_t m, n, k;
+    uint32_t groups;             /* 1 = dense; >1 = grouped masked-M with m = m_max */
+    uint32_t expected_m;         /* grouped: hint for tile choice (0 = m) */
+    uint8_t layoutTagA, layoutTagB, layoutTagC;
+    uint8_t dtype;               /* DGA_DT_* of the inputs */
+} dga_problem_t;
+
+/* ---- operator hooks -------------------------------------------------------------------- */
+
+/* InferShape: aclnn_catlass_dynamic_matmul/op_host/catlass_dynamic_matmul.cpp:16-35.
+ * self [m,k], mat2 logical [k,n] -> out [m,n]; both ranks must be 2. */
+int dga_infer_shape(const int64_t *self_shape, int self_rank, const int64_t *mat2_shape, int mat2_rank,
+                    int64_t *out_shape /*[2]*/);
+
+/* InferDataType: catlass_dynamic_matmul.cpp:37-46 (inputs must match; out = in).
+ * fp8 inputs are the extension: out = bf16. */
+int dga_infer_dtype(int self_dtype, int mat2_dtype, int *out_dtype);
+
+/* TilingFunc: catlass_dynamic_matmul_tiling.cpp:77-122 = shape checks + TilingParams ctor +
+ * SelectKernelWithCache (select_kernel.cpp:371-378).  Consults the (m,n,k)-keyed tiling cache,
+ * optionally CSV-backed through $CACHE_FILE_PATH / $DGA_CACHE_FILE_PATH (cache.cpp:22-101). */
+int dga_tiling(const dga_problem_t *problem, dga_tiling_t *out);
+
+/* SelectKernel without the cache, on an explicit platform (select_kernel.cpp:333-369).
+ * platform == NULL -> MI355X.  With dga_platform_ascend910b() it replays the reference's
+ * DoTilingLayout01 + handler chain for parity tests. */
+int dga_select_kernel(const dga_problem_t *problem, const dga_platform_t *platform, dga_tiling_t *out);
+
+void dga_platform_mi355x(dga_platform_t *out);
+void dga_platform_ascend910b(dga_platform_t *out, uint32_t core_num /*24 C++ default, 20 Python default*/);
+
+/* Tiling cache control (TilingCache, cache.cpp:69-100; CSV::Document, csv.cpp:31-140). */
+int dga_tiling_cache_open(const char *csv_path);  /* NULL/"" = memory only */
+int dga_tiling_cache_clear(void);
+int dga_tiling_cache_size(void);
+
+/* workspace: the reference asks the runtime for a fixed 200 MB
+ * (catlass_dynamic_matmul_tiling.cpp:115-120); we size it from the tiling (0 unless split-K). */
+size_t dga_workspace_bytes(const dga_tiling_t *tiling);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+
+/* gemm_fp8_fp8_bf16_nt: out[M,N] (bf16) = dequant(A[M,K] e4m3fn, sfa[M,ceil(K/128)] f32)
+ *                                       . dequant(B[N,K] e4m3fn, sfb[ceil(N/128),ceil(K/128)] f32)^T
+ * Replaces the launch half of run_mmad_rtc / mmad_rtc
+ * (deep_gemm_ascend/framework/csrc/python_api.cpp:18, jit_kernels/impls/gemm.hpp:68-111) and of the
+ * aclnn op's device entry (op_kernel/catlass_dynamic_matmul.cpp:16-45), NT layout as in
+ * catlass_dynamic_matmul_tiling.cpp:83-84.  All rows contiguous (lda = ldb = K, ldc = N).
+ * tiling == NULL -> dga_tiling() is called.  Asynchronous on `stream`. */
+int dga_gemm_fp8_fp8_bf16_nt(const void *a, const float *sfa, const void *b, const float *sfb, void *out,
+                             int m, int n, int k, const dga_tiling_t *tiling, void *workspace,
+                             size_t workspace_bytes, void *stream);
+
+/* m_grouped_gemm_fp8_fp8_bf16_nt_masked: G independent problems
+ *   a [G,m_max,K], sfa [G,m_max,KB], b [G,N,K], sfb [G,NB,KB], out [G,m_max,N];
+ *   only rows < masked_m[g] (device int32[G]) of out[g] are written.
+ * No reference counterpart beyond the uniform batch loop (generate_code.hpp:149-153); SURVEY.md 8(b). */
+int dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked(const void *a, const float *sfa, const void *b, const float *sfb,
+                                              void *out, const int32_t *masked_m, int groups, int m_max, int n,
+                                              int k, int expected_m, const dga_tiling_t *tiling, void *workspace,
+                                              size_t workspace_bytes, void *stream);
+
+/* ---- the framework's 28-int Config (deep_gemm_ascend/framework/csrc/jit/get_best_config.hpp) ---- */
+
+/* struct Config in declaration order (get_best_config.hpp:12-31), 28 uint32. */
+int dga_get_best_config(uint32_t batch, uint32_t m, uint32_t n, uint32_t k, uint32_t out[28]);
+int dga_get_bench_config(uint32_t m, uint32_t n, uint32_t k, uint32_t m_sections, uint32_t n_sections,
+                         uint32_t m_sec_o_blocks, uint32_t n_sec_o_blocks, uint32_t k_o_iter_blocks,
+                         uint32_t db_o_blocks, uint32_t out[28]);
+/* run_mmad_bench's host write-back: slots 0..5 are the knobs in, slots 6..27 are filled in the
+ * Python-binding order of gemm_bench.hpp:68-81 (m,n,k,batch,k_iters,...,r_db_num). */
+int dga_bench_params_fill(uint32_t m, uint32_t n, uint32_t k, int32_t params[28]);
+/* benchmark_msprof's order (benchmark_util.h:78-85): m,n,k,6 knobs,batch,k_iters,... */
+int dga_bbit_params(uint32_t m, uint32_t n, uint32_t k, uint32_t m_sections, uint32_t n_sections,
+                    uint32_t m_sec_o_blocks, uint32_t n_sec_o_blocks, uint32_t k_o_iter_blocks,
+                    uint32_t db_o_blocks, uint32_t out[28]);
+
+/* ---- the framework's 16-bit path (what the reference ships today) ----------------------- */
+
+/* run_mmad_rtc (python_api.cpp:18, gemm.hpp:68-111): z[B,M,N] f32 = x[B,M,K] . y[B,K,N], x/y bf16 or fp16. */
+int dga_run_mmad_rtc(const void *x, const void *y, float *z, int batch, int m, int n, int k, int dtype,
+                     void *stream);
+/* run_mmad_bench (python_api.cpp:23, gemm_bench.hpp:49-113): z[M,N] f32 = x[M,K] . y[K,N];
+ * params_host = the 28 ints after dga_bench_params_fill (the knobs only steer the Ascend kernel). */
+int dga_run_mmad_bench(const void *x, const void *y, float *z, int m, int n, int k, int dtype,
+                       const int32_t *params_host, void *stream);
+
+/* ---- misc -------------------------------------------------------------------------------- */
+const char *dga_status_string(int status);
+int dga_last_hip_error(void);
+int dga_abi_version(void);
+/* fills coreNum etc. from hipDeviceProp of the current device */
+int dga_device_platform(dga_platform_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGA_HIP_H */

@@ -1,0 +1,138 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerance (BASELINE.json north_star): every output element within 2 bf16 ULP of the oracle
+(fp32 accumulate, oracle/dga_oracle.c).  NaN positions must coincide."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+MAX_ULP = 2
+
+
+def _dev(x, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    return t
+
+
+def _run(dga, a, sfa, b, sfb, tiling=None):
+    m, n = a.shape[0], b.shape[0]
+    out = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dga.gemm_fp8_fp8_bf16_nt((_dev(a), _dev(sfa)), (_dev(b), _dev(sfb)), out, tiling_=tiling, sync=True)
+    return out.view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+def _check(oracle, got, a, sfa, b, sfb, threads=8):
+    want = oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, threads=threads)
+    d = oracle.bf16_ulp_diff(got, want)
+    assert d.max(initial=0) <= MAX_ULP, f"max ulp {d.max()} at {np.unravel_index(d.argmax(), d.shape)}"
+    return int(d.max(initial=0))
+
+
+@pytest.mark.parametrize("m,n,k", [
+    (128, 128, 128),      # BASELINE config 1 shape
+    (64, 256, 384),
+    (256, 256, 512),
+    (300, 200, 256),      # M, N tails
+    (1, 128, 128),        # M = 1 (the reference's special case, generate_code.hpp:233-236)
+    (7, 136, 1024),       # N not a multiple of 8: scalar stores
+    (129, 257, 144),      # K tail chunk (K % 128 = 16), every axis ragged
+    (512, 384, 7168),     # DeepSeek K
+    (33, 4096, 512),
+])
+def test_dense_parity_scaled(dga, oracle, m, n, k):
+    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=m * 31 + n * 7 + k)
+    got = _run(dga, a, sfa, b, sfb)
+    _check(oracle, got, a, sfa, b, sfb)
+
+
+def test_config1_unit_scales_matches_reference_golden_formula(dga, oracle):
+    """BASELINE config 1: 128^3, unit scales.  K = 128 is one scale block, so the oracle is exactly the
+    reference golden np.matmul(f32, f32) (test.py:37) rounded to bf16."""
+    a, sfa, b, sfb = oracle.make_inputs(128, 128, 128, seed=0, unit_scales=True)
+    got = _run(dga, a, sfa, b, sfb)
+    tab = oracle.np_e4m3fn_table()
+    golden = np.matmul(tab[a].astype(np.float32), tab[b].astype(np.float32).T).astype(np.float32)
+    d = oracle.bf16_ulp_diff(got, oracle.f32_to_bf16_bits(golden))
+    assert d.max() <= MAX_ULP
+    _check(oracle, got, a, sfa, b, sfb)
+
+
+@pytest.mark.parametrize("bm,bn", [(256, 256), (128, 256), (256, 128), (128, 128), (64, 256), (64, 128),
+                                   (32, 256), (32, 128), (16, 256), (16, 128)])
+def test_every_kernel_variant(dga, oracle, bm, bn):
+    """Force each compiled tile variant on a ragged problem (tails in M, N and K)."""
+    m, n, k = 2 * bm + 5, 2 * bn + 24, 400
+    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=bm + bn)
+    t = dga.tiling(m, n, k)
+    t.m1, t.n1 = bm, bn
+    got = _run(dga, a, sfa, b, sfb, tiling=t)
+    _check(oracle, got, a, sfa, b, sfb)
+
+
+def test_random_bit_patterns_and_wild_scales(dga, oracle):
+    """All e4m3fn encodings (subnormals, -0, max) and scales over many binades."""
+    m, n, k = 192, 256, 640
+    rng = np.random.default_rng(5)
+    a = oracle.random_fp8_bytes((m, k), seed=1)
+    b = oracle.random_fp8_bytes((n, k), seed=2)
+    sfa = np.exp2(rng.uniform(-12, 4, size=(m, 5))).astype(np.float32)
+    sfb = np.exp2(rng.uniform(-12, 4, size=(2, 5))).astype(np.float32)
+    got = _run(dga, a, sfa, b, sfb)
+    _check(oracle, got, a, sfa, b, sfb)
+
+
+def test_nan_bytes_propagate(dga, oracle):
+    m, n, k = 64, 128, 256
+    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=9)
+    a[3, 17] = 0x7F
+    b[100, 200] = 0xFF
+    got = _run(dga, a, sfa, b, sfb)
+    want = oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb)
+    nan_g = (got & 0x7FFF) > 0x7F80
+    nan_w = (want & 0x7FFF) > 0x7F80
+    assert nan_w[3, :].all() and nan_w[:, 100].all() and nan_w.sum() == n + m - 1
+    assert np.array_equal(nan_g, nan_w)
+    assert oracle.bf16_ulp_diff(got, want).max() <= MAX_ULP
+
+
+@pytest.mark.parametrize("m,n,k", [(40, 130, 100), (17, 33, 7), (5, 5, 129), (64, 128, 0)])
+def test_generic_kernel_odd_k(dga, oracle, m, n, k):
+    """K % 16 != 0 (and K = 0) take the element-wise HIP kernel."""
+    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=3)
+    got = _run(dga, a, sfa, b, sfb)
+    _check(oracle, got, a, sfa, b, sfb)
+
+
+def test_empty_problem_is_a_noop(dga):
+    out = torch.empty((0, 128), dtype=torch.bfloat16, device="cuda")
+    a = torch.empty((0, 256), dtype=torch.uint8, device="cuda")
+    sfa = torch.empty((0, 2), dtype=torch.float32, device="cuda")
+    b = torch.zeros((128, 256), dtype=torch.uint8, device="cuda")
+    sfb = torch.ones((1, 2), dtype=torch.float32, device="cuda")
+    dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, sync=True)
+
+
+def test_linearity_in_scales_full_size(dga, oracle):
+    """Size-independent property at BASELINE config 2 (4096^3): doubling sfa doubles the fp32 sum exactly,
+    so the bf16 outputs differ by exactly one exponent step; and a column-block of B scaled by 4 likewise."""
+    m = n = k = 4096
+    g = torch.Generator(device="cuda").manual_seed(0)
+    a = torch.randint(0, 256, (m, k), dtype=torch.uint8, device="cuda", generator=g)
+    b = torch.randint(0, 256, (n, k), dtype=torch.uint8, device="cuda", generator=g)
+    a = torch.where((a & 0x7F) == 0x7F, a & 0x80, a)
+    b = torch.where((b & 0x7F) == 0x7F, b & 0x80, b)
+    sfa = torch.rand((m, k // 128), device="cuda") + 0.5
+    sfb = torch.rand((n // 128, k // 128), device="cuda") + 0.5
+    o1 = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    o2 = torch.empty_like(o1)
+    dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), o1)
+    dga.gemm_fp8_fp8_bf16_nt((a, sfa * 2), (b, sfb), o2, sync=True)
+    assert torch.equal(o1.float() * 2, o2.float())
+    # spot-check 64 rows against the oracle
+    rows = np.arange(0, m, 64)
+    an, bn = a.cpu().numpy(), b.cpu().numpy()
+    want = oracle.gemm_fp8_fp8_bf16_nt(an[rows], sfa.cpu().numpy()[rows], bn, sfb.cpu().numpy(), threads=16)
+    got = o1[torch.from_numpy(rows).cuda()].view(torch.int16).cpu().numpy().view(np.uint16)
+    assert oracle.bf16_ulp_diff(got, want).max() <= MAX_ULP

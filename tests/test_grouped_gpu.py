@@ -1,0 +1,73 @@
+"""GPU parity of the grouped masked-M path against the oracle (semantics: rows >= masked_m[g] untouched)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+MAX_ULP = 2
+
+
+def _grouped_inputs(oracle, g, mmax, n, k, seed):
+    A, SFA, B, SFB = [], [], [], []
+    for i in range(g):
+        a, sfa, b, sfb = oracle.make_inputs(mmax, n, k, seed=seed * 1000 + i)
+        A.append(a); SFA.append(sfa); B.append(b); SFB.append(sfb)
+    return np.stack(A), np.stack(SFA), np.stack(B), np.stack(SFB)
+
+
+def _bits(t):
+    return t.view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+@pytest.mark.parametrize("g,mmax,n,k,masks", [
+    (4, 16, 128, 256, [0, 1, 7, 16]),          # SURVEY.md 8c golden (iv)
+    (6, 128, 256, 512, [128, 0, 64, 127, 1, 65]),
+    (3, 200, 384, 384, [200, 129, 3]),          # m_max not a tile multiple, two m-tiles
+    (5, 48, 136, 144, [48, 0, 0, 17, 33]),      # N tail with scalar stores, K tail chunk
+])
+def test_grouped_masked_parity(dga, oracle, g, mmax, n, k, masks):
+    a, sfa, b, sfb = _grouped_inputs(oracle, g, mmax, n, k, seed=g + mmax)
+    masked = np.array(masks, np.int32)
+    sentinel = np.uint16(0x7FC1)  # a NaN pattern the kernel never produces: untouched rows keep it
+    init = np.full((g, mmax, n), sentinel, np.uint16)
+    out = torch.from_numpy(init.view(np.int16)).cuda().view(torch.bfloat16)
+    dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked(
+        (torch.from_numpy(a).cuda(), torch.from_numpy(sfa).cuda()),
+        (torch.from_numpy(b).cuda(), torch.from_numpy(sfb).cuda()),
+        out, torch.from_numpy(masked).cuda(), expected_m=int(max(masks)), sync=True)
+    got = _bits(out)
+    want = oracle.m_grouped_gemm_fp8_fp8_bf16_nt_masked(a, sfa, b, sfb, init, masked, threads=8)
+    for gi in range(g):
+        mm = masks[gi]
+        assert (got[gi, mm:] == sentinel).all(), f"group {gi}: rows >= masked_m were written"
+        assert oracle.bf16_ulp_diff(got[gi, :mm], want[gi, :mm]).max(initial=0) <= MAX_ULP
+
+
+def test_grouped_equals_dense_per_group(dga, oracle):
+    """Size-independent property: a grouped call equals G dense calls (bitwise, same kernel arithmetic)."""
+    g, mmax, n, k = 8, 128, 512, 1024
+    a, sfa, b, sfb = _grouped_inputs(oracle, g, mmax, n, k, seed=77)
+    ta, tsfa, tb, tsfb = [torch.from_numpy(x).cuda() for x in (a, sfa, b, sfb)]
+    masked = torch.full((g,), mmax, dtype=torch.int32, device="cuda")
+    out = torch.zeros((g, mmax, n), dtype=torch.bfloat16, device="cuda")
+    dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((ta, tsfa), (tb, tsfb), out, masked, expected_m=mmax)
+    ref = torch.zeros_like(out)
+    t = dga.tiling(mmax, n, k, groups=g, expected_m=mmax)
+    for i in range(g):
+        dga.gemm_fp8_fp8_bf16_nt((ta[i], tsfa[i]), (tb[i], tsfb[i]), ref[i], tiling_=None)
+    torch.cuda.synchronize()
+    d = oracle.bf16_ulp_diff(_bits(out), _bits(ref))
+    assert d.max() <= 1  # different tile shapes may pick different (still in-order) fp32 sums: none here
+
+
+def test_masked_m_out_of_range_is_clamped(dga, oracle):
+    g, mmax, n, k = 2, 32, 128, 128
+    a, sfa, b, sfb = _grouped_inputs(oracle, g, mmax, n, k, seed=5)
+    masked = torch.tensor([1000, 5], dtype=torch.int32, device="cuda")
+    out = torch.zeros((g, mmax, n), dtype=torch.bfloat16, device="cuda")
+    dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked(
+        (torch.from_numpy(a).cuda(), torch.from_numpy(sfa).cuda()),
+        (torch.from_numpy(b).cuda(), torch.from_numpy(sfb).cuda()), out, masked, expected_m=32, sync=True)
+    want = oracle.gemm_fp8_fp8_bf16_nt(a[0], sfa[0], b[0], sfb[0])
+    assert oracle.bf16_ulp_diff(_bits(out[0]), want).max() <= MAX_ULP
+    assert (out[1, 5:] == 0).all()
