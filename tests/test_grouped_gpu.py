@@ -40,7 +40,8 @@ def test_grouped_masked_parity(dga, oracle, g, mmax, n, k, masks):
     for gi in range(g):
         mm = masks[gi]
         assert (got[gi, mm:] == sentinel).all(), f"group {gi}: rows >= masked_m were written"
-        assert oracle.bf16_ulp_diff(got[gi, :mm], want[gi, :mm]).max(initial=0) <= MAX_ULP
+        if mm:
+            oracle.assert_parity(got[gi, :mm], want[gi, :mm], a[gi, :mm], sfa[gi, :mm], b[gi], sfb[gi])
 
 
 def test_grouped_equals_dense_per_group(dga, oracle):
@@ -56,8 +57,8 @@ def test_grouped_equals_dense_per_group(dga, oracle):
     for i in range(g):
         dga.gemm_fp8_fp8_bf16_nt((ta[i], tsfa[i]), (tb[i], tsfb[i]), ref[i], tiling_=None)
     torch.cuda.synchronize()
-    d = oracle.bf16_ulp_diff(_bits(out), _bits(ref))
-    assert d.max() <= 1  # different tile shapes may pick different (still in-order) fp32 sums: none here
+    # the tile shape changes neither the per-128-block MFMA nor the order of the fp32 promotion: bitwise equal
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
 
 
 def test_masked_m_out_of_range_is_clamped(dga, oracle):
@@ -69,5 +70,5 @@ def test_masked_m_out_of_range_is_clamped(dga, oracle):
         (torch.from_numpy(a).cuda(), torch.from_numpy(sfa).cuda()),
         (torch.from_numpy(b).cuda(), torch.from_numpy(sfb).cuda()), out, masked, expected_m=32, sync=True)
     want = oracle.gemm_fp8_fp8_bf16_nt(a[0], sfa[0], b[0], sfb[0])
-    assert oracle.bf16_ulp_diff(_bits(out[0]), want).max() <= MAX_ULP
+    oracle.assert_parity(_bits(out[0]), want, a[0], sfa[0], b[0], sfb[0])
     assert (out[1, 5:] == 0).all()
