@@ -8,9 +8,9 @@
 // and of its Python mirror get_best_config/tiling_calculator.py.
 //
 // Two modes share one arithmetic core:
-//   * platform.xcdNum <= 1 (Ascend numbers): the reference's own NT tile search replayed,
-//     16-element granularity, L1/L0C limits -- exists so tests can pin the restatement
-//     against the reference's golden tuples (tests/golden/op_tiling_vectors.json).
+//   * platform.xcdNum <= 1 (Ascend numbers): the reference's own NT tile search, padding cost model
+//     and handler chain replayed, 16-element granularity, L1/L0C limits -- exists so tests can pin
+//     the restatement against the reference's golden tuples (tests/golden/op_tiling_vectors.json).
 //   * platform.xcdNum  > 1 (MI355X): same search skeleton (start from the aspect-ratio tile,
 //     balance the block count against the core count, bound by on-chip space), but the result
 //     is drawn from the compiled kernel menu (dga_launch.hip kVariants), space is LDS + VGPR
@@ -109,32 +109,126 @@ void do_tiling_nt_reference(dga_tiling_t &t, const dga_platform_t &pf, uint32_t 
     t.m1 = static_cast<uint16_t>(m1); t.n1 = static_cast<uint16_t>(n1); t.k1 = static_cast<uint16_t>(k1);
 }
 
-// ---- handler chain, reference mode (select_kernel.cpp:270-331) ---------------------------
-// The padding cost model (GetPaddingTag :82-268) prices Ascend ND->NZ re-layout on vector cores;
-// it has no CDNA4 meaning.  In reference mode we evaluate only its *outcome class* that the NT
-// configs of SURVEY.md 8(a7) exercise -- (NONE,NONE,NONE) -- via the cheap structural exits of that
-// model (inner axis >= 32 and 16-aligned, inner axis not a >8192 multiple of 8192, n % 128 == 0 or
-// small output); anything else is reported as kernelSerial 2 without attempting the cost fit.
-bool padding_free_nt(const dga_tiling_t &t)
+// ---- padding cost model, reference mode only (select_kernel.cpp:22-80, 82-268) ----------------
+// Prices the Ascend ND->NZ re-layout of an operand on the vector cores against loading it
+// unpadded.  It has no CDNA4 meaning (the LDS image is swizzled by the DMA source address) and is
+// restated only so that the handler chain can be replayed against the reference's golden tuples.
+// GetBandwidth (:22-80): GB/s a cube core reaches loading `rows` x `cols` pieces of a matrix whose
+// contiguous axis is `src_cols` long.
+double cube_bandwidth(uint32_t rows, uint32_t cols, uint64_t src_cols)
 {
-    const uint64_t inner = t.k;  // NT: both operands are K-contiguous
-    if (inner < 8 || (inner < 32 && inner % 16 != 0)) return false;
-    if (inner > 8192 && inner % 8192 == 0 && (t.m >= 2048 || t.n >= 2048)) return false;
-    if (static_cast<uint64_t>(t.m) * t.n > 2048ull * 2048ull && t.n > 256 && t.n % 128 != 0) return false;
-    return true;
+    const double d = cols;
+    // 6th-order fit of unaligned-load bandwidth vs piece width (constants: select_kernel.cpp:23-29)
+    double bw = 0.000000000000020146121020 * std::pow(d, 6) - 0.000000000012456944162142 * std::pow(d, 5) -
+                0.000000006738536427145036 * std::pow(d, 4) + 0.000007301215580838747961 * std::pow(d, 3) -
+                0.002146456956750821074703 * std::pow(d, 2) + 0.312849910814454512664184 * d + 0.1;
+    if (cols == src_cols && cols <= 128 && cols % 16 == 0) bw = 60;
+    if (src_cols >= 65536) bw = 1;
+    if (src_cols % 256 == 0) bw *= 100.0 / 30;
+    else if (src_cols % 128 == 0) bw *= 80.0 / 30;
+    else if (src_cols % 64 == 0) bw *= 50.0 / 30;
+    else if (src_cols % 16 == 0) bw *= 40.0 / 30;
+    bw = std::min(bw, 80.0);
+    const double r = rows;
+    if (cols % 256 == 0) {
+        if (rows < 16) bw *= -0.003332381309698882569659 * r * r + 0.113578920178116271610946 * r + 0.016102868630357251855667;
+    } else if (cols % 32 == 0) {
+        if (rows < 32) bw *= -0.000298086120946179481978 * r * r + 0.045309519479127147167929 * r + 0.035130178145161221336945;
+    } else if (rows < 64) {
+        bw *= 0.000001809180573350345869 * r * r * r - 0.000469676727179688081274 * r * r +
+              0.038963259596073690493867 * r + 0.003942641759904389614499;
+    }
+    return bw;
 }
 
+struct OperandCost {
+    uint64_t outer, inner;       // matrix extent across / along the contiguous axis
+    double bw_plain, bw_padded;  // cube-core GB/s without / with NZ padding
+    double bw_vec;               // vector-core GB/s for the padding pass
+    uint64_t cube_bytes;         // bytes the busiest cube core loads
+    uint64_t vec_bytes;          // bytes the busiest vector core re-lays out
+    uint32_t vec_tasks;
+};
+
+// one operand of GetPaddingTag: (outer, inner) extents, (tile_outer, tile_inner) piece, `tile_cnt` tiles along
+// the non-K axis, `actual` = min(extent, tile) of that axis
+OperandCost operand_cost(uint64_t outer, uint64_t inner, uint32_t piece_rows, uint32_t piece_cols, uint64_t elems,
+                         uint32_t tile_cnt, uint32_t actual, uint32_t round_max, uint32_t block_dim, uint32_t k,
+                         uint32_t k1, uint32_t splitk, const dga_platform_t &pf)
+{
+    OperandCost c{};
+    c.outer = outer; c.inner = inner;
+    c.bw_vec = (elems * 2 > 192ull * 1024 * 1024) ? 10 : 30;   // beyond the 192 MB L2 (:113-117)
+    c.bw_plain = cube_bandwidth(piece_rows, piece_cols, inner);
+    if (tile_cnt < block_dim / 2 && k <= k1 && tile_cnt <= 2) c.bw_plain = c.bw_plain / (block_dim / tile_cnt) * 1.5;
+    c.bw_padded = 80;
+    if (piece_rows < 16) c.bw_padded *= static_cast<double>(piece_rows) / 16;
+    c.cube_bytes = static_cast<uint64_t>(round_max) * actual * ceil_div(k, splitk) * 2;
+    // padding simulator (:147-180): 16-row tasks of up to 48 KB spread over 2 vector cores per cube core
+    uint32_t task_rows = 16, task_cols = 48 * 1024 / 2 / 16;
+    if (inner < task_cols) task_cols = static_cast<uint32_t>(inner);
+    if (outer < task_rows) task_rows = static_cast<uint32_t>(outer);
+    task_cols = round_up(static_cast<uint32_t>(inner) / ceil_div(static_cast<uint32_t>(inner), task_cols), 16);
+    c.vec_tasks = ceil_div(static_cast<uint32_t>(outer), task_rows) * ceil_div(static_cast<uint32_t>(inner), task_cols);
+    c.vec_bytes = static_cast<uint64_t>(ceil_div(c.vec_tasks, pf.coreNum * 2)) * task_cols * task_rows * 2;
+    return c;
+}
+
+// GetPaddingTag (:82-268), NT layout: A is [m][k], B is [n][k] (both K-contiguous)
+void padding_tags_reference(dga_tiling_t &t, const dga_platform_t &pf)
+{
+    const uint32_t m = t.m, n = t.n, k = t.k, m1 = t.m1, n1 = t.n1, k1 = t.k1, sk = t.splitkFactor;
+    const uint32_t tiles_m = ceil_div(m, m1), tiles_n = ceil_div(n, n1);
+    const uint32_t tasks = tiles_m * tiles_n * sk;
+    const uint32_t block_dim = std::min(tasks, pf.coreNum);
+    const uint32_t round_max = ceil_div(tasks, pf.coreNum);
+    const OperandCost A = operand_cost(m, k, std::min(m, m1), std::min(k, k1), static_cast<uint64_t>(m) * k, tiles_m,
+                                       std::min(m, m1), round_max, block_dim, k, k1, sk, pf);
+    const OperandCost B = operand_cost(n, k, std::min(n, n1), std::min(k, k1), static_cast<uint64_t>(k) * n, tiles_n,
+                                       std::min(n, n1), round_max, block_dim, k, k1, sk, pf);
+    const double head = sk > 1 ? 1.0 : 1 + 7 * static_cast<double>(block_dim) / pf.coreNum;  // us
+    auto us = [](uint64_t bytes, double gbps) { return static_cast<double>(bytes) / gbps / 1000; };
+    const double t00 = us(A.cube_bytes, A.bw_plain) + us(B.cube_bytes, B.bw_plain);
+    const double t01 = us(A.cube_bytes, A.bw_plain) + us(B.cube_bytes, B.bw_padded) + us(B.vec_bytes, B.bw_vec) + head;
+    const double t10 = us(A.cube_bytes, A.bw_padded) + us(B.cube_bytes, B.bw_plain) + us(A.vec_bytes, A.bw_vec) + head;
+    const double t11 = us(A.cube_bytes, A.bw_padded) + us(B.cube_bytes, B.bw_padded) + us(A.vec_bytes, A.bw_vec) +
+                       us(B.vec_bytes, B.bw_vec) + head + 2;
+    uint8_t pa = DGA_PADDING_NONE, pb = DGA_PADDING_NONE;
+    double best = t00;
+    if (t01 < best) { best = t01; pa = DGA_PADDING_NONE; pb = DGA_PADDING_NZ; }
+    if (t10 < best) { best = t10; pa = DGA_PADDING_NZ; pb = DGA_PADDING_NONE; }
+    if (t11 < best) { best = t11; pa = DGA_PADDING_NZ; pb = DGA_PADDING_NZ; }
+    auto forced = [](const OperandCost &c) {
+        if ((c.inner < 8 || (c.inner < 32 && c.inner % 16 != 0)) && c.outer > 512) return true;
+        return c.outer >= 2048 && c.inner > 8192 && c.inner % 8192 == 0;  // "meta conflicts" (:229-235)
+    };
+    if (forced(A)) pa = DGA_PADDING_NZ;
+    if (forced(B)) pb = DGA_PADDING_NZ;
+    uint8_t pc = DGA_PADDING_NONE;
+    if (static_cast<uint64_t>(m) * n > 2048ull * 2048 && n > 256 && n % 128 != 0) {
+        const uint64_t total = static_cast<uint64_t>(m) * k * tiles_n * 2 + static_cast<uint64_t>(k) * n * tiles_m * 2 +
+                               static_cast<uint64_t>(m) * n * 2;
+        if (total < 192ull * 1024 * 1024) pc = DGA_PADDING_ND;
+    }
+    t.paddingTagA = pa; t.paddingTagB = pb; t.paddingTagC = pc;
+    uint32_t vec_a = (pa && A.inner > 192) ? A.vec_tasks : 0, vec_b = (pb && B.inner > 192) ? B.vec_tasks : 0;
+    const uint32_t vec = std::max(vec_a, vec_b);
+    const uint32_t bd_vec = std::min(ceil_div(vec, 2), pf.coreNum);
+    t.blockDim = (pa || pb) ? std::max(block_dim, bd_vec) : block_dim;
+}
+
+// ---- handler chain, reference mode (select_kernel.cpp:270-369): Small -> StreamK -> PaddingCommon -> Common
 void select_reference(dga_tiling_t &t, const dga_platform_t &pf)
 {
     do_tiling_nt_reference(t, pf, 2);
-    const uint32_t blocks = ceil_div(t.m, t.m1) * ceil_div(t.n, t.n1);
-    const bool nopad = padding_free_nt(t);
-    t.paddingTagA = t.paddingTagB = t.paddingTagC = DGA_PADDING_NONE;
     // Small (:278-293)
-    if (nopad && blocks <= pf.coreNum && t.k <= t.k1) {
-        t.kernelSerial = DGA_KERNEL_SMALL;
-        t.blockDim = blocks;
-        return;
+    padding_tags_reference(t, pf);
+    if (!t.paddingTagA && !t.paddingTagB && !t.paddingTagC) {
+        const uint32_t blocks = ceil_div(t.m, t.m1) * ceil_div(t.n, t.n1);
+        if (blocks <= pf.coreNum && t.k <= t.k1) {
+            t.kernelSerial = DGA_KERNEL_SMALL;
+            return;
+        }
     }
     // Stream-K (:303-331): best-bandwidth tile, all cores, when the tail round is < 80 % full and K is long
     {
@@ -142,18 +236,18 @@ void select_reference(dga_tiling_t &t, const dga_platform_t &pf)
         const uint32_t rem = sb % pf.coreNum;
         if (sb > pf.coreNum && sb < 8 * pf.coreNum && rem > 0 && rem < 0.8 * pf.coreNum && t.k > 3072) {
             t.m1 = 128; t.n1 = 256; t.k1 = 256;
+            padding_tags_reference(t, pf);
             t.blockDim = pf.coreNum;
             t.kernelSerial = DGA_KERNEL_STREAMK;
             return;
         }
     }
-    if (!nopad) {
+    if (t.paddingTagA || t.paddingTagB || t.paddingTagC) {  // PaddingCommon (:295-301)
         t.kernelSerial = DGA_KERNEL_PADDING_COMMON;
-        t.blockDim = std::min(blocks, pf.coreNum);
         return;
     }
-    t.kernelSerial = DGA_KERNEL_COMMON;  // :270-276
-    t.blockDim = std::min(blocks, pf.coreNum);
+    t.blockDim = std::min(ceil_div(t.m, t.m1) * ceil_div(t.n, t.n1), pf.coreNum);  // Common (:270-276)
+    t.kernelSerial = DGA_KERNEL_COMMON;
 }
 
 // ---- MI355X mode -------------------------------------------------------------------------

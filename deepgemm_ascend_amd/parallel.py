@@ -1,0 +1,207 @@
+"""Expert sharding of the grouped masked-M GEMM over the GPUs of one node.
+
+The reference has no collective of any kind ("multi-card" = rank-sliced independent processes,
+/root/reference/deep_gemm_ascend/benchmark_msprof/main.cpp:24-26,
+framework/benchmark/benchmark.py:249-253); this module is new work for BASELINE.json configs[4].
+
+Partitioning: expert g lives on rank g // (G / world); its weights never move.  One exchange each way:
+  dispatch  all-to-all-v of token rows (fp8 [K] bytes + their fp32 [K/128] scales packed in one byte row)
+            from the token's home rank to the expert's rank -> masked layout [G_local, m_max, K]
+  compute   m_grouped_gemm_fp8_fp8_bf16_nt_masked with masked_m = received counts
+  combine   all-to-all-v of bf16 [N] rows back, restored to the original token order
+`torch.distributed` backend "nccl" is RCCL on ROCm; on MI355X's fully connected xGMI mesh every peer pair has
+its own link, so an all-to-all is per-link bound.  world == 1 skips the exchange.
+
+`compute` is injectable so that the routing can be covered by world_size-2 gloo tests on CPU with the oracle
+as the checker; the default is the HIP operator (no CPU fallback in the product path).
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import torch
+
+
+@dataclass
+class RouteState:
+    order: torch.Tensor        # permutation that sorts my tokens by expert
+    dest: torch.Tensor         # slot (g_local * m_max + row) of every received row
+    send_splits: list
+    recv_splits: list
+    tokens: int
+
+
+def _default_compute(a, sfa, b, sfb, out, masked_m, expected_m):
+    from . import api
+    api.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), out, masked_m, expected_m)
+
+
+class ExpertShardedGroupedGemm:
+    def __init__(self, rank: int, world: int, groups_total: int, m_max: int, n: int, k: int, device,
+                 dist=None, compute: Optional[Callable] = None):
+        assert groups_total % world == 0, "experts must divide evenly over ranks"
+        self.rank, self.world, self.dist = rank, world, dist
+        self.G, self.Gl = groups_total, groups_total // world
+        self.m_max, self.n, self.k = m_max, n, k
+        self.kb = (k + 127) // 128
+        self.nb = (n + 127) // 128
+        self.row_bytes = k + 4 * self.kb
+        self.device = device
+        self.compute = compute or _default_compute
+        # resident buffers sized once (288 GB HBM: weights + masked activations stay put)
+        self.a = torch.zeros((self.Gl, m_max, k), dtype=torch.uint8, device=device)
+        self.sfa = torch.ones((self.Gl, m_max, self.kb), dtype=torch.float32, device=device)
+        self.out = torch.zeros((self.Gl, m_max, n), dtype=torch.bfloat16, device=device)
+        self.masked_m = torch.zeros((self.Gl,), dtype=torch.int32, device=device)
+        self.b = None
+        self.sfb = None
+
+    def set_weights(self, b: torch.Tensor, sfb: torch.Tensor):
+        assert tuple(b.shape) == (self.Gl, self.n, self.k) and tuple(sfb.shape) == (self.Gl, self.nb, self.kb)
+        self.b, self.sfb = b, sfb
+
+    def owner(self, g):
+        return g // self.Gl
+
+    # ------------------------------------------------------------------ dispatch
+    def dispatch(self, tok_q: torch.Tensor, tok_sf: torch.Tensor, expert_ids: torch.Tensor) -> RouteState:
+        """tok_q [T,K] u8, tok_sf [T,KB] f32, expert_ids [T] int64 (global expert of each token)."""
+        T = tok_q.shape[0]
+        order = torch.argsort(expert_ids, stable=True)
+        counts = torch.bincount(expert_ids, minlength=self.G).to(torch.int64)        # [G]
+        if self.world > 1:
+            flat = torch.empty((self.world * self.G,), dtype=torch.int64, device=counts.device)
+            self.dist.all_gather_into_tensor(flat, counts)
+            allc = flat.view(self.world, self.G)
+        else:
+            allc = counts[None, :]
+        mine = allc[:, self.rank * self.Gl:(self.rank + 1) * self.Gl]                # [world, Gl] rows I receive
+        send_splits = counts.view(self.world, self.Gl).sum(1).tolist()
+        recv_splits = mine.sum(1).tolist()
+        # one byte row per token: K fp8 bytes followed by KB fp32 scales
+        payload = torch.empty((T, self.row_bytes), dtype=torch.uint8, device=tok_q.device)
+        payload[:, :self.k] = tok_q[order]
+        payload[:, self.k:] = tok_sf[order].contiguous().view(torch.uint8).view(T, 4 * self.kb)
+        total = int(sum(recv_splits))
+        if self.world > 1:
+            recv = torch.empty((total, self.row_bytes), dtype=torch.uint8, device=tok_q.device)
+            self.dist.all_to_all_single(recv, payload, recv_splits, send_splits)
+        else:
+            recv = payload
+        # slot of every received row: source-major, expert-minor arrival order -> [g, row] masked layout
+        masked = mine.sum(0)                                                          # [Gl]
+        if int(masked.max().item() if masked.numel() else 0) > self.m_max:
+            raise ValueError(f"an expert received {int(masked.max())} rows > m_max {self.m_max}")
+        start = (torch.cumsum(mine, 0) - mine) + (torch.arange(self.Gl, device=mine.device) * self.m_max)[None, :]
+        flat_cnt = mine.reshape(-1)
+        flat_start = start.reshape(-1)
+        seg_begin = torch.cumsum(flat_cnt, 0) - flat_cnt
+        idx = torch.arange(total, device=mine.device)
+        dest = torch.repeat_interleave(flat_start - seg_begin, flat_cnt) + idx
+        self.a.view(self.Gl * self.m_max, self.k)[dest] = recv[:, :self.k]
+        self.sfa.view(self.Gl * self.m_max, self.kb)[dest] = \
+            recv[:, self.k:].contiguous().view(torch.float32).view(total, self.kb)
+        self.masked_m.copy_(masked.to(torch.int32))
+        return RouteState(order, dest, send_splits, recv_splits, T)
+
+    # ------------------------------------------------------------------ compute
+    def run_local(self, expected_m: int = 0):
+        self.compute(self.a, self.sfa, self.b, self.sfb, self.out, self.masked_m, expected_m or self.m_max)
+
+    # ------------------------------------------------------------------ combine
+    def combine(self, st: RouteState) -> torch.Tensor:
+        rows = self.out.view(self.Gl * self.m_max, self.n)[st.dest]                   # arrival order
+        if self.world > 1:
+            back = torch.empty((st.tokens, self.n), dtype=self.out.dtype, device=rows.device)
+            self.dist.all_to_all_single(back, rows.contiguous(), st.send_splits, st.recv_splits)
+        else:
+            back = rows
+        res = torch.empty_like(back)
+        res[st.order] = back
+        return res
+
+    def forward(self, tok_q, tok_sf, expert_ids, expected_m: int = 0) -> torch.Tensor:
+        st = self.dispatch(tok_q, tok_sf, expert_ids)
+        self.run_local(expected_m)
+        return self.combine(st)
+
+
+# ---------------------------------------------------------------------- benchmark leg (called from bench.py)
+
+def _rand_fp8(shape, gen, device):
+    x = torch.randint(0, 256, shape, dtype=torch.uint8, device=device, generator=gen)
+    return torch.where((x & 0x7F) == 0x7F, x & 0x80, x)
+
+
+def bench_grouped(rank, world, dist, steps=10, warmup=3, groups_total=256, m_max=128, n=2048, k=7168, mask="full"):
+    """BASELINE.json configs[3] (world 1) / configs[4] (world 8): G experts x (M<=128, K=7168, N=2048).
+    Tokens are born uniformly on the ranks; `full` = every expert gets m_max rows, `random` = randint(0, m_max+1)."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    eng = ExpertShardedGroupedGemm(rank, world, groups_total, m_max, n, k, dev, dist)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    kb, nb = eng.kb, eng.nb
+    eng.set_weights(_rand_fp8((eng.Gl, n, k), g, dev), torch.rand((eng.Gl, nb, kb), device=dev, generator=g) + 0.5)
+    # tokens per expert contributed by this rank
+    gc = torch.Generator().manual_seed(99)  # same on every rank
+    if mask == "full":
+        per_expert = torch.full((groups_total,), m_max, dtype=torch.int64)
+    else:
+        per_expert = torch.randint(0, m_max + 1, (groups_total,), generator=gc)
+    base = per_expert // world
+    extra = per_expert % world
+    mine = base + (rank < extra).to(torch.int64)
+    expert_ids = torch.repeat_interleave(torch.arange(groups_total), mine).to(dev)
+    expert_ids = expert_ids[torch.randperm(expert_ids.numel(), device=dev, generator=g)]
+    T = expert_ids.numel()
+    tok_q = _rand_fp8((T, k), g, dev)
+    tok_sf = torch.rand((T, kb), device=dev, generator=g) + 0.5
+    total_tokens = int(per_expert.sum())
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None and world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # end to end: dispatch + GEMM + combine
+    for _ in range(warmup):
+        eng.forward(tok_q, tok_sf, expert_ids)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.forward(tok_q, tok_sf, expert_ids)
+    sync()
+    e2e = (time.perf_counter() - t0) / steps
+    # GEMM only (activations already in the masked layout on the owning rank)
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    sync()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        eng.run_local()
+    ev1.record()
+    sync()
+    gemm = (time.perf_counter() - t0) / steps
+    kernel_us = ev0.elapsed_time(ev1) * 1e3 / steps
+    if dist is not None and world > 1:
+        tt = torch.tensor([e2e, gemm, kernel_us], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        e2e, gemm, kernel_us = (float(x) for x in tt)
+    rows_local = int(eng.masked_m.sum().item())
+    active = int((eng.masked_m > 0).sum().item())
+    alg_bytes = active * n * k + rows_local * (k + 4 * kb + 2 * n) + eng.Gl * nb * kb * 4
+    flops_local = 2.0 * n * k * rows_local
+    return {
+        "workload": f"m_grouped_gemm_fp8_fp8_bf16_nt_masked G={groups_total} x (M<={m_max}, K={k}, N={n}), "
+                    f"mask={mask}, {groups_total // world} experts/GPU",
+        "n_gpus": world, "tokens": total_tokens,
+        "tok_per_s_gemm_only": round(total_tokens / gemm, 1),
+        "tok_per_s_with_alltoall": round(total_tokens / e2e, 1),
+        "ms_gemm": round(gemm * 1e3, 4), "ms_end_to_end": round(e2e * 1e3, 4),
+        "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (kernel_us * 1e-6) / 1e9, 1), "peak": 8000.0,
+                     "unit": "GB/s", "frac": round(alg_bytes / (kernel_us * 1e-6) / 1e9 / 8000.0, 4),
+                     "traffic": None, "kernel_us": round(kernel_us, 2), "algorithmic_bytes": alg_bytes,
+                     "tflops": round(flops_local / (kernel_us * 1e-6) / 1e12, 1)},
+    }

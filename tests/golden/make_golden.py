@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Generates the fixtures under tests/golden/.  Run in the authoring container only
+(`python tests/golden/make_golden.py`): it imports the reference's Python autotuner mirror from
+/root/reference/get_best_config and runs oracle/_ref/ref_config (the reference's get_best_config.hpp
+compiled where it lies).  Only DATA is written here (inputs + expected outputs); no reference source.
+
+Fixtures (SURVEY.md 8c "Golden vectors to commit"):
+  e4m3fn_table.json       (i)   256-entry decode table, from torch.float8_e4m3fn (an independent implementation)
+  c1_unit_128.npz         (ii)  BASELINE config 1: 128^3, unit scales; expected = the reference golden formula
+                                np.matmul(x1.astype(f32), x2.astype(f32)) (framework/tests/test.py:37) + bf16 RNE
+  scaled_64x256x400.npz   (iii) non-unit scales and a K tail block; expected from the oracle (parity unpinned)
+  grouped_g4_m16.npz      (iv)  G=4, M_max=16, masked_m=[0,1,7,16]; expected from the oracle (parity unpinned)
+  config_vectors.json     (v)   28-int Config tuples from the reference header itself
+  op_tiling_vectors.json  (vi)  (m1,n1,k1,kernelSerial,blockDim,padding) from the reference's Python mirror
+                                (coreNum 20) and the C++ probes recorded in SURVEY.md 8(a7) (coreNum 24)
+"""
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+sys.path.insert(0, str(ROOT))
+from oracle import oracle as O  # noqa: E402
+
+REF = Path("/root/reference")
+
+
+def table():
+    import torch
+    t = torch.arange(256, dtype=torch.uint8).view(torch.float8_e4m3fn).float().numpy()
+    (HERE / "e4m3fn_table.json").write_text(json.dumps(
+        {"source": "torch.float8_e4m3fn", "f32_bits_hex": [f"{int(v):08x}" for v in t.view(np.uint32)]}))
+
+
+def c1():
+    a, sfa, b, sfb = O.make_inputs(128, 128, 128, seed=0, unit_scales=True)
+    tab = O.np_e4m3fn_table()
+    x1 = tab[a].astype(np.float32); x2 = tab[b].astype(np.float32).T          # [M,K], [K,N]
+    golden = np.matmul(x1.astype(np.float32), x2.astype(np.float32)).astype(np.float32)  # test.py:37
+    np.savez_compressed(HERE / "c1_unit_128.npz", a=a, b=b, sfa=sfa, sfb=sfb, golden_f32=golden,
+                        expected_bf16=O.f32_to_bf16_bits(golden))
+
+
+def scaled():
+    a, sfa, b, sfb = O.make_inputs(64, 256, 400, seed=3)
+    out, acc = O.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, want_f32=True)
+    np.savez_compressed(HERE / "scaled_64x256x400.npz", a=a, b=b, sfa=sfa, sfb=sfb, expected_bf16=out, acc_f32=acc)
+
+
+def grouped():
+    g, mmax, n, k = 4, 16, 128, 256
+    parts = [O.make_inputs(mmax, n, k, seed=40 + i) for i in range(g)]
+    a, sfa, b, sfb = (np.stack([p[j] for p in parts]) for j in range(4))
+    masked = np.array([0, 1, 7, 16], np.int32)
+    init = np.full((g, mmax, n), 0x7FC1, np.uint16)
+    out = O.m_grouped_gemm_fp8_fp8_bf16_nt_masked(a, sfa, b, sfb, init, masked)
+    np.savez_compressed(HERE / "grouped_g4_m16.npz", a=a, b=b, sfa=sfa, sfb=sfb, masked_m=masked, init=init,
+                        expected_bf16=out)
+
+
+def configs():
+    best = [(1, 4096, 4096, 4096), (1, 4096, 2048, 7168), (1, 1, 512, 128), (2, 100, 200, 300), (1, 128, 128, 128),
+            (3, 17, 33, 65), (1, 1279, 5003, 7681), (1, 16, 16, 16), (1, 48, 128, 320)]
+    bench = [(96, 1536, 5952, 1, 1, 3, 8, 20, 10), (4096, 4096, 4096, 4, 6, 8, 8, 16, 8), (64, 4096, 7168, 1, 24, 4, 16, 12, 4),
+             (1279, 5003, 7681, 3, 8, 5, 7, 9, 3), (8, 7168, 18432, 1, 20, 1, 32, 15, 5), (33, 65, 129, 2, 2, 1, 1, 1, 1),
+             (1024, 4096, 7168, 2, 12, 16, 8, 10, 10)]
+    out = {"order": "struct Config declaration order, get_best_config.hpp:12-31",
+           "best": [{"args": list(a), "config": O.ref_config("best", *a)} for a in best],
+           "bench": [{"args": list(a), "config": O.ref_config("bench", *a)} for a in bench]}
+    (HERE / "config_vectors.json").write_text(json.dumps(out, indent=0))
+
+
+def op_tiling():
+    sys.path.insert(0, str(REF / "get_best_config"))
+    import tiling_calculator as tc  # the reference's own module (imported, never copied)
+    shapes = [(128, 128, 128), (4096, 4096, 4096), (4096, 2048, 7168), (128, 2048, 7168), (8, 7168, 18432),
+              (8, 18432, 7168), (64, 4096, 7168), (64, 7168, 18432), (64, 24576, 1536), (64, 32768, 512),
+              (128, 4096, 7168), (1024, 4096, 7168), (1024, 18432, 7168), (2048, 4096, 7168), (1279, 5003, 7681),
+              (3511, 6151, 8191), (5119, 6997, 9901), (16, 16, 16), (256, 256, 256), (512, 512, 512), (1, 512, 128),
+              (300, 200, 100), (2000, 100, 4000), (100, 2000, 4000), (4096, 4096, 128), (768, 768, 4096)]
+    rows = []
+    for core in (20, 24):
+        pf = tc.PlatformInfo(); pf.coreNum = core
+        calc = tc.MatmulTilingCalculator(pf)
+        for (m, n, k) in shapes:
+            r = calc.calculate(m, n, k, tc.LayoutTag.TagRowMajor, tc.LayoutTag.TagColumnMajor)
+            dt = list(calc.calculate_tiling(m, n, k, tc.LayoutTag.TagRowMajor, tc.LayoutTag.TagColumnMajor))
+            # The Python mirror has a branch the C++ op_tiling lacks (tiling_calculator.py "m1t_alt": it swaps to
+            # 256x128 when the *alternative* stream-K tile would qualify, then falls through to Common).  Rows where it
+            # fired are flagged; the C++ (select_kernel.cpp:333-369), which is what we restate, keeps `do_tiling`.
+            alt = (list(r["tiling"]) != dt) and int(r["kernelSerial"]) in (0, 2)
+            rows.append({"coreNum": core, "shape": [m, n, k], "tiling": list(r["tiling"]), "do_tiling": dt,
+                         "python_only_alt_branch": bool(alt),
+                         "kernelSerial": int(r["kernelSerial"]), "blockDim": int(r["blockDim"]),
+                         "padding": [int(r["paddingTagA"]), int(r["paddingTagB"]), int(r["paddingTagC"])],
+                         "operator_type": r["operator_type"]})
+    survey = [  # C++ op_tiling probes quoted in SURVEY.md 8(a7), coreNum 24
+        {"shape": [128, 128, 128], "tiling": [64, 64, 1024], "kernelSerial": 1, "blockDim": 4},
+        {"shape": [4096, 4096, 4096], "tiling": [128, 256, 256], "kernelSerial": 0, "blockDim": 24},
+        {"shape": [4096, 2048, 7168], "tiling": [256, 128, 256], "kernelSerial": 0, "blockDim": 24},
+        {"shape": [128, 2048, 7168], "tiling": [128, 96, 512], "kernelSerial": 0, "blockDim": 22}]
+    (HERE / "op_tiling_vectors.json").write_text(json.dumps(
+        {"layout": "NT (A row-major, B column-major)", "python_mirror": rows, "survey_cpp_probes": survey}, indent=0))
+
+
+if __name__ == "__main__":
+    O.build()
+    table(); c1(); scaled(); grouped(); configs(); op_tiling()
+    print("fixtures written to", HERE)
