@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -15,8 +16,6 @@
 #include "gemm_fp8_kernel.hpp"
 
 namespace dga {
-
-__device__ uint8_t g_zero_chunk[256];
 
 static std::atomic<int> g_last_hip_error{0};
 int record_hip(hipError_t e)
@@ -32,24 +31,6 @@ int record_hip(hipError_t e)
         int _rc = dga::record_hip((expr));    \
         if (_rc != DGA_OK) return _rc;        \
     } while (0)
-
-static int zero_chunk_ptr(const uint8_t **out)
-{
-    // one address per device (the symbol lives in each device's copy of the code object)
-    static std::mutex mu;
-    static const uint8_t *cache[64] = {};
-    int dev = 0;
-    DGA_HIP_TRY(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(mu);
-    if (dev < 0 || dev >= 64) return DGA_E_HIP;
-    if (!cache[dev]) {
-        void *ptr = nullptr;
-        DGA_HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_zero_chunk)));
-        cache[dev] = static_cast<const uint8_t *>(ptr);
-    }
-    *out = cache[dev];
-    return DGA_OK;
-}
 
 template <class Cfg>
 static int launch_cfg(const GemmParams &p, hipStream_t stream)
@@ -142,11 +123,9 @@ static int run_fp8(const void *a, const float *sfa, const void *b, const float *
     p.sfa_gs = static_cast<int64_t>(m) * p.kb_n;
     p.sfb_gs = static_cast<int64_t>(p.nb_n) * p.kb_n;
     p.groups = groups;
-    int rc = zero_chunk_ptr(&p.zeros);
-    if (rc != DGA_OK) return rc;
-
+    // LDS-DMA kernel: 16-byte chunks (K % 16 == 0, 16-byte aligned bases) and 32-bit in-tile byte offsets
     const bool fast_ok = (k % 16 == 0) && k > 0 && ((reinterpret_cast<uintptr_t>(a) & 15) == 0) &&
-                         ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
+                         ((reinterpret_cast<uintptr_t>(b) & 15) == 0) && (static_cast<int64_t>(k) * 257 < 0x7FFFFFFFll);
     if (!fast_ok) {
         // K not a multiple of the 16-byte DMA chunk (or k == 0): element-wise kernel
         dim3 grid((n + 15) / 16, (m + 15) / 16, groups);
@@ -159,6 +138,8 @@ static int run_fp8(const void *a, const float *sfa, const void *b, const float *
     p.tiles_m = (m + v->bm - 1) / v->bm;
     p.tiles_n = (n + v->bn - 1) / v->bn;
     p.raster_group = tiling->swizzleOffset ? tiling->swizzleOffset : 1;
+    static const int xcd_remap = [] { const char *e = std::getenv("DGA_XCD_REMAP"); return e ? std::atoi(e) : 1; }();
+    p.xcd_remap = xcd_remap;
     return v->launch(p, stream);
 }
 

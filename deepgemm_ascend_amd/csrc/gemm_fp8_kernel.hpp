@@ -39,7 +39,6 @@ struct GemmParams {
     const float *sfb;      // [G][nb_n][kb_n]
     uint16_t *out;         // [G][m_rows][ldc] bf16 bits
     const int32_t *masked_m;  // grouped: device int32[G]; dense: nullptr
-    const uint8_t *zeros;  // >= 16 zero bytes (k tail source)
     int m;                 // dense: M; grouped: m_max (rows allocated per group)
     int n, k, kb_n, nb_n;
     int64_t lda, ldb, ldc;       // row strides in elements
@@ -47,6 +46,8 @@ struct GemmParams {
     int64_t sfa_gs, sfb_gs;
     int tiles_m, tiles_n, groups;
     int raster_group;            // tile-rows walked together (swizzleOffset analogue, tiling_params.h:63)
+    int xcd_remap;               // 1: contiguous tile chunk per XCD (blocks b, b+8, ... share an XCD)
+    unsigned long long *stamps;  // diagnostic builds only (-DDGA_STAMPS): per-wave segment cycle sums
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -82,14 +83,62 @@ __device__ __forceinline__ int swz_b(int row) { return ((row >> 1) & 1) | (((row
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-__device__ __forceinline__ void glds16(const void *src, uint8_t *lds_wave_base)
+// Buffer descriptor (raw, stride 0): base address, byte extent, DATA_FORMAT=32 flags word as in the guide's T8.
+__device__ __forceinline__ v4i make_rsrc(const void *base, int64_t bytes)
 {
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+    const uint64_t b = (uint64_t)(uintptr_t)base;
+    const uint32_t n = bytes > 0x7FFFFFFFll ? 0x7FFFFFFFu : (uint32_t)bytes;
+    v4i r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((b >> 32) & 0xFFFFu));
+    r.z = __builtin_amdgcn_readfirstlane((int)n);
+    r.w = 0x00020000;
+    return r;
 }
-__device__ __forceinline__ void glds4(const void *src, uint8_t *lds_wave_base)
+
+// LDS-DMA, 16 B per lane: LDS[m0 + 16*lane] = buffer[voff + soff .. +16).  M0 is written in the same statement
+// that uses it; `s_nop 4` covers a descriptor word that was produced by v_readfirstlane just before.
+__device__ __forceinline__ void dma16(uint32_t voff, v4i rsrc, uint32_t soff, uint32_t lds_addr)
 {
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 4, 0, 0);
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr) : "memory");
 }
+// LDS-DMA, 4 B per lane from a per-lane 64-bit address (the strided scale gather)
+__device__ __forceinline__ void dma4(const void *src, uint32_t lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
+                 :: "v"(src), "s"(lds_addr) : "memory");
+}
+
+// In-kernel stamps (diagnostic build only; cdna_hip_programming.md section 7 "In-kernel stamps").
+#ifdef DGA_STAMPS
+#define DGA_STAMP_DECL unsigned long long st_prev = 0, st_seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define DGA_STAMP_START()                                                                       \
+    do {                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");         \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    } while (0)
+#define DGA_STAMP(i)                                                                            \
+    do {                                                                                        \
+        unsigned long long st_now;                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        st_seg[i] += st_now - st_prev;                                                          \
+        st_prev = st_now;                                                                       \
+    } while (0)
+#define DGA_STAMP_FLUSH()                                                                       \
+    do {                                                                                        \
+        if (p.stamps && lane == 0)                                                              \
+            for (int q = 0; q < 8; ++q) p.stamps[((size_t)blockIdx.x * (NT / 64) + wave) * 8 + q] = st_seg[q]; \
+    } while (0)
+#else
+#define DGA_STAMP_DECL
+#define DGA_STAMP_START() do { } while (0)
+#define DGA_STAMP(i) do { } while (0)
+#define DGA_STAMP_FLUSH() do { } while (0)
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt()
@@ -115,7 +164,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
     int tile;
     {
         const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        tile = p.xcd_remap ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3) : bid;
     }
     const int tiles_per_group = p.tiles_m * p.tiles_n;
     const int g = tile / tiles_per_group;
@@ -141,26 +190,28 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
     const float *SFB = p.sfb + (int64_t)g * p.sfb_gs;
     uint16_t *C = p.out + (int64_t)g * p.c_gs;
 
-    // ---- per-thread LDS-DMA sources.  Chunk id c = it*NT + tid lands at LDS byte 16*c
-    //      (wave-uniform base + 16*lane); it holds source chunk (c&7) ^ x(row) of row c>>3.
-    const uint8_t *a_src[Cfg::A_ITERS];
-    int a_col[Cfg::A_ITERS];
+    // ---- per-thread LDS-DMA sources.  Chunk id c = it*NT + tid lands at LDS byte 16*c (wave-uniform base +
+    //      16*lane); it holds source chunk (c&7) ^ x(row) of row c>>3.  A and B are read through buffer
+    //      descriptors based at this tile's first row: the per-lane part is a 32-bit byte offset (row*ld + col), the
+    //      k advance rides in the scalar offset, and a lane whose chunk lies beyond K is sent out of range, for
+    //      which the hardware stores zeros (no branch, no zero page).
+    //      NT is a multiple of 64*8, so (c&7) and x(row) -- hence col -- do not depend on `it`.
+    constexpr uint32_t kOutOfRange = 0x80000000u;  // > num_records (host guarantees tile extents < 2^31)
+    const int a_col = ((tid & 7) ^ swz_a(tid >> 3)) * 16;
+    const int b_col = ((tid & 7) ^ swz_b(tid >> 3)) * 16;
+    uint32_t a_voff[Cfg::A_ITERS], b_voff[Cfg::B_ITERS];
 #pragma unroll
     for (int it = 0; it < Cfg::A_ITERS; ++it) {
-        const int c = it * NT + tid, row = c >> 3, col = ((c & 7) ^ swz_a(row)) * 16;
-        const int gr = min(m0 + row, M - 1);
-        a_src[it] = A + (int64_t)gr * p.lda + col;
-        a_col[it] = col;
+        const int row = (it * NT + tid) >> 3;
+        a_voff[it] = (uint32_t)min(row, M - 1 - m0) * (uint32_t)p.lda + a_col;
     }
-    const uint8_t *b_src[Cfg::B_ITERS];
-    int b_col[Cfg::B_ITERS];
 #pragma unroll
     for (int it = 0; it < Cfg::B_ITERS; ++it) {
-        const int c = it * NT + tid, row = c >> 3, col = ((c & 7) ^ swz_b(row)) * 16;
-        const int gr = min(n0 + row, p.n - 1);
-        b_src[it] = B + (int64_t)gr * p.ldb + col;
-        b_col[it] = col;
+        const int row = (it * NT + tid) >> 3;
+        b_voff[it] = (uint32_t)min(row, p.n - 1 - n0) * (uint32_t)p.ldb + b_col;
     }
+    const v4i a_rsrc = make_rsrc(A + (int64_t)m0 * p.lda, (int64_t)(M - m0) * p.lda);
+    const v4i b_rsrc = make_rsrc(B + (int64_t)n0 * p.ldb, (int64_t)(p.n - n0) * p.ldb);
     // scale slots: [0,BM) = sfa rows of this tile, [BM, BM+8) = sfb blocks of this tile, rest = padding
     const float *sc_src[Cfg::SC_ITERS];
 #pragma unroll
@@ -173,25 +224,30 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
             sc_src[it] = SFB + (int64_t)nb * p.kb_n;
         }
     }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
 
-    auto issue_stage = [&](int stage, int kb) {
-        uint8_t *sa = smem + stage * Cfg::STAGE_BYTES;
-        uint8_t *sb = sa + Cfg::A_BYTES;
-        uint8_t *ss = sb + Cfg::B_BYTES;
+    // one LDS-DMA wave-instruction of a stage: idx in [0, LOADS_PER_STAGE) = A pieces, B pieces, scale pieces.
+    // Inline asm on purpose: hipcc waits vmcnt(0) in front of every ds_read that follows an LDS-DMA builtin it can
+    // see (it cannot tell the two stages apart), which would serialise the pipeline; the landing of these loads is
+    // ordered by the loop's own vmcnt(0) + barrier instead.
+    // `kb` past the last block (the refill issued from inside the last k block) is branch-free: every chunk is
+    // then beyond K and zero-fills the idle stage; the scale gather re-reads the last block's scales.
+    auto issue_one = [&](int idx, int stage, int kb) {
+        const uint32_t sa = lds0 + stage * Cfg::STAGE_BYTES;
+        const uint32_t sb = sa + Cfg::A_BYTES;
+        const uint32_t ss = sb + Cfg::B_BYTES;
         const int k0 = kb * 128;
-#pragma unroll
-        for (int it = 0; it < Cfg::A_ITERS; ++it) {
-            const uint8_t *src = (k0 + a_col[it] < p.k) ? a_src[it] + k0 : p.zeros;
-            glds16(src, sa + (it * NT + wave * 64) * 16);
-        }
-#pragma unroll
-        for (int it = 0; it < Cfg::B_ITERS; ++it) {
-            const uint8_t *src = (k0 + b_col[it] < p.k) ? b_src[it] + k0 : p.zeros;
-            glds16(src, sb + (it * NT + wave * 64) * 16);
-        }
-#pragma unroll
-        for (int it = 0; it < Cfg::SC_ITERS; ++it) {
-            glds4(sc_src[it] + kb, ss + (it * NT + wave * 64) * 4);
+        if (idx < Cfg::A_ITERS) {
+            const int it = idx;
+            const uint32_t voff = (k0 + a_col < p.k) ? a_voff[it] : kOutOfRange;
+            dma16(voff, a_rsrc, (uint32_t)k0, sa + (it * NT + wave * 64) * 16);
+        } else if (idx < Cfg::A_ITERS + Cfg::B_ITERS) {
+            const int it = idx - Cfg::A_ITERS;
+            const uint32_t voff = (k0 + b_col < p.k) ? b_voff[it] : kOutOfRange;
+            dma16(voff, b_rsrc, (uint32_t)k0, sb + (it * NT + wave * 64) * 16);
+        } else {
+            const int it = idx - Cfg::A_ITERS - Cfg::B_ITERS;
+            dma4(sc_src[it] + min(kb, p.kb_n - 1), ss + (it * NT + wave * 64) * 4);
         }
     };
 
@@ -214,49 +270,92 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
 
+    // ---- main loop.  ONE barrier per k block: passing it means (a) every wave's DMA of this stage has landed
+    //      (each waited vmcnt(0) first) and (b) every wave has left the previous k block, i.e. the other stage is
+    //      free -- so its refill is issued from inside this k block's MFMA pipeline, one DMA wave-instruction every
+    //      few MFMAs.  (Issued in a burst at the top, the 9 DMA instructions cost a wave 800-1600 cycles of blocked
+    //      issue per k block: the vector-memory path takes 64 B/clk/CU; measured with the -DDGA_STAMPS build.)
     const int KB = p.kb_n;
-    issue_stage(0, 0);
+    DGA_STAMP_DECL
+#pragma unroll
+    for (int idx = 0; idx < Cfg::LOADS_PER_STAGE; ++idx) issue_one(idx, 0, 0);
+    DGA_STAMP_START();
     for (int kb = 0; kb < KB; ++kb) {
         const int stage = kb & 1;
-        if (kb + 1 < KB) {
-            issue_stage(stage ^ 1, kb + 1);
-            wait_vmcnt<Cfg::LOADS_PER_STAGE>();  // this stage's DMA has landed; next stage's stays in flight
-        } else {
-            wait_vmcnt<0>();
-        }
+        wait_vmcnt<0>();
+        DGA_STAMP(1);                            // segment 1: vmcnt wait
         __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");           // no LDS read may be hoisted above the barrier
+        DGA_STAMP(2);                            // segment 2: barrier "stage ready, other stage free"
 
         const uint8_t *st = smem + stage * Cfg::STAGE_BYTES;
-        const float sfb_v = *(const float *)(st + sb_off);
-        float s[TM];
+        // Fragment reads are ordered so that the first MFMA waits only for ITS operands (B n-tile 0, A m-tile 0):
+        // all 8 waves hit the LDS at once here, and a wave that waited for its whole 15-read burst would idle the
+        // matrix pipe for ~450 cycles per k block.  The scale reads come last; they are first needed LAG steps later.
+        constexpr int STEPS = TM * TN, LAG = 3, RING = LAG + 1;
+        constexpr int ISSUE_STEPS = (STEPS * 5) / 8 > 0 ? (STEPS * 5) / 8 : 1;  // refill DMA rides on the first 5/8 of the steps
+        v4f part[RING];
+        v8i bf[2];
         v8i af[TM];
+        float s[TM];
+        {
+            const v4i lo = *(const v4i *)(st + b_off0);
+            const v4i hi = *(const v4i *)(st + b_off1);
+            bf[0] = v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        }
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt) {
-            s[mt] = *(const float *)(st + sa_off + mt * 64) * sfb_v;
             const v4i lo = *(const v4i *)(st + a_off0 + mt * 2048);
             const v4i hi = *(const v4i *)(st + a_off1 + mt * 2048);
             af[mt] = v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            if (mt == 0) __builtin_amdgcn_sched_barrier(0);
         }
+        const float sfb_v = *(const float *)(st + sb_off);
 #pragma unroll
-        for (int nt = 0; nt < TN; ++nt) {
-            const int boff = (nt >> 1) * 4096 + (nt & 1) * 512;
-            const v4i lo = *(const v4i *)(st + b_off0 + boff);
-            const v4i hi = *(const v4i *)(st + b_off1 + boff);
-            const v8i bf = v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        for (int mt = 0; mt < TM; ++mt) s[mt] = *(const float *)(st + sa_off + mt * 64);
+        DGA_STAMP(3);                            // segment 3: first fragments + scales out of LDS
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mt = 0; mt < TM; ++mt) {
-                const v4f part = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
-                    bf, af[mt], v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
+        for (int i = 0; i < STEPS + LAG; ++i) {
+            if (i < STEPS) {
+                const int nt = i / TM, mt = i % TM;
+                part[i % RING] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                    bf[nt & 1], af[mt], v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i < ISSUE_STEPS) {
+#pragma unroll
+                    for (int idx = (i * Cfg::LOADS_PER_STAGE) / ISSUE_STEPS;
+                         idx < ((i + 1) * Cfg::LOADS_PER_STAGE) / ISSUE_STEPS; ++idx)
+                        issue_one(idx, stage ^ 1, kb + 1);
+                }
+                // next n-tile's fragment: issued right AFTER this n-tile's first MFMA, so that the (whole-counter)
+                // lgkmcnt wait hipcc places in front of that MFMA never covers reads that were only just issued
+                if (mt == 0 && nt + 1 < TN) {
+                    const int boff = ((nt + 1) >> 1) * 4096 + ((nt + 1) & 1) * 512;
+                    const v4i lo = *(const v4i *)(st + b_off0 + boff);
+                    const v4i hi = *(const v4i *)(st + b_off1 + boff);
+                    bf[(nt + 1) & 1] = v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                }
+            }
+            if (i == LAG) {
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) s[mt] *= sfb_v;  // two-level scale: sfa[m,kb] * sfb[n/128,kb]
+            }
+            if (i >= LAG) {
+                const int j = i - LAG, nt = j / TM, mt = j % TM;
+                const v4f pr = part[j % RING];
                 // scalar FMAs on purpose: v_pk_fma_f32 beside MFMAs is slower than two v_fma_f32
                 // (MI355X_MICROARCH "price of one filler beside MFMAs")
-                acc[mt][nt].x = __builtin_fmaf(part.x, s[mt], acc[mt][nt].x);
-                acc[mt][nt].y = __builtin_fmaf(part.y, s[mt], acc[mt][nt].y);
-                acc[mt][nt].z = __builtin_fmaf(part.z, s[mt], acc[mt][nt].z);
-                acc[mt][nt].w = __builtin_fmaf(part.w, s[mt], acc[mt][nt].w);
+                acc[mt][nt].x = __builtin_fmaf(pr.x, s[mt], acc[mt][nt].x);
+                acc[mt][nt].y = __builtin_fmaf(pr.y, s[mt], acc[mt][nt].y);
+                acc[mt][nt].z = __builtin_fmaf(pr.z, s[mt], acc[mt][nt].z);
+                acc[mt][nt].w = __builtin_fmaf(pr.w, s[mt], acc[mt][nt].w);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_s_barrier();  // everyone is done with this stage before it is refilled
+        DGA_STAMP(4);                            // segment 4: the MFMA / promotion pipeline (+ refill DMA issue)
     }
+    DGA_STAMP_FLUSH();
 
     // ---- epilogue: lane owns row m, columns n0w + 32*j + 8*(lane>>4) + [0,8)
     const int m_row = m0 + wm * (BM / Cfg::kWM) + li;

@@ -1,0 +1,72 @@
+// Micro-benchmark: what the matrix pipe sustains for v_mfma_f32_16x16x128_f8f6f4 alone and with the
+// block-scale promotion FMAs beside it (development aid, not part of the product).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int MODE>  // 0: MFMA only (accumulate chain x4 indep), 1: MFMA(C=0) + 4 FMA pipelined lag 3, 2: 32x32x64 variant
+__global__ void __launch_bounds__(512) k(const int *seed, float *out, int iters)
+{
+    v8i a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = seed[threadIdx.x & 63] * (i + 1); b[i] = seed[(threadIdx.x + 7) & 63] * (i + 3); }
+    v4f acc[16];
+    for (int i = 0; i < 16; ++i) acc[i] = v4f{0, 0, 0, 0};
+    float s = 1.0001f;
+    if (MODE == 0) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                acc[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc[i], 0, 0, 0, 0, 0, 0);
+        }
+    } else {
+        v4f part[4];
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 16 + 3; ++i) {
+                if (i < 16) {
+                    asm volatile("" : "+v"(a));  // opaque: no CSE of the loop-invariant MFMA
+                    part[i & 3] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, v4f{0, 0, 0, 0}, 0, 0, 0, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (i >= 3) {
+                    const int j = i - 3;
+                    acc[j].x = __builtin_fmaf(part[j & 3].x, s, acc[j].x);
+                    acc[j].y = __builtin_fmaf(part[j & 3].y, s, acc[j].y);
+                    acc[j].z = __builtin_fmaf(part[j & 3].z, s, acc[j].z);
+                    acc[j].w = __builtin_fmaf(part[j & 3].w, s, acc[j].w);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    float r = 0;
+    for (int i = 0; i < 16; ++i) r += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+int main(int argc, char **argv)
+{
+    int iters = 2000;
+    int *seed; float *out;
+    hipMalloc(&seed, 64 * 4); hipMalloc(&out, 256 * 8 * 512 * 4);
+    std::vector<int> h(64);
+    for (int i = 0; i < 64; ++i) h[i] = 0x38383838 + i * 0x01010101;  // plausible e4m3 bytes
+    hipMemcpy(seed, h.data(), 256, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int mode = 0; mode < 2; ++mode)
+        for (int threads : {256, 512}) {
+            for (int rep = 0; rep < 3; ++rep) {
+                hipEventRecord(e0);
+                if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(threads), 0, 0, seed, out, iters);
+                else hipLaunchKernelGGL(k<1>, dim3(256), dim3(threads), 0, 0, seed, out, iters);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                double flops = 2.0 * 16 * 16 * 128 * 16.0 * iters * (threads / 64) * 256;
+                if (rep == 2) printf("mode %d (%s) waves/SIMD %d: %.3f ms  %.0f TFLOP/s\n", mode, mode ? "MFMA+4FMA lag3" : "MFMA only", threads / 256, ms, flops / ms / 1e9);
+            }
+        }
+    return 0;
+}

@@ -1,0 +1,55 @@
+// Diagnostic build of the fp8 GEMM kernel with s_memtime stamps (shares, not run time, are meaningful).
+#define DGA_STAMPS 1
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../../deepgemm_ascend_amd/csrc/gemm_fp8_kernel.hpp"
+using namespace dga;
+__device__ uint8_t zero_chunk[256];
+int main(int argc, char **argv)
+{
+    const int m = argc > 1 ? atoi(argv[1]) : 4096, n = argc > 2 ? atoi(argv[2]) : 4096, k = argc > 3 ? atoi(argv[3]) : 4096;
+    typedef GemmCfg<256, 256, 4, 2> Cfg;
+    GemmParams p{};
+    std::vector<uint8_t> ha((size_t)m * k), hb((size_t)n * k);
+    srand(1);
+    for (auto &v : ha) { v = rand() & 0xFF; if ((v & 0x7F) == 0x7F) v &= 0x80; if ((v & 0x78) > 0x60) v &= 0xBF; }
+    for (auto &v : hb) { v = rand() & 0xFF; if ((v & 0x7F) == 0x7F) v &= 0x80; if ((v & 0x78) > 0x60) v &= 0xBF; }
+    const int kb = (k + 127) / 128, nb = (n + 127) / 128;
+    std::vector<float> hsa((size_t)m * kb, 1.0f), hsb((size_t)nb * kb, 0.5f);
+    uint8_t *a, *b; float *sfa, *sfb; uint16_t *out; unsigned long long *st;
+    hipMalloc(&a, ha.size()); hipMalloc(&b, hb.size()); hipMalloc(&sfa, hsa.size() * 4); hipMalloc(&sfb, hsb.size() * 4);
+    hipMalloc(&out, (size_t)m * n * 2);
+    hipMemcpy(a, ha.data(), ha.size(), hipMemcpyHostToDevice); hipMemcpy(b, hb.data(), hb.size(), hipMemcpyHostToDevice);
+    hipMemcpy(sfa, hsa.data(), hsa.size() * 4, hipMemcpyHostToDevice); hipMemcpy(sfb, hsb.data(), hsb.size() * 4, hipMemcpyHostToDevice);
+    p.a = a; p.sfa = sfa; p.b = b; p.sfb = sfb; p.out = out; p.m = m; p.n = n; p.k = k; p.kb_n = kb; p.nb_n = nb;
+    p.lda = k; p.ldb = k; p.ldc = n; p.groups = 1; p.tiles_m = (m + 255) / 256; p.tiles_n = (n + 255) / 256;
+    p.raster_group = 8; p.xcd_remap = 1;
+    const int grid = p.tiles_m * p.tiles_n;
+    hipMalloc(&st, (size_t)grid * 8 * 8 * 8); hipMemset(st, 0, (size_t)grid * 8 * 8 * 8);
+    p.stamps = st;
+    auto kfn = gemm_fp8_blockscaled_nt_kernel<Cfg>;
+    hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, 0, p);
+    hipEventRecord(e0);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, 0, p);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("stamped kernel: %.1f us per launch (%d x %d x %d)\n", ms * 1000 / 20, m, n, k);
+    std::vector<unsigned long long> h((size_t)grid * 8 * 8);
+    hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
+    const char *names[6] = {"issue next-stage DMA", "vmcnt wait", "barrier stage-ready", "first frags from LDS", "MFMA+promotion pipeline", "barrier stage-free"};
+    for (int half = 0; half < 2; ++half) {
+        double tot = 0, seg[6] = {0};
+        for (int w = 0; w < grid * 8; ++w) {
+            if (((w % 8) >= 4) != half) continue;
+            for (int q = 0; q < 6; ++q) { seg[q] += h[(size_t)w * 8 + q]; tot += h[(size_t)w * 8 + q]; }
+        }
+        printf("waves %s: per k-step cycles (s_memtime ticks), share\n", half ? "4-7" : "0-3");
+        for (int q = 0; q < 6; ++q) printf("  %-26s %8.0f  %5.1f%%\n", names[q], seg[q] / (grid * 4) / kb, 100 * seg[q] / tot);
+        printf("  total per k-step %.0f\n", tot / (grid * 4) / kb);
+    }
+    return 0;
+}
