@@ -56,21 +56,25 @@ struct GemmCfg {
     static constexpr int NT = WM * WN * 64;
     static constexpr int TM = BM / WM / 16;  // m-tiles (16 rows) per wave
     static constexpr int TN = BN / WN / 16;  // n-tiles per wave (even)
-    static constexpr int A_ROWS = BM * 8 >= NT ? BM : NT / 8;  // tiny BM: pad the image to whole wave-instructions
+    // Waves that issue the LDS-DMA.  (Giving all of it to the first-dispatched half of an 8-wave workgroup -- the
+    // half that wins every MFMA arbitration -- evens the two halves out but measured 2-4 % slower overall, r01.)
+    static constexpr int DMA_WAVES = WM * WN;
+    static constexpr int DNT = DMA_WAVES * 64;  // threads that issue DMA
+    static constexpr int A_ROWS = BM * 8 >= DNT ? BM : DNT / 8;  // tiny BM: pad the image to whole wave-instructions
     static constexpr int A_BYTES = A_ROWS * 128;
     static constexpr int B_BYTES = BN * 128;
-    static constexpr int SC_SLOTS = ((BM + 8 + NT - 1) / NT) * NT;  // sfa rows, then sfb entries, padded
+    static constexpr int SC_SLOTS = ((BM + 8 + DNT - 1) / DNT) * DNT;  // sfa rows, then sfb entries, padded
     static constexpr int SC_BYTES = SC_SLOTS * 4;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES + SC_BYTES;
     static constexpr int STAGES = 2;
     static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
-    static constexpr int A_ITERS = A_ROWS * 8 / NT;
-    static constexpr int B_ITERS = BN * 8 / NT;
-    static constexpr int SC_ITERS = SC_SLOTS / NT;
+    static constexpr int A_ITERS = A_ROWS * 8 / DNT;
+    static constexpr int B_ITERS = BN * 8 / DNT;
+    static constexpr int SC_ITERS = SC_SLOTS / DNT;
     static constexpr int LOADS_PER_STAGE = A_ITERS + B_ITERS + SC_ITERS;
     static_assert(BM % (WM * 16) == 0 && BN % (WN * 32) == 0, "wave tile");
     static_assert(BN % 128 == 0 && BN / WN <= 128 && 128 % (BN / WN) == 0, "a wave's n range lies in one 128-wide scale block");
-    static_assert((A_ROWS * 8) % NT == 0 && (BN * 8) % NT == 0, "whole wave-instructions per tile");
+    static_assert((A_ROWS * 8) % DNT == 0 && (BN * 8) % DNT == 0, "whole wave-instructions per tile");
     static_assert(BN / 128 + (BN % 128 != 0) <= 8, "sfb slots");
 };
 
@@ -98,16 +102,20 @@ __device__ __forceinline__ v4i make_rsrc(const void *base, int64_t bytes)
 
 // LDS-DMA, 16 B per lane: LDS[m0 + 16*lane] = buffer[voff + soff .. +16).  M0 is written in the same statement
 // that uses it; `s_nop 4` covers a descriptor word that was produced by v_readfirstlane just before.
-__device__ __forceinline__ void dma16(uint32_t voff, v4i rsrc, uint32_t soff, uint32_t lds_addr)
+// `on` (wave-uniform) skips the instruction with a scalar branch INSIDE the statement, so the compiler's
+// scheduling region around the MFMA pipeline stays one straight line.
+__device__ __forceinline__ void dma16(uint32_t voff, v4i rsrc, uint32_t soff, uint32_t lds_addr, int on)
 {
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-                 :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr) : "memory");
+    asm volatile("s_cmp_eq_u32 %4, 0\n\ts_cbranch_scc1 1f\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"
+                 "buffer_load_dwordx4 %0, %1, %2 offen lds\n1:"
+                 :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr), "s"(on) : "memory", "scc");
 }
 // LDS-DMA, 4 B per lane from a per-lane 64-bit address (the strided scale gather)
-__device__ __forceinline__ void dma4(const void *src, uint32_t lds_addr)
+__device__ __forceinline__ void dma4(const void *src, uint32_t lds_addr, int on)
 {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
-                 :: "v"(src), "s"(lds_addr) : "memory");
+    asm volatile("s_cmp_eq_u32 %2, 0\n\ts_cbranch_scc1 1f\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "global_load_lds_dword %0, off\n1:"
+                 :: "v"(src), "s"(lds_addr), "s"(on) : "memory", "scc");
 }
 
 // In-kernel stamps (diagnostic build only; cdna_hip_programming.md section 7 "In-kernel stamps").
@@ -128,6 +136,13 @@ __device__ __forceinline__ void dma4(const void *src, uint32_t lds_addr)
         st_seg[i] += st_now - st_prev;                                                          \
         st_prev = st_now;                                                                       \
     } while (0)
+#define DGA_STAMP_CLOCK(slot_t, slot_rt)                                                        \
+    do {                                                                                        \
+        unsigned long long c0, c1;                                                              \
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(c1)::"memory"); \
+        st_seg[slot_t] = c0 - st_seg[slot_t];                                                   \
+        st_seg[slot_rt] = c1 - st_seg[slot_rt];                                                 \
+    } while (0)
 #define DGA_STAMP_FLUSH()                                                                       \
     do {                                                                                        \
         if (p.stamps && lane == 0)                                                              \
@@ -135,6 +150,7 @@ __device__ __forceinline__ void dma4(const void *src, uint32_t lds_addr)
     } while (0)
 #else
 #define DGA_STAMP_DECL
+#define DGA_STAMP_CLOCK(a, b) do { } while (0)
 #define DGA_STAMP_START() do { } while (0)
 #define DGA_STAMP(i) do { } while (0)
 #define DGA_STAMP_FLUSH() do { } while (0)
@@ -195,19 +211,22 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
     //      descriptors based at this tile's first row: the per-lane part is a 32-bit byte offset (row*ld + col), the
     //      k advance rides in the scalar offset, and a lane whose chunk lies beyond K is sent out of range, for
     //      which the hardware stores zeros (no branch, no zero page).
-    //      NT is a multiple of 64*8, so (c&7) and x(row) -- hence col -- do not depend on `it`.
+    //      DNT is a multiple of 64*4, so (c&7) and x(row) -- hence col -- do not depend on `it`.
+    constexpr int DNT = Cfg::DNT;
+    const int dma_on = __builtin_amdgcn_readfirstlane(wave < Cfg::DMA_WAVES ? 1 : 0);
+    const int dtid = tid & (DNT - 1);
     constexpr uint32_t kOutOfRange = 0x80000000u;  // > num_records (host guarantees tile extents < 2^31)
-    const int a_col = ((tid & 7) ^ swz_a(tid >> 3)) * 16;
-    const int b_col = ((tid & 7) ^ swz_b(tid >> 3)) * 16;
+    const int a_col = ((dtid & 7) ^ swz_a(dtid >> 3)) * 16;
+    const int b_col = ((dtid & 7) ^ swz_b(dtid >> 3)) * 16;
     uint32_t a_voff[Cfg::A_ITERS], b_voff[Cfg::B_ITERS];
 #pragma unroll
     for (int it = 0; it < Cfg::A_ITERS; ++it) {
-        const int row = (it * NT + tid) >> 3;
+        const int row = (it * DNT + dtid) >> 3;
         a_voff[it] = (uint32_t)min(row, M - 1 - m0) * (uint32_t)p.lda + a_col;
     }
 #pragma unroll
     for (int it = 0; it < Cfg::B_ITERS; ++it) {
-        const int row = (it * NT + tid) >> 3;
+        const int row = (it * DNT + dtid) >> 3;
         b_voff[it] = (uint32_t)min(row, p.n - 1 - n0) * (uint32_t)p.ldb + b_col;
     }
     const v4i a_rsrc = make_rsrc(A + (int64_t)m0 * p.lda, (int64_t)(M - m0) * p.lda);
@@ -216,7 +235,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
     const float *sc_src[Cfg::SC_ITERS];
 #pragma unroll
     for (int it = 0; it < Cfg::SC_ITERS; ++it) {
-        const int s = it * NT + tid;
+        const int s = it * DNT + dtid;
         if (s < BM) {
             sc_src[it] = SFA + (int64_t)min(m0 + s, M - 1) * p.kb_n;
         } else {
@@ -240,14 +259,14 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         if (idx < Cfg::A_ITERS) {
             const int it = idx;
             const uint32_t voff = (k0 + a_col < p.k) ? a_voff[it] : kOutOfRange;
-            dma16(voff, a_rsrc, (uint32_t)k0, sa + (it * NT + wave * 64) * 16);
+            dma16(voff, a_rsrc, (uint32_t)k0, sa + (it * DNT + wave * 64) * 16, dma_on);
         } else if (idx < Cfg::A_ITERS + Cfg::B_ITERS) {
             const int it = idx - Cfg::A_ITERS;
             const uint32_t voff = (k0 + b_col < p.k) ? b_voff[it] : kOutOfRange;
-            dma16(voff, b_rsrc, (uint32_t)k0, sb + (it * NT + wave * 64) * 16);
+            dma16(voff, b_rsrc, (uint32_t)k0, sb + (it * DNT + wave * 64) * 16, dma_on);
         } else {
             const int it = idx - Cfg::A_ITERS - Cfg::B_ITERS;
-            dma4(sc_src[it] + min(kb, p.kb_n - 1), ss + (it * NT + wave * 64) * 4);
+            dma4(sc_src[it] + min(kb, p.kb_n - 1), ss + (it * DNT + wave * 64) * 4, dma_on);
         }
     };
 
@@ -280,6 +299,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
 #pragma unroll
     for (int idx = 0; idx < Cfg::LOADS_PER_STAGE; ++idx) issue_one(idx, 0, 0);
     DGA_STAMP_START();
+    DGA_STAMP_CLOCK(6, 7);   // slots 6/7: shader-clock and 100 MHz real-time ticks across the main loop
     for (int kb = 0; kb < KB; ++kb) {
         const int stage = kb & 1;
         wait_vmcnt<0>();
@@ -355,6 +375,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         }
         DGA_STAMP(4);                            // segment 4: the MFMA / promotion pipeline (+ refill DMA issue)
     }
+    DGA_STAMP_CLOCK(6, 7);
     DGA_STAMP_FLUSH();
 
     // ---- epilogue: lane owns row m, columns n0w + 32*j + 8*(lane>>4) + [0,8)

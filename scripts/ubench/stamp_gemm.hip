@@ -51,5 +51,9 @@ int main(int argc, char **argv)
         for (int q = 0; q < 6; ++q) printf("  %-26s %8.0f  %5.1f%%\n", names[q], seg[q] / (grid * 4) / kb, 100 * seg[q] / tot);
         printf("  total per k-step %.0f\n", tot / (grid * 4) / kb);
     }
+    double ct = 0, crt = 0;
+    for (int w = 0; w < grid * 8; ++w) { ct += (double)h[(size_t)w * 8 + 6]; crt += (double)h[(size_t)w * 8 + 7]; }
+    printf("main loop: %.0f shader ticks, %.0f realtime ticks (100 MHz) per wave -> clock %.3f GHz, loop %.1f us\n",
+           ct / (grid * 8), crt / (grid * 8), ct / crt * 0.1, crt / (grid * 8) / 100.0);
     return 0;
 }
