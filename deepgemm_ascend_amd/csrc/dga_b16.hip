@@ -1,6 +1,156 @@
-// placeholder, replaced below
+// The framework's 16-bit path: z (f32) = x . y with x [M,K], y [K,N] row-major bf16 / fp16 ("NN").
+// Replaces the device side of run_mmad_rtc / run_mmad_bench
+//   /root/reference/deep_gemm_ascend/framework/csrc/jit_kernels/impls/gemm.hpp:68-111   (batched, bf16)
+//   /root/reference/deep_gemm_ascend/framework/csrc/jit_kernels/impls/gemm_bench.hpp:49-113 (single, fp16, params[28])
+// whose generated AscendC kernel (framework/csrc/jit/generate_code.hpp:123-369) accumulates in fp32 and writes fp32.
+//
+// gfx950 form: v_mfma_f32_16x16x32_{bf16,f16}.  y is K-major in memory but the MFMA wants 8 consecutive k per
+// lane for one column, so each lane gathers its B fragment straight from global memory (8 two-byte loads down a
+// column; the 16 lanes of a row group read 32 contiguous bytes) -- no LDS, no transposition pass.  This path is
+// SURVEY.md 8(f).4 ("next"); it is correct and MFMA-based, not yet tuned.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
 #include "dga_hip.h"
-extern "C" {
-int dga_run_mmad_rtc(const void *, const void *, float *, int, int, int, int, int, void *) { return DGA_E_TILING; }
-int dga_run_mmad_bench(const void *, const void *, float *, int, int, int, int, const int32_t *, void *) { return DGA_E_TILING; }
+#include "dga_internal.hpp"
+
+namespace dga {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef uint16_t v8u __attribute__((ext_vector_type(8)));
+
+struct B16Params {
+    const uint16_t *x, *y;
+    float *z;
+    int m, n, k;
+    int64_t x_bs, y_bs, z_bs;  // batch strides (elements)
+};
+
+template <bool BF16>
+__device__ __forceinline__ v4f mfma16(v8u a, v8u b, v4f c)
+{
+    if constexpr (BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
 }
+
+// workgroup = 4 waves (2 x 2), wave tile 64 x 64 = 4 x 4 MFMA tiles, K step 32
+template <bool BF16>
+__global__ void __launch_bounds__(256) mmad_nn_f32_kernel(const B16Params p)
+{
+    constexpr int TM = 4, TN = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kg = lane >> 4;
+    const int m0 = blockIdx.y * 128 + (wave >> 1) * 64, n0 = blockIdx.x * 128 + (wave & 1) * 64;
+    const uint16_t *X = p.x + (int64_t)blockIdx.z * p.x_bs;
+    const uint16_t *Y = p.y + (int64_t)blockIdx.z * p.y_bs;
+    float *Z = p.z + (int64_t)blockIdx.z * p.z_bs;
+    if (m0 >= p.m || n0 >= p.n) return;
+
+    v4f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    const bool x_vec = ((p.k & 7) == 0) && ((((uintptr_t)X) & 15) == 0);
+    for (int k0 = 0; k0 < p.k; k0 += 32) {
+        const int kk = k0 + 8 * kg;  // this lane's 8 consecutive k
+        v8u af[TM], bf[TN];
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            const int r = m0 + mt * 16 + li;
+            v8u v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (r < p.m) {
+                const uint16_t *src = X + (int64_t)r * p.k + kk;
+                if (x_vec && kk + 8 <= p.k) {
+                    v = *(const v8u *)src;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (kk + j < p.k) v[j] = src[j];
+                }
+            }
+            af[mt] = v;
+        }
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+            const int c = n0 + nt * 16 + li;
+            v8u v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (c < p.n) {
+                const uint16_t *src = Y + (int64_t)kk * p.n + c;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (kk + j < p.k) v[j] = src[(int64_t)j * p.n];
+            }
+            bf[nt] = v;
+        }
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = mfma16<BF16>(af[mt], bf[nt], acc[mt][nt]);
+    }
+    // D layout: col = lane & 15, row = 4 * (lane >> 4) + r
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+            const int c = n0 + nt * 16 + li;
+            if (c >= p.n) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + mt * 16 + 4 * kg + r;
+                if (row < p.m) Z[(int64_t)row * p.n + c] = acc[mt][nt][r];
+            }
+        }
+}
+
+static int launch_b16(const void *x, const void *y, float *z, int batch, int m, int n, int k, int dtype,
+                      hipStream_t stream)
+{
+    if (batch < 0 || m < 0 || n < 0 || k < 0) return DGA_E_SHAPE;
+    if (dtype != DGA_DT_BF16 && dtype != DGA_DT_FP16) return DGA_E_DTYPE;
+    if (batch == 0 || m == 0 || n == 0) return DGA_OK;
+    if (!z || ((!x || !y) && k != 0)) return DGA_E_NULL;
+    B16Params p{};
+    p.x = static_cast<const uint16_t *>(x);
+    p.y = static_cast<const uint16_t *>(y);
+    p.z = z;
+    p.m = m; p.n = n; p.k = k;
+    p.x_bs = static_cast<int64_t>(m) * k;
+    p.y_bs = static_cast<int64_t>(k) * n;
+    p.z_bs = static_cast<int64_t>(m) * n;
+    dim3 grid((n + 127) / 128, (m + 127) / 128, batch);
+    if (dtype == DGA_DT_BF16)
+        hipLaunchKernelGGL(mmad_nn_f32_kernel<true>, grid, dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL(mmad_nn_f32_kernel<false>, grid, dim3(256), 0, stream, p);
+    return record_hip(hipGetLastError());
+}
+
+}  // namespace dga
+
+extern "C" {
+
+int dga_run_mmad_rtc(const void *x, const void *y, float *z, int batch, int m, int n, int k, int dtype, void *stream)
+{
+    return dga::launch_b16(x, y, z, batch, m, n, k, dtype, static_cast<hipStream_t>(stream));
+}
+
+int dga_run_mmad_bench(const void *x, const void *y, float *z, int m, int n, int k, int dtype,
+                       const int32_t *params_host, void *stream)
+{
+    // The 28 ints steer the Ascend kernel's L1/L0 blocking only; they are validated (the knobs must be positive,
+    // as the reference's derivation divides by them) and otherwise have no CDNA4 meaning.
+    if (params_host) {
+        for (int i = 0; i < 6; ++i)
+            if (params_host[i] <= 0) return DGA_E_RANGE;
+        if (params_host[6] != m || params_host[7] != n || params_host[8] != k) return DGA_E_SHAPE;
+    }
+    return dga::launch_b16(x, y, z, 1, m, n, k, dtype, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

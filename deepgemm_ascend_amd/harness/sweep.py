@@ -1,0 +1,164 @@
+"""Tuning sweep -- the counterpart of the reference's grid-search driver
+(/root/reference/deep_gemm_ascend/framework/benchmark/benchmark.py): same shape list (:24-44), per-rank slice of
+the candidate list (:249-253), jsonl results (:322-332), crash-skip checkpoint written BEFORE each run
+(:256-304: a combo found in the checkpoint on restart is the one that crashed -> recorded as time -1 and skipped),
+correctness gate before timing (:307-315).  Candidates here are the compiled tile variants x raster groups
+(the CDNA4 knobs) instead of the Ascend L1/L0 block counts; timing is hipEvents in-process instead of `msprof op`.
+The winner per shape is appended to the tiling cache CSV the operator consults ($DGA_CACHE_FILE_PATH).
+
+  python -m deepgemm_ascend_amd.harness.sweep --out sweep_out [--rank R --num-processes P] [--shapes 4096,4096,4096 ...]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+from dataclasses import asdict, dataclass, field
+from pathlib import Path
+
+import torch
+
+SHAPE_GROUP = [  # M, N, K  (benchmark.py:24-44)
+    [4096, 4096, 4096], [8, 7168, 18432], [8, 18432, 7168], [64, 4096, 7168], [64, 7168, 18432], [64, 18432, 7168],
+    [64, 24576, 1536], [64, 32768, 512], [64, 7168, 16384], [128, 4096, 7168], [128, 7168, 18432], [128, 18432, 7168],
+    [1024, 4096, 7168], [1024, 18432, 7168], [2048, 4096, 7168], [1279, 5003, 7681], [3511, 6151, 8191], [5119, 6997, 9901],
+]
+TILES = [(256, 256), (128, 256), (256, 128), (128, 128), (64, 256), (64, 128), (32, 256), (32, 128), (16, 256), (16, 128)]
+RASTERS = [1, 2, 4, 8, 16]
+ERROR_TOL = 1e-4
+
+
+@dataclass
+class Result:
+    idx: int
+    M: int
+    N: int
+    K: int
+    time: float
+    diff: float
+    negative: bool
+    parameters: dict = field(default_factory=dict)
+
+
+def candidates(m, n, k):
+    out = []
+    for bm, bn in TILES:
+        if bm >= 2 * max(m, 16) and bm > 16:      # filter_parameters analogue: tiles twice the problem are pointless
+            continue
+        for r in RASTERS:
+            if r > max(1, -(-m // bm)):
+                continue
+            out.append({"m1": bm, "n1": bn, "raster": r})
+    return out
+
+
+def gen_data(m, n, k, seed=0):
+    """benchmark.py:343-367 analogue, fp8: N(0,1) data, amax block scaling, e4m3fn codes; golden = fp32 matmul of the
+    dequantised operands on the device (TF32 is not a thing on gfx950: this is exact-fp32 MFMA / VALU)."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    kp, np_ = -(-k // 128) * 128, -(-n // 128) * 128
+    xa = torch.zeros((m, kp), device="cuda"); xa[:, :k] = torch.randn((m, k), device="cuda", generator=g)
+    xb = torch.zeros((np_, kp), device="cuda"); xb[:n, :k] = torch.randn((n, k), device="cuda", generator=g)
+    sa = xa.view(m, kp // 128, 128).abs().amax(2).clamp_min(1e-30) / 448
+    qa = (xa.view(m, kp // 128, 128) / sa[..., None]).reshape(m, kp).to(torch.float8_e4m3fn)
+    sb = xb.view(np_ // 128, 128, kp // 128, 128).abs().amax((1, 3)).clamp_min(1e-30) / 448
+    qb = (xb.view(np_ // 128, 128, kp // 128, 128) / sb[:, None, :, None]).reshape(np_, kp).to(torch.float8_e4m3fn)
+    da = (qa.float().view(m, kp // 128, 128) * sa[..., None]).reshape(m, kp)[:, :k]
+    dbm = (qb.float().view(np_ // 128, 128, kp // 128, 128) * sb[:, None, :, None]).reshape(np_, kp)[:n, :k]
+    golden = da @ dbm.T
+    a = qa.view(torch.uint8)[:, :k].contiguous(); b = qb.view(torch.uint8)[:n, :k].contiguous()
+    return a, sa.contiguous(), b, sb.contiguous(), golden
+
+
+def is_correct(golden, out):
+    """benchmark.py:384-398 with the bf16 tolerance: |o-g| <= 2^-7 |g| + cancellation floor; mismatch ratio <= 1e-4."""
+    o = out.float()
+    tol = golden.abs() * 2.0 ** -7 + golden.abs().max() * 2.0 ** -12
+    ratio = float(((o - golden).abs() > tol).float().mean())
+    return ratio <= ERROR_TOL, ratio
+
+
+def time_us(fn, warm=3, iters=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def benchmark_shape(shape, out_dir: Path, rank=0, num_processes=1, iters=10):
+    import deepgemm_ascend_amd as dga
+    m, n, k = shape
+    cands = candidates(m, n, k)
+    per = -(-len(cands) // num_processes)
+    lo, hi = rank * per, min(len(cands), (rank + 1) * per)
+    res_path = out_dir / f"shape_{m}_{n}_{k}_rank_{rank}.jsonl"
+    ck_path = out_dir / f"shape_{m}_{n}_{k}_rank_{rank}_checkpoint.jsonl"
+    last = -1
+    if ck_path.exists():
+        try:
+            last = json.loads(ck_path.read_text().strip().splitlines()[-1])["last_process_idx"]
+        except Exception:
+            last = -1
+    a, sfa, b, sfb, golden = gen_data(m, n, k)
+    out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    best = None
+    for idx in range(lo, hi):
+        if idx < last:
+            continue
+        p = cands[idx]
+        if idx == last:   # the previous process died while running this combo: record and skip
+            with open(res_path, "a") as f:
+                f.write(json.dumps(asdict(Result(idx, m, n, k, -1, -1, True, p))) + "\n")
+            continue
+        ck_path.write_text(json.dumps({"last_process_idx": idx}) + "\n")
+        t = dga.tiling(m, n, k)
+        t.m1, t.n1, t.swizzleOffset = p["m1"], p["n1"], p["raster"]
+        fn = lambda: dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, tiling_=t)
+        fn(); torch.cuda.synchronize()
+        ok, diff = is_correct(golden, out)
+        us = time_us(fn, iters=iters) if ok else 999999999
+        with open(res_path, "a") as f:
+            f.write(json.dumps(asdict(Result(idx, m, n, k, us, diff, not ok, p))) + "\n")
+        if ok and (best is None or us < best[0]):
+            best = (us, p)
+    ck_path.write_text(json.dumps({"last_process_idx": hi}) + "\n")
+    return best
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="sweep_out")
+    ap.add_argument("--rank", type=int, default=int(os.environ.get("RANK", 0)))
+    ap.add_argument("--num-processes", type=int, default=int(os.environ.get("WORLD_SIZE", 1)))
+    ap.add_argument("--shapes", nargs="*", default=None, help="M,N,K ...")
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--cache-csv", default=None, help="append winners to this tiling-cache CSV")
+    a = ap.parse_args(argv)
+    torch.cuda.set_device(a.rank % max(1, torch.cuda.device_count()))
+    out_dir = Path(a.out); out_dir.mkdir(parents=True, exist_ok=True)
+    shapes = [[int(x) for x in s.split(",")] for s in a.shapes] if a.shapes else SHAPE_GROUP
+    winners = []
+    for shape in shapes:
+        best = benchmark_shape(shape, out_dir, a.rank, a.num_processes, a.iters)
+        if best:
+            us, p = best
+            m, n, k = shape
+            print(json.dumps({"shape": shape, "best_us": round(us, 2), "tflops": round(2.0 * m * n * k / us / 1e6, 1), **p}), flush=True)
+            winners.append((shape, p))
+    if a.cache_csv and winners:
+        new = not Path(a.cache_csv).exists()
+        with open(a.cache_csv, "a") as f:
+            if new:
+                f.write("m,n,k,m1,n1,k1,kernelSerial,paddingTagA,paddingTagB,paddingTagC,blockDim\n")
+            for (m, n, k), p in winners:
+                blocks = -(-m // p["m1"]) * -(-n // p["n1"])
+                f.write(f"{m},{n},{k},{p['m1']},{p['n1']},128,0,0,0,0,{blocks}\n")
+
+
+if __name__ == "__main__":
+    main()
