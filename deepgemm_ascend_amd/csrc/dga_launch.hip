@@ -32,10 +32,10 @@ int record_hip(hipError_t e)
         if (_rc != DGA_OK) return _rc;        \
     } while (0)
 
-template <class Cfg>
-static int launch_cfg(const GemmParams &p, hipStream_t stream)
+template <class Cfg, int PP, bool KTAIL>
+static int launch_one(const GemmParams &p, hipStream_t stream)
 {
-    auto kfn = gemm_fp8_blockscaled_nt_kernel<Cfg>;
+    auto kfn = gemm_fp8_blockscaled_nt_kernel<Cfg, PP, KTAIL>;
     static std::once_flag once[64];
     static hipError_t attr_err[64];
     int dev = 0;
@@ -52,18 +52,33 @@ static int launch_cfg(const GemmParams &p, hipStream_t stream)
     return DGA_OK;
 }
 
+// K % 128 != 0 takes the instantiation with the per-lane beyond-K test in its DMA slots
+template <class Cfg, int PP>
+static int launch_cfg(const GemmParams &p, hipStream_t stream)
+{
+    return (p.k % 128) ? launch_one<Cfg, PP, true>(p, stream) : launch_one<Cfg, PP, false>(p, stream);
+}
+
 struct Variant {
     int bm, bn, wm, wn;
     int (*launch)(const GemmParams &, hipStream_t);
     int lds;
+    int (*launch_pp)(const GemmParams &, hipStream_t);  // ping-pong schedule (dispatchPolicyTag 1), or null
+    int (*launch_cont)(const GemmParams &, hipStream_t);  // continuous pipeline (dispatchPolicyTag 2), or null
 };
 
 #define DGA_VARIANT(BM, BN, WM, WN) \
-    Variant { BM, BN, WM, WN, &launch_cfg<GemmCfg<BM, BN, WM, WN>>, GemmCfg<BM, BN, WM, WN>::LDS_BYTES }
+    Variant { BM, BN, WM, WN, &launch_cfg<GemmCfg<BM, BN, WM, WN>, 0>, GemmCfg<BM, BN, WM, WN>::LDS_BYTES, nullptr, nullptr }
+#define DGA_VARIANT_C(BM, BN, WM, WN) \
+    Variant { BM, BN, WM, WN, &launch_cfg<GemmCfg<BM, BN, WM, WN>, 0>, GemmCfg<BM, BN, WM, WN>::LDS_BYTES, nullptr, \
+              &launch_cfg<GemmCfg<BM, BN, WM, WN>, 2> }
+#define DGA_VARIANT_PP(BM, BN, WM, WN)                                                                       \
+    Variant { BM, BN, WM, WN, &launch_cfg<GemmCfg<BM, BN, WM, WN>, 0>, GemmCfg<BM, BN, WM, WN>::LDS_BYTES, \
+              &launch_cfg<GemmCfg<BM, BN, WM, WN>, 1>, &launch_cfg<GemmCfg<BM, BN, WM, WN>, 2> }
 
 static const Variant kVariants[] = {
-    DGA_VARIANT(256, 256, 4, 2), DGA_VARIANT(128, 256, 2, 2), DGA_VARIANT(256, 128, 4, 1),
-    DGA_VARIANT(128, 128, 2, 2), DGA_VARIANT(64, 256, 1, 4),  DGA_VARIANT(64, 128, 1, 4),
+    DGA_VARIANT_PP(256, 256, 4, 2), DGA_VARIANT_C(128, 256, 2, 2), DGA_VARIANT_C(256, 128, 4, 1),
+    DGA_VARIANT_C(128, 128, 2, 2), DGA_VARIANT_C(64, 256, 1, 4),  DGA_VARIANT(64, 128, 1, 4),
     DGA_VARIANT(32, 256, 1, 4),  DGA_VARIANT(32, 128, 1, 4),  DGA_VARIANT(16, 256, 1, 4),
     DGA_VARIANT(16, 128, 1, 4),
 };
@@ -140,6 +155,10 @@ static int run_fp8(const void *a, const float *sfa, const void *b, const float *
     p.raster_group = tiling->swizzleOffset ? tiling->swizzleOffset : 1;
     static const int xcd_remap = [] { const char *e = std::getenv("DGA_XCD_REMAP"); return e ? std::atoi(e) : 1; }();
     p.xcd_remap = xcd_remap;
+    static const int pp_env = [] { const char *e = std::getenv("DGA_PINGPONG"); return e ? std::atoi(e) : -1; }();
+    const int policy = pp_env >= 0 ? pp_env : tiling->dispatchPolicyTag;
+    if (policy == 1 && v->launch_pp) return v->launch_pp(p, stream);
+    if (policy == 2 && v->launch_cont) return v->launch_cont(p, stream);
     return v->launch(p, stream);
 }
 

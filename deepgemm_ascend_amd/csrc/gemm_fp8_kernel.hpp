@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace dga {
 
@@ -101,21 +102,17 @@ __device__ __forceinline__ v4i make_rsrc(const void *base, int64_t bytes)
 }
 
 // LDS-DMA, 16 B per lane: LDS[m0 + 16*lane] = buffer[voff + soff .. +16).  M0 is written in the same statement
-// that uses it; `s_nop 4` covers a descriptor word that was produced by v_readfirstlane just before.
-// `on` (wave-uniform) skips the instruction with a scalar branch INSIDE the statement, so the compiler's
-// scheduling region around the MFMA pipeline stays one straight line.
-__device__ __forceinline__ void dma16(uint32_t voff, v4i rsrc, uint32_t soff, uint32_t lds_addr, int on)
+// that uses it (the descriptor is built once, long before the first use: no readfirstlane hazard to cover).
+__device__ __forceinline__ void dma16(uint32_t voff, v4i rsrc, uint32_t soff, uint32_t lds_addr)
 {
-    asm volatile("s_cmp_eq_u32 %4, 0\n\ts_cbranch_scc1 1f\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"
-                 "buffer_load_dwordx4 %0, %1, %2 offen lds\n1:"
-                 :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr), "s"(on) : "memory", "scc");
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr) : "memory");
 }
 // LDS-DMA, 4 B per lane from a per-lane 64-bit address (the strided scale gather)
-__device__ __forceinline__ void dma4(const void *src, uint32_t lds_addr, int on)
+__device__ __forceinline__ void dma4(const void *src, uint32_t lds_addr)
 {
-    asm volatile("s_cmp_eq_u32 %2, 0\n\ts_cbranch_scc1 1f\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
-                 "global_load_lds_dword %0, off\n1:"
-                 :: "v"(src), "s"(lds_addr), "s"(on) : "memory", "scc");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
+                 :: "v"(src), "s"(lds_addr) : "memory");
 }
 
 // In-kernel stamps (diagnostic build only; cdna_hip_programming.md section 7 "In-kernel stamps").
@@ -162,7 +159,10 @@ __device__ __forceinline__ void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <class Cfg>
+// PP = 0: every wave runs the same k-block loop (one barrier per k block).
+// PP = 1 ("ping-pong", 256x256 tile with 8 waves only): the second-dispatched half of the workgroup runs half a k
+//         block behind the first, so one half's LDS fragment burst always overlaps the other half's MFMAs.
+template <class Cfg, int PP, bool KTAIL>
 __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const GemmParams p)
 {
     constexpr int BM = Cfg::kBM, BN = Cfg::kBN, WN = Cfg::kWN;
@@ -213,7 +213,6 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
     //      which the hardware stores zeros (no branch, no zero page).
     //      DNT is a multiple of 64*4, so (c&7) and x(row) -- hence col -- do not depend on `it`.
     constexpr int DNT = Cfg::DNT;
-    const int dma_on = __builtin_amdgcn_readfirstlane(wave < Cfg::DMA_WAVES ? 1 : 0);
     const int dtid = tid & (DNT - 1);
     constexpr uint32_t kOutOfRange = 0x80000000u;  // > num_records (host guarantees tile extents < 2^31)
     const int a_col = ((dtid & 7) ^ swz_a(dtid >> 3)) * 16;
@@ -251,22 +250,28 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
     // ordered by the loop's own vmcnt(0) + barrier instead.
     // `kb` past the last block (the refill issued from inside the last k block) is branch-free: every chunk is
     // then beyond K and zero-fills the idle stage; the scale gather re-reads the last block's scales.
+    // One DMA = add (LDS address), s_mov m0, s_nop, buffer_load: every extra scalar or vector instruction here is paid
+    // 9 times per wave per k block in issue slots the MFMA stream needs.  KTAIL (K % 128 != 0) adds the per-lane
+    // beyond-K test; without it a refill that runs past the last k block (issued from inside the last blocks) just
+    // reads the following bytes of the tile -- valid memory inside the descriptor's range -- into a stage nobody
+    // consumes.
     auto issue_one = [&](int idx, int stage, int kb) {
-        const uint32_t sa = lds0 + stage * Cfg::STAGE_BYTES;
-        const uint32_t sb = sa + Cfg::A_BYTES;
-        const uint32_t ss = sb + Cfg::B_BYTES;
+        const uint32_t sa = lds0 + stage * Cfg::STAGE_BYTES + wave * 1024;
         const int k0 = kb * 128;
         if (idx < Cfg::A_ITERS) {
             const int it = idx;
-            const uint32_t voff = (k0 + a_col < p.k) ? a_voff[it] : kOutOfRange;
-            dma16(voff, a_rsrc, (uint32_t)k0, sa + (it * DNT + wave * 64) * 16, dma_on);
+            uint32_t voff = a_voff[it];
+            if constexpr (KTAIL) voff = (k0 + a_col < p.k) ? voff : kOutOfRange;
+            dma16(voff, a_rsrc, (uint32_t)k0, sa + it * DNT * 16);
         } else if (idx < Cfg::A_ITERS + Cfg::B_ITERS) {
             const int it = idx - Cfg::A_ITERS;
-            const uint32_t voff = (k0 + b_col < p.k) ? b_voff[it] : kOutOfRange;
-            dma16(voff, b_rsrc, (uint32_t)k0, sb + (it * DNT + wave * 64) * 16, dma_on);
+            uint32_t voff = b_voff[it];
+            if constexpr (KTAIL) voff = (k0 + b_col < p.k) ? voff : kOutOfRange;
+            dma16(voff, b_rsrc, (uint32_t)k0, sa + Cfg::A_BYTES + it * DNT * 16);
         } else {
             const int it = idx - Cfg::A_ITERS - Cfg::B_ITERS;
-            dma4(sc_src[it] + min(kb, p.kb_n - 1), ss + (it * DNT + wave * 64) * 4, dma_on);
+            dma4(sc_src[it] + min(kb, p.kb_n - 1), lds0 + stage * Cfg::STAGE_BYTES + Cfg::A_BYTES + Cfg::B_BYTES +
+                                                       (it * DNT + wave * 64) * 4);
         }
     };
 
@@ -283,129 +288,477 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
     const int sa_off = Cfg::A_BYTES + Cfg::B_BYTES + (wm * (BM / Cfg::kWM) + li) * 4;
     const int sb_off = Cfg::A_BYTES + Cfg::B_BYTES + (BM + (wn * (BN / WN)) / 128) * 4;
 
-    v4f acc[TM][TN];
+    // ---- epilogue (a lambda so that each wave-group path of the ping-pong loop ends in its own copy: no register
+    //      assignment has to agree across the two paths): lane owns row m, columns n0w + 32*j + 8*(lane>>4) + [0,8)
+    auto epilogue = [&](v4f (&acc)[TM][TN]) {
+        const int m_row = m0 + wm * (BM / Cfg::kWM) + li;
+        const int n_base = n0 + wn * (BN / WN) + 8 * kg;
+        const bool vec_ok = ((p.ldc & 7) == 0) && ((((uintptr_t)C) & 15) == 0);
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int mt = 0; mt < TM; ++mt) {
+            const int m = m_row + mt * 16;
+            if (m >= M) continue;
+            uint16_t *crow = C + (int64_t)m * p.ldc;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < TN / 2; ++j) {
+                const int n = n_base + 32 * j;
+                const v4f lo = acc[mt][2 * j], hi = acc[mt][2 * j + 1];
+                const v2bf h0 = __builtin_convertvector(v2f{lo.x, lo.y}, v2bf);
+                const v2bf h1 = __builtin_convertvector(v2f{lo.z, lo.w}, v2bf);
+                const v2bf h2 = __builtin_convertvector(v2f{hi.x, hi.y}, v2bf);
+                const v2bf h3 = __builtin_convertvector(v2f{hi.z, hi.w}, v2bf);
+                const v4i pk = v4i{__builtin_bit_cast(int, h0), __builtin_bit_cast(int, h1),
+                                   __builtin_bit_cast(int, h2), __builtin_bit_cast(int, h3)};
+                if (vec_ok && n + 8 <= p.n) {
+                    *(v4i *)(crow + n) = pk;
+                } else {
+                    const uint16_t *e = (const uint16_t *)&pk;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (n + q < p.n) crow[n + q] = e[q];
+                }
+            }
+        }
+    };
 
-    // ---- main loop.  ONE barrier per k block: passing it means (a) every wave's DMA of this stage has landed
-    //      (each waited vmcnt(0) first) and (b) every wave has left the previous k block, i.e. the other stage is
-    //      free -- so its refill is issued from inside this k block's MFMA pipeline, one DMA wave-instruction every
-    //      few MFMAs.  (Issued in a burst at the top, the 9 DMA instructions cost a wave 800-1600 cycles of blocked
-    //      issue per k block: the vector-memory path takes 64 B/clk/CU; measured with the -DDGA_STAMPS build.)
-    const int KB = p.kb_n;
-    DGA_STAMP_DECL
-#pragma unroll
-    for (int idx = 0; idx < Cfg::LOADS_PER_STAGE; ++idx) issue_one(idx, 0, 0);
-    DGA_STAMP_START();
-    DGA_STAMP_CLOCK(6, 7);   // slots 6/7: shader-clock and 100 MHz real-time ticks across the main loop
-    for (int kb = 0; kb < KB; ++kb) {
-        const int stage = kb & 1;
-        wait_vmcnt<0>();
-        DGA_STAMP(1);                            // segment 1: vmcnt wait
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");           // no LDS read may be hoisted above the barrier
-        DGA_STAMP(2);                            // segment 2: barrier "stage ready, other stage free"
-
-        const uint8_t *st = smem + stage * Cfg::STAGE_BYTES;
-        // Fragment reads are ordered so that the first MFMA waits only for ITS operands (B n-tile 0, A m-tile 0):
-        // all 8 waves hit the LDS at once here, and a wave that waited for its whole 15-read burst would idle the
-        // matrix pipe for ~450 cycles per k block.  The scale reads come last; they are first needed LAG steps later.
-        constexpr int STEPS = TM * TN, LAG = 3, RING = LAG + 1;
-        constexpr int ISSUE_STEPS = (STEPS * 5) / 8 > 0 ? (STEPS * 5) / 8 : 1;  // refill DMA rides on the first 5/8 of the steps
+    if constexpr (PP == 1) {
+        // ---- ping-pong main loop -----------------------------------------------------------------------------
+        // Halves: X = waves 0-3 (A rows 0-127), Y = waves 4-7 (A rows 128-255); both read all of B.  A k block is two
+        // half-phases of 16 MFMAs per wave: H1 = n-tiles 0-3 (B rows 0-63 of the wave's 128-row block), H2 = n-tiles
+        // 4-7 (rows 64-127).  Two barriers per k block, Ba(kb) and Bb(kb), delimit intervals
+        //     I1(kb) = Ba..Bb : X reads its fragments of kb and runs H1(kb)   |  Y runs H2(kb-1)
+        //     I2(kb) = Bb..Ba': X runs H2(kb)                                 |  Y reads its fragments of kb, runs H1(kb)
+        // so one half's fragment burst (the ~450 idle cycles per k block of the PP = 0 loop) hides under the other's
+        // MFMAs.  The refill of a stage is split the same way:
+        //     early(kb+1) = A tile, scales, B rows used by H1 -> issued during I1(kb), must have landed at Ba(kb+1)
+        //     late(kb+1)  = B rows used by H2                 -> issued during I2(kb), must have landed at Bb(kb+1)
+        // WAR: early(kb+1) overwrites what X last read in I1(kb-1) and Y in I2(kb-1) (both before Ba(kb));
+        //      late(kb+1) overwrites what X last read in I2(kb-1) and Y in I1(kb) (both before Bb(kb)).
+        // Each wave's DMA stream is E(0) L(0) | E(1) L(1) | ... in issue order, so "E(kb) landed" = all but the
+        // youngest LATE_N, and "L(kb) landed" = all but the youngest EARLY_N (E(kb+1) is already in flight).
+        static_assert(PP == 0 || (BM == 256 && BN == 256 && Cfg::kWM == 4 && WN == 2), "ping-pong: 256x256, 8 waves");
+        constexpr int LAG = 3, RING = LAG + 1, HS = TM * TN / 2;
+        constexpr int LATE_N = Cfg::B_ITERS / 2, EARLY_N = Cfg::A_ITERS + Cfg::B_ITERS / 2 + Cfg::SC_ITERS;
+        static_assert(Cfg::B_ITERS * Cfg::DNT / 8 == BN && (Cfg::DNT / 8) * 2 == BN / WN, "B piece = half an n block");
+        auto early_idx = [](int j) {
+            return j < Cfg::A_ITERS ? j
+                 : j < Cfg::A_ITERS + Cfg::B_ITERS / 2 ? Cfg::A_ITERS + 2 * (j - Cfg::A_ITERS)
+                 : Cfg::A_ITERS + Cfg::B_ITERS + (j - Cfg::A_ITERS - Cfg::B_ITERS / 2);
+        };
+        auto late_idx = [](int j) { return Cfg::A_ITERS + 2 * j + 1; };
         v4f part[RING];
         v8i bf[2];
         v8i af[TM];
         float s[TM];
-        {
-            const v4i lo = *(const v4i *)(st + b_off0);
-            const v4i hi = *(const v4i *)(st + b_off1);
-            bf[0] = v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        }
+        float sfb_v = 0.f;
+        auto read_frags = [&](const uint8_t *st) {
 #pragma unroll
-        for (int mt = 0; mt < TM; ++mt) {
+            for (int mt = 0; mt < TM; ++mt) {
+                const v4i lo = *(const v4i *)(st + a_off0 + mt * 2048);
+                const v4i hi = *(const v4i *)(st + a_off1 + mt * 2048);
+                af[mt] = v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+            sfb_v = *(const float *)(st + sb_off);
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) s[mt] = *(const float *)(st + sa_off + mt * 64);
+        };
+        // one half-phase: H (0/1) selects the n-tiles, KIND the DMA list riding on it (0 none, 1 early, 2 late)
+        auto run_half = [&](v4f (&acc)[TM][TN], const uint8_t *st, auto Hc, auto KINDc, auto FRESHc, int dstage, int dkb) {
+            constexpr int H = decltype(Hc)::value, KIND = decltype(KINDc)::value;
+            constexpr bool FRESH = decltype(FRESHc)::value;  // s[] holds raw sfa values: fold sfb in first
+            constexpr int NDMA = KIND == 1 ? EARLY_N : (KIND == 2 ? LATE_N : 0);
+            constexpr int ISSUE_STEPS = (HS * 3) / 4;
+            {
+                const int boff = ((H * 4) >> 1) * 4096;
+                const v4i lo = *(const v4i *)(st + b_off0 + boff);
+                const v4i hi = *(const v4i *)(st + b_off1 + boff);
+                bf[0] = v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < HS + LAG; ++i) {
+                if (i < HS) {
+                    const int q = i / TM, mt = i % TM, nt = H * 4 + q;
+                    part[i % RING] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                        bf[q & 1], af[mt], v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (NDMA > 0 && i < ISSUE_STEPS) {
+#pragma unroll
+                        for (int j = (i * NDMA) / ISSUE_STEPS; j < ((i + 1) * NDMA) / ISSUE_STEPS; ++j)
+                            issue_one(KIND == 1 ? early_idx(j) : late_idx(j), dstage, dkb);
+                    }
+                    if (mt == 0 && q + 1 < 4) {
+                        const int boff = ((nt + 1) >> 1) * 4096 + ((nt + 1) & 1) * 512;
+                        const v4i lo = *(const v4i *)(st + b_off0 + boff);
+                        const v4i hi = *(const v4i *)(st + b_off1 + boff);
+                        bf[(q + 1) & 1] = v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    }
+                }
+                if (FRESH && i == LAG) {
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt) s[mt] *= sfb_v;
+                }
+                if (i >= LAG) {
+                    const int j = i - LAG, nt = H * 4 + j / TM, mt = j % TM;
+                    const v4f pr = part[j % RING];
+                    acc[mt][nt].x = __builtin_fmaf(pr.x, s[mt], acc[mt][nt].x);
+                    acc[mt][nt].y = __builtin_fmaf(pr.y, s[mt], acc[mt][nt].y);
+                    acc[mt][nt].z = __builtin_fmaf(pr.z, s[mt], acc[mt][nt].z);
+                    acc[mt][nt].w = __builtin_fmaf(pr.w, s[mt], acc[mt][nt].w);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using Bt = std::integral_constant<bool, true>;
+        using Bf = std::integral_constant<bool, false>;
+        const int KB = p.kb_n;
+        DGA_STAMP_DECL
+        DGA_STAMP_CLOCK(6, 7);
+        // prologue: E(0) then L(0), in that order
+#pragma unroll
+        for (int j = 0; j < EARLY_N; ++j) issue_one(early_idx(j), 0, 0);
+#pragma unroll
+        for (int j = 0; j < LATE_N; ++j) issue_one(late_idx(j), 0, 0);
+        auto barrier = [&]() {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        if (wave < 4) {  // ---------------- X
+            v4f acc[TM][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+            DGA_STAMP_START();
+            for (int kb = 0; kb < KB; ++kb) {
+                const uint8_t *st = smem + (kb & 1) * Cfg::STAGE_BYTES;
+                wait_vmcnt<LATE_N>();
+                barrier();  // Ba(kb)
+                DGA_STAMP(0);
+                read_frags(st);
+                DGA_STAMP(1);
+                run_half(acc, st, I0{}, I1{}, Bt{}, (kb & 1) ^ 1, kb + 1);
+                DGA_STAMP(2);
+                wait_vmcnt<EARLY_N>();
+                barrier();  // Bb(kb)
+                DGA_STAMP(3);
+                run_half(acc, st, I1{}, I2{}, Bf{}, (kb & 1) ^ 1, kb + 1);
+                DGA_STAMP(4);
+            }
+            barrier();  // Ba(KB): Y starts its last H2 while X stores
+            DGA_STAMP_CLOCK(6, 7);
+            DGA_STAMP_FLUSH();
+            epilogue(acc);
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();  // Bb(KB): matches Y's last barrier
+        } else {         // ---------------- Y
+            v4f acc[TM][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+            // first and last interval pairs are peeled so that the steady-state loop has no conditional around a
+            // half-phase (a conditionally reloaded A fragment keeps both copies alive: +32 VGPRs, spills)
+            wait_vmcnt<LATE_N>();
+            barrier();  // Ba(0): nothing to compute yet, just start the refill
+#pragma unroll
+            for (int j = 0; j < EARLY_N; ++j) issue_one(early_idx(j), 1, 1);
+            wait_vmcnt<EARLY_N>();
+            barrier();  // Bb(0)
+            read_frags(smem);
+            run_half(acc, smem, I0{}, I2{}, Bt{}, 1, 1);
+            DGA_STAMP_START();
+            for (int kb = 1; kb < KB; ++kb) {
+                const uint8_t *st = smem + (kb & 1) * Cfg::STAGE_BYTES;
+                wait_vmcnt<LATE_N>();
+                barrier();  // Ba(kb)
+                DGA_STAMP(0);
+                run_half(acc, smem + ((kb - 1) & 1) * Cfg::STAGE_BYTES, I1{}, I1{}, Bf{}, (kb & 1) ^ 1, kb + 1);
+                DGA_STAMP(4);
+                wait_vmcnt<EARLY_N>();
+                barrier();  // Bb(kb)
+                DGA_STAMP(3);
+                read_frags(st);
+                DGA_STAMP(1);
+                run_half(acc, st, I0{}, I2{}, Bt{}, (kb & 1) ^ 1, kb + 1);
+                DGA_STAMP(2);
+            }
+            wait_vmcnt<0>();
+            barrier();  // Ba(KB)
+            run_half(acc, smem + ((KB - 1) & 1) * Cfg::STAGE_BYTES, I1{}, I0{}, Bf{}, 0, 0);
+            barrier();  // Bb(KB)
+            DGA_STAMP_CLOCK(6, 7);
+            DGA_STAMP_FLUSH();
+            epilogue(acc);
+        }
+    } else if constexpr (PP == 2) {
+        // ---- continuous pipeline ---------------------------------------------------------------------------------
+        // The k-block boundary disappears from the MFMA stream.  Per k block (stage s = kb & 1), steps i = 0..STEPS-1:
+        //   * every step: MFMA(i) -> part ring; FMAs of step i-LAG (the first LAG steps promote the LAST LAG results of
+        //     the previous k block, with that block's scales);
+        //   * B fragments rotate through two register sets, the rotation simply continues into the next k block;
+        //   * step SB (after the last LDS read of stage s has returned): vmcnt(0) + the ONE barrier.  Passing it means
+        //     stage s^1 (k block kb+1, whose DMA was issued during the steps since the previous barrier) has landed
+        //     everywhere AND nobody reads stage s any more;
+        //   * steps STEPS-TM..STEPS-1: as each A fragment sees its last MFMA it is reloaded IN PLACE from stage s^1,
+        //     together with the next block's first B fragment and scales -- their LDS latency hides under the block's
+        //     last MFMAs and the next block's first step finds its operands in registers;
+        //   * the refill of stage s (k block kb+2) starts right behind the barrier and continues over the first steps
+        //     of the next k block: every batch has more than half a k block to land.
+        constexpr int STEPS = TM * TN, LAG = 3, RING = 4;
+        static_assert(STEPS % RING == 0 && STEPS > 2 * TM + LAG, "ring positions must line up across k blocks");
+        constexpr int SB = STEPS - TM - 1;         // barrier step (just before the in-place reloads)
+        constexpr int NL = Cfg::LOADS_PER_STAGE;
+        constexpr int TAIL_DMA = NL / 4;           // DMA slots on the steps behind the barrier
+        constexpr int HEAD_STEPS = (STEPS * 9) / 16;  // ... the rest rides on the first steps of the next k block
+        v4f acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+        v4f part[RING];
+#pragma unroll
+        for (int i = 0; i < RING; ++i) part[i] = v4f{0.f, 0.f, 0.f, 0.f};
+        v8i bf[2], af[TM];
+        float s[TM], s_prev[TM], s_next[TM], sfb_next = 0.f;
+        const int KB = p.kb_n;
+        DGA_STAMP_DECL
+        DGA_STAMP_CLOCK(6, 7);
+        auto barrier = [&]() {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        auto read_b = [&](const uint8_t *st, int nt) {
+            const int boff = (nt >> 1) * 4096 + (nt & 1) * 512;
+            const v4i lo = *(const v4i *)(st + b_off0 + boff);
+            const v4i hi = *(const v4i *)(st + b_off1 + boff);
+            return v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        };
+        auto read_a = [&](const uint8_t *st, int mt) {
             const v4i lo = *(const v4i *)(st + a_off0 + mt * 2048);
             const v4i hi = *(const v4i *)(st + a_off1 + mt * 2048);
-            af[mt] = v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            if (mt == 0) __builtin_amdgcn_sched_barrier(0);
+            return v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        };
+        // DMA schedule.  Block d's refill = tail part (slots 0..TAIL_DMA-1), issued on the steps behind the barrier of
+        // k block d-2, then head part (the rest), issued on the first HEAD_STEPS steps of k block d-1; the vmcnt(0) at
+        // step SB of k block d-1 covers both.  Prologue: all of block 0, then tail(1).
+#pragma unroll
+        for (int idx = 0; idx < NL; ++idx) issue_one(idx, 0, 0);
+#pragma unroll
+        for (int idx = 0; idx < TAIL_DMA; ++idx) issue_one(idx, 1, 1);
+        wait_vmcnt<TAIL_DMA>();
+        barrier();
+        bf[0] = read_b(smem, 0);
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) af[mt] = read_a(smem, mt);
+        {
+            const float sfb0 = *(const float *)(smem + sb_off);
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                s[mt] = *(const float *)(smem + sa_off + mt * 64) * sfb0;
+                s_prev[mt] = 0.f;   // the first LAG "previous block" promotions add part (= 0) * 0
+                s_next[mt] = 0.f;
+            }
         }
-        const float sfb_v = *(const float *)(st + sb_off);
+        for (int kb = 0; kb < KB; ++kb) {
+            const uint8_t *st = smem + (kb & 1) * Cfg::STAGE_BYTES;
+            const uint8_t *sn = smem + ((kb & 1) ^ 1) * Cfg::STAGE_BYTES;
 #pragma unroll
-        for (int mt = 0; mt < TM; ++mt) s[mt] = *(const float *)(st + sa_off + mt * 64);
-        DGA_STAMP(3);                            // segment 3: first fragments + scales out of LDS
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < STEPS + LAG; ++i) {
-            if (i < STEPS) {
+            for (int i = 0; i < STEPS; ++i) {
                 const int nt = i / TM, mt = i % TM;
+                if (i == SB) {
+                    wait_vmcnt<0>();
+                    barrier();
+                }
                 part[i % RING] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
                     bf[nt & 1], af[mt], v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (i < ISSUE_STEPS) {
+                // refill DMA: head part of block kb+1 (stage s^1 is free since the previous barrier) ...
+#ifndef DGA_ABL_NODMA
+                // refill DMA: head part of block kb+1 (stage s^1 is free since the previous barrier) on the first
+                // HEAD_STEPS steps, tail part of block kb+2 into THIS stage on the TM steps behind the barrier.
+                // (Giving each SIMD its own issue steps -- 4 predicated copies of every slot -- measured 13 % MORE
+                // cycles: the skipped copies cost more issue slots than the queueing they avoid.)
+                if (i < HEAD_STEPS) {
 #pragma unroll
-                    for (int idx = (i * Cfg::LOADS_PER_STAGE) / ISSUE_STEPS;
-                         idx < ((i + 1) * Cfg::LOADS_PER_STAGE) / ISSUE_STEPS; ++idx)
-                        issue_one(idx, stage ^ 1, kb + 1);
+                    for (int j = (i * (NL - TAIL_DMA)) / HEAD_STEPS; j < ((i + 1) * (NL - TAIL_DMA)) / HEAD_STEPS; ++j)
+                        issue_one(TAIL_DMA + j, (kb & 1) ^ 1, kb + 1);
                 }
-                // next n-tile's fragment: issued right AFTER this n-tile's first MFMA, so that the (whole-counter)
-                // lgkmcnt wait hipcc places in front of that MFMA never covers reads that were only just issued
-                if (mt == 0 && nt + 1 < TN) {
-                    const int boff = ((nt + 1) >> 1) * 4096 + ((nt + 1) & 1) * 512;
-                    const v4i lo = *(const v4i *)(st + b_off0 + boff);
-                    const v4i hi = *(const v4i *)(st + b_off1 + boff);
-                    bf[(nt + 1) & 1] = v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                }
-            }
-            if (i == LAG) {
+                if (i > SB) {
 #pragma unroll
-                for (int mt = 0; mt < TM; ++mt) s[mt] *= sfb_v;  // two-level scale: sfa[m,kb] * sfb[n/128,kb]
+                    for (int j = ((i - SB - 1) * TAIL_DMA) / TM; j < ((i - SB) * TAIL_DMA) / TM; ++j)
+                        issue_one(j, kb & 1, kb + 2);
+                }
+#endif
+                // B fragment rotation (continues into the next k block at the last n-tile)
+#ifndef DGA_ABL_NOLDS
+                if (mt == 0) {
+                    if (nt + 1 < TN) bf[(nt + 1) & 1] = read_b(st, nt + 1);
+                    else bf[(nt + 1) & 1] = read_b(sn, 0);
+                }
+#else
+                if (mt == 0) { bf[(nt + 1) & 1] = bf[nt & 1]; asm volatile("" : "+v"(bf[(nt + 1) & 1])); }
+#endif
+                // in-place reload of the A fragment that has just seen its last MFMA of this k block
+#ifdef DGA_ABL_NOLDS
+                if (false) {
+#else
+                if (nt == TN - 1) {
+#endif
+                    af[mt] = read_a(sn, mt);
+                    if (mt == 0) sfb_next = *(const float *)(sn + sb_off);
+                    s_next[mt] = *(const float *)(sn + sa_off + mt * 64);
+                }
+                // promotion of step i - LAG
+                if (i >= LAG) {
+                    const int j = i - LAG, jn = j / TM, jm = j % TM;
+                    const v4f pr = part[j % RING];
+#ifdef DGA_ABL_NOFMA
+                    asm volatile("" :: "v"(pr), "v"(s[jm]));
+#else
+                    acc[jm][jn].x = __builtin_fmaf(pr.x, s[jm], acc[jm][jn].x);
+                    acc[jm][jn].y = __builtin_fmaf(pr.y, s[jm], acc[jm][jn].y);
+                    acc[jm][jn].z = __builtin_fmaf(pr.z, s[jm], acc[jm][jn].z);
+                    acc[jm][jn].w = __builtin_fmaf(pr.w, s[jm], acc[jm][jn].w);
+#endif
+                } else {
+                    const int j = STEPS - LAG + i, jn = j / TM, jm = j % TM;  // previous k block's last steps
+                    const v4f pr = part[j % RING];
+                    acc[jm][jn].x = __builtin_fmaf(pr.x, s_prev[jm], acc[jm][jn].x);
+                    acc[jm][jn].y = __builtin_fmaf(pr.y, s_prev[jm], acc[jm][jn].y);
+                    acc[jm][jn].z = __builtin_fmaf(pr.z, s_prev[jm], acc[jm][jn].z);
+                    acc[jm][jn].w = __builtin_fmaf(pr.w, s_prev[jm], acc[jm][jn].w);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (i >= LAG) {
-                const int j = i - LAG, nt = j / TM, mt = j % TM;
-                const v4f pr = part[j % RING];
-                // scalar FMAs on purpose: v_pk_fma_f32 beside MFMAs is slower than two v_fma_f32
-                // (MI355X_MICROARCH "price of one filler beside MFMAs")
-                acc[mt][nt].x = __builtin_fmaf(pr.x, s[mt], acc[mt][nt].x);
-                acc[mt][nt].y = __builtin_fmaf(pr.y, s[mt], acc[mt][nt].y);
-                acc[mt][nt].z = __builtin_fmaf(pr.z, s[mt], acc[mt][nt].z);
-                acc[mt][nt].w = __builtin_fmaf(pr.w, s[mt], acc[mt][nt].w);
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                s_prev[mt] = s[mt];
+                s[mt] = s_next[mt] * sfb_next;
             }
+        }
+        // drain: the last LAG results of the last k block
+#pragma unroll
+        for (int i = 0; i < LAG; ++i) {
+            const int j = STEPS - LAG + i, jn = j / TM, jm = j % TM;
+            const v4f pr = part[j % RING];
+            acc[jm][jn].x = __builtin_fmaf(pr.x, s_prev[jm], acc[jm][jn].x);
+            acc[jm][jn].y = __builtin_fmaf(pr.y, s_prev[jm], acc[jm][jn].y);
+            acc[jm][jn].z = __builtin_fmaf(pr.z, s_prev[jm], acc[jm][jn].z);
+            acc[jm][jn].w = __builtin_fmaf(pr.w, s_prev[jm], acc[jm][jn].w);
+        }
+        wait_vmcnt<0>();
+        DGA_STAMP_CLOCK(6, 7);
+        DGA_STAMP_FLUSH();
+        epilogue(acc);
+    } else {
+        v4f acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+    // ---- main loop.  ONE barrier per k block: passing it means (a) every wave's DMA of this stage has landed
+        //      (each waited vmcnt(0) first) and (b) every wave has left the previous k block, i.e. the other stage is
+        //      free -- so its refill is issued from inside this k block's MFMA pipeline, one DMA wave-instruction every
+        //      few MFMAs.  (Issued in a burst at the top, the 9 DMA instructions cost a wave 800-1600 cycles of blocked
+        //      issue per k block: the vector-memory path takes 64 B/clk/CU; measured with the -DDGA_STAMPS build.)
+        const int KB = p.kb_n;
+        DGA_STAMP_DECL
+#pragma unroll
+        for (int idx = 0; idx < Cfg::LOADS_PER_STAGE; ++idx) issue_one(idx, 0, 0);
+        DGA_STAMP_START();
+        DGA_STAMP_CLOCK(6, 7);   // slots 6/7: shader-clock and 100 MHz real-time ticks across the main loop
+        for (int kb = 0; kb < KB; ++kb) {
+            const int stage = kb & 1;
+            wait_vmcnt<0>();
+            DGA_STAMP(1);                            // segment 1: vmcnt wait
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");           // no LDS read may be hoisted above the barrier
+            DGA_STAMP(2);                            // segment 2: barrier "stage ready, other stage free"
+    
+            const uint8_t *st = smem + stage * Cfg::STAGE_BYTES;
+            // Fragment reads are ordered so that the first MFMA waits only for ITS operands (B n-tile 0, A m-tile 0):
+            // all 8 waves hit the LDS at once here, and a wave that waited for its whole 15-read burst would idle the
+            // matrix pipe for ~450 cycles per k block.  The scale reads come last; they are first needed LAG steps later.
+            constexpr int STEPS = TM * TN, LAG = 3, RING = LAG + 1;
+            constexpr int ISSUE_STEPS = (STEPS * 5) / 8 > 0 ? (STEPS * 5) / 8 : 1;  // refill DMA rides on the first 5/8 of the steps
+            v4f part[RING];
+            v8i bf[2];
+            v8i af[TM];
+            float s[TM];
+            {
+                const v4i lo = *(const v4i *)(st + b_off0);
+                const v4i hi = *(const v4i *)(st + b_off1);
+                bf[0] = v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const v4i lo = *(const v4i *)(st + a_off0 + mt * 2048);
+                const v4i hi = *(const v4i *)(st + a_off1 + mt * 2048);
+                af[mt] = v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                if (mt == 0) __builtin_amdgcn_sched_barrier(0);
+            }
+            const float sfb_v = *(const float *)(st + sb_off);
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) s[mt] = *(const float *)(st + sa_off + mt * 64);
+            DGA_STAMP(3);                            // segment 3: first fragments + scales out of LDS
             __builtin_amdgcn_sched_barrier(0);
-        }
-        DGA_STAMP(4);                            // segment 4: the MFMA / promotion pipeline (+ refill DMA issue)
-    }
-    DGA_STAMP_CLOCK(6, 7);
-    DGA_STAMP_FLUSH();
-
-    // ---- epilogue: lane owns row m, columns n0w + 32*j + 8*(lane>>4) + [0,8)
-    const int m_row = m0 + wm * (BM / Cfg::kWM) + li;
-    const int n_base = n0 + wn * (BN / WN) + 8 * kg;
-    const bool vec_ok = ((p.ldc & 7) == 0) && ((((uintptr_t)C) & 15) == 0);
 #pragma unroll
-    for (int mt = 0; mt < TM; ++mt) {
-        const int m = m_row + mt * 16;
-        if (m >= M) continue;
-        uint16_t *crow = C + (int64_t)m * p.ldc;
+            for (int i = 0; i < STEPS + LAG; ++i) {
+                if (i < STEPS) {
+                    const int nt = i / TM, mt = i % TM;
+                    part[i % RING] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                        bf[nt & 1], af[mt], v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#ifndef DGA_ABL_NODMA
+                    if (i < ISSUE_STEPS) {
 #pragma unroll
-        for (int j = 0; j < TN / 2; ++j) {
-            const int n = n_base + 32 * j;
-            const v4f lo = acc[mt][2 * j], hi = acc[mt][2 * j + 1];
-            const v2bf h0 = __builtin_convertvector(v2f{lo.x, lo.y}, v2bf);
-            const v2bf h1 = __builtin_convertvector(v2f{lo.z, lo.w}, v2bf);
-            const v2bf h2 = __builtin_convertvector(v2f{hi.x, hi.y}, v2bf);
-            const v2bf h3 = __builtin_convertvector(v2f{hi.z, hi.w}, v2bf);
-            const v4i pk = v4i{__builtin_bit_cast(int, h0), __builtin_bit_cast(int, h1),
-                               __builtin_bit_cast(int, h2), __builtin_bit_cast(int, h3)};
-            if (vec_ok && n + 8 <= p.n) {
-                *(v4i *)(crow + n) = pk;
-            } else {
-                const uint16_t *e = (const uint16_t *)&pk;
+                        for (int idx = (i * Cfg::LOADS_PER_STAGE) / ISSUE_STEPS;
+                             idx < ((i + 1) * Cfg::LOADS_PER_STAGE) / ISSUE_STEPS; ++idx)
+                            issue_one(idx, stage ^ 1, kb + 1);
+                    }
+#endif
+                    // next n-tile's fragment: issued right AFTER this n-tile's first MFMA, so that the (whole-counter)
+                    // lgkmcnt wait hipcc places in front of that MFMA never covers reads that were only just issued
+#ifndef DGA_ABL_NOLDS
+                    if (mt == 0 && nt + 1 < TN) {
+                        const int boff = ((nt + 1) >> 1) * 4096 + ((nt + 1) & 1) * 512;
+                        const v4i lo = *(const v4i *)(st + b_off0 + boff);
+                        const v4i hi = *(const v4i *)(st + b_off1 + boff);
+                        bf[(nt + 1) & 1] = v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    }
+#else
+                    if (mt == 0 && nt + 1 < TN) { bf[(nt + 1) & 1] = bf[nt & 1]; asm volatile("" : "+v"(bf[(nt + 1) & 1])); }
+#endif
+                }
+                if (i == LAG) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (n + q < p.n) crow[n + q] = e[q];
+                    for (int mt = 0; mt < TM; ++mt) s[mt] *= sfb_v;  // two-level scale: sfa[m,kb] * sfb[n/128,kb]
+                }
+                if (i >= LAG) {
+                    const int j = i - LAG, nt = j / TM, mt = j % TM;
+                    const v4f pr = part[j % RING];
+                    // scalar FMAs on purpose: v_pk_fma_f32 beside MFMAs is slower than two v_fma_f32
+                    // (MI355X_MICROARCH "price of one filler beside MFMAs")
+#ifdef DGA_ABL_NOFMA
+                    asm volatile("" :: "v"(pr), "v"(s[mt]));
+#else
+                    acc[mt][nt].x = __builtin_fmaf(pr.x, s[mt], acc[mt][nt].x);
+                    acc[mt][nt].y = __builtin_fmaf(pr.y, s[mt], acc[mt][nt].y);
+                    acc[mt][nt].z = __builtin_fmaf(pr.z, s[mt], acc[mt][nt].z);
+                    acc[mt][nt].w = __builtin_fmaf(pr.w, s[mt], acc[mt][nt].w);
+#endif
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            DGA_STAMP(4);                            // segment 4: the MFMA / promotion pipeline (+ refill DMA issue)
         }
+        DGA_STAMP_CLOCK(6, 7);
+        DGA_STAMP_FLUSH();
+        epilogue(acc);
     }
 }
 

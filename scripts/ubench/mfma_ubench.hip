@@ -11,7 +11,7 @@ template <int MODE>  // 0: MFMA only (accumulate chain x4 indep), 1: MFMA(C=0) +
 __global__ void __launch_bounds__(512) k(const int *seed, float *out, int iters)
 {
     v8i a, b;
-    for (int i = 0; i < 8; ++i) { a[i] = seed[threadIdx.x & 63] * (i + 1); b[i] = seed[(threadIdx.x + 7) & 63] * (i + 3); }
+    for (int i = 0; i < 8; ++i) { a[i] = seed[(threadIdx.x * 8 + i) & 4095]; b[i] = seed[(threadIdx.x * 8 + i + 2048) & 4095]; }
     v4f acc[16];
     for (int i = 0; i < 16; ++i) acc[i] = v4f{0, 0, 0, 0};
     float s = 1.0001f;
@@ -51,10 +51,22 @@ int main(int argc, char **argv)
 {
     int iters = 2000;
     int *seed; float *out;
-    hipMalloc(&seed, 64 * 4); hipMalloc(&out, 256 * 8 * 512 * 4);
-    std::vector<int> h(64);
-    for (int i = 0; i < 64; ++i) h[i] = 0x38383838 + i * 0x01010101;  // plausible e4m3 bytes
-    hipMemcpy(seed, h.data(), 256, hipMemcpyHostToDevice);
+    hipMalloc(&seed, 4096 * 4); hipMalloc(&out, 256 * 8 * 512 * 4);
+    std::vector<int> h(4096);
+    const int randomise = argc > 1 ? atoi(argv[1]) : 1;
+    srand(7);
+    for (int i = 0; i < 4096; ++i) {
+        unsigned v = 0;
+        for (int b = 0; b < 4; ++b) {
+            unsigned byte = randomise ? (rand() & 0xFF) : 0x38;
+            if ((byte & 0x7F) == 0x7F) byte &= 0x80;      // no NaN
+            if ((byte & 0x78) > 0x58) byte &= 0xDF;        // keep magnitudes moderate (no overflow to inf in acc chains)
+            v |= byte << (8 * b);
+        }
+        h[i] = (int)v;
+    }
+    hipMemcpy(seed, h.data(), 4096 * 4, hipMemcpyHostToDevice);
+    printf("operands: %s\n", randomise ? "random e4m3 bytes" : "constant 0x38");
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int mode = 0; mode < 2; ++mode)
         for (int threads : {256, 512}) {

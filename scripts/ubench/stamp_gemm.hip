@@ -29,7 +29,8 @@ int main(int argc, char **argv)
     const int grid = p.tiles_m * p.tiles_n;
     hipMalloc(&st, (size_t)grid * 8 * 8 * 8); hipMemset(st, 0, (size_t)grid * 8 * 8 * 8);
     p.stamps = st;
-    auto kfn = gemm_fp8_blockscaled_nt_kernel<Cfg>;
+    const int pp = argc > 4 ? atoi(argv[4]) : 0;
+    auto kfn = pp == 2 ? gemm_fp8_blockscaled_nt_kernel<Cfg, 2, false> : pp ? gemm_fp8_blockscaled_nt_kernel<Cfg, 1, false> : gemm_fp8_blockscaled_nt_kernel<Cfg, 0, false>;
     hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, 0, p);
@@ -37,10 +38,12 @@ int main(int argc, char **argv)
     for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, 0, p);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("stamped kernel: %.1f us per launch (%d x %d x %d)\n", ms * 1000 / 20, m, n, k);
+    printf("stamped kernel (pp=%d): %.1f us per launch (%d x %d x %d)\n", pp, ms * 1000 / 20, m, n, k);
     std::vector<unsigned long long> h((size_t)grid * 8 * 8);
     hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
-    const char *names[6] = {"issue next-stage DMA", "vmcnt wait", "barrier stage-ready", "first frags from LDS", "MFMA+promotion pipeline", "barrier stage-free"};
+    const char *names0[6] = {"issue next-stage DMA", "vmcnt wait", "barrier stage-ready", "first frags from LDS", "MFMA+promotion pipeline", "barrier stage-free"};
+    const char *names1[6] = {"wait + barrier Ba", "read A frags + scales", "H1 (+DMA)", "wait + barrier Bb", "H2 (+DMA)", "-"};
+    const char **names = pp ? names1 : names0;
     for (int half = 0; half < 2; ++half) {
         double tot = 0, seg[6] = {0};
         for (int w = 0; w < grid * 8; ++w) {
