@@ -65,6 +65,7 @@ struct Variant {
     int lds;
     int (*launch_pp)(const GemmParams &, hipStream_t);  // ping-pong schedule (dispatchPolicyTag 1), or null
     int (*launch_cont)(const GemmParams &, hipStream_t);  // continuous pipeline (dispatchPolicyTag 2), or null
+    int stages = 2;
 };
 
 #define DGA_VARIANT(BM, BN, WM, WN) \
@@ -79,6 +80,11 @@ struct Variant {
 static const Variant kVariants[] = {
     DGA_VARIANT_PP(256, 256, 4, 2), DGA_VARIANT_C(128, 256, 2, 2), DGA_VARIANT_C(256, 128, 4, 1),
     DGA_VARIANT_C(128, 128, 2, 2), DGA_VARIANT_C(64, 256, 1, 4),  DGA_VARIANT(64, 128, 1, 4),
+    DGA_VARIANT_C(128, 256, 2, 4),  // 8 waves on a 128x256 tile: two waves per SIMD cover each other's DMA stalls
+    // three LDS stages (two refills in flight) for the HBM-bound grouped / small-M shapes
+    Variant{128, 256, 2, 2, &launch_cfg<GemmCfg<128, 256, 2, 2, 3>, 0>, GemmCfg<128, 256, 2, 2, 3>::LDS_BYTES, nullptr, nullptr, 3},
+    Variant{128, 128, 2, 2, &launch_cfg<GemmCfg<128, 128, 2, 2, 3>, 0>, GemmCfg<128, 128, 2, 2, 3>::LDS_BYTES, nullptr, nullptr, 3},
+    Variant{64, 256, 1, 4, &launch_cfg<GemmCfg<64, 256, 1, 4, 3>, 0>, GemmCfg<64, 256, 1, 4, 3>::LDS_BYTES, nullptr, nullptr, 3},
     DGA_VARIANT(32, 256, 1, 4),  DGA_VARIANT(32, 128, 1, 4),  DGA_VARIANT(16, 256, 1, 4),
     DGA_VARIANT(16, 128, 1, 4),
 };
@@ -91,11 +97,15 @@ void variant_info(int i, int *bm, int *bn, int *wm, int *wn, int *lds)
     *lds = kVariants[i].lds;
 }
 
-static const Variant *find_variant(int bm, int bn)
+// (wm, wn) == (0, 0): first variant of that tile size (the menu order is the preference order)
+static const Variant *find_variant(int bm, int bn, int wm, int wn, int stages)
 {
     for (int i = 0; i < kNumVariants; ++i)
-        if (kVariants[i].bm == bm && kVariants[i].bn == bn) return &kVariants[i];
-    return nullptr;
+        if (kVariants[i].bm == bm && kVariants[i].bn == bn && (!wm || (kVariants[i].wm == wm && kVariants[i].wn == wn)) &&
+            kVariants[i].stages == (stages == 3 ? 3 : 2))
+            return &kVariants[i];
+    if (stages == 3) return find_variant(bm, bn, wm, wn, 2);
+    return wm ? find_variant(bm, bn, 0, 0, 2) : nullptr;
 }
 
 static int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, void *out,
@@ -148,7 +158,7 @@ static int run_fp8(const void *a, const float *sfa, const void *b, const float *
         DGA_HIP_TRY(hipGetLastError());
         return DGA_OK;
     }
-    const Variant *v = find_variant(tiling->m1, tiling->n1);
+    const Variant *v = find_variant(tiling->m1, tiling->n1, tiling->wavesM, tiling->wavesN, tiling->stages);
     if (!v) return DGA_E_TILING;
     p.tiles_m = (m + v->bm - 1) / v->bm;
     p.tiles_n = (n + v->bn - 1) / v->bn;

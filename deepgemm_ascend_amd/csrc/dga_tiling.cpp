@@ -287,7 +287,12 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
     double best = 1e300;
     MenuEntry pick{};
     bool found = false;
+    std::vector<MenuEntry> seen;
     for (const MenuEntry &e : menu()) {
+        bool dup = false;
+        for (const MenuEntry &q : seen) dup |= (q.bm == e.bm && q.bn == e.bn);
+        if (dup) continue;  // later entries of a tile size are alternative builds (waves / stages), chosen below
+        seen.push_back(e);
         if (static_cast<uint64_t>(e.lds) > pf.l1Size) continue;
         if (4ull * e.bm * e.bn > pf.l0CSize) continue;  // accumulators: JudgeSpace's L0C test on VGPRs
         const uint32_t wg_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(pf.l1Size / e.lds, 2048 / (e.wm * e.wn * 64)));
@@ -306,6 +311,11 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
     t.wavesM = static_cast<uint8_t>(pick.wm); t.wavesN = static_cast<uint8_t>(pick.wn);
     t.stages = 2;
     t.ldsBytes = pick.lds;
+    // One tile row covers M (grouped experts, decode shapes): B is streamed once and the kernel is HBM-bound; the
+    // tiles whose stage is <= 48 KB have a three-stage build that keeps two refills in flight (measured +6 % GB/s).
+    if (ceil_div(m_eff, pick.bm) == 1 && pick.lds / 2 * 3 <= static_cast<int>(pf.l1Size) &&
+        ((pick.bm == 128 && pick.bn == 256 && pick.wm == 2) || (pick.bm == 64 && pick.bn == 256)))
+        t.stages = 3;
     const uint32_t tiles_m = ceil_div(t.m, t.m1), tiles_n = ceil_div(t.n, t.n1);
     const uint64_t blocks = static_cast<uint64_t>(groups) * tiles_m * tiles_n;
     t.blockDim = static_cast<uint32_t>(blocks);

@@ -51,7 +51,7 @@ struct GemmParams {
     unsigned long long *stamps;  // diagnostic builds only (-DDGA_STAMPS): per-wave segment cycle sums
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int ST = 2>
 struct GemmCfg {
     static constexpr int kBM = BM, kBN = BN, kWM = WM, kWN = WN;
     static constexpr int NT = WM * WN * 64;
@@ -67,7 +67,7 @@ struct GemmCfg {
     static constexpr int SC_SLOTS = ((BM + 8 + DNT - 1) / DNT) * DNT;  // sfa rows, then sfb entries, padded
     static constexpr int SC_BYTES = SC_SLOTS * 4;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES + SC_BYTES;
-    static constexpr int STAGES = 2;
+    static constexpr int STAGES = ST;  // LDS stages (3 only with the PP = 0 loop)
     static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
     static constexpr int A_ITERS = A_ROWS * 8 / DNT;
     static constexpr int B_ITERS = BN * 8 / DNT;
@@ -108,6 +108,7 @@ __device__ __forceinline__ void dma16(uint32_t voff, v4i rsrc, uint32_t soff, ui
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
                  :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr) : "memory");
 }
+// (The non-temporal form, `... offen nt lds`, was measured on the grouped weight stream: no difference, r01.)
 // LDS-DMA, 4 B per lane from a per-lane 64-bit address (the strided scale gather)
 __device__ __forceinline__ void dma4(const void *src, uint32_t lds_addr)
 {
@@ -665,21 +666,36 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         //      free -- so its refill is issued from inside this k block's MFMA pipeline, one DMA wave-instruction every
         //      few MFMAs.  (Issued in a burst at the top, the 9 DMA instructions cost a wave 800-1600 cycles of blocked
         //      issue per k block: the vector-memory path takes 64 B/clk/CU; measured with the -DDGA_STAMPS build.)
+        // With STAGES = 3 (tiles whose stage is <= 48 KB) two refills are in flight instead of one: the wait at the
+        // top leaves the newest batch outstanding.
         const int KB = p.kb_n;
+        constexpr int STG = Cfg::STAGES;
         DGA_STAMP_DECL
 #pragma unroll
-        for (int idx = 0; idx < Cfg::LOADS_PER_STAGE; ++idx) issue_one(idx, 0, 0);
+        for (int d = 0; d < STG - 1; ++d)
+#pragma unroll
+            for (int idx = 0; idx < Cfg::LOADS_PER_STAGE; ++idx) issue_one(idx, d, d);
         DGA_STAMP_START();
         DGA_STAMP_CLOCK(6, 7);   // slots 6/7: shader-clock and 100 MHz real-time ticks across the main loop
+        int stage = 0, fill = STG - 1;   // stage being consumed / stage being refilled (with k block kb + STG - 1)
+        const bool wave_has_rows = m0 + wm * (BM / Cfg::kWM) < M;  // wave-uniform (wm comes from readfirstlane)
         for (int kb = 0; kb < KB; ++kb) {
-            const int stage = kb & 1;
-            wait_vmcnt<0>();
+            wait_vmcnt<(STG - 2) * Cfg::LOADS_PER_STAGE>();
             DGA_STAMP(1);                            // segment 1: vmcnt wait
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");           // no LDS read may be hoisted above the barrier
             DGA_STAMP(2);                            // segment 2: barrier "stage ready, other stage free"
-    
+
             const uint8_t *st = smem + stage * Cfg::STAGE_BYTES;
+            if (!wave_has_rows) {
+                // masked-M: every row of this wave's m range is >= masked_m[g].  It still carries its share of the
+                // refill (and the barrier), but computes nothing.
+#pragma unroll
+                for (int idx = 0; idx < Cfg::LOADS_PER_STAGE; ++idx) issue_one(idx, fill, kb + STG - 1);
+                stage = stage + 1 == STG ? 0 : stage + 1;
+                fill = fill + 1 == STG ? 0 : fill + 1;
+                continue;
+            }
             // Fragment reads are ordered so that the first MFMA waits only for ITS operands (B n-tile 0, A m-tile 0):
             // all 8 waves hit the LDS at once here, and a wave that waited for its whole 15-read burst would idle the
             // matrix pipe for ~450 cycles per k block.  The scale reads come last; they are first needed LAG steps later.
@@ -718,7 +734,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
 #pragma unroll
                         for (int idx = (i * Cfg::LOADS_PER_STAGE) / ISSUE_STEPS;
                              idx < ((i + 1) * Cfg::LOADS_PER_STAGE) / ISSUE_STEPS; ++idx)
-                            issue_one(idx, stage ^ 1, kb + 1);
+                            issue_one(idx, fill, kb + STG - 1);
                     }
 #endif
                     // next n-tile's fragment: issued right AFTER this n-tile's first MFMA, so that the (whole-counter)
@@ -755,6 +771,8 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
                 __builtin_amdgcn_sched_barrier(0);
             }
             DGA_STAMP(4);                            // segment 4: the MFMA / promotion pipeline (+ refill DMA issue)
+            stage = stage + 1 == STG ? 0 : stage + 1;
+            fill = fill + 1 == STG ? 0 : fill + 1;
         }
         DGA_STAMP_CLOCK(6, 7);
         DGA_STAMP_FLUSH();

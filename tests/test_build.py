@@ -1,0 +1,30 @@
+"""CPU: compile-time guards on the HIP kernels (hipcc cross-compiles for gfx950 without a GPU).
+A register spill in the MFMA pipeline is a silent 1.6x slowdown (seen in r01 when a runtime branch was added
+inside the software pipeline), so no kernel may spill or use scratch."""
+import re
+import subprocess
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "deepgemm_ascend_amd" / "csrc"
+
+
+def test_no_kernel_spills_or_scratch():
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT / 'include'}", f"-I{CSRC}",
+           "-fno-slp-vectorize", "-x", "hip", "--cuda-device-only", "-S", "-o", "/dev/null",
+           "-Rpass-analysis=kernel-resource-usage", str(CSRC / "dga_launch.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    name, seen = None, 0
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            seen += 1
+        m = re.search(r"(VGPRs Spill|SGPRs Spill|ScratchSize \[bytes/lane\]): (\d+)", line)
+        if m:
+            assert int(m.group(2)) == 0, f"{name}: {m.group(1)} = {m.group(2)}"
+        m = re.search(r"VGPRs: (\d+)", line)
+        if m and "gemm_fp8_blockscaled_nt_kernel" in (name or ""):
+            assert int(m.group(1)) <= 256, name
+    assert seen >= 40
