@@ -60,6 +60,17 @@ def make_dense_inputs(m, n, k, seed):
     return qa.contiguous(), sa.contiguous().float(), qb.contiguous(), sb.contiguous().float()
 
 
+def pmc_traffic(workload: str):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate passes and corrected as MI355X_MICROARCH.md prescribes).  PMC counters cannot be
+    read from inside this process, so this is the figure of the profiled run of the same kernel, not of this run."""
+    try:
+        d = json.loads((ROOT / "profiles" / "r01_traffic.json").read_text())
+        return int(d[workload]["traffic_bytes"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(m, n, k, a, sfa, b, sfb, budget_s=15.0):
     """The CPU oracle (oracle/dga_oracle.c, kind "port") on a bounded row sample of the same workload."""
     import numpy as np
@@ -74,16 +85,22 @@ def cpu_baseline(m, n, k, a, sfa, b, sfb, budget_s=15.0):
     rows = int(min(m, max(cores, probe * budget_s / dt)))
     rows -= rows % cores or 0
     rows = max(rows, cores)
+    reps = 0
     t0 = time.perf_counter()
-    O.gemm_fp8_fp8_bf16_nt(an[:rows], san[:rows], bn, sbn, threads=cores)
-    dt = time.perf_counter() - t0
+    while True:
+        O.gemm_fp8_fp8_bf16_nt(an[:rows], san[:rows], bn, sbn, threads=cores)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= 0.6 * budget_s or reps >= 50:
+            break
+    dt /= reps
     # the reference's own CPU path restated: np.matmul(f32, f32) per 128-wide k block (BLAS), same rows
     t1 = time.perf_counter()
     O.np_gemm_fp8_fp8_bf16_nt(an[:min(rows, 512)], san[:min(rows, 512)], bn, sbn)
     dt_blas = time.perf_counter() - t1
     return {
         "value": round(2.0 * rows * n * k / dt / 1e12, 6), "unit": "TFLOP/s", "cores": cores, "kind": "port",
-        "sample": f"first {rows} of {m} rows of A against all of B ({dt:.1f} s of scalar fp32-accumulate oracle)",
+        "sample": f"first {rows} of {m} rows of A against all of B, {reps} passes of {dt:.2f} s each (scalar fp32-accumulate C oracle, one thread per core)",
         "blas_value": round(2.0 * min(rows, 512) * n * k / dt_blas / 1e12, 6),
         "blas_note": "reference golden formula np.matmul(f32,f32) per k block, numpy BLAS threads",
     }
@@ -179,11 +196,14 @@ def main():
         "config": {"workload": f"{args.workload}: gemm_fp8_fp8_bf16_nt M={m} N={n} K={k}, per-1x128 / per-128x128 f32 scales, bf16 out",
                    "tile": f"{t.m1}x{t.n1}x{t.k1}", "parallelism": "replicas" if world > 1 else "single"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_FP8_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / PEAK_FP8_TFLOPS, 4),
+                     "traffic": pmc_traffic("dense") if args.workload == "dense_4096" else None,
                      "kernel_us": round(kernel_us, 3), "algorithmic_bytes": alg_bytes,
                      "kernel": "gemm_fp8_blockscaled_nt_kernel"},
     }
     if grouped is not None:
+        if isinstance(grouped.get("roofline"), dict) and world == 1 and args.groups == 256 and args.grouped_mask == "full":
+            grouped["roofline"]["traffic"] = pmc_traffic("grouped")
         res["grouped"] = grouped
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(m, n, k, a, sfa, b, sfb, budget_s=args.cpu_budget)

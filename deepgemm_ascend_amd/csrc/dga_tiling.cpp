@@ -551,14 +551,16 @@ int dga_tiling(const dga_problem_t *problem, dga_tiling_t *out)
     if (!problem || !out) return DGA_E_NULL;
     init_params(*problem, *out);
     if (Cache::instance().get(*out)) {
-        complete_from_menu(*out);
-        if (!out->swizzleOffset || out->groups >= 1) {
-            // raster group is derived, not cached
-            dga_tiling_t fresh;
-            if (dga_select_kernel(problem, nullptr, &fresh) == DGA_OK && fresh.m1 == out->m1 && fresh.n1 == out->n1)
-                out->swizzleOffset = fresh.swizzleOffset;
-            else
-                out->swizzleOffset = 4;
+        // The cache (and its CSV) stores the reference's columns only; the CDNA4-only fields (waves, stages, LDS bytes,
+        // raster group) are re-derived.  If the cached tile is the one the heuristic would pick, take the heuristic's
+        // build of it; a tile that came from a sweep / hand-written CSV gets the menu's first build of that size.
+        dga_tiling_t fresh;
+        if (dga_select_kernel(problem, nullptr, &fresh) == DGA_OK && fresh.m1 == out->m1 && fresh.n1 == out->n1) {
+            out->wavesM = fresh.wavesM; out->wavesN = fresh.wavesN; out->stages = fresh.stages;
+            out->ldsBytes = fresh.ldsBytes; out->swizzleOffset = fresh.swizzleOffset;
+        } else {
+            complete_from_menu(*out);
+            out->swizzleOffset = 4;
         }
         return DGA_OK;
     }

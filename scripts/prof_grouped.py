@@ -1,0 +1,19 @@
+"""Launch the grouped masked-M GEMM a few times (for rocprofv3 runs)."""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+import deepgemm_ascend_amd as dga
+G, MMAX, N, K = 256, 128, 2048, 7168
+g = torch.Generator(device="cuda").manual_seed(0)
+def rf(shape):
+    x = torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda", generator=g)
+    return torch.where((x & 0x7F) == 0x7F, x & 0x80, x)
+a = rf((G, MMAX, K)); b = rf((G, N, K))
+sfa = torch.rand((G, MMAX, K // 128), device="cuda") + 0.5; sfb = torch.rand((G, N // 128, K // 128), device="cuda") + 0.5
+out = torch.zeros((G, MMAX, N), dtype=torch.bfloat16, device="cuda")
+masked = torch.full((G,), MMAX, dtype=torch.int32, device="cuda")
+for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10):
+    dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), out, masked, MMAX)
+torch.cuda.synchronize()
+print("done")
