@@ -46,6 +46,22 @@ def _fp8_bytes(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+_WORKSPACES = {}
+
+
+def _workspace(t: Tiling, device) -> Tuple[Optional[int], int]:
+    """Device scratch for split-K slabs / odd-K padding, sized by dga_workspace_bytes and kept per device
+    (grow-only).  The callee never allocates (the op runtime hands the workspace in)."""
+    need = workspace_bytes(t)
+    if need == 0:
+        return None, 0
+    buf = _WORKSPACES.get(device)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty((need,), dtype=torch.uint8, device=device)
+        _WORKSPACES[device] = buf
+    return buf.data_ptr(), buf.numel()
+
+
 def _device_guard(*ts: torch.Tensor):
     dev = ts[0].device
     for t in ts:
@@ -181,9 +197,12 @@ def gemm_fp8_fp8_bf16_nt(lhs: Tuple[torch.Tensor, torch.Tensor], rhs: Tuple[torc
     for t in (a, b, sfa, sfb, out):
         _require(t.is_contiguous(), "operands must be contiguous")
     with _device_guard(a, b, sfa, sfb, out):
-        tp = ctypes.byref(tiling_) if tiling_ is not None else None
+        if tiling_ is None:
+            tiling_ = tiling(m, n, k)
+        ws_ptr, ws_bytes = _workspace(tiling_, out.device)
         rc = _lib.lib().dga_gemm_fp8_fp8_bf16_nt(a.data_ptr(), sfa.data_ptr(), b.data_ptr(), sfb.data_ptr(),
-                                                 out.data_ptr(), m, n, k, tp, None, 0, _stream_ptr(out))
+                                                 out.data_ptr(), m, n, k, ctypes.byref(tiling_), ws_ptr, ws_bytes,
+                                                 _stream_ptr(out))
         _lib.check(rc, "gemm_fp8_fp8_bf16_nt")
         if sync:
             torch.cuda.current_stream(out.device).synchronize()
@@ -208,10 +227,12 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_masked(lhs, rhs, out: torch.Tensor, masked_m:
     for t in (a, b, sfa, sfb, out, masked_m):
         _require(t.is_contiguous(), "operands must be contiguous")
     with _device_guard(a, b, sfa, sfb, out, masked_m):
-        tp = ctypes.byref(tiling_) if tiling_ is not None else None
+        if tiling_ is None:
+            tiling_ = tiling(mmax, n, k, groups=g, expected_m=int(expected_m))
+        ws_ptr, ws_bytes = _workspace(tiling_, out.device)
         rc = _lib.lib().dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked(
             a.data_ptr(), sfa.data_ptr(), b.data_ptr(), sfb.data_ptr(), out.data_ptr(), masked_m.data_ptr(),
-            g, mmax, n, k, int(expected_m), tp, None, 0, _stream_ptr(out))
+            g, mmax, n, k, int(expected_m), ctypes.byref(tiling_), ws_ptr, ws_bytes, _stream_ptr(out))
         _lib.check(rc, "m_grouped_gemm_fp8_fp8_bf16_nt_masked")
         if sync:
             torch.cuda.current_stream(out.device).synchronize()

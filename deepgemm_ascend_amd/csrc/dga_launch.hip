@@ -112,7 +112,6 @@ static int run_fp8(const void *a, const float *sfa, const void *b, const float *
                    const int32_t *masked_m, int groups, int m, int n, int k, int expected_m,
                    const dga_tiling_t *tiling, void *workspace, size_t workspace_bytes, hipStream_t stream)
 {
-    (void)workspace;
     if (m < 0 || n < 0 || k < 0 || groups < 0) return DGA_E_SHAPE;
     if (groups == 0 || m == 0 || n == 0) return DGA_OK;  // empty problem: nothing to write
     if (!a || !b || !sfa || !sfb || !out) {
@@ -129,8 +128,9 @@ static int run_fp8(const void *a, const float *sfa, const void *b, const float *
         if (rc != DGA_OK) return rc;
         tiling = &local;
     }
-    if (dga_workspace_bytes(tiling) > workspace_bytes) return DGA_E_WORKSPACE;
-
+    // workspace == NULL is allowed (split-K and the odd-K padding pass are then skipped: single-pass / element-wise
+    // kernels, same results); a workspace that is passed must be as large as dga_workspace_bytes() says
+    if (workspace && dga_workspace_bytes(tiling) > workspace_bytes) return DGA_E_WORKSPACE;
     GemmParams p{};
     p.a = static_cast<const uint8_t *>(a);
     p.sfa = sfa;
@@ -148,11 +148,43 @@ static int run_fp8(const void *a, const float *sfa, const void *b, const float *
     p.sfa_gs = static_cast<int64_t>(m) * p.kb_n;
     p.sfb_gs = static_cast<int64_t>(p.nb_n) * p.kb_n;
     p.groups = groups;
+    p.splitk = 1;
+
+    // ---- workspace carve: [padded A | padded B] (K % 16 != 0), then [split-K slabs]
+    uint8_t *ws = static_cast<uint8_t *>(workspace);
+    size_t ws_used = 0;
+    auto carve = [&](size_t bytes) -> uint8_t * {
+        const size_t at = (ws_used + 255) & ~size_t(255);
+        if (!ws || at + bytes > workspace_bytes) return nullptr;
+        ws_used = at + bytes;
+        return ws + at;
+    };
+    if (k > 0 && (k % 16) != 0) {
+        const int kp = p.kb_n * 128;
+        const int64_t rows_a = static_cast<int64_t>(groups) * m, rows_b = static_cast<int64_t>(groups) * n;
+        uint8_t *pa = carve(static_cast<size_t>(rows_a) * kp);
+        uint8_t *pb = pa ? carve(static_cast<size_t>(rows_b) * kp) : nullptr;
+        if (pa && pb) {
+            const int cpr = kp / 16;
+            hipLaunchKernelGGL(pad_rows_kernel, dim3(static_cast<unsigned>((rows_a * cpr + 255) / 256)), dim3(256), 0,
+                               stream, p.a, pa, rows_a, k, kp);
+            hipLaunchKernelGGL(pad_rows_kernel, dim3(static_cast<unsigned>((rows_b * cpr + 255) / 256)), dim3(256), 0,
+                               stream, p.b, pb, rows_b, k, kp);
+            DGA_HIP_TRY(hipGetLastError());
+            p.a = pa; p.b = pb;
+            p.k = kp; p.lda = kp; p.ldb = kp;
+            p.a_gs = static_cast<int64_t>(m) * kp;
+            p.b_gs = static_cast<int64_t>(n) * kp;
+            k = kp;  // the padded operands are what the tile kernel sees (scales and k-block count are unchanged)
+        }
+        // no (or too small a) workspace: the element-wise kernel below still computes the right answer
+    }
+
     // LDS-DMA kernel: 16-byte chunks (K % 16 == 0, 16-byte aligned bases) and 32-bit in-tile byte offsets
-    const bool fast_ok = (k % 16 == 0) && k > 0 && ((reinterpret_cast<uintptr_t>(a) & 15) == 0) &&
-                         ((reinterpret_cast<uintptr_t>(b) & 15) == 0) && (static_cast<int64_t>(k) * 257 < 0x7FFFFFFFll);
+    const bool fast_ok = (k % 16 == 0) && k > 0 && ((reinterpret_cast<uintptr_t>(p.a) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(p.b) & 15) == 0) && (static_cast<int64_t>(k) * 257 < 0x7FFFFFFFll);
     if (!fast_ok) {
-        // K not a multiple of the 16-byte DMA chunk (or k == 0): element-wise kernel
+        // K not a multiple of the 16-byte DMA chunk and no workspace to pad into (or k == 0): element-wise kernel
         dim3 grid((n + 15) / 16, (m + 15) / 16, groups);
         hipLaunchKernelGGL(gemm_fp8_blockscaled_nt_generic_kernel, grid, dim3(256), 0, stream, p);
         DGA_HIP_TRY(hipGetLastError());
@@ -165,6 +197,29 @@ static int run_fp8(const void *a, const float *sfa, const void *b, const float *
     p.raster_group = tiling->swizzleOffset ? tiling->swizzleOffset : 1;
     static const int xcd_remap = [] { const char *e = std::getenv("DGA_XCD_REMAP"); return e ? std::atoi(e) : 1; }();
     p.xcd_remap = xcd_remap;
+
+    // ---- split-K (kernelSerial 4): partial fp32 slabs + combine; dense only
+    if (tiling->splitkFactor > 1 && groups == 1 && !masked_m) {
+        int s = tiling->splitkFactor;
+        const int kbps = (p.kb_n + s - 1) / s;
+        s = (p.kb_n + kbps - 1) / kbps;  // no empty split
+        float *slabs = s > 1 ? reinterpret_cast<float *>(carve(static_cast<size_t>(s) * m * n * sizeof(float))) : nullptr;
+        if (slabs) {
+            p.splitk = s;
+            p.kb_per_split = kbps;
+            p.partial = slabs;
+            GemmParams pk = p;
+            pk.groups = s;  // grid = splitk x tiles
+            int rc = v->launch(pk, stream);
+            if (rc != DGA_OK) return rc;
+            const int64_t mn = static_cast<int64_t>(m) * n;
+            hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3(static_cast<unsigned>((mn / 8 + 255) / 256 + 1)), dim3(256),
+                               0, stream, slabs, p.out, mn, s);
+            DGA_HIP_TRY(hipGetLastError());
+            return DGA_OK;
+        }
+        // workspace missing: fall through to the single-pass kernel (same result, fewer CUs busy)
+    }
     static const int pp_env = [] { const char *e = std::getenv("DGA_PINGPONG"); return e ? std::atoi(e) : -1; }();
     const int policy = pp_env >= 0 ? pp_env : tiling->dispatchPolicyTag;
     if (policy == 1 && v->launch_pp) return v->launch_pp(p, stream);

@@ -295,6 +295,10 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
         seen.push_back(e);
         if (static_cast<uint64_t>(e.lds) > pf.l1Size) continue;
         if (4ull * e.bm * e.bn > pf.l0CSize) continue;  // accumulators: JudgeSpace's L0C test on VGPRs
+        // M fits one tile row (decode / grouped shapes): B is the whole stream, so never cut M (every extra tile row
+        // re-reads B) -- take the smallest tile height that covers M and let N tiles and split-K supply parallelism
+        if (m_eff <= 128 && e.bm != static_cast<int>(std::max(16u, round_up(m_eff, m_eff <= 16 ? 16 : m_eff <= 32 ? 32 : m_eff <= 64 ? 64 : 128))))
+            continue;
         const uint32_t wg_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(pf.l1Size / e.lds, 2048 / (e.wm * e.wn * 64)));
         const uint64_t tiles = static_cast<uint64_t>(groups) * ceil_div(m_eff, e.bm) * ceil_div(t.n, e.bn);
         const uint64_t slots = static_cast<uint64_t>(pf.coreNum) * wg_per_cu;
@@ -320,8 +324,22 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
     const uint64_t blocks = static_cast<uint64_t>(groups) * tiles_m * tiles_n;
     t.blockDim = static_cast<uint32_t>(blocks);
     t.paddingTagA = t.paddingTagB = t.paddingTagC = DGA_PADDING_NONE;
-    // variant menu in the reference's order: Small (one tile per core, single K step) -> Common
+    // variant menu in the reference's order: Small (one tile per core, single K step) -> Stream-K -> Common.
+    // Stream-K handler (select_kernel.cpp:303-331, CDNA4 reading): when the tiles fill less than half of the CUs and K
+    // is long, K is cut so that every CU streams a share of the operands; the fp32 partial tiles are combined by a
+    // second kernel.  Worth it only while the partial slabs stay small next to the operand stream.
     t.kernelSerial = (blocks <= pf.coreNum && t.k <= t.k1) ? DGA_KERNEL_SMALL : DGA_KERNEL_COMMON;
+    if (groups == 1 && blocks * 4 <= pf.coreNum * 3 && kb >= 8) {
+        uint32_t s = std::min<uint32_t>({pf.coreNum * 2 / static_cast<uint32_t>(blocks), kb / 4, 32u});
+        const uint64_t operand_bytes = static_cast<uint64_t>(t.m + t.n) * t.k;
+        while (s > 1 && static_cast<uint64_t>(s) * t.m * t.n * 8 * 2 > operand_bytes) --s;  // slab write + read <= half the operand read
+        if (s > 1) {
+            const uint32_t per = ceil_div(kb, s);
+            t.splitkFactor = static_cast<uint16_t>(ceil_div(kb, per));
+            t.kernelSerial = DGA_KERNEL_STREAMK;
+            t.blockDim = static_cast<uint32_t>(blocks) * t.splitkFactor;
+        }
+    }
     // raster: walk `swizzleOffset` tile-rows together so that an XCD's slice of the grid
     // (blocks/8 consecutive tiles) is a near-square patch sharing A and B panels in its L2.
     const uint32_t per_xcd = std::max<uint32_t>(1, static_cast<uint32_t>(blocks / std::max(1u, pf.xcdNum)));
@@ -577,9 +595,16 @@ int dga_tiling_cache_size(void) { return Cache::instance().size(); }
 size_t dga_workspace_bytes(const dga_tiling_t *tiling)
 {
     if (!tiling) return 0;
-    if (tiling->kernelSerial == DGA_KERNEL_STREAMK && tiling->splitkFactor > 1)
-        return static_cast<size_t>(tiling->splitkFactor) * tiling->m * tiling->n * 4 + 4096;
-    return 0;
+    size_t bytes = 0;
+    auto add = [&](size_t b) { bytes = ((bytes + 255) & ~size_t(255)) + b; };
+    const size_t groups = tiling->groups ? tiling->groups : 1;
+    if (tiling->k % 16 != 0 && tiling->k > 0) {  // padded copies of A and B (rows zero-filled to a multiple of 128)
+        const size_t kp = (static_cast<size_t>(tiling->k) + 127) / 128 * 128;
+        add(groups * tiling->m * kp);
+        add(groups * tiling->n * kp);
+    }
+    if (tiling->splitkFactor > 1) add(static_cast<size_t>(tiling->splitkFactor) * tiling->m * tiling->n * 4);
+    return bytes ? bytes + 256 : 0;
 }
 
 const char *dga_status_string(int status)

@@ -48,6 +48,8 @@ struct GemmParams {
     int tiles_m, tiles_n, groups;
     int raster_group;            // tile-rows walked together (swizzleOffset analogue, tiling_params.h:63)
     int xcd_remap;               // 1: contiguous tile chunk per XCD (blocks b, b+8, ... share an XCD)
+    float *partial;              // split-K: fp32 slabs [splitk][m][n] in the caller's workspace (dense only)
+    int splitk, kb_per_split;    // splitk > 1: block -> (split, tile); split s covers k blocks [s*kb_per_split, +kb_per_split)
     unsigned long long *stamps;  // diagnostic builds only (-DDGA_STAMPS): per-wave segment cycle sums
 };
 
@@ -184,8 +186,11 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         tile = p.xcd_remap ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3) : bid;
     }
     const int tiles_per_group = p.tiles_m * p.tiles_n;
-    const int g = tile / tiles_per_group;
-    int t_in = tile - g * tiles_per_group;
+    // split-K (dense only, groups == 1): the grid is splitk x tiles, split-major, so the splits of one tile run on
+    // different XCDs/CUs at the same time; grouped: group-major
+    const int split = p.splitk > 1 ? tile / tiles_per_group : 0;
+    const int g = p.splitk > 1 ? 0 : tile / tiles_per_group;
+    int t_in = tile - (p.splitk > 1 ? split : g) * tiles_per_group;
     int tm, tn;
     {
         const int gm = p.raster_group;
@@ -200,6 +205,8 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
     const int M = p.masked_m ? min(p.masked_m[g], p.m) : p.m;
     const int m0 = tm * BM, n0 = tn * BN;
     if (m0 >= M) return;  // empty expert / fully masked tile: nothing read, nothing written
+    const int kb_begin = p.splitk > 1 ? split * p.kb_per_split : 0;
+    const int kb_end = p.splitk > 1 ? min(p.kb_n, kb_begin + p.kb_per_split) : p.kb_n;
 
     const uint8_t *A = p.a + (int64_t)g * p.a_gs;
     const uint8_t *B = p.b + (int64_t)g * p.b_gs;
@@ -294,6 +301,29 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
     auto epilogue = [&](v4f (&acc)[TM][TN]) {
         const int m_row = m0 + wm * (BM / Cfg::kWM) + li;
         const int n_base = n0 + wn * (BN / WN) + 8 * kg;
+        if (p.splitk > 1) {
+            // split-K: this block's fp32 partial tile goes to its slab; lane owns 4 consecutive n per MFMA tile
+            float *slab = p.partial + (int64_t)split * p.m * p.n;
+            const bool v_ok = (p.n & 3) == 0;
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const int m = m_row + mt * 16;
+                if (m >= M) continue;
+                float *prow = slab + (int64_t)m * p.n;
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt) {
+                    const int n = n_base + 32 * (nt >> 1) + 4 * (nt & 1);
+                    if (v_ok && n + 4 <= p.n) {
+                        *(v4f *)(prow + n) = acc[mt][nt];
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (n + q < p.n) prow[n + q] = acc[mt][nt][q];
+                    }
+                }
+            }
+            return;
+        }
         const bool vec_ok = ((p.ldc & 7) == 0) && ((((uintptr_t)C) & 15) == 0);
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt) {
@@ -668,18 +698,17 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         //      issue per k block: the vector-memory path takes 64 B/clk/CU; measured with the -DDGA_STAMPS build.)
         // With STAGES = 3 (tiles whose stage is <= 48 KB) two refills are in flight instead of one: the wait at the
         // top leaves the newest batch outstanding.
-        const int KB = p.kb_n;
         constexpr int STG = Cfg::STAGES;
         DGA_STAMP_DECL
 #pragma unroll
         for (int d = 0; d < STG - 1; ++d)
 #pragma unroll
-            for (int idx = 0; idx < Cfg::LOADS_PER_STAGE; ++idx) issue_one(idx, d, d);
+            for (int idx = 0; idx < Cfg::LOADS_PER_STAGE; ++idx) issue_one(idx, d, kb_begin + d);
         DGA_STAMP_START();
         DGA_STAMP_CLOCK(6, 7);   // slots 6/7: shader-clock and 100 MHz real-time ticks across the main loop
         int stage = 0, fill = STG - 1;   // stage being consumed / stage being refilled (with k block kb + STG - 1)
         const bool wave_has_rows = m0 + wm * (BM / Cfg::kWM) < M;  // wave-uniform (wm comes from readfirstlane)
-        for (int kb = 0; kb < KB; ++kb) {
+        for (int kb = kb_begin; kb < kb_end; ++kb) {
             wait_vmcnt<(STG - 2) * Cfg::LOADS_PER_STAGE>();
             DGA_STAMP(1);                            // segment 1: vmcnt wait
             __builtin_amdgcn_s_barrier();
@@ -816,6 +845,51 @@ __global__ void __launch_bounds__(256) gemm_fp8_blockscaled_nt_generic_kernel(co
     }
     const v2bf h = __builtin_convertvector(v2f{acc, 0.f}, v2bf);
     p.out[(int64_t)g * p.c_gs + (int64_t)m * p.ldc + n] = (uint16_t)(__builtin_bit_cast(uint32_t, h) & 0xFFFFu);
+}
+
+// split-K combine: out[m][n] = bf16( sum_s slab[s][m][n] ), s ascending (= k ascending; deterministic).  The fp32
+// counterpart of the reference's StreamkReduceAdd (op_kernel/kernel/padding_streamk_matmul_kernel.h:96-98).
+__global__ void __launch_bounds__(256) splitk_reduce_bf16_kernel(const float *partial, uint16_t *out, int64_t mn,
+                                                                 int splitk)
+{
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= mn) return;
+    if (((mn & 7) == 0) && ((((uintptr_t)out) & 15) == 0)) {
+        v4f a0 = *(const v4f *)(partial + i), a1 = *(const v4f *)(partial + i + 4);
+        for (int s = 1; s < splitk; ++s) {
+            a0 += *(const v4f *)(partial + (int64_t)s * mn + i);
+            a1 += *(const v4f *)(partial + (int64_t)s * mn + i + 4);
+        }
+        const v2bf h0 = __builtin_convertvector(v2f{a0.x, a0.y}, v2bf), h1 = __builtin_convertvector(v2f{a0.z, a0.w}, v2bf);
+        const v2bf h2 = __builtin_convertvector(v2f{a1.x, a1.y}, v2bf), h3 = __builtin_convertvector(v2f{a1.z, a1.w}, v2bf);
+        *(v4i *)(out + i) = v4i{__builtin_bit_cast(int, h0), __builtin_bit_cast(int, h1), __builtin_bit_cast(int, h2),
+                               __builtin_bit_cast(int, h3)};
+    } else {
+        for (int q = 0; q < 8 && i + q < mn; ++q) {
+            float acc = partial[i + q];
+            for (int s = 1; s < splitk; ++s) acc += partial[(int64_t)s * mn + i + q];
+            const v2bf h = __builtin_convertvector(v2f{acc, 0.f}, v2bf);
+            out[i + q] = (uint16_t)(__builtin_bit_cast(uint32_t, h) & 0xFFFFu);
+        }
+    }
+}
+
+// K not a multiple of 16: rows cannot be cut into aligned 16-byte DMA chunks.  Re-lay the operand once into the
+// workspace with its rows padded (zero-filled) to a multiple of 128 -- the CDNA4 reading of the reference's
+// PaddingCommon variant (op_kernel/kernel/padding_common_matmul_kernel.h:33-107: a re-layout pass on the vector
+// cores in front of the matmul) -- and run the LDS-DMA kernel on that.
+__global__ void __launch_bounds__(256) pad_rows_kernel(const uint8_t *src, uint8_t *dst, int64_t rows, int k, int kp)
+{
+    const int64_t chunk = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one 16-byte output chunk per thread
+    const int cpr = kp / 16;
+    const int64_t r = chunk / cpr;
+    if (r >= rows) return;
+    const int c0 = (int)(chunk - r * cpr) * 16;
+    const uint8_t *s = src + r * k + c0;
+    uint8_t v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = (c0 + j < k) ? s[j] : (uint8_t)0;
+    *(v4i *)(dst + r * kp + c0) = *(const v4i *)v;
 }
 
 }  // namespace dga

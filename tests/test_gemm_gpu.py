@@ -136,3 +136,48 @@ def test_linearity_in_scales_full_size(dga, oracle):
     want = oracle.gemm_fp8_fp8_bf16_nt(an[rows], sfa.cpu().numpy()[rows], bn, sfb.cpu().numpy(), threads=16)
     got = o1[torch.from_numpy(rows).cuda()].view(torch.int16).cpu().numpy().view(np.uint16)
     oracle.assert_parity(got, want, an[rows], sfa.cpu().numpy()[rows], bn, sfb.cpu().numpy(), eps=2.0 ** -12, frac=1e-2)
+
+
+@pytest.mark.parametrize("m,n,k,split", [(8, 1024, 4096, 4), (64, 512, 2048, 3), (100, 300, 1536, 5), (16, 128, 1024, 8)])
+def test_split_k_parity(dga, oracle, m, n, k, split):
+    """kernelSerial 4: K cut over `split` workgroups per tile, fp32 slabs in the workspace, combine kernel."""
+    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=m + n + k)
+    t = dga.tiling(m, n, k)
+    t.splitkFactor, t.kernelSerial = split, 4
+    assert dga.workspace_bytes(t) >= split * m * n * 4
+    got = _run(dga, a, sfa, b, sfb, tiling=t)
+    _check(oracle, got, a, sfa, b, sfb)
+    # the heuristic picks split-K by itself for a decode shape
+    th = dga.select_kernel(8, 7168, 18432)
+    assert th.kernelSerial == 4 and th.splitkFactor > 1 and th.blockDim == 56 * th.splitkFactor
+
+
+def test_split_k_without_workspace_still_correct(dga, oracle):
+    """The C ABI accepts workspace == NULL: the single-pass kernel runs instead (same answer)."""
+    import ctypes
+    from deepgemm_ascend_amd import _lib
+    m, n, k = 16, 256, 2048
+    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=2)
+    t = dga.tiling(m, n, k)
+    t.splitkFactor, t.kernelSerial = 4, 4
+    ta, tsa, tb, tsb = _dev(a), _dev(sfa), _dev(b), _dev(sfb)
+    out = torch.zeros((m, n), dtype=torch.bfloat16, device="cuda")
+    rc = _lib.lib().dga_gemm_fp8_fp8_bf16_nt(ta.data_ptr(), tsa.data_ptr(), tb.data_ptr(), tsb.data_ptr(), out.data_ptr(),
+                                             m, n, k, ctypes.byref(t), None, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    _check(oracle, out.view(torch.int16).cpu().numpy().view(np.uint16), a, sfa, b, sfb)
+    small = torch.empty(16, dtype=torch.uint8, device="cuda")   # a workspace that is passed must be big enough
+    rc = _lib.lib().dga_gemm_fp8_fp8_bf16_nt(ta.data_ptr(), tsa.data_ptr(), tb.data_ptr(), tsb.data_ptr(), out.data_ptr(),
+                                             m, n, k, ctypes.byref(t), small.data_ptr(), 16, 0)
+    assert rc == -7
+
+
+@pytest.mark.parametrize("m,n,k", [(129, 257, 1001), (64, 384, 1921), (5, 130, 17)])
+def test_odd_k_padding_pass(dga, oracle, m, n, k):
+    """K % 16 != 0 with a workspace: operands are re-laid with zero-padded rows, then the LDS-DMA kernel runs."""
+    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=k)
+    t = dga.tiling(m, n, k)
+    assert dga.workspace_bytes(t) >= (m + n) * (-(-k // 128) * 128)
+    got = _run(dga, a, sfa, b, sfb)
+    _check(oracle, got, a, sfa, b, sfb)

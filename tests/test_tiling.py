@@ -62,7 +62,8 @@ def test_mi355x_selection_is_launchable(dga):
         t = dga.select_kernel(*shape)
         assert (t.m1, t.n1) in menu and t.k1 == 128
         assert t.ldsBytes <= pf.l1Size and t.m1 * t.n1 * 4 <= pf.l0CSize
-        assert t.blockDim == -(-shape[0] // t.m1) * -(-shape[1] // t.n1)
+        assert t.blockDim == -(-shape[0] // t.m1) * -(-shape[1] // t.n1) * max(1, t.splitkFactor)
+        assert (t.kernelSerial == 4) == (t.splitkFactor > 1)
         assert (t.paddingTagA, t.paddingTagB, t.paddingTagC) == (0, 0, 0)
         assert t.swizzleOffset >= 1
     t = dga.select_kernel(4096, 4096, 4096)
