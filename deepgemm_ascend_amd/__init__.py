@@ -10,6 +10,7 @@ from .api import (  # noqa: F401
     CONFIG_FIELDS,
     bbit_params,
     bench_params_fill,
+    copy_rows,
     gemm_fp8_fp8_bf16_nt,
     get_bench_config,
     get_best_config,

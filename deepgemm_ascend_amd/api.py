@@ -238,6 +238,25 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_masked(lhs, rhs, out: torch.Tensor, masked_m:
             torch.cuda.current_stream(out.device).synchronize()
 
 
+def copy_rows(dst: torch.Tensor, src: torch.Tensor, dst_index: Optional[torch.Tensor] = None,
+              src_index: Optional[torch.Tensor] = None, rows: Optional[int] = None, row_bytes: Optional[int] = None,
+              dst_byte_offset: int = 0, src_byte_offset: int = 0) -> None:
+    """Indexed row copy between 2-D (row-strided) device tensors viewed as bytes (dga_copy_rows)."""
+    _require(dst.dim() == 2 and src.dim() == 2 and dst.stride(1) == 1 and src.stride(1) == 1, "2-D row tensors")
+    n = rows if rows is not None else (dst_index.numel() if dst_index is not None else
+                                       src_index.numel() if src_index is not None else src.shape[0])
+    rb = row_bytes if row_bytes is not None else min(dst.shape[1] * dst.element_size(), src.shape[1] * src.element_size())
+    for ix in (dst_index, src_index):
+        if ix is not None:
+            _require(ix.dtype == torch.int64 and ix.is_contiguous() and ix.numel() >= n, "index must be int64[rows]")
+    with _device_guard(dst, src):
+        rc = _lib.lib().dga_copy_rows(dst.data_ptr() + dst_byte_offset, dst.stride(0) * dst.element_size(),
+                                      dst_index.data_ptr() if dst_index is not None else None,
+                                      src.data_ptr() + src_byte_offset, src.stride(0) * src.element_size(),
+                                      src_index.data_ptr() if src_index is not None else None, rb, n, _stream_ptr(dst))
+        _lib.check(rc, "copy_rows")
+
+
 # ----------------------------------------------------------------------------- the framework's 16-bit entry points
 
 def _dt16(t: torch.Tensor) -> int:

@@ -1,0 +1,61 @@
+// Indexed row copy: the pack / unpack step on either side of the expert-sharding all-to-all
+// (deepgemm_ascend_amd/parallel.py).  No reference counterpart: the reference has no collective and no
+// token routing (SURVEY.md section 2 "Parallelism / communication: none implemented"); this belongs to row 8(e).
+//   dst[ (dst_index ? dst_index[r] : r) * dst_stride + 0 .. row_bytes ) = src[ (src_index ? src_index[r] : r) * src_stride + ... )
+// HBM-bound byte work: one workgroup per row (several for long rows), 16-byte lanes when everything is 16-byte aligned.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "dga_hip.h"
+#include "dga_internal.hpp"
+
+namespace dga {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) copy_rows_kernel(uint8_t *dst, int64_t dst_stride, const int64_t *dst_index,
+                                                        const uint8_t *src, int64_t src_stride, const int64_t *src_index,
+                                                        int64_t row_bytes, int64_t rows, int parts)
+{
+    const int64_t r = blockIdx.x / parts;
+    const int part = blockIdx.x % parts;
+    if (r >= rows) return;
+    const int64_t dr = dst_index ? dst_index[r] : r, sr = src_index ? src_index[r] : r;
+    uint8_t *d = dst + dr * dst_stride;
+    const uint8_t *s = src + sr * src_stride;
+    if (VEC) {
+        const int64_t chunks = row_bytes / 16;
+        for (int64_t c = part * 256 + threadIdx.x; c < chunks; c += 256 * parts)
+            *(v4i *)(d + c * 16) = *(const v4i *)(s + c * 16);
+    } else {
+        for (int64_t c = part * 256 + threadIdx.x; c < row_bytes; c += 256 * parts) d[c] = s[c];
+    }
+}
+
+}  // namespace dga
+
+extern "C" int dga_copy_rows(void *dst, int64_t dst_row_stride, const int64_t *dst_index, const void *src,
+                             int64_t src_row_stride, const int64_t *src_index, int64_t row_bytes, int64_t rows,
+                             void *stream)
+{
+    if (rows < 0 || row_bytes < 0) return DGA_E_SHAPE;
+    if (rows == 0 || row_bytes == 0) return DGA_OK;
+    if (!dst || !src) return DGA_E_NULL;
+    const bool vec = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) | dst_row_stride |
+                       src_row_stride | row_bytes) & 15) == 0;
+    int parts = static_cast<int>((row_bytes / (vec ? 16 : 1) + 256 * 4 - 1) / (256 * 4));  // <= 4 chunks per thread
+    if (parts < 1) parts = 1;
+    if (parts > 64) parts = 64;
+    if (rows * parts > 0x7FFFFFFFll) return DGA_E_RANGE;
+    dim3 grid(static_cast<unsigned>(rows * parts));
+    if (vec)
+        hipLaunchKernelGGL(dga::copy_rows_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<uint8_t *>(dst), dst_row_stride, dst_index, static_cast<const uint8_t *>(src),
+                           src_row_stride, src_index, row_bytes, rows, parts);
+    else
+        hipLaunchKernelGGL(dga::copy_rows_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<uint8_t *>(dst), dst_row_stride, dst_index, static_cast<const uint8_t *>(src),
+                           src_row_stride, src_index, row_bytes, rows, parts);
+    return dga::record_hip(hipGetLastError());
+}

@@ -38,6 +38,22 @@ def _default_compute(a, sfa, b, sfb, out, masked_m, expected_m):
     api.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), out, masked_m, expected_m)
 
 
+def _rows(dst, src, dst_index=None, src_index=None, row_bytes=None, dst_off=0, src_off=0):
+    """Indexed row copy on byte views: the HIP kernel (dga_copy_rows) for device tensors; torch indexing for the CPU
+    tensors of the gloo routing tests (where nothing in this module touches a GPU)."""
+    if dst.is_cuda:
+        from . import api
+        api.copy_rows(dst, src, dst_index, src_index, row_bytes=row_bytes, dst_byte_offset=dst_off,
+                      src_byte_offset=src_off)
+        return
+    rb = row_bytes if row_bytes is not None else min(dst.shape[1], src.shape[1])
+    s = src[:, src_off:src_off + rb] if src_index is None else src[src_index, src_off:src_off + rb]
+    if dst_index is None:
+        dst[:s.shape[0], dst_off:dst_off + rb] = s
+    else:
+        dst[dst_index, dst_off:dst_off + rb] = s
+
+
 class ExpertShardedGroupedGemm:
     def __init__(self, rank: int, world: int, groups_total: int, m_max: int, n: int, k: int, device,
                  dist=None, compute: Optional[Callable] = None):
@@ -69,7 +85,7 @@ class ExpertShardedGroupedGemm:
     def dispatch(self, tok_q: torch.Tensor, tok_sf: torch.Tensor, expert_ids: torch.Tensor) -> RouteState:
         """tok_q [T,K] u8, tok_sf [T,KB] f32, expert_ids [T] int64 (global expert of each token)."""
         T = tok_q.shape[0]
-        order = torch.argsort(expert_ids, stable=True)
+        order = torch.argsort(expert_ids, stable=True).contiguous()
         counts = torch.bincount(expert_ids, minlength=self.G).to(torch.int64)        # [G]
         if self.world > 1:
             flat = torch.empty((self.world * self.G,), dtype=torch.int64, device=counts.device)
@@ -80,10 +96,10 @@ class ExpertShardedGroupedGemm:
         mine = allc[:, self.rank * self.Gl:(self.rank + 1) * self.Gl]                # [world, Gl] rows I receive
         send_splits = counts.view(self.world, self.Gl).sum(1).tolist()
         recv_splits = mine.sum(1).tolist()
-        # one byte row per token: K fp8 bytes followed by KB fp32 scales
+        # one byte row per token: K fp8 bytes followed by KB fp32 scales, gathered in expert order
         payload = torch.empty((T, self.row_bytes), dtype=torch.uint8, device=tok_q.device)
-        payload[:, :self.k] = tok_q[order]
-        payload[:, self.k:] = tok_sf[order].contiguous().view(torch.uint8).view(T, 4 * self.kb)
+        _rows(payload, tok_q, src_index=order, row_bytes=self.k)
+        _rows(payload, tok_sf.view(torch.uint8), src_index=order, row_bytes=4 * self.kb, dst_off=self.k)
         total = int(sum(recv_splits))
         if self.world > 1:
             recv = torch.empty((total, self.row_bytes), dtype=torch.uint8, device=tok_q.device)
@@ -99,10 +115,10 @@ class ExpertShardedGroupedGemm:
         flat_start = start.reshape(-1)
         seg_begin = torch.cumsum(flat_cnt, 0) - flat_cnt
         idx = torch.arange(total, device=mine.device)
-        dest = torch.repeat_interleave(flat_start - seg_begin, flat_cnt) + idx
-        self.a.view(self.Gl * self.m_max, self.k)[dest] = recv[:, :self.k]
-        self.sfa.view(self.Gl * self.m_max, self.kb)[dest] = \
-            recv[:, self.k:].contiguous().view(torch.float32).view(total, self.kb)
+        dest = (torch.repeat_interleave(flat_start - seg_begin, flat_cnt) + idx).contiguous()
+        _rows(self.a.view(self.Gl * self.m_max, self.k), recv, dst_index=dest, row_bytes=self.k)
+        _rows(self.sfa.view(self.Gl * self.m_max, self.kb).view(torch.uint8), recv, dst_index=dest,
+              row_bytes=4 * self.kb, src_off=self.k)
         self.masked_m.copy_(masked.to(torch.int32))
         return RouteState(order, dest, send_splits, recv_splits, T)
 
@@ -112,14 +128,17 @@ class ExpertShardedGroupedGemm:
 
     # ------------------------------------------------------------------ combine
     def combine(self, st: RouteState) -> torch.Tensor:
-        rows = self.out.view(self.Gl * self.m_max, self.n)[st.dest]                   # arrival order
+        total = st.dest.numel()
+        rows = torch.empty((total, self.n), dtype=self.out.dtype, device=self.out.device)   # arrival order
+        _rows(rows.view(torch.uint8), self.out.view(self.Gl * self.m_max, self.n).view(torch.uint8), src_index=st.dest,
+              row_bytes=2 * self.n)
         if self.world > 1:
             back = torch.empty((st.tokens, self.n), dtype=self.out.dtype, device=rows.device)
-            self.dist.all_to_all_single(back, rows.contiguous(), st.send_splits, st.recv_splits)
+            self.dist.all_to_all_single(back, rows, st.send_splits, st.recv_splits)
         else:
             back = rows
         res = torch.empty_like(back)
-        res[st.order] = back
+        _rows(res.view(torch.uint8), back.view(torch.uint8), dst_index=st.order, row_bytes=2 * self.n)
         return res
 
     def forward(self, tok_q, tok_sf, expert_ids, expected_m: int = 0) -> torch.Tensor:

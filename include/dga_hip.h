@@ -174,6 +174,15 @@ int dga_run_mmad_rtc(const void *x, const void *y, float *z, int batch, int m, i
 int dga_run_mmad_bench(const void *x, const void *y, float *z, int m, int n, int k, int dtype,
                        const int32_t *params_host, void *stream);
 
+/* ---- expert sharding helper (the reference has no routing or collective of any kind) ------- */
+
+/* Indexed row copy on the device: for r in [0, rows):
+ *   dst[(dst_index ? dst_index[r] : r) * dst_row_stride .. +row_bytes) = src[(src_index ? src_index[r] : r) * src_row_stride ..)
+ * (strides in bytes; index arrays are device int64).  Packs token rows for the dispatch all-to-all, scatters the
+ * received rows into the masked [G, m_max, K] layout, and the reverse for the combine. */
+int dga_copy_rows(void *dst, int64_t dst_row_stride, const int64_t *dst_index, const void *src, int64_t src_row_stride,
+                  const int64_t *src_index, int64_t row_bytes, int64_t rows, void *stream);
+
 /* ---- misc -------------------------------------------------------------------------------- */
 const char *dga_status_string(int status);
 int dga_last_hip_error(void);
