@@ -391,6 +391,10 @@ public:
                 e.m1 = get("m1"); e.n1 = get("n1"); e.k1 = get("k1"); e.serial = get("kernelSerial");
                 e.pa = get("paddingTagA"); e.pb = get("paddingTagB"); e.pc = get("paddingTagC");
                 e.block_dim = get("blockDim");
+                // optional CDNA4 columns (a sweep writes them; a reference-format file simply lacks them)
+                auto opt = [&](const char *name) -> uint32_t { return col.count(name) ? get(name) : 0; };
+                e.splitk = opt("splitkFactor"); e.stages = opt("stages"); e.raster = opt("swizzleOffset");
+                e.waves_m = opt("wavesM"); e.waves_n = opt("wavesN"); e.policy = opt("dispatchPolicyTag");
                 data_[std::make_tuple(get("m"), get("n"), get("k"), 1u)] = e;
             }
         }
@@ -414,6 +418,7 @@ public:
         std::lock_guard<std::mutex> lk(mu_);
         return static_cast<int>(data_.size());
     }
+    bool last_hit_had_cdna4_columns() const { return has_cdna4_; }
     bool get(dga_tiling_t &t)
     {
         std::lock_guard<std::mutex> lk(mu_);
@@ -422,6 +427,11 @@ public:
         const Entry &e = it->second;
         t.m1 = e.m1; t.n1 = e.n1; t.k1 = e.k1; t.kernelSerial = e.serial;
         t.paddingTagA = e.pa; t.paddingTagB = e.pb; t.paddingTagC = e.pc; t.blockDim = e.block_dim;
+        t.splitkFactor = e.splitk ? static_cast<uint16_t>(e.splitk) : 1;
+        t.stages = static_cast<uint8_t>(e.stages); t.wavesM = static_cast<uint8_t>(e.waves_m);
+        t.wavesN = static_cast<uint8_t>(e.waves_n); t.dispatchPolicyTag = static_cast<uint8_t>(e.policy);
+        if (e.raster) t.swizzleOffset = static_cast<uint8_t>(e.raster);
+        has_cdna4_ = e.stages != 0;
         return true;
     }
     void put(const dga_tiling_t &t)
@@ -430,6 +440,8 @@ public:
         const auto key = std::make_tuple(t.m, t.n, t.k, t.groups);
         if (data_.count(key)) return;
         Entry e{t.m1, t.n1, t.k1, t.kernelSerial, t.paddingTagA, t.paddingTagB, t.paddingTagC, t.blockDim};
+        e.splitk = t.splitkFactor; e.stages = t.stages; e.raster = t.swizzleOffset; e.waves_m = t.wavesM;
+        e.waves_n = t.wavesN; e.policy = t.dispatchPolicyTag;
         data_[key] = e;
         if (!path_.empty() && t.groups <= 1) {  // the CSV schema has no group column: dense rows only
             std::ofstream out(path_, std::ios::app);
@@ -441,7 +453,7 @@ public:
     }
 
 private:
-    struct Entry { uint32_t m1, n1, k1, serial, pa, pb, pc, block_dim; };
+    struct Entry { uint32_t m1, n1, k1, serial, pa, pb, pc, block_dim, splitk = 0, stages = 0, raster = 0, waves_m = 0, waves_n = 0, policy = 0; };
     Cache()
     {
         const char *p = std::getenv("DGA_CACHE_FILE_PATH");
@@ -460,6 +472,7 @@ private:
         return out;
     }
     std::mutex mu_;
+    bool has_cdna4_ = false;
     std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, Entry> data_;
     std::string path_;
 };
@@ -485,7 +498,9 @@ void complete_from_menu(dga_tiling_t &t)
 {
     for (const MenuEntry &e : menu())
         if (e.bm == t.m1 && e.bn == t.n1) {
-            t.wavesM = e.wm; t.wavesN = e.wn; t.stages = 2; t.ldsBytes = e.lds;
+            if (!t.wavesM) { t.wavesM = e.wm; t.wavesN = e.wn; }
+            if (!t.stages) t.stages = 2;
+            t.ldsBytes = e.lds;
             return;
         }
 }
@@ -569,7 +584,11 @@ int dga_tiling(const dga_problem_t *problem, dga_tiling_t *out)
     if (!problem || !out) return DGA_E_NULL;
     init_params(*problem, *out);
     if (Cache::instance().get(*out)) {
-        // The cache (and its CSV) stores the reference's columns only; the CDNA4-only fields (waves, stages, LDS bytes,
+        if (Cache::instance().last_hit_had_cdna4_columns()) {  // a swept entry is complete: use it as it stands
+            complete_from_menu(*out);
+            return DGA_OK;
+        }
+        // A reference-format CSV stores the reference's columns only; the CDNA4-only fields (waves, stages, LDS bytes,
         // raster group) are re-derived.  If the cached tile is the one the heuristic would pick, take the heuristic's
         // build of it; a tile that came from a sweep / hand-written CSV gets the menu's first build of that size.
         dga_tiling_t fresh;

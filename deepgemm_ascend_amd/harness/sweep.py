@@ -40,15 +40,25 @@ class Result:
     parameters: dict = field(default_factory=dict)
 
 
+THREE_STAGE = {(128, 256), (128, 128), (64, 256)}   # tiles that also have a 3-stage build
+PINGPONG = {(256, 256)}                               # ... a ping-pong schedule (dispatchPolicyTag 1)
+
+
 def candidates(m, n, k):
     out = []
+    kb = -(-k // 128)
     for bm, bn in TILES:
         if bm >= 2 * max(m, 16) and bm > 16:      # filter_parameters analogue: tiles twice the problem are pointless
             continue
+        blocks = -(-m // bm) * -(-n // bn)
+        splits = [1] + [s for s in (2, 4, 8, 16) if blocks * s <= 1024 and kb // s >= 4 and blocks < 192]
         for r in RASTERS:
             if r > max(1, -(-m // bm)):
                 continue
-            out.append({"m1": bm, "n1": bn, "raster": r})
+            for st in ([2, 3] if (bm, bn) in THREE_STAGE else [2]):
+                for sk in splits:
+                    for pol in ([0, 1] if (bm, bn) in PINGPONG and sk == 1 else [0]):
+                        out.append({"m1": bm, "n1": bn, "raster": r, "stages": st, "splitk": sk, "policy": pol})
     return out
 
 
@@ -118,6 +128,8 @@ def benchmark_shape(shape, out_dir: Path, rank=0, num_processes=1, iters=10):
         ck_path.write_text(json.dumps({"last_process_idx": idx}) + "\n")
         t = dga.tiling(m, n, k)
         t.m1, t.n1, t.swizzleOffset = p["m1"], p["n1"], p["raster"]
+        t.stages, t.wavesM, t.wavesN, t.dispatchPolicyTag = p["stages"], 0, 0, p["policy"]
+        t.splitkFactor = p["splitk"]; t.kernelSerial = 4 if p["splitk"] > 1 else 0
         fn = lambda: dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, tiling_=t)
         fn(); torch.cuda.synchronize()
         ok, diff = is_correct(golden, out)
@@ -153,11 +165,13 @@ def main(argv=None):
     if a.cache_csv and winners:
         new = not Path(a.cache_csv).exists()
         with open(a.cache_csv, "a") as f:
-            if new:
-                f.write("m,n,k,m1,n1,k1,kernelSerial,paddingTagA,paddingTagB,paddingTagC,blockDim\n")
+            if new:   # the reference's 11 columns (csv.cpp:23-26) + the CDNA4 columns the cache reads when present
+                f.write("m,n,k,m1,n1,k1,kernelSerial,paddingTagA,paddingTagB,paddingTagC,blockDim,"
+                        "splitkFactor,stages,swizzleOffset,wavesM,wavesN,dispatchPolicyTag\n")
             for (m, n, k), p in winners:
-                blocks = -(-m // p["m1"]) * -(-n // p["n1"])
-                f.write(f"{m},{n},{k},{p['m1']},{p['n1']},128,0,0,0,0,{blocks}\n")
+                blocks = -(-m // p["m1"]) * -(-n // p["n1"]) * p["splitk"]
+                f.write(f"{m},{n},{k},{p['m1']},{p['n1']},128,{4 if p['splitk'] > 1 else 0},0,0,0,{blocks},"
+                        f"{p['splitk']},{p['stages']},{p['raster']},0,0,{p['policy']}\n")
 
 
 if __name__ == "__main__":

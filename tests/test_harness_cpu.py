@@ -47,5 +47,6 @@ def test_verify_semantics(tmp_path):
 def test_sweep_candidates_and_shapes():
     assert len(sweep.SHAPE_GROUP) == 18 and sweep.SHAPE_GROUP[0] == [4096, 4096, 4096]   # benchmark.py:24-44
     c = sweep.candidates(4096, 4096, 4096)
-    assert {"m1": 256, "n1": 256, "raster": 8} in c
+    assert {"m1": 256, "n1": 256, "raster": 8, "stages": 2, "splitk": 1, "policy": 0} in c
+    assert any(x["splitk"] > 1 for x in sweep.candidates(8, 7168, 18432))
     assert all(x["m1"] <= 16 for x in sweep.candidates(8, 7168, 18432))

@@ -124,3 +124,22 @@ def test_tiling_cache_creates_header_for_new_file(dga, tmp_path):
 
 def test_workspace_bytes(dga):
     assert dga.workspace_bytes(dga.select_kernel(4096, 4096, 4096)) == 0
+
+
+def test_tiling_cache_reads_swept_cdna4_columns(dga, tmp_path):
+    """A sweep's CSV carries the reference's 11 columns plus CDNA4 columns; a hit then reproduces the swept build."""
+    path = tmp_path / "swept.csv"
+    path.write_text("m,n,k,m1,n1,k1,kernelSerial,paddingTagA,paddingTagB,paddingTagC,blockDim,"
+                    "splitkFactor,stages,swizzleOffset,wavesM,wavesN,dispatchPolicyTag\n"
+                    "64,4096,7168,64,256,128,4,0,0,0,64,4,3,1,0,0,0\n"
+                    "4096,4096,4096,256,256,128,0,0,0,0,256,1,2,16,0,0,1\n")
+    try:
+        dga.tiling_cache_open(str(path))
+        t = dga.tiling(64, 4096, 7168)
+        assert (t.m1, t.n1, t.kernelSerial, t.splitkFactor, t.stages, t.swizzleOffset) == (64, 256, 4, 4, 3, 1)
+        assert dga.workspace_bytes(t) >= 4 * 64 * 4096 * 4
+        t = dga.tiling(4096, 4096, 4096)
+        assert (t.m1, t.n1, t.dispatchPolicyTag, t.swizzleOffset, t.splitkFactor) == (256, 256, 1, 16, 1)
+    finally:
+        dga.tiling_cache_open(None)
+        dga.tiling_cache_clear()
