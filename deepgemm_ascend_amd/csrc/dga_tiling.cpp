@@ -317,6 +317,9 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
     t.wavesM = static_cast<uint8_t>(pick.wm); t.wavesN = static_cast<uint8_t>(pick.wn);
     t.stages = 2;
     t.ldsBytes = pick.lds;
+    // schedule: the 8-wave 256x256 tile runs the continuous pipeline (dispatchPolicyTag 2: -16 % cycles per k block,
+    // +3..5 % wall at 4096^3); with one wave per SIMD (the 4-wave tiles) the plain loop is faster
+    t.dispatchPolicyTag = (pick.bm == 256 && pick.bn == 256) ? 2 : 0;
     // The tiles whose stage is <= 48 KB have a three-stage build that keeps two refills in flight: +6 % GB/s on the
     // HBM-bound grouped stream, and the r01 sweep picked it for every shape on these tiles (profiles/r01_sweep).
     if ((pick.bm == 128 && pick.bn == 256 && pick.wm == 2 && pick.wn == 2) || (pick.bm == 128 && pick.bn == 128) ||

@@ -107,8 +107,18 @@ __device__ __forceinline__ v4i make_rsrc(const void *base, int64_t bytes)
 // that uses it (the descriptor is built once, long before the first use: no readfirstlane hazard to cover).
 __device__ __forceinline__ void dma16(uint32_t voff, v4i rsrc, uint32_t soff, uint32_t lds_addr)
 {
+#if defined(DGA_ABL_DMA_EXEC0)   // diagnostic: the instruction issues with every lane off (no TA / LDS / memory work)
+    unsigned long long keep;
+    asm volatile("s_mov_b64 %4, exec\n\ts_mov_b64 exec, 0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_mov_b64 exec, %4"
+                 :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr), "s"(keep) : "memory");
+#elif defined(DGA_ABL_DMA_OOB)   // diagnostic: every lane out of range (TA + LDS zero-fill, no memory fetch)
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :: "v"(0x80000000u), "s"(rsrc), "s"(soff), "s"(lds_addr) : "memory");
+#else
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
                  :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr) : "memory");
+#endif
 }
 // (The non-temporal form, `... offen nt lds`, was measured on the grouped weight stream: no difference, r01.)
 // LDS-DMA, 4 B per lane from a per-lane 64-bit address (the strided scale gather)
@@ -543,8 +553,18 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         static_assert(STEPS % RING == 0 && STEPS > 2 * TM + LAG, "ring positions must line up across k blocks");
         constexpr int SB = STEPS - TM - 1;         // barrier step (just before the in-place reloads)
         constexpr int NL = Cfg::LOADS_PER_STAGE;
-        constexpr int TAIL_DMA = NL / 4;           // DMA slots on the steps behind the barrier
-        constexpr int HEAD_STEPS = (STEPS * 9) / 16;  // ... the rest rides on the first steps of the next k block
+        // Placement of the refill DMA (measured, stamped build, cycles per 32 k blocks at 4096^3): spread thin over 18
+        // steps 91.3k; 4 behind the barrier + 5 on the first 9 steps 83.8k.  The DMA costs little to ISSUE (an
+        // all-lanes-out-of-range build runs as fast as one with no DMA at all); what costs is data that has not landed
+        // when the vmcnt(0) at step SB asks for it -- so issue as early as the stage is free.
+#ifndef DGA_TAIL_DMA
+#define DGA_TAIL_DMA (TM < NL / 2 ? TM : NL / 2)
+#endif
+#ifndef DGA_HEAD_STEPS
+#define DGA_HEAD_STEPS ((STEPS * 9) / 32 > NL - DGA_TAIL_DMA ? (STEPS * 9) / 32 : NL - DGA_TAIL_DMA)
+#endif
+        constexpr int TAIL_DMA = DGA_TAIL_DMA < NL ? DGA_TAIL_DMA : NL - 1;  // DMA slots on the steps behind the barrier
+        constexpr int HEAD_STEPS = DGA_HEAD_STEPS;  // ... the rest rides on the first steps of the next k block
         v4f acc[TM][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -729,7 +749,10 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
             // all 8 waves hit the LDS at once here, and a wave that waited for its whole 15-read burst would idle the
             // matrix pipe for ~450 cycles per k block.  The scale reads come last; they are first needed LAG steps later.
             constexpr int STEPS = TM * TN, LAG = 3, RING = LAG + 1;
-            constexpr int ISSUE_STEPS = (STEPS * 5) / 8 > 0 ? (STEPS * 5) / 8 : 1;  // refill DMA rides on the first 5/8 of the steps
+#ifndef DGA_ISSUE_STEPS
+#define DGA_ISSUE_STEPS ((STEPS * 5) / 8)
+#endif
+            constexpr int ISSUE_STEPS = DGA_ISSUE_STEPS > 0 ? (DGA_ISSUE_STEPS < STEPS ? DGA_ISSUE_STEPS : STEPS) : 1;  // refill DMA rides on the first steps
             v4f part[RING];
             v8i bf[2];
             v8i af[TM];

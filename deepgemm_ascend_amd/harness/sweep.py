@@ -41,7 +41,7 @@ class Result:
 
 
 THREE_STAGE = {(128, 256), (128, 128), (64, 256)}   # tiles that also have a 3-stage build
-PINGPONG = {(256, 256)}                               # ... a ping-pong schedule (dispatchPolicyTag 1)
+PINGPONG = {(256, 256)}                               # ... ping-pong / continuous schedules (dispatchPolicyTag 1 / 2)
 
 
 def candidates(m, n, k):
@@ -57,7 +57,7 @@ def candidates(m, n, k):
                 continue
             for st in ([2, 3] if (bm, bn) in THREE_STAGE else [2]):
                 for sk in splits:
-                    for pol in ([0, 1] if (bm, bn) in PINGPONG and sk == 1 else [0]):
+                    for pol in ([0, 1, 2] if (bm, bn) in PINGPONG and sk == 1 else [0]):
                         out.append({"m1": bm, "n1": bn, "raster": r, "stages": st, "splitk": sk, "policy": pol})
     return out
 

@@ -5,17 +5,19 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
 import deepgemm_ascend_amd as dga
 import bench
-shapes = [(4096, 4096, 4096), (8192, 8192, 8192), (4096, 2048, 7168), (8192, 4096, 7168)]
+shapes = [(4096, 4096, 4096), (8192, 8192, 8192), (4096, 2048, 7168), (1024, 4096, 7168)]
 for (m, n, k) in shapes:
     a, sfa, b, sfb = bench.make_dense_inputs(m, n, k, seed=0)
     out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
     ref = torch.empty_like(out)
     variants = {}
     for name, (tile, pp) in {"256x256": ((256, 256), 0), "256x256-pp": ((256, 256), 1), "256x256-cont": ((256, 256), 2),
-                             "128x256-cont": ((128, 256), 2), "128x128-cont": ((128, 128), 2), "auto": (None, 0)}.items():
+                             "128x256": ((128, 256), 0), "128x256-cont": ((128, 256), 2),
+                             "128x128": ((128, 128), 0), "128x128-cont": ((128, 128), 2), "auto": (None, -1)}.items():
         t = dga.tiling(m, n, k)
-        if tile: t.m1, t.n1 = tile
-        t.dispatchPolicyTag = pp
+        if tile:
+            t.m1, t.n1 = tile; t.stages = 2; t.wavesM = t.wavesN = 0; t.splitkFactor = 1; t.kernelSerial = 0
+        if pp >= 0: t.dispatchPolicyTag = pp
         variants[name] = t
     res = {k_: [] for k_ in variants}
     t0 = variants["256x256"]
