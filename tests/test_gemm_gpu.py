@@ -181,3 +181,62 @@ def test_odd_k_padding_pass(dga, oracle, m, n, k):
     assert dga.workspace_bytes(t) >= (m + n) * (-(-k // 128) * 128)
     got = _run(dga, a, sfa, b, sfb)
     _check(oracle, got, a, sfa, b, sfb)
+
+
+def test_config3_full_size_properties(dga, oracle):
+    """BASELINE config 3 (M=4096, K=7168, N=2048) at full size: (a) scaling a whole column block of sfb by 2 doubles
+    exactly those 128 output columns, (b) row-permuting A permutes the output rows (bitwise), (c) 48 sampled rows
+    against the oracle."""
+    m, k, n = 4096, 7168, 2048
+    import bench
+    a, sfa, b, sfb = bench.make_dense_inputs(m, n, k, seed=3)
+    o1 = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), o1)
+    sfb2 = sfb.clone(); sfb2[5] *= 2
+    o2 = torch.empty_like(o1)
+    dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb2), o2)
+    perm = torch.randperm(m, device="cuda")
+    o3 = torch.empty_like(o1)
+    dga.gemm_fp8_fp8_bf16_nt((a[perm].contiguous(), sfa[perm].contiguous()), (b, sfb), o3, sync=True)
+    assert torch.equal(o2[:, 640:768].float(), o1[:, 640:768].float() * 2)
+    assert torch.equal(torch.cat([o2[:, :640], o2[:, 768:]], 1), torch.cat([o1[:, :640], o1[:, 768:]], 1))
+    assert torch.equal(o3, o1[perm])
+    rows = np.arange(17, m, 85)
+    want = oracle.gemm_fp8_fp8_bf16_nt(a.cpu().numpy()[rows], sfa.cpu().numpy()[rows], b.cpu().numpy(), sfb.cpu().numpy(), threads=16)
+    got = o1[torch.from_numpy(rows).cuda()].view(torch.int16).cpu().numpy().view(np.uint16)
+    oracle.assert_parity(got, want, a.cpu().numpy()[rows], sfa.cpu().numpy()[rows], b.cpu().numpy(), sfb.cpu().numpy())
+
+
+def test_every_schedule_is_bitwise_identical(dga, oracle):
+    """dispatchPolicyTag 0 / 1 / 2 (plain, ping-pong, continuous) order the same MFMAs and FMAs differently in time
+    only: outputs must agree bit for bit."""
+    m, n, k = 1000, 1300, 2176
+    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=8)
+    outs = []
+    for pol in (0, 1, 2):
+        t = dga.tiling(m, n, k)
+        t.m1, t.n1, t.stages, t.wavesM, t.wavesN, t.splitkFactor, t.kernelSerial = 256, 256, 2, 0, 0, 1, 0
+        t.dispatchPolicyTag = pol
+        outs.append(_run(dga, a, sfa, b, sfb, tiling=t))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    _check(oracle, outs[0], a, sfa, b, sfb)
+
+
+def test_hip_graph_capture_and_replay(dga, oracle):
+    """The launch path does no allocation or synchronisation: it can be captured into a HIP graph and replayed."""
+    m, n, k = 512, 768, 1024
+    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=4)
+    ta, tsa, tb, tsb = _dev(a), _dev(sfa), _dev(b), _dev(sfb)
+    out = torch.zeros((m, n), dtype=torch.bfloat16, device="cuda")
+    t = dga.tiling(m, n, k)
+    dga.gemm_fp8_fp8_bf16_nt((ta, tsa), (tb, tsb), out, tiling_=t, sync=True)   # warm: function attributes set outside capture
+    out.zero_()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            dga.gemm_fp8_fp8_bf16_nt((ta, tsa), (tb, tsb), out, tiling_=t)
+    torch.cuda.synchronize()
+    assert (out == 0).all()          # capture does not execute
+    g.replay(); torch.cuda.synchronize()
+    _check(oracle, out.view(torch.int16).cpu().numpy().view(np.uint16), a, sfa, b, sfb)

@@ -109,3 +109,37 @@ def test_expert_sharding_world1_on_gpu(dga, oracle):
     for t in range(T):
         want = oracle.gemm_fp8_fp8_bf16_nt(q[t:t + 1], sf[t:t + 1], b[ids[t]], sfb[ids[t]])
         oracle.assert_parity(got[t:t + 1], want, q[t:t + 1], sf[t:t + 1], b[ids[t]], sfb[ids[t]], eps=2.0 ** -12, frac=1.0)
+
+
+def test_config4_full_size(dga, oracle):
+    """BASELINE config 4 at full size (256 experts x (M<=128, K=7168, N=2048), random masks): rows >= masked_m keep
+    their sentinel everywhere; 6 sampled experts (incl. an empty one) against the oracle; and the grouped result of
+    an expert equals the dense operator on that expert's rows (bitwise)."""
+    G, MMAX, N, K = 256, 128, 2048, 7168
+    g = torch.Generator(device="cuda").manual_seed(11)
+    def rf(shape):
+        x = torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda", generator=g)
+        x = torch.where((x & 0x7F) == 0x7F, x & 0x80, x)
+        return torch.where((x & 0x78) > 0x60, x & 0xBF, x)     # keep magnitudes moderate
+    a = rf((G, MMAX, K)); b = rf((G, N, K))
+    sfa = torch.rand((G, MMAX, K // 128), device="cuda", generator=g) + 0.5
+    sfb = torch.rand((G, N // 128, K // 128), device="cuda", generator=g) + 0.5
+    masked = torch.randint(0, MMAX + 1, (G,), dtype=torch.int32, device="cuda", generator=g)
+    masked[7] = 0; masked[8] = 128; masked[9] = 1
+    out = torch.full((G, MMAX, N), -7.0, dtype=torch.bfloat16, device="cuda")
+    dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), out, masked, expected_m=64, sync=True)
+    mm = masked.cpu().numpy()
+    row_ix = torch.arange(MMAX, device="cuda")[None, :, None]
+    untouched = (row_ix >= masked[:, None, None])
+    assert ((out == -7.0) | ~untouched).all()
+    for e in (7, 8, 9, 100, 200, 255):
+        r = int(mm[e])
+        if r == 0:
+            continue
+        an, san, bn, sbn = a[e, :r].cpu().numpy(), sfa[e, :r].cpu().numpy(), b[e].cpu().numpy(), sfb[e].cpu().numpy()
+        want = oracle.gemm_fp8_fp8_bf16_nt(an, san, bn, sbn, threads=16)
+        oracle.assert_parity(_bits(out[e, :r]), want, an, san, bn, sbn, eps=2.0 ** -12, frac=1e-2)
+        dense = torch.zeros((r, N), dtype=torch.bfloat16, device="cuda")
+        t = dga.tiling(r, N, K); t.m1, t.n1, t.stages, t.splitkFactor, t.kernelSerial, t.wavesM, t.wavesN = 128, 256, 3, 1, 0, 2, 2
+        dga.gemm_fp8_fp8_bf16_nt((a[e, :r].contiguous(), sfa[e, :r].contiguous()), (b[e], sfb[e]), dense, tiling_=t, sync=True)
+        assert torch.equal(dense, out[e, :r])
