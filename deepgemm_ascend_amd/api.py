@@ -62,6 +62,18 @@ def _workspace(t: Tiling, device) -> Tuple[Optional[int], int]:
     return buf.data_ptr(), buf.numel()
 
 
+def _mmad_workspace(batch, m, n, k, x) -> Tuple[Optional[int], int]:
+    need = int(_lib.lib().dga_mmad_workspace_bytes(batch, m, n, k, x.data_ptr()))
+    if need == 0:
+        return None, 0
+    key = ("mmad", x.device)
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty((need,), dtype=torch.uint8, device=x.device)
+        _WORKSPACES[key] = buf
+    return buf.data_ptr(), buf.numel()
+
+
 def _device_guard(*ts: torch.Tensor):
     dev = ts[0].device
     for t in ts:
@@ -277,8 +289,9 @@ def run_mmad_rtc(x: torch.Tensor, y: torch.Tensor, z: torch.Tensor) -> None:
     for t in (x, y, z):
         _require(t.is_contiguous(), "operands must be contiguous")
     with _device_guard(x, y, z):
-        rc = _lib.lib().dga_run_mmad_rtc(x.data_ptr(), y.data_ptr(), z.data_ptr(), batch, m, n, k, _dt16(x),
-                                         _stream_ptr(z))
+        ws_ptr, ws_bytes = _mmad_workspace(batch, m, n, k, x)
+        rc = _lib.lib().dga_run_mmad_rtc_ws(x.data_ptr(), y.data_ptr(), z.data_ptr(), batch, m, n, k, _dt16(x),
+                                            ws_ptr, ws_bytes, _stream_ptr(z))
         _lib.check(rc, "run_mmad_rtc")
         torch.cuda.current_stream(z.device).synchronize()  # gemm.hpp:110
 
@@ -296,8 +309,9 @@ def run_mmad_bench(x: torch.Tensor, y: torch.Tensor, z: torch.Tensor, params: to
     params.copy_(torch.tensor(filled, dtype=torch.int32))  # gemm_bench.hpp:79-81
     with _device_guard(x, y, z):
         arr = (ctypes.c_int32 * 28)(*filled)
-        rc = _lib.lib().dga_run_mmad_bench(x.data_ptr(), y.data_ptr(), z.data_ptr(), m, n, k, _dt16(x), arr,
-                                           _stream_ptr(z))
+        ws_ptr, ws_bytes = _mmad_workspace(1, m, n, k, x)
+        rc = _lib.lib().dga_run_mmad_bench_ws(x.data_ptr(), y.data_ptr(), z.data_ptr(), m, n, k, _dt16(x), arr,
+                                              ws_ptr, ws_bytes, _stream_ptr(z))
         _lib.check(rc, "run_mmad_bench")
         torch.cuda.current_stream(z.device).synchronize()
 

@@ -4,24 +4,26 @@
 //   /root/reference/deep_gemm_ascend/framework/csrc/jit_kernels/impls/gemm_bench.hpp:49-113 (single, fp16, params[28])
 // whose generated AscendC kernel (framework/csrc/jit/generate_code.hpp:123-369) accumulates in fp32 and writes fp32.
 //
-// gfx950 form: v_mfma_f32_16x16x32_{bf16,f16}.  y is K-major in memory but the MFMA wants 8 consecutive k per
-// lane for one column, so each lane gathers its B fragment straight from global memory (8 two-byte loads down a
-// column; the 16 lanes of a row group read 32 contiguous bytes) -- no LDS, no transposition pass.  This path is
-// SURVEY.md 8(f).4 ("next"); it is correct and MFMA-based, not yet tuned.
+// Two device paths, both on v_mfma_f32_16x16x32_{bf16,f16}:
+//   * with a workspace (dga_run_mmad_*_ws; what the Python entry points use): y is transposed into the workspace
+//     and the LDS-DMA tile kernel of gemm_b16_kernel.hpp runs (0.9-1.0 PFLOP/s at 4096^3..8192^3, r01);
+//   * without one (the plain C entry points): each lane gathers its B fragment straight from global memory
+//     (8 two-byte loads down a column) -- no LDS, no transposition pass; correct, slow.
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <mutex>
 
 #include "dga_hip.h"
 #include "dga_internal.hpp"
+#include "gemm_b16_kernel.hpp"
 
 namespace dga {
 
-typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef uint16_t v8u __attribute__((ext_vector_type(8)));
 
-struct B16Params {
+struct B16DirectParams {
     const uint16_t *x, *y;
     float *z;
     int m, n, k;
@@ -39,7 +41,7 @@ __device__ __forceinline__ v4f mfma16(v8u a, v8u b, v4f c)
 
 // workgroup = 4 waves (2 x 2), wave tile 64 x 64 = 4 x 4 MFMA tiles, K step 32
 template <bool BF16>
-__global__ void __launch_bounds__(256) mmad_nn_f32_kernel(const B16Params p)
+__global__ void __launch_bounds__(256) mmad_nn_f32_kernel(const B16DirectParams p)
 {
     constexpr int TM = 4, TN = 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -108,14 +110,83 @@ __global__ void __launch_bounds__(256) mmad_nn_f32_kernel(const B16Params p)
         }
 }
 
+static size_t b16_workspace_bytes(int batch, int m, int n, int k, const void *x)
+{
+    if (batch <= 0 || m <= 0 || n <= 0 || k <= 0) return 0;
+    const size_t kp = (static_cast<size_t>(k) + 63) / 64 * 64;
+    size_t bytes = ((static_cast<size_t>(batch) * n * kp * 2 + 255) & ~size_t(255));       // yT
+    const bool x_in_place = (k % 64 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    if (!x_in_place) bytes += ((static_cast<size_t>(batch) * m * kp * 2 + 255) & ~size_t(255));  // padded x
+    return bytes + 256;
+}
+
+template <class Cfg, bool BF16>
+static int launch_tiled(const B16Params &p, int batch, hipStream_t stream)
+{
+    auto kfn = gemm_b16_nt_f32_kernel<Cfg, BF16>;
+    constexpr int lds = 2 * (Cfg::A_BYTES + Cfg::B_BYTES);
+    static std::once_flag once[64];
+    static hipError_t attr_err[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return DGA_E_HIP;
+    std::call_once(once[dev], [&] {
+        attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    });
+    if (record_hip(attr_err[dev]) != DGA_OK) return DGA_E_HIP;
+    hipLaunchKernelGGL(kfn, dim3(static_cast<unsigned>(batch) * p.tiles_m * p.tiles_n), dim3(Cfg::NT), lds, stream, p);
+    return record_hip(hipGetLastError());
+}
+
 static int launch_b16(const void *x, const void *y, float *z, int batch, int m, int n, int k, int dtype,
-                      hipStream_t stream)
+                      void *workspace, size_t workspace_bytes, hipStream_t stream)
 {
     if (batch < 0 || m < 0 || n < 0 || k < 0) return DGA_E_SHAPE;
     if (dtype != DGA_DT_BF16 && dtype != DGA_DT_FP16) return DGA_E_DTYPE;
     if (batch == 0 || m == 0 || n == 0) return DGA_OK;
     if (!z || ((!x || !y) && k != 0)) return DGA_E_NULL;
-    B16Params p{};
+    const size_t need = b16_workspace_bytes(batch, m, n, k, x);
+    if (workspace && workspace_bytes < need) return DGA_E_WORKSPACE;
+    const size_t kp = (static_cast<size_t>(k) + 63) / 64 * 64;
+    if (workspace && k > 0 && kp * 257 * 2 < 0x7FFFFFFFull) {
+        // tiled path: transpose y into the workspace (the re-layout the reference does on the way into L1,
+        // generate_code.hpp:250-260), pad x if its rows are not whole 128-byte k steps, then the LDS-DMA kernel
+        uint8_t *ws = static_cast<uint8_t *>(workspace);
+        uint16_t *yt = reinterpret_cast<uint16_t *>(ws);
+        const size_t yt_bytes = (static_cast<size_t>(batch) * n * kp * 2 + 255) & ~size_t(255);
+        const bool x_in_place = (k % 64 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+        dim3 tg((n + 63) / 64, static_cast<unsigned>(kp / 64), batch);
+        hipLaunchKernelGGL(transpose_b16_kernel, tg, dim3(256), 0, stream, static_cast<const uint16_t *>(y), yt, k, n,
+                           static_cast<int>(kp), static_cast<int64_t>(k) * n, static_cast<int64_t>(n) * kp);
+        const uint16_t *xs = static_cast<const uint16_t *>(x);
+        if (!x_in_place) {
+            uint16_t *xp = reinterpret_cast<uint16_t *>(ws + yt_bytes);
+            const int64_t rows = static_cast<int64_t>(batch) * m;
+            hipLaunchKernelGGL(pad_rows_b16_kernel, dim3(static_cast<unsigned>((rows * kp + 255) / 256)), dim3(256), 0, stream,
+                               xs, xp, rows, k, static_cast<int>(kp));
+            xs = xp;
+        }
+        if (record_hip(hipGetLastError()) != DGA_OK) return DGA_E_HIP;
+        B16Params p{};
+        p.x = xs; p.yt = yt; p.z = z;
+        p.m = m; p.n = n; p.k = static_cast<int>(kp);
+        p.ldx = x_in_place ? k : static_cast<int64_t>(kp);
+        p.ldy = static_cast<int64_t>(kp);
+        p.x_bs = static_cast<int64_t>(m) * p.ldx;
+        p.y_bs = static_cast<int64_t>(n) * kp;
+        p.z_bs = static_cast<int64_t>(m) * n;
+        const bool big = static_cast<int64_t>(batch) * ((m + 255) / 256) * ((n + 255) / 256) >= 192;
+        const int bm = big ? 256 : 128, bn = big ? 256 : 128;
+        p.tiles_m = (m + bm - 1) / bm;
+        p.tiles_n = (n + bn - 1) / bn;
+        p.raster_group = p.tiles_m >= 8 ? 8 : (p.tiles_m >= 4 ? 4 : 1);
+        const bool bf = dtype == DGA_DT_BF16;
+        if (big) return bf ? launch_tiled<GemmCfg<256, 256, 4, 2>, true>(p, batch, stream)
+                           : launch_tiled<GemmCfg<256, 256, 4, 2>, false>(p, batch, stream);
+        return bf ? launch_tiled<GemmCfg<128, 128, 2, 2>, true>(p, batch, stream)
+                  : launch_tiled<GemmCfg<128, 128, 2, 2>, false>(p, batch, stream);
+    }
+    // no workspace: fragments gathered straight from global memory (correct, slow)
+    B16DirectParams p{};
     p.x = static_cast<const uint16_t *>(x);
     p.y = static_cast<const uint16_t *>(y);
     p.z = z;
@@ -135,13 +206,23 @@ static int launch_b16(const void *x, const void *y, float *z, int batch, int m, 
 
 extern "C" {
 
-int dga_run_mmad_rtc(const void *x, const void *y, float *z, int batch, int m, int n, int k, int dtype, void *stream)
+size_t dga_mmad_workspace_bytes(int batch, int m, int n, int k, const void *x)
 {
-    return dga::launch_b16(x, y, z, batch, m, n, k, dtype, static_cast<hipStream_t>(stream));
+    return dga::b16_workspace_bytes(batch, m, n, k, x);
 }
 
-int dga_run_mmad_bench(const void *x, const void *y, float *z, int m, int n, int k, int dtype,
-                       const int32_t *params_host, void *stream)
+int dga_run_mmad_rtc_ws(const void *x, const void *y, float *z, int batch, int m, int n, int k, int dtype,
+                        void *workspace, size_t workspace_bytes, void *stream)
+{
+    return dga::launch_b16(x, y, z, batch, m, n, k, dtype, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int dga_run_mmad_rtc(const void *x, const void *y, float *z, int batch, int m, int n, int k, int dtype, void *stream)
+{
+    return dga::launch_b16(x, y, z, batch, m, n, k, dtype, nullptr, 0, static_cast<hipStream_t>(stream));
+}
+
+static int check_bench_params(const int32_t *params_host, int m, int n, int k)
 {
     // The 28 ints steer the Ascend kernel's L1/L0 blocking only; they are validated (the knobs must be positive,
     // as the reference's derivation divides by them) and otherwise have no CDNA4 meaning.
@@ -150,7 +231,21 @@ int dga_run_mmad_bench(const void *x, const void *y, float *z, int m, int n, int
             if (params_host[i] <= 0) return DGA_E_RANGE;
         if (params_host[6] != m || params_host[7] != n || params_host[8] != k) return DGA_E_SHAPE;
     }
-    return dga::launch_b16(x, y, z, 1, m, n, k, dtype, static_cast<hipStream_t>(stream));
+    return DGA_OK;
+}
+
+int dga_run_mmad_bench_ws(const void *x, const void *y, float *z, int m, int n, int k, int dtype,
+                          const int32_t *params_host, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const int rc = check_bench_params(params_host, m, n, k);
+    if (rc != DGA_OK) return rc;
+    return dga::launch_b16(x, y, z, 1, m, n, k, dtype, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int dga_run_mmad_bench(const void *x, const void *y, float *z, int m, int n, int k, int dtype,
+                       const int32_t *params_host, void *stream)
+{
+    return dga_run_mmad_bench_ws(x, y, z, m, n, k, dtype, params_host, nullptr, 0, stream);
 }
 
 }  // extern "C"

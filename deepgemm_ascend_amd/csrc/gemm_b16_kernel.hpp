@@ -1,0 +1,197 @@
+// 16-bit (bf16 / fp16) GEMM with fp32 output for the framework's own entry points -- run_mmad_rtc / run_mmad_bench
+// (/root/reference/deep_gemm_ascend/framework/csrc/jit_kernels/impls/gemm.hpp:68-111, gemm_bench.hpp:49-113; device
+// algorithm /root/reference/deep_gemm_ascend/framework/csrc/jit/generate_code.hpp:123-369: fp32 accumulate, fp32 out).
+//
+// The reference kernel takes y as [K,N] and re-lays both operands on the way into L1 (ND->NZ DataCopy, :231-260).
+// Here the re-layout of y is a separate transposing pass into the caller's workspace (yT [N,Kp], Kp = K rounded up
+// to 64, zero filled), after which both operands are K-contiguous and the GEMM is the same LDS-DMA / swizzled-image /
+// one-barrier-per-k-step structure as the fp8 kernel (gemm_fp8_kernel.hpp), with
+//   k step = 64 elements = 128 bytes per row  (identical LDS image, swizzle and DMA addressing),
+//   two v_mfma_f32_16x16x32_{bf16,f16} per 16x16 tile per k step accumulating in place (no promotion FMAs),
+//   fp32 epilogue: a lane owns 4 consecutive n of one row -> 16-byte stores.
+#pragma once
+#include "dga_device_common.hpp"
+
+namespace dga {
+
+typedef __bf16 v8bf16 __attribute__((ext_vector_type(8)));
+typedef _Float16 v8f16 __attribute__((ext_vector_type(8)));
+
+struct B16Params {
+    const uint16_t *x;   // [batch][m][ldx]   (K-contiguous rows)
+    const uint16_t *yt;  // [batch][n][ldy]   (transposed y: K-contiguous rows)
+    float *z;            // [batch][m][n]
+    int m, n, k;         // k = padded K (multiple of 64)
+    int64_t ldx, ldy;
+    int64_t x_bs, y_bs, z_bs;
+    int tiles_m, tiles_n, raster_group;
+};
+
+template <bool BF16>
+__device__ __forceinline__ v4f mfma_b16(v4i a, v4i b, v4f c)
+{
+    if constexpr (BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf16, a), __builtin_bit_cast(v8bf16, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8f16, a), __builtin_bit_cast(v8f16, b), c, 0, 0, 0);
+}
+
+template <class Cfg, bool BF16>
+__global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Params p)
+{
+    constexpr int BM = Cfg::kBM, BN = Cfg::kBN, WN = Cfg::kWN;
+    constexpr int NT = Cfg::NT, TM = Cfg::TM, TN = Cfg::TN, DNT = Cfg::DNT;
+    constexpr int STAGE = Cfg::A_BYTES + Cfg::B_BYTES;  // no scale slots
+    constexpr int NL = Cfg::A_ITERS + Cfg::B_ITERS;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nwg = gridDim.x;
+    int tile;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int per_batch = p.tiles_m * p.tiles_n;
+    const int bi = tile / per_batch;
+    const int t_in = tile - bi * per_batch;
+    int tm, tn;
+    {
+        const int gm = p.raster_group, per = gm * p.tiles_n, band = t_in / per, first = band * gm;
+        const int rows = min(p.tiles_m - first, gm), loc = t_in - band * per;
+        tm = first + loc % rows;
+        tn = loc / rows;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const uint8_t *X = (const uint8_t *)(p.x + (int64_t)bi * p.x_bs);
+    const uint8_t *Y = (const uint8_t *)(p.yt + (int64_t)bi * p.y_bs);
+    float *Z = p.z + (int64_t)bi * p.z_bs;
+    const int64_t ldxb = p.ldx * 2, ldyb = p.ldy * 2;  // row strides in bytes
+
+    const int dtid = tid & (DNT - 1);
+    const int a_col = ((dtid & 7) ^ swz_a(dtid >> 3)) * 16, b_col = ((dtid & 7) ^ swz_b(dtid >> 3)) * 16;
+    uint32_t a_voff[Cfg::A_ITERS], b_voff[Cfg::B_ITERS];
+#pragma unroll
+    for (int it = 0; it < Cfg::A_ITERS; ++it)
+        a_voff[it] = (uint32_t)min((it * DNT + dtid) >> 3, p.m - 1 - m0) * (uint32_t)ldxb + a_col;
+#pragma unroll
+    for (int it = 0; it < Cfg::B_ITERS; ++it)
+        b_voff[it] = (uint32_t)min((it * DNT + dtid) >> 3, p.n - 1 - n0) * (uint32_t)ldyb + b_col;
+    const v4i a_rsrc = make_rsrc(X + (int64_t)m0 * ldxb, (int64_t)(p.m - m0) * ldxb);
+    const v4i b_rsrc = make_rsrc(Y + (int64_t)n0 * ldyb, (int64_t)(p.n - n0) * ldyb);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    auto issue_one = [&](int idx, int stage, int ks) {
+        const uint32_t sa = lds0 + stage * STAGE + wave * 1024;
+        if (idx < Cfg::A_ITERS) dma16(a_voff[idx], a_rsrc, (uint32_t)(ks * 128), sa + idx * DNT * 16);
+        else dma16(b_voff[idx - Cfg::A_ITERS], b_rsrc, (uint32_t)(ks * 128), sa + Cfg::A_BYTES + (idx - Cfg::A_ITERS) * DNT * 16);
+    };
+
+    const int li = lane & 15, kg = lane >> 4;
+    const int a_row = wm * (BM / Cfg::kWM) + li;
+    const int a_off0 = a_row * 128 + ((kg ^ swz_a(a_row)) * 16), a_off1 = a_row * 128 + (((kg + 4) ^ swz_a(a_row)) * 16);
+    const int b_row = wn * (BN / WN) + 8 * (li >> 2) + (li & 3);
+    const int b_off0 = Cfg::A_BYTES + b_row * 128 + ((kg ^ swz_b(b_row)) * 16);
+    const int b_off1 = Cfg::A_BYTES + b_row * 128 + (((kg + 4) ^ swz_b(b_row)) * 16);
+
+    v4f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    const int KS = p.k / 64;
+#pragma unroll
+    for (int idx = 0; idx < NL; ++idx) issue_one(idx, 0, 0);
+    for (int ks = 0; ks < KS; ++ks) {
+        const int stage = ks & 1;
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const uint8_t *st = smem + stage * STAGE;
+        v4i af[TM][2], bf[2][2];
+        bf[0][0] = *(const v4i *)(st + b_off0);
+        bf[0][1] = *(const v4i *)(st + b_off1);
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            af[mt][0] = *(const v4i *)(st + a_off0 + mt * 2048);
+            af[mt][1] = *(const v4i *)(st + a_off1 + mt * 2048);
+        }
+        // per n-tile: the first-half MFMAs of every m-tile, then the second halves (no back-to-back dependent pair);
+        // the refill DMA of the other stage rides on the first 5/8 of the n-tiles
+        constexpr int ISSUE_NT = (TN * 5) / 8 > 0 ? (TN * 5) / 8 : 1;
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) acc[mt][nt] = mfma_b16<BF16>(bf[nt & 1][0], af[mt][0], acc[mt][nt]);
+            if (nt < ISSUE_NT) {
+#pragma unroll
+                for (int idx = (nt * NL) / ISSUE_NT; idx < ((nt + 1) * NL) / ISSUE_NT; ++idx)
+                    issue_one(idx, stage ^ 1, ks + 1);  // past the last k step: reads the tile's following bytes, unused
+            }
+            if (nt + 1 < TN) {
+                const int boff = ((nt + 1) >> 1) * 4096 + ((nt + 1) & 1) * 512;
+                bf[(nt + 1) & 1][0] = *(const v4i *)(st + b_off0 + boff);
+                bf[(nt + 1) & 1][1] = *(const v4i *)(st + b_off1 + boff);
+            }
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) acc[mt][nt] = mfma_b16<BF16>(bf[nt & 1][1], af[mt][1], acc[mt][nt]);
+        }
+    }
+    wait_vmcnt<0>();
+
+    // epilogue: lane owns row m, 4 consecutive n per 16x16 tile (same n permutation as the fp8 kernel)
+    const int m_row = m0 + wm * (BM / Cfg::kWM) + li;
+    const int n_base = n0 + wn * (BN / WN) + 8 * kg;
+    const bool v_ok = ((p.n & 3) == 0) && ((((uintptr_t)Z) & 15) == 0);
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+        const int m = m_row + mt * 16;
+        if (m >= p.m) continue;
+        float *zr = Z + (int64_t)m * p.n;
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+            const int n = n_base + 32 * (nt >> 1) + 4 * (nt & 1);
+            if (v_ok && n + 4 <= p.n) {
+                *(v4f *)(zr + n) = acc[mt][nt];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (n + q < p.n) zr[n + q] = acc[mt][nt][q];
+            }
+        }
+    }
+}
+
+// y [K][N] (16-bit) -> yT [N][kp], kp = K rounded up to 64, zero filled: 64 x 64 tiles through LDS, coalesced both ways.
+__global__ void __launch_bounds__(256) transpose_b16_kernel(const uint16_t *y, uint16_t *yt, int k, int n, int kp,
+                                                            int64_t y_bs, int64_t yt_bs)
+{
+    __shared__ uint16_t tile[64][66];
+    const uint16_t *src = y + (int64_t)blockIdx.z * y_bs;
+    uint16_t *dst = yt + (int64_t)blockIdx.z * yt_bs;
+    const int k0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int kk = k0 + r, nn = n0 + tx;
+        tile[r][tx] = (kk < k && nn < n) ? src[(int64_t)kk * n + nn] : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int nn = n0 + r, kk = k0 + tx;
+        if (nn < n && kk < kp) dst[(int64_t)nn * kp + kk] = tile[tx][r];
+    }
+}
+
+// x [M][K] -> xp [M][kp] zero filled (only when K is not a multiple of 64 or x is not 16-byte aligned)
+__global__ void __launch_bounds__(256) pad_rows_b16_kernel(const uint16_t *x, uint16_t *xp, int64_t rows, int k, int kp)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = i / kp;
+    if (r >= rows) return;
+    const int c = (int)(i - r * kp);
+    xp[i] = c < k ? x[r * k + c] : (uint16_t)0;
+}
+
+}  // namespace dga

@@ -174,6 +174,15 @@ int dga_run_mmad_rtc(const void *x, const void *y, float *z, int batch, int m, i
 int dga_run_mmad_bench(const void *x, const void *y, float *z, int m, int n, int k, int dtype,
                        const int32_t *params_host, void *stream);
 
+/* The same with a caller-provided workspace of dga_mmad_workspace_bytes(): y is transposed (and x padded when K is not
+ * a multiple of 64) into it and the LDS-DMA / MFMA tile kernel runs; without a workspace the entry points above gather
+ * fragments straight from global memory (same results, much slower). */
+size_t dga_mmad_workspace_bytes(int batch, int m, int n, int k, const void *x);
+int dga_run_mmad_rtc_ws(const void *x, const void *y, float *z, int batch, int m, int n, int k, int dtype,
+                        void *workspace, size_t workspace_bytes, void *stream);
+int dga_run_mmad_bench_ws(const void *x, const void *y, float *z, int m, int n, int k, int dtype,
+                          const int32_t *params_host, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- expert sharding helper (the reference has no routing or collective of any kind) ------- */
 
 /* Indexed row copy on the device: for r in [0, rows):

@@ -47,3 +47,33 @@ def test_run_mmad_custom_is_a_noop(dga):
     z = torch.full((2, 4, 4), 7.0, device="cuda")
     dga.run_mmad_custom(torch.zeros((2, 4, 4), device="cuda"), torch.zeros((2, 4, 4), device="cuda"), z)
     assert (z == 7).all()   # include/impls/mmad.cpp:79 returns immediately
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("batch,m,n,k", [(1, 1024, 1024, 1024), (2, 300, 520, 200), (1, 4096, 512, 136), (3, 64, 64, 64)])
+def test_tiled_16bit_path(dga, oracle, dtype, batch, m, n, k):
+    """The workspace (tiled MFMA) path of run_mmad_rtc: transposing pre-pass + LDS-DMA kernel, all tails."""
+    rng = np.random.default_rng(m + n + k)
+    x = torch.tensor(heavy_tail(rng, (batch, m, k))).to(dtype)
+    y = torch.tensor(heavy_tail(rng, (batch, k, n))).to(dtype)
+    golden = np.matmul(x.float().numpy(), y.float().numpy()).astype(np.float32)
+    z = torch.full((batch, m, n), float("nan"), dtype=torch.float32, device="cuda")
+    dga.run_mmad_rtc(x.cuda(), y.cuda(), z)
+    ok, ratio = oracle.verify_isclose(z.cpu().numpy(), golden, rtol=2e-4)
+    assert ok, ratio
+
+
+def test_16bit_path_without_workspace_matches(dga, oracle):
+    import ctypes
+    from deepgemm_ascend_amd import _lib
+    rng = np.random.default_rng(0)
+    m, n, k = 200, 264, 192
+    x = torch.tensor(heavy_tail(rng, (m, k))).to(torch.bfloat16).cuda()
+    y = torch.tensor(heavy_tail(rng, (k, n))).to(torch.bfloat16).cuda()
+    z0 = torch.zeros((m, n), dtype=torch.float32, device="cuda"); z1 = torch.zeros_like(z0)
+    rc = _lib.lib().dga_run_mmad_rtc(x.data_ptr(), y.data_ptr(), z0.data_ptr(), 1, m, n, k, _lib.DT_BF16, 0)
+    assert rc == 0
+    dga.run_mmad_rtc(x[None], y[None], z1[None])
+    torch.cuda.synchronize()
+    ok, ratio = oracle.verify_isclose(z1.cpu().numpy(), z0.cpu().numpy(), rtol=2e-5)
+    assert ok, ratio
