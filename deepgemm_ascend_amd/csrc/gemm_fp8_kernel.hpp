@@ -623,11 +623,11 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
-    // ---- main loop.  ONE barrier per k block: passing it means (a) every wave's DMA of this stage has landed
-        //      (each waited vmcnt(0) first) and (b) every wave has left the previous k block, i.e. the other stage is
-        //      free -- so its refill is issued from inside this k block's MFMA pipeline, one DMA wave-instruction every
-        //      few MFMAs.  (Issued in a burst at the top, the 9 DMA instructions cost a wave 800-1600 cycles of blocked
-        //      issue per k block: the vector-memory path takes 64 B/clk/CU; measured with the -DDGA_STAMPS build.)
+        // ---- plain main loop (PP = 0).  ONE barrier per k block: passing it means (a) every wave's DMA of this stage
+        // has landed (each waited vmcnt first) and (b) every wave has left the previous k block, i.e. the stage being
+        // refilled is free -- so its refill is issued from inside this k block's MFMA pipeline, one DMA wave-instruction
+        // every few MFMAs.  (Issued in a burst at the top, the 9 DMA instructions cost a wave 800-1600 cycles of blocked
+        // issue per k block; measured with the -DDGA_STAMPS build.)
         // With STAGES = 3 (tiles whose stage is <= 48 KB) two refills are in flight instead of one: the wait at the
         // top leaves the newest batch outstanding.
         constexpr int STG = Cfg::STAGES;
