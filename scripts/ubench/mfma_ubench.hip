@@ -6,6 +6,7 @@
 #include <vector>
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
 template <int MODE>  // 0: MFMA only (accumulate chain x4 indep), 1: MFMA(C=0) + 4 FMA pipelined lag 3, 2: 32x32x64 variant
 __global__ void __launch_bounds__(512) k(const int *seed, float *out, int iters)
@@ -15,6 +16,21 @@ __global__ void __launch_bounds__(512) k(const int *seed, float *out, int iters)
     v4f acc[16];
     for (int i = 0; i < 16; ++i) acc[i] = v4f{0, 0, 0, 0};
     float s = 1.0001f;
+    if (MODE == 2) {   // 32x32x64 form, MFMA only, 4 independent accumulators (same flops per wave-iteration as 16 x 16x16x128)
+        v16f a32[4];
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) a32[i][j] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    a32[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, a32[i], 0, 0, 0, 0, 0, 0);
+        }
+        float r = 0;
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) r += a32[i][j];
+        out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+        return;
+    }
     if (MODE == 0) {
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -68,16 +84,17 @@ int main(int argc, char **argv)
     hipMemcpy(seed, h.data(), 4096 * 4, hipMemcpyHostToDevice);
     printf("operands: %s\n", randomise ? "random e4m3 bytes" : "constant 0x38");
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 2; ++mode)
+    for (int mode = 0; mode < 3; ++mode)
         for (int threads : {256, 512}) {
             for (int rep = 0; rep < 3; ++rep) {
                 hipEventRecord(e0);
                 if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(threads), 0, 0, seed, out, iters);
-                else hipLaunchKernelGGL(k<1>, dim3(256), dim3(threads), 0, 0, seed, out, iters);
+                else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(threads), 0, 0, seed, out, iters);
+                else hipLaunchKernelGGL(k<2>, dim3(256), dim3(threads), 0, 0, seed, out, iters);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 double flops = 2.0 * 16 * 16 * 128 * 16.0 * iters * (threads / 64) * 256;
-                if (rep == 2) printf("mode %d (%s) waves/SIMD %d: %.3f ms  %.0f TFLOP/s\n", mode, mode ? "MFMA+4FMA lag3" : "MFMA only", threads / 256, ms, flops / ms / 1e9);
+                if (rep == 2) printf("mode %d (%s) waves/SIMD %d: %.3f ms  %.0f TFLOP/s\n", mode, mode == 1 ? "MFMA+4FMA lag3" : mode == 2 ? "32x32x64 MFMA only" : "MFMA only", threads / 256, ms, flops / ms / 1e9);
             }
         }
     return 0;
