@@ -16,7 +16,11 @@ from .api import (  # noqa: F401
     get_best_config,
     infer_dtype,
     infer_shape,
+    get_m_alignment_for_contiguous_layout,
+    m_grouped_gemm_fp8_fp8_bf16_nt_contiguous,
     m_grouped_gemm_fp8_fp8_bf16_nt_masked,
+    per_block_cast_to_fp8,
+    per_token_cast_to_fp8,
     platform_ascend910b,
     platform_mi355x,
     run_mmad_bench,

@@ -43,7 +43,7 @@ class Tiling(ctypes.Structure):
                 ("layoutTagA", c_uint8), ("layoutTagB", c_uint8), ("layoutTagC", c_uint8),
                 ("paddingTagA", c_uint8), ("paddingTagB", c_uint8), ("paddingTagC", c_uint8),
                 ("kernelSerial", c_uint8), ("dispatchPolicyTag", c_uint8), ("blockDim", c_uint32),
-                ("wavesM", c_uint8), ("wavesN", c_uint8), ("stages", c_uint8), ("reserved0", c_uint8),
+                ("wavesM", c_uint8), ("wavesN", c_uint8), ("stages", c_uint8), ("contiguous", c_uint8),
                 ("ldsBytes", c_uint32), ("groups", c_uint32)]
 
     def as_dict(self):
@@ -52,7 +52,12 @@ class Tiling(ctypes.Structure):
 
 class Problem(ctypes.Structure):
     _fields_ = [("m", c_uint32), ("n", c_uint32), ("k", c_uint32), ("groups", c_uint32), ("expected_m", c_uint32),
-                ("layoutTagA", c_uint8), ("layoutTagB", c_uint8), ("layoutTagC", c_uint8), ("dtype", c_uint8)]
+                ("layoutTagA", c_uint8), ("layoutTagB", c_uint8), ("layoutTagC", c_uint8), ("dtype", c_uint8),
+                ("flags", c_uint32)]
+
+
+PROBLEM_CONTIGUOUS_M = 1
+CONTIGUOUS_M_ALIGNMENT = 128
 
 
 DT_FP16, DT_BF16, DT_FP8_E4M3FN, DT_FP32 = 1, 2, 3, 4
@@ -75,6 +80,11 @@ SIGNATURES = {
     "dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                           c_int, c_int, c_int, c_int, c_int, POINTER(Tiling),
                                                           c_void_p, c_size_t, c_void_p]),
+    "dga_m_grouped_gemm_fp8_fp8_bf16_nt_contiguous": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                              c_void_p, c_int, c_int, c_int, c_int, POINTER(Tiling),
+                                                              c_void_p, c_size_t, c_void_p]),
+    "dga_cast_to_fp8_1x128": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "dga_cast_to_fp8_128x128": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "dga_get_best_config": (c_int, [c_uint32] * 4 + [POINTER(c_uint32)]),
     "dga_get_bench_config": (c_int, [c_uint32] * 9 + [POINTER(c_uint32)]),
     "dga_bench_params_fill": (c_int, [c_uint32] * 3 + [POINTER(c_int32)]),
@@ -124,7 +134,7 @@ def lib() -> ctypes.CDLL:
                 raise DGALibraryError(f"{LIB_PATH} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
-        if L.dga_abi_version() != 1:
+        if L.dga_abi_version() != 2:
             raise DGALibraryError("ABI version mismatch")
         _lib = L
     return _lib

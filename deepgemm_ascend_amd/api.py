@@ -100,15 +100,16 @@ def infer_dtype(self_dtype: int, mat2_dtype: int) -> int:
     return out.value
 
 
-def _problem(m, n, k, groups=1, expected_m=0, dtype=_lib.DT_FP8_E4M3FN) -> Problem:
+def _problem(m, n, k, groups=1, expected_m=0, dtype=_lib.DT_FP8_E4M3FN, contiguous=False) -> Problem:
     return Problem(m, n, k, groups, expected_m, _lib.LAYOUT_ROW_MAJOR, _lib.LAYOUT_COLUMN_MAJOR,
-                   _lib.LAYOUT_ROW_MAJOR, dtype)
+                   _lib.LAYOUT_ROW_MAJOR, dtype, _lib.PROBLEM_CONTIGUOUS_M if contiguous else 0)
 
 
-def tiling(m: int, n: int, k: int, groups: int = 1, expected_m: int = 0) -> Tiling:
-    """TilingFunc hook with the (m,n,k) cache (catlass_dynamic_matmul_tiling.cpp:77-122)."""
+def tiling(m: int, n: int, k: int, groups: int = 1, expected_m: int = 0, contiguous: bool = False) -> Tiling:
+    """TilingFunc hook with the (m,n,k) cache (catlass_dynamic_matmul_tiling.cpp:77-122).
+    contiguous=True: the contiguous-grouped layout (m = total rows, groups = number of B matrices)."""
     t = Tiling()
-    p = _problem(m, n, k, groups, expected_m)
+    p = _problem(m, n, k, groups, expected_m, contiguous=contiguous)
     _lib.check(_lib.lib().dga_tiling(ctypes.byref(p), ctypes.byref(t)), "tiling")
     return t
 
@@ -248,6 +249,71 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_masked(lhs, rhs, out: torch.Tensor, masked_m:
         _lib.check(rc, "m_grouped_gemm_fp8_fp8_bf16_nt_masked")
         if sync:
             torch.cuda.current_stream(out.device).synchronize()
+
+
+def get_m_alignment_for_contiguous_layout() -> int:
+    """Row alignment of the group segments in the contiguous-grouped layout (upstream DeepGEMM's name)."""
+    return _lib.CONTIGUOUS_M_ALIGNMENT
+
+
+def m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(lhs, rhs, out: torch.Tensor, m_indices: torch.Tensor,
+                                              tiling_: Optional[Tiling] = None, sync: bool = False) -> None:
+    """Contiguous-grouped GEMM (the prefill-side MoE layout): a [Msum,K], sfa [Msum,KB], b [G,N,K], sfb [G,NB,KB],
+    out [Msum,N] bf16, m_indices int32 [Msum].  Row r is multiplied with b[m_indices[r]]; rows with a negative index
+    are padding and stay untouched.  Group segments start at multiples of get_m_alignment_for_contiguous_layout()
+    rows, padding rows follow a segment's valid rows."""
+    a, sfa = lhs
+    b, sfb = rhs
+    a = _fp8_bytes(a); b = _fp8_bytes(b)
+    _require(a.dim() == 2 and b.dim() == 3 and out.dim() == 2, "a/out rank 2, b rank 3")
+    msum, k = a.shape
+    g, n, k2 = b.shape
+    _require(k == k2, "k mismatch")
+    _require(tuple(out.shape) == (msum, n) and out.dtype == torch.bfloat16, "out must be [Msum,N] bfloat16")
+    kb, nb = (k + 127) // 128, (n + 127) // 128
+    _require(tuple(sfa.shape) == (msum, kb) and sfa.dtype == torch.float32, f"sfa must be [{msum},{kb}] f32")
+    _require(tuple(sfb.shape) == (g, nb, kb) and sfb.dtype == torch.float32, f"sfb must be [{g},{nb},{kb}] f32")
+    _require(m_indices.dtype == torch.int32 and tuple(m_indices.shape) == (msum,), "m_indices must be int32 [Msum]")
+    for t in (a, b, sfa, sfb, out, m_indices):
+        _require(t.is_contiguous(), "operands must be contiguous")
+    with _device_guard(a, b, sfa, sfb, out, m_indices):
+        if tiling_ is None:
+            tiling_ = tiling(msum, n, k, groups=g, contiguous=True)
+        ws_ptr, ws_bytes = _workspace(tiling_, out.device)
+        rc = _lib.lib().dga_m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(
+            a.data_ptr(), sfa.data_ptr(), b.data_ptr(), sfb.data_ptr(), out.data_ptr(), m_indices.data_ptr(),
+            msum, g, n, k, ctypes.byref(tiling_), ws_ptr, ws_bytes, _stream_ptr(out))
+        _lib.check(rc, "m_grouped_gemm_fp8_fp8_bf16_nt_contiguous")
+        if sync:
+            torch.cuda.current_stream(out.device).synchronize()
+
+
+_CAST_DT = {torch.float32: _lib.DT_FP32, torch.bfloat16: _lib.DT_BF16, torch.float16: _lib.DT_FP16}
+
+
+def _cast(fn_name: str, x: torch.Tensor, block_rows: int):
+    _require(x.dim() == 2 and x.is_contiguous(), "x must be a contiguous [rows, k] tensor")
+    _require(x.dtype in _CAST_DT, "x must be float32, bfloat16 or float16")
+    rows, k = x.shape
+    q = torch.empty((rows, k), dtype=torch.uint8, device=x.device)
+    sf = torch.empty(((rows + block_rows - 1) // block_rows, (k + 127) // 128), dtype=torch.float32, device=x.device)
+    with _device_guard(x):
+        rc = getattr(_lib.lib(), fn_name)(x.data_ptr(), _CAST_DT[x.dtype], rows, k, q.data_ptr(), sf.data_ptr(),
+                                          _stream_ptr(x))
+        _lib.check(rc, fn_name)
+    return q.view(torch.float8_e4m3fn), sf
+
+
+def per_token_cast_to_fp8(x: torch.Tensor):
+    """Activation quantiser: x [rows,k] -> (e4m3fn [rows,k], fp32 scales [rows, ceil(k/128)]), one scale per 1x128
+    block: scale = amax/448, q = RNE-satfinite(x/scale) (the A-operand format of gemm_fp8_fp8_bf16_nt)."""
+    return _cast("dga_cast_to_fp8_1x128", x, 1)
+
+
+def per_block_cast_to_fp8(x: torch.Tensor):
+    """Weight quantiser: x [rows,k] -> (e4m3fn [rows,k], fp32 scales [ceil(rows/128), ceil(k/128)]), one scale per
+    128x128 block (the B-operand format)."""
+    return _cast("dga_cast_to_fp8_128x128", x, 128)
 
 
 def copy_rows(dst: torch.Tensor, src: torch.Tensor, dst_index: Optional[torch.Tensor] = None,

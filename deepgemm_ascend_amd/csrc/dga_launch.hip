@@ -108,11 +108,14 @@ static const Variant *find_variant(int bm, int bn, int wm, int wn, int stages)
     return wm ? find_variant(bm, bn, 0, 0, 2) : nullptr;
 }
 
+// m_indices != nullptr: contiguous-grouped layout -- one A/out matrix of m rows (groups == 1 on that side), b_groups
+// B matrices picked per row block by m_indices.  Otherwise b_groups == groups.
 static int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, void *out,
-                   const int32_t *masked_m, int groups, int m, int n, int k, int expected_m,
-                   const dga_tiling_t *tiling, void *workspace, size_t workspace_bytes, hipStream_t stream)
+                   const int32_t *masked_m, const int32_t *m_indices, int b_groups, int groups, int m, int n, int k,
+                   int expected_m, const dga_tiling_t *tiling, void *workspace, size_t workspace_bytes,
+                   hipStream_t stream)
 {
-    if (m < 0 || n < 0 || k < 0 || groups < 0) return DGA_E_SHAPE;
+    if (m < 0 || n < 0 || k < 0 || groups < 0 || b_groups < 0) return DGA_E_SHAPE;
     if (groups == 0 || m == 0 || n == 0) return DGA_OK;  // empty problem: nothing to write
     if (!a || !b || !sfa || !sfb || !out) {
         // k == 0 still reads nothing but must write zeros: pointers to out are required
@@ -124,6 +127,7 @@ static int run_fp8(const void *a, const float *sfa, const void *b, const float *
         pr.m = m; pr.n = n; pr.k = k; pr.groups = groups; pr.expected_m = expected_m;
         pr.layoutTagA = DGA_LAYOUT_ROW_MAJOR; pr.layoutTagB = DGA_LAYOUT_COLUMN_MAJOR;
         pr.layoutTagC = DGA_LAYOUT_ROW_MAJOR; pr.dtype = DGA_DT_FP8_E4M3FN;
+        pr.flags = m_indices ? DGA_PROBLEM_CONTIGUOUS_M : 0;
         int rc = dga_tiling(&pr, &local);
         if (rc != DGA_OK) return rc;
         tiling = &local;
@@ -131,6 +135,9 @@ static int run_fp8(const void *a, const float *sfa, const void *b, const float *
     // workspace == NULL is allowed (split-K and the odd-K padding pass are then skipped: single-pass / element-wise
     // kernels, same results); a workspace that is passed must be as large as dga_workspace_bytes() says
     if (workspace && dga_workspace_bytes(tiling) > workspace_bytes) return DGA_E_WORKSPACE;
+    // contiguous layout: group segments are aligned to DGA_CONTIGUOUS_M_ALIGNMENT rows, so a tile may not be taller
+    if (m_indices && (tiling->m1 == 0 || tiling->m1 > DGA_CONTIGUOUS_M_ALIGNMENT || DGA_CONTIGUOUS_M_ALIGNMENT % tiling->m1))
+        return DGA_E_TILING;
     GemmParams p{};
     p.a = static_cast<const uint8_t *>(a);
     p.sfa = sfa;
@@ -138,6 +145,8 @@ static int run_fp8(const void *a, const float *sfa, const void *b, const float *
     p.sfb = sfb;
     p.out = static_cast<uint16_t *>(out);
     p.masked_m = masked_m;
+    p.m_indices = m_indices;
+    p.b_groups = b_groups;
     p.m = m; p.n = n; p.k = k;
     p.kb_n = (k + 127) / 128;
     p.nb_n = (n + 127) / 128;
@@ -161,7 +170,7 @@ static int run_fp8(const void *a, const float *sfa, const void *b, const float *
     };
     if (k > 0 && (k % 16) != 0) {
         const int kp = p.kb_n * 128;
-        const int64_t rows_a = static_cast<int64_t>(groups) * m, rows_b = static_cast<int64_t>(groups) * n;
+        const int64_t rows_a = static_cast<int64_t>(groups) * m, rows_b = static_cast<int64_t>(b_groups) * n;
         uint8_t *pa = carve(static_cast<size_t>(rows_a) * kp);
         uint8_t *pb = pa ? carve(static_cast<size_t>(rows_b) * kp) : nullptr;
         if (pa && pb) {
@@ -199,7 +208,7 @@ static int run_fp8(const void *a, const float *sfa, const void *b, const float *
     p.xcd_remap = xcd_remap;
 
     // ---- split-K (kernelSerial 4): partial fp32 slabs + combine; dense only
-    if (tiling->splitkFactor > 1 && groups == 1 && !masked_m) {
+    if (tiling->splitkFactor > 1 && groups == 1 && !masked_m && !m_indices) {
         int s = tiling->splitkFactor;
         const int kbps = (p.kb_n + s - 1) / s;
         s = (p.kb_n + kbps - 1) / kbps;  // no empty split
@@ -235,7 +244,7 @@ int dga_gemm_fp8_fp8_bf16_nt(const void *a, const float *sfa, const void *b, con
                              int n, int k, const dga_tiling_t *tiling, void *workspace, size_t workspace_bytes,
                              void *stream)
 {
-    return dga::run_fp8(a, sfa, b, sfb, out, nullptr, 1, m, n, k, 0, tiling, workspace, workspace_bytes,
+    return dga::run_fp8(a, sfa, b, sfb, out, nullptr, nullptr, 1, 1, m, n, k, 0, tiling, workspace, workspace_bytes,
                         static_cast<hipStream_t>(stream));
 }
 
@@ -245,7 +254,19 @@ int dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked(const void *a, const float *sfa, c
                                               size_t workspace_bytes, void *stream)
 {
     if (groups > 0 && m_max > 0 && !masked_m) return DGA_E_NULL;
-    return dga::run_fp8(a, sfa, b, sfb, out, masked_m, groups, m_max, n, k, expected_m, tiling, workspace,
+    return dga::run_fp8(a, sfa, b, sfb, out, masked_m, nullptr, groups, groups, m_max, n, k, expected_m, tiling,
+                        workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int dga_m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(const void *a, const float *sfa, const void *b, const float *sfb,
+                                                  void *out, const int32_t *m_indices, int m_sum, int groups, int n,
+                                                  int k, const dga_tiling_t *tiling, void *workspace,
+                                                  size_t workspace_bytes, void *stream)
+{
+    if (groups < 0) return DGA_E_SHAPE;
+    if (m_sum > 0 && n > 0 && groups > 0 && !m_indices) return DGA_E_NULL;
+    if (groups == 0) return DGA_OK;  // no B matrices: every row is a padding row
+    return dga::run_fp8(a, sfa, b, sfb, out, nullptr, m_indices, groups, 1, m_sum, n, k, 0, tiling, workspace,
                         workspace_bytes, static_cast<hipStream_t>(stream));
 }
 

@@ -282,7 +282,8 @@ static double tile_cycles_per_kblock(const MenuEntry &e)
     return std::max({mfma, lds, dma}) + 200.0;                // + barrier/issue overhead per k block
 }
 
-void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, uint32_t expected_m)
+void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, uint32_t expected_m,
+                   bool contiguous = false)
 {
     const uint32_t m_eff = (groups > 1 && expected_m) ? std::min(expected_m, t.m) : t.m;
     const uint32_t kb = ceil_div(std::max(t.k, 1u), 128);
@@ -297,6 +298,8 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
         seen.push_back(e);
         if (static_cast<uint64_t>(e.lds) > pf.l1Size) continue;
         if (4ull * e.bm * e.bn > pf.l0CSize) continue;  // accumulators: JudgeSpace's L0C test on VGPRs
+        // contiguous-grouped layout: a tile must not straddle two group segments (aligned to 128 rows)
+        if (contiguous && (e.bm > DGA_CONTIGUOUS_M_ALIGNMENT || DGA_CONTIGUOUS_M_ALIGNMENT % e.bm)) continue;
         // M fits one tile row (decode / grouped shapes): B is the whole stream, so never cut M (every extra tile row
         // re-reads B) -- take the smallest tile height that covers M and let N tiles and split-K supply parallelism
         if (m_eff <= 128 && e.bm != static_cast<int>(std::max(16u, round_up(m_eff, m_eff <= 16 ? 16 : m_eff <= 32 ? 32 : m_eff <= 64 ? 64 : 128))))
@@ -334,7 +337,7 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
     // is long, K is cut so that every CU streams a share of the operands; the fp32 partial tiles are combined by a
     // second kernel.  Worth it only while the partial slabs stay small next to the operand stream.
     t.kernelSerial = (blocks <= pf.coreNum && t.k <= t.k1) ? DGA_KERNEL_SMALL : DGA_KERNEL_COMMON;
-    if (groups == 1 && blocks * 4 <= pf.coreNum * 3 && kb >= 8) {
+    if (groups == 1 && !contiguous && blocks * 4 <= pf.coreNum * 3 && kb >= 8) {
         uint32_t s = std::min<uint32_t>({pf.coreNum * 2 / static_cast<uint32_t>(blocks), kb / 4, 32u});
         const uint64_t operand_bytes = static_cast<uint64_t>(t.m + t.n) * t.k;
         while (s > 1 && static_cast<uint64_t>(s) * t.m * t.n * 8 * 2 > operand_bytes) --s;  // slab write + read <= half the operand read
@@ -514,6 +517,7 @@ int init_params(const dga_problem_t &p, dga_tiling_t &t)
     t.swizzleDirection = (p.m > p.n) ? 0 : 1;
     t.splitkFactor = 1;
     t.groups = p.groups ? p.groups : 1;
+    t.contiguous = (p.flags & DGA_PROBLEM_CONTIGUOUS_M) ? 1 : 0;
     return DGA_OK;
 }
 
@@ -597,7 +601,8 @@ int dga_select_kernel(const dga_problem_t *problem, const dga_platform_t *platfo
     if (pf.xcdNum <= 1) {
         select_reference(*out, pf);
     } else {
-        select_mi355x(*out, pf, out->groups, problem->expected_m);
+        if (out->contiguous) select_mi355x(*out, pf, 1, 0, true);  // one A/out matrix; groups counts the B matrices
+        else select_mi355x(*out, pf, out->groups, problem->expected_m);
         if (!out->m1) return DGA_E_TILING;
     }
     return DGA_OK;
@@ -607,6 +612,7 @@ int dga_tiling(const dga_problem_t *problem, dga_tiling_t *out)
 {
     if (!problem || !out) return DGA_E_NULL;
     init_params(*problem, *out);
+    if (out->contiguous) return dga_select_kernel(problem, nullptr, out);  // the (m,n,k) cache holds dense tilings
     if (Cache::instance().get(*out)) {
         if (Cache::instance().last_hit_had_cdna4_columns()) {  // a swept entry is complete: use it as it stands
             complete_from_menu(*out);
@@ -643,7 +649,7 @@ size_t dga_workspace_bytes(const dga_tiling_t *tiling)
     const size_t groups = tiling->groups ? tiling->groups : 1;
     if (tiling->k % 16 != 0 && tiling->k > 0) {  // padded copies of A and B (rows zero-filled to a multiple of 128)
         const size_t kp = (static_cast<size_t>(tiling->k) + 127) / 128 * 128;
-        add(groups * tiling->m * kp);
+        add((tiling->contiguous ? 1 : groups) * tiling->m * kp);
         add(groups * tiling->n * kp);
     }
     if (tiling->splitkFactor > 1) add(static_cast<size_t>(tiling->splitkFactor) * tiling->m * tiling->n * 4);

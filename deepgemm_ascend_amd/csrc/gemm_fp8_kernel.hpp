@@ -32,6 +32,8 @@ struct GemmParams {
     const float *sfb;      // [G][nb_n][kb_n]
     uint16_t *out;         // [G][m_rows][ldc] bf16 bits
     const int32_t *masked_m;  // grouped: device int32[G]; dense: nullptr
+    const int32_t *m_indices;  // contiguous-grouped: device int32[m], the B group of every row (-1 = skip); else nullptr
+    int b_groups;              // contiguous-grouped: number of B groups (bounds the device-side index)
     int m;                 // dense: M; grouped: m_max (rows allocated per group)
     int n, k, kb_n, nb_n;
     int64_t lda, ldb, ldc;       // row strides in elements
@@ -127,13 +129,20 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
     const int M = p.masked_m ? min(p.masked_m[g], p.m) : p.m;
     const int m0 = tm * BM, n0 = tn * BN;
     if (m0 >= M) return;  // empty expert / fully masked tile: nothing read, nothing written
+    // contiguous-grouped layout: one A/out matrix, the B group comes from the index of the tile's first row (the
+    // layout contract aligns group segments to the tile height); padding tiles (index -1) do nothing
+    int bg = g;
+    if (p.m_indices) {
+        bg = p.m_indices[m0];
+        if (bg < 0 || bg >= p.b_groups) return;
+    }
     const int kb_begin = p.splitk > 1 ? split * p.kb_per_split : 0;
     const int kb_end = p.splitk > 1 ? min(p.kb_n, kb_begin + p.kb_per_split) : p.kb_n;
 
     const uint8_t *A = p.a + (int64_t)g * p.a_gs;
-    const uint8_t *B = p.b + (int64_t)g * p.b_gs;
+    const uint8_t *B = p.b + (int64_t)bg * p.b_gs;
     const float *SFA = p.sfa + (int64_t)g * p.sfa_gs;
-    const float *SFB = p.sfb + (int64_t)g * p.sfb_gs;
+    const float *SFB = p.sfb + (int64_t)bg * p.sfb_gs;
     uint16_t *C = p.out + (int64_t)g * p.c_gs;
 
     // ---- per-thread LDS-DMA sources.  Chunk id c = it*NT + tid lands at LDS byte 16*c (wave-uniform base +
@@ -251,6 +260,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         for (int mt = 0; mt < TM; ++mt) {
             const int m = m_row + mt * 16;
             if (m >= M) continue;
+            if (p.m_indices && p.m_indices[m] != bg) continue;  // a row of another group / a padding row: untouched
             uint16_t *crow = C + (int64_t)m * p.ldc;
 #pragma unroll
             for (int j = 0; j < TN / 2; ++j) {
@@ -767,10 +777,15 @@ __global__ void __launch_bounds__(256) gemm_fp8_blockscaled_nt_generic_kernel(co
     const int n = blockIdx.x * 16 + (threadIdx.x & 15);
     const int m = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (m >= M || n >= p.n) return;
+    int bg = g;
+    if (p.m_indices) {  // contiguous-grouped: per-row B group
+        bg = p.m_indices[m];
+        if (bg < 0 || bg >= p.b_groups) return;
+    }
     const uint8_t *ar = p.a + (int64_t)g * p.a_gs + (int64_t)m * p.lda;
-    const uint8_t *br = p.b + (int64_t)g * p.b_gs + (int64_t)n * p.ldb;
+    const uint8_t *br = p.b + (int64_t)bg * p.b_gs + (int64_t)n * p.ldb;
     const float *sa = p.sfa + (int64_t)g * p.sfa_gs + (int64_t)m * p.kb_n;
-    const float *sb = p.sfb + (int64_t)g * p.sfb_gs + (int64_t)(n / 128) * p.kb_n;
+    const float *sb = p.sfb + (int64_t)bg * p.sfb_gs + (int64_t)(n / 128) * p.kb_n;
     float acc = 0.f;
     for (int kb = 0; kb < p.kb_n; ++kb) {
         const int k0 = kb * 128, k1 = min(p.k, k0 + 128);

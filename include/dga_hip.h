@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define DGA_ABI_VERSION 1
+#define DGA_ABI_VERSION 2
 
 /* ---- status codes (reference: DGA_HOST_ASSERT throws DGAException,
  *      deep_gemm_ascend/framework/csrc/utils/exception.hpp:9-33; op hooks return
@@ -81,7 +81,7 @@ typedef struct dga_tiling_t {
     /* CDNA4 */
     uint8_t wavesM, wavesN;      /* wave grid inside the workgroup */
     uint8_t stages;              /* LDS stages */
-    uint8_t reserved0;
+    uint8_t contiguous;          /* 1 = contiguous-grouped layout (groups = number of B matrices) */
     uint32_t ldsBytes;
     uint32_t groups;             /* 1 = dense */
 } dga_tiling_t;
@@ -92,7 +92,11 @@ typedef struct dga_problem_t {
     uint32_t expected_m;         /* grouped: hint for tile choice (0 = m) */
     uint8_t layoutTagA, layoutTagB, layoutTagC;
     uint8_t dtype;               /* DGA_DT_* of the inputs */
+    uint32_t flags;              /* DGA_PROBLEM_* */
 } dga_problem_t;
+
+#define DGA_PROBLEM_CONTIGUOUS_M 1u   /* contiguous-grouped layout: tile height <= DGA_CONTIGUOUS_M_ALIGNMENT */
+#define DGA_CONTIGUOUS_M_ALIGNMENT 128
 
 /* ---- operator hooks -------------------------------------------------------------------- */
 
@@ -148,6 +152,26 @@ int dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked(const void *a, const float *sfa, c
                                               void *out, const int32_t *masked_m, int groups, int m_max, int n,
                                               int k, int expected_m, const dga_tiling_t *tiling, void *workspace,
                                               size_t workspace_bytes, void *stream);
+
+/* m_grouped_gemm_fp8_fp8_bf16_nt_contiguous: the prefill-side MoE layout.
+ *   a [m_sum,K], sfa [m_sum,KB], b [G,N,K], sfb [G,NB,KB], out [m_sum,N], m_indices device int32[m_sum].
+ * Row r is multiplied with b[m_indices[r]]; rows with m_indices[r] < 0 are padding and are not written.
+ * Layout contract: the rows of one group are consecutive, every group segment starts at a multiple of
+ * DGA_CONTIGUOUS_M_ALIGNMENT rows, and a segment's padding rows (-1) follow its valid rows.
+ * No reference counterpart (the reference has only the uniform batch loop, generate_code.hpp:149-153). */
+int dga_m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(const void *a, const float *sfa, const void *b, const float *sfb,
+                                                  void *out, const int32_t *m_indices, int m_sum, int groups, int n,
+                                                  int k, const dga_tiling_t *tiling, void *workspace,
+                                                  size_t workspace_bytes, void *stream);
+
+/* Quantisers upstream of the GEMM: x [rows,k] contiguous, x_dtype in
+ * {DGA_DT_FP32, DGA_DT_BF16, DGA_DT_FP16} -> q [rows,k] e4m3fn bytes and fp32 scales
+ *   1x128:    sf [rows, ceil(k/128)]              (the A-operand / activation format)
+ *   128x128:  sf [ceil(rows/128), ceil(k/128)]    (the B-operand / weight format)
+ * scale = amax/448 (1 when the block is all zero), q = RNE-satfinite(x / scale).  The reference's inputs are fp16
+ * files from numpy (scripts/gen_data.py:10-30); it has no quantiser. */
+int dga_cast_to_fp8_1x128(const void *x, int x_dtype, int64_t rows, int64_t k, void *q, float *sf, void *stream);
+int dga_cast_to_fp8_128x128(const void *x, int x_dtype, int64_t rows, int64_t k, void *q, float *sf, void *stream);
 
 /* ---- the framework's 28-int Config (deep_gemm_ascend/framework/csrc/jit/get_best_config.hpp) ---- */
 

@@ -231,6 +231,19 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_masked(a, sfa, b, sfb, out_init, masked_m, th
     return out
 
 
+def m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(a, sfa, b, sfb, out_init, m_indices, threads: int = 1) -> np.ndarray:
+    """Contiguous-grouped layout: row r of a [Msum,K] is multiplied with b[m_indices[r]]; rows with a negative index
+    keep out_init.  Stated row-wise on top of the dense C oracle (no alignment assumption)."""
+    a = _c(a, np.uint8); sfa = _c(sfa, np.float32)
+    m_indices = _c(m_indices, np.int32)
+    out = np.array(out_init, dtype=np.uint16, copy=True, order="C")
+    for g in range(b.shape[0]):
+        rows = np.nonzero(m_indices == g)[0]
+        if rows.size:
+            out[rows] = gemm_fp8_fp8_bf16_nt(a[rows], sfa[rows], b[g], sfb[g], threads=threads)
+    return out
+
+
 # --------------------------------------------------------------------------- inputs
 
 def quant_1x128(x: np.ndarray):

@@ -121,3 +121,17 @@ def test_parity_metric_behaves(oracle):
     bad = want.copy(); bad[3, 7] ^= 0x0040  # flip a high mantissa bit: ~64 ulp
     with pytest.raises(AssertionError):
         oracle.assert_parity(bad, want, a, sfa, b, sfb)
+
+
+def test_contiguous_layout_is_rowwise_dense(oracle):
+    """The contiguous-grouped oracle equals the dense oracle applied per row group; padding rows keep out_init."""
+    k, n = 256, 128
+    a, sfa, _, _ = oracle.make_inputs(40, 8, k, seed=1)
+    bs = [oracle.make_inputs(8, n, k, seed=10 + g)[2:] for g in range(3)]
+    b = np.stack([x[0] for x in bs]); sfb = np.stack([x[1] for x in bs])
+    idx = np.array([0] * 10 + [-1] * 6 + [2] * 16 + [1] * 8, np.int32)
+    init = np.full((40, n), 0x7FC1, np.uint16)
+    out = oracle.m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(a, sfa, b, sfb, init, idx)
+    assert (out[10:16] == 0x7FC1).all()
+    for g, rows in ((0, slice(0, 10)), (2, slice(16, 32)), (1, slice(32, 40))):
+        assert (out[rows] == oracle.gemm_fp8_fp8_bf16_nt(a[rows], sfa[rows], b[g], sfb[g])).all()
