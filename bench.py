@@ -114,6 +114,50 @@ def grouped_leg(args, rank, world, dist):
                                   mask=args.grouped_mask)
 
 
+def _time_us(fn, iters, warm):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def widen_leg():
+    """The rows either side of the hot path, reported beside the headline metric:
+    the contiguous-grouped (prefill MoE) layout and the activation quantiser that feeds the GEMM."""
+    import deepgemm_ascend_amd as dga
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    groups, per, n, k = 8, 1024, 4096, 7168
+    msum = groups * per
+    a = _rand_fp8((msum, k), gen); b = _rand_fp8((groups, n, k), gen)
+    sfa = torch.rand((msum, k // 128), device="cuda") + 0.5
+    sfb = torch.rand((groups, n // 128, k // 128), device="cuda") + 0.5
+    idx = torch.arange(groups, device="cuda", dtype=torch.int32).repeat_interleave(per).contiguous()
+    out = torch.empty((msum, n), dtype=torch.bfloat16, device="cuda")
+    t = dga.tiling(msum, n, k, groups=groups, contiguous=True)
+    us = _time_us(lambda: dga.m_grouped_gemm_fp8_fp8_bf16_nt_contiguous((a, sfa), (b, sfb), out, idx, tiling_=t), 20, 5)
+    tf = 2.0 * msum * n * k / us / 1e6
+    res = {"contiguous": {"workload": f"m_grouped_gemm_fp8_fp8_bf16_nt_contiguous G={groups} x {per} rows, N={n} K={k}",
+                          "tile": f"{t.m1}x{t.n1}", "kernel_us": round(us, 1),
+                          "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_FP8_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": round(tf / PEAK_FP8_TFLOPS, 4)}}}
+    del a, b, out
+    rows, kk = 32768, 7168
+    x = torch.randn((rows, kk), device="cuda", dtype=torch.bfloat16)
+    us = _time_us(lambda: dga.per_token_cast_to_fp8(x), 20, 5)
+    byt = rows * kk * 3 + rows * (kk // 128) * 4
+    res["per_token_cast"] = {"workload": f"per_token_cast_to_fp8 bf16 [{rows},{kk}] -> e4m3fn + 1x128 f32 scales",
+                             "kernel_us": round(us, 1), "algorithmic_bytes": byt,
+                             "roofline": {"bound": "hbm", "achieved": round(byt / us / 1e3, 1), "peak": PEAK_HBM_GBPS,
+                                          "unit": "GB/s", "frac": round(byt / us / 1e3 / PEAK_HBM_GBPS, 4)}}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +166,7 @@ def main():
     ap.add_argument("--workload", default="dense_4096", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grouped", action="store_true")
+    ap.add_argument("--no-widen", action="store_true")
     ap.add_argument("--groups", type=int, default=256)
     ap.add_argument("--grouped-mask", default="full", choices=["full", "random"])
     ap.add_argument("--cpu-budget", type=float, default=15.0)
@@ -205,6 +250,11 @@ def main():
         if isinstance(grouped.get("roofline"), dict) and world == 1 and args.groups == 256 and args.grouped_mask == "full":
             grouped["roofline"]["traffic"] = pmc_traffic("grouped")
         res["grouped"] = grouped
+    if rank == 0 and world == 1 and not args.no_widen:
+        try:
+            res["widen"] = widen_leg()
+        except Exception as e:
+            res["widen"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(m, n, k, a, sfa, b, sfb, budget_s=args.cpu_budget)
     if rank == 0:

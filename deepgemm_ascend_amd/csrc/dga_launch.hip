@@ -46,7 +46,8 @@ static int launch_one(const GemmParams &p, hipStream_t stream)
                                             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     });
     DGA_HIP_TRY(attr_err[dev]);
-    const unsigned grid = static_cast<unsigned>(p.groups) * p.tiles_m * p.tiles_n;
+    unsigned grid = static_cast<unsigned>(p.groups) * p.tiles_m * p.tiles_n;
+    if (p.m_indices && Cfg::kBM > DGA_CONTIGUOUS_M_ALIGNMENT) grid *= 2;  // pass-1 copies for straddling tiles
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p);
     DGA_HIP_TRY(hipGetLastError());
     return DGA_OK;
@@ -136,7 +137,9 @@ static int run_fp8(const void *a, const float *sfa, const void *b, const float *
     // kernels, same results); a workspace that is passed must be as large as dga_workspace_bytes() says
     if (workspace && dga_workspace_bytes(tiling) > workspace_bytes) return DGA_E_WORKSPACE;
     // contiguous layout: group segments are aligned to DGA_CONTIGUOUS_M_ALIGNMENT rows, so a tile may not be taller
-    if (m_indices && (tiling->m1 == 0 || tiling->m1 > DGA_CONTIGUOUS_M_ALIGNMENT || DGA_CONTIGUOUS_M_ALIGNMENT % tiling->m1))
+    // (256-row tiles are legal too: the kernel then runs a second pass on the tiles that straddle two groups)
+    if (m_indices && tiling->m1 != 2 * DGA_CONTIGUOUS_M_ALIGNMENT &&
+        (tiling->m1 == 0 || tiling->m1 > DGA_CONTIGUOUS_M_ALIGNMENT || DGA_CONTIGUOUS_M_ALIGNMENT % tiling->m1))
         return DGA_E_TILING;
     GemmParams p{};
     p.a = static_cast<const uint8_t *>(a);

@@ -299,7 +299,14 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
         if (static_cast<uint64_t>(e.lds) > pf.l1Size) continue;
         if (4ull * e.bm * e.bn > pf.l0CSize) continue;  // accumulators: JudgeSpace's L0C test on VGPRs
         // contiguous-grouped layout: a tile must not straddle two group segments (aligned to 128 rows)
-        if (contiguous && (e.bm > DGA_CONTIGUOUS_M_ALIGNMENT || DGA_CONTIGUOUS_M_ALIGNMENT % e.bm)) continue;
+        // Long groups (>= 512 rows on average) take the 256x256 tile all the same: it runs a second pass on the tiles
+        // that straddle two groups (about every second group boundary) and still wins by 15-25 % (scripts/contig_ab.py).
+        if (contiguous) {
+            const bool tall = t.m / std::max(1u, t.groups) >= 512 && t.n >= 256;
+            if (tall ? !(e.bm == 2 * DGA_CONTIGUOUS_M_ALIGNMENT && e.bn == 256)
+                     : (e.bm > DGA_CONTIGUOUS_M_ALIGNMENT || DGA_CONTIGUOUS_M_ALIGNMENT % e.bm))
+                continue;
+        }
         // M fits one tile row (decode / grouped shapes): B is the whole stream, so never cut M (every extra tile row
         // re-reads B) -- take the smallest tile height that covers M and let N tiles and split-K supply parallelism
         if (m_eff <= 128 && e.bm != static_cast<int>(std::max(16u, round_up(m_eff, m_eff <= 16 ? 16 : m_eff <= 32 ? 32 : m_eff <= 64 ? 64 : 128))))
@@ -330,7 +337,7 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
         t.stages = 3;
     const uint32_t tiles_m = ceil_div(t.m, t.m1), tiles_n = ceil_div(t.n, t.n1);
     const uint64_t blocks = static_cast<uint64_t>(groups) * tiles_m * tiles_n;
-    t.blockDim = static_cast<uint32_t>(blocks);
+    t.blockDim = static_cast<uint32_t>(blocks) * ((contiguous && t.m1 > DGA_CONTIGUOUS_M_ALIGNMENT) ? 2 : 1);
     t.paddingTagA = t.paddingTagB = t.paddingTagC = DGA_PADDING_NONE;
     // variant menu in the reference's order: Small (one tile per core, single K step) -> Stream-K -> Common.
     // Stream-K handler (select_kernel.cpp:303-331, CDNA4 reading): when the tiles fill less than half of the CUs and K

@@ -22,6 +22,7 @@
 // bytes [16*kg,+16) and [64+16*kg,+16) of the 128-byte k block (kg = lane>>4).
 #pragma once
 #include "dga_device_common.hpp"
+#include "dga_hip.h"
 
 namespace dga {
 
@@ -103,10 +104,17 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
 
     // ---- tile id: XCD-aware remap (blocks b, b+8, ... share an XCD and its L2), then
     //      a grouped raster so that an XCD's consecutive tiles share A and B panels.
-    const int nwg = gridDim.x;
+    int nwg = gridDim.x, bid = blockIdx.x;
+    // contiguous-grouped layout with tiles taller than the segment alignment: the grid is doubled, the second copy
+    // of a tile ("pass 1") only works when the tile straddles two groups (see below)
+    int pass = 0;
+    if (BM > DGA_CONTIGUOUS_M_ALIGNMENT && p.m_indices) {
+        nwg >>= 1;
+        if (bid >= nwg) { pass = 1; bid -= nwg; }
+    }
     int tile;
     {
-        const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         tile = p.xcd_remap ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3) : bid;
     }
     const int tiles_per_group = p.tiles_m * p.tiles_n;
@@ -131,9 +139,20 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
     if (m0 >= M) return;  // empty expert / fully masked tile: nothing read, nothing written
     // contiguous-grouped layout: one A/out matrix, the B group comes from the index of the tile's first row (the
     // layout contract aligns group segments to the tile height); padding tiles (index -1) do nothing
+    //   A tile taller than the alignment (256 rows = two 128-row blocks) may hold two groups: pass 0 computes the
+    //   tile against the first block's group, pass 1 -- a second workgroup -- against the second block's group if
+    //   that differs; each stores only the rows whose index matches (epilogue).  Uniform tiles cost pass 1 two loads.
     int bg = g;
     if (p.m_indices) {
         bg = p.m_indices[m0];
+        if (BM > DGA_CONTIGUOUS_M_ALIGNMENT) {
+            const int m1 = m0 + DGA_CONTIGUOUS_M_ALIGNMENT;
+            const int g1 = m1 < M ? p.m_indices[m1] : bg;
+            if (pass == 1) {
+                if (g1 == bg) return;
+                bg = g1;
+            }
+        }
         if (bg < 0 || bg >= p.b_groups) return;
     }
     const int kb_begin = p.splitk > 1 ? split * p.kb_per_split : 0;

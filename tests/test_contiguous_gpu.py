@@ -63,7 +63,7 @@ def test_contiguous_parity(dga, oracle, counts, n, k):
             oracle.assert_parity(got[rows], want[rows], a[rows], sfa[rows], b[g], sfb[g])
 
 
-@pytest.mark.parametrize("bm", [16, 32, 64, 128])
+@pytest.mark.parametrize("bm", [16, 32, 64, 128, 256])
 def test_contiguous_every_tile_height(dga, oracle, bm):
     """Every tile height that divides the alignment gives the same bytes (the group lookup is per tile)."""
     counts, n, k = [70, 128, 3], 256, 256
@@ -76,12 +76,37 @@ def test_contiguous_every_tile_height(dga, oracle, bm):
     assert (got == base).all()
 
 
-def test_contiguous_rejects_tall_tiles(dga, oracle):
+@pytest.mark.parametrize("counts", [
+    [384, 384, 200, 700],       # group boundaries at odd multiples of 128: every other 256-row tile straddles two groups
+    [128, 128, 128, 128, 128],  # every tile straddles
+    [0, 300, 0, 1, 512],        # empty groups, a padding-only second block, a one-row group
+])
+def test_contiguous_two_pass_tiles(dga, oracle, counts):
+    """256-row tiles (taller than the alignment): pass 0 / pass 1 of a straddling tile each store their own group's
+    rows; parity against the oracle and bitwise equality with the 128-row tiling."""
+    n, k = 256, 384
+    a, sfa, b, sfb, m_indices = _inputs(oracle, counts, n, k, seed=sum(counts))
+    t = dga.tiling(m_indices.size, n, k, groups=len(counts), contiguous=True)
+    t.m1, t.n1, t.wavesM, t.wavesN, t.stages, t.dispatchPolicyTag = 128, 256, 0, 0, 2, 0
+    _, base = _run(dga, a, sfa, b, sfb, m_indices, n, tiling_=t)
+    for policy in (0, 2):
+        t2 = dga.tiling(m_indices.size, n, k, groups=len(counts), contiguous=True)
+        t2.m1, t2.n1, t2.wavesM, t2.wavesN, t2.stages, t2.dispatchPolicyTag = 256, 256, 0, 0, 2, policy
+        init, got = _run(dga, a, sfa, b, sfb, m_indices, n, tiling_=t2)
+        assert (got[m_indices < 0] == SENTINEL).all()
+        assert (got == base).all()
+    want = oracle.m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(a, sfa, b, sfb, init, m_indices, threads=8)
+    for g in range(b.shape[0]):
+        rows = np.nonzero(m_indices == g)[0]
+        if rows.size >= 32:
+            oracle.assert_parity(got[rows], want[rows], a[rows], sfa[rows], b[g], sfb[g])
+
+
+def test_contiguous_rejects_tile_heights_outside_the_menu(dga, oracle):
     counts, n, k = [128, 128], 256, 256
     a, sfa, b, sfb, m_indices = _inputs(oracle, counts, n, k, seed=3)
-    t = dga.tiling(256, n, k)  # a dense tiling: 256-row tiles are not legal for this layout
-    if t.m1 <= ALIGN:
-        t.m1 = 256; t.n1 = 256
+    t = dga.tiling(256, n, k, groups=2, contiguous=True)
+    t.m1 = 96  # does not divide the 128-row alignment
     with pytest.raises(dga.DGAError):
         _run(dga, a, sfa, b, sfb, m_indices, n, tiling_=t)
 

@@ -145,9 +145,10 @@ def test_tiling_cache_reads_swept_cdna4_columns(dga, tmp_path):
         dga.tiling_cache_clear()
 
 
-@pytest.mark.parametrize("m,n,k,g", [(4096, 2048, 7168, 8), (16384, 7168, 2048, 32), (384, 4096, 7168, 3), (128, 128, 128, 1)])
+@pytest.mark.parametrize("m,n,k,g", [(4096, 2048, 7168, 32), (16384, 7168, 2048, 128), (384, 4096, 7168, 3), (128, 128, 128, 1)])
 def test_contiguous_layout_tiles_divide_the_alignment(dga, m, n, k, g):
-    """Contiguous-grouped layout: tile height <= 128 and a divisor of it, no split-K, groups = number of B matrices."""
+    """Contiguous-grouped layout, short groups: tile height <= 128 and a divisor of it, no split-K, groups = number of
+    B matrices."""
     t = dga.tiling(m, n, k, groups=g, contiguous=True)
     assert t.contiguous == 1 and t.groups == g
     assert 0 < t.m1 <= 128 and 128 % t.m1 == 0
@@ -155,3 +156,11 @@ def test_contiguous_layout_tiles_divide_the_alignment(dga, m, n, k, g):
     assert t.blockDim == -(-m // t.m1) * -(-n // t.n1)
     # the dense tiling of the same (m,n,k) is unaffected (the cache is not shared)
     assert dga.tiling(m, n, k).contiguous == 0
+
+
+@pytest.mark.parametrize("m,n,k,g", [(8192, 4096, 7168, 8), (32768, 7168, 2048, 4)])
+def test_contiguous_layout_long_groups_take_two_pass_tiles(dga, m, n, k, g):
+    """>= 512 rows per group on average: the 256x256 tile with a doubled grid (pass 1 covers straddling tiles)."""
+    t = dga.tiling(m, n, k, groups=g, contiguous=True)
+    assert (t.m1, t.n1, t.contiguous) == (256, 256, 1)
+    assert t.blockDim == 2 * -(-m // 256) * -(-n // 256)
