@@ -22,6 +22,11 @@ from .api import (  # noqa: F401
     per_block_cast_to_fp8,
     per_token_cast_to_fp8,
     platform_ascend910b,
+    predict_time_us,
+    predictor_load,
+    predictor_loaded,
+    predictor_unload,
+    select_kernel_with_predictor,
     platform_mi355x,
     run_mmad_bench,
     run_mmad_custom,

@@ -71,6 +71,12 @@ SIGNATURES = {
     "dga_select_kernel": (c_int, [POINTER(Problem), POINTER(Platform), POINTER(Tiling)]),
     "dga_platform_mi355x": (None, [POINTER(Platform)]),
     "dga_platform_ascend910b": (None, [POINTER(Platform), c_uint32]),
+    "dga_predictor_load": (c_int, [c_char_p]),
+    "dga_predictor_unload": (None, []),
+    "dga_predictor_loaded": (c_int, []),
+    "dga_predict_time_us": (c_int, [POINTER(Problem), POINTER(Tiling), POINTER(ctypes.c_float)]),
+    "dga_select_kernel_with_predictor": (c_int, [POINTER(Problem), POINTER(Tiling), POINTER(ctypes.c_float),
+                                                 POINTER(ctypes.c_float)]),
     "dga_tiling_cache_open": (c_int, [c_char_p]),
     "dga_tiling_cache_clear": (c_int, []),
     "dga_tiling_cache_size": (c_int, []),

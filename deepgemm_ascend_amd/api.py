@@ -124,6 +124,38 @@ def select_kernel(m: int, n: int, k: int, platform: Optional[Platform] = None, g
     return t
 
 
+def predictor_load(path: Optional[str] = None) -> None:
+    """Load a predictor weights file (None = tuned/predictor_mi355x.txt next to the library)."""
+    _lib.check(_lib.lib().dga_predictor_load(path.encode() if path else None), "predictor_load")
+
+
+def predictor_unload() -> None:
+    _lib.lib().dga_predictor_unload()
+
+
+def predictor_loaded() -> bool:
+    return bool(_lib.lib().dga_predictor_loaded())
+
+
+def predict_time_us(m: int, n: int, k: int, t: Tiling) -> float:
+    """The model's time for running (m,n,k) with tiling t (TilingPredictor.predict_batch for one row)."""
+    us = ctypes.c_float(0)
+    p = _problem(m, n, k)
+    _lib.check(_lib.lib().dga_predict_time_us(ctypes.byref(p), ctypes.byref(t), ctypes.byref(us)), "predict_time_us")
+    return us.value
+
+
+def select_kernel_with_predictor(m: int, n: int, k: int):
+    """SelectKernelWithPredictor: (tiling, predicted_us, native_us); falls back to the heuristic tiling when the model
+    is absent, the candidate list is short or the promised gain is below 3 % (get_best_config.py:587-621)."""
+    t = Tiling()
+    p = _problem(m, n, k)
+    a, b = ctypes.c_float(0), ctypes.c_float(0)
+    _lib.check(_lib.lib().dga_select_kernel_with_predictor(ctypes.byref(p), ctypes.byref(t), ctypes.byref(a),
+                                                           ctypes.byref(b)), "select_kernel_with_predictor")
+    return t, a.value, b.value
+
+
 def platform_mi355x() -> Platform:
     p = Platform()
     _lib.lib().dga_platform_mi355x(ctypes.byref(p))

@@ -1,0 +1,294 @@
+// Learned tiling predictor -- the counterpart of the reference's predictor
+// (/root/reference/get_best_config/get_best_config.py:166-670 TilingPredictor: candidate grid -> feature rows ->
+//  standardise -> MLP -> greedy pick with two fallbacks to the native tiling; model /root/reference/get_best_config/
+//  model.py:5-30; the C++ hook /root/reference/aclnn_catlass_dynamic_matmul/op_host/op_tiling/predictor.cpp:107-157
+//  embeds CPython and is commented out of select_kernel.cpp:380-388).
+// Here the model is evaluated natively: the weights are a plain-text export of harness/train_predictor.py (BatchNorm
+// folded), the candidate list is the compiled variant menu x stages x split-K x schedule (the same list the sweep
+// driver times, harness/sweep.py candidates()), and no Python runs in the operator path.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include <fstream>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "dga_hip.h"
+#include "dga_internal.hpp"
+
+namespace dga {
+namespace predictor {
+
+constexpr int kFeatures = 14;
+constexpr int kMinCandidates = 4;        // get_best_config.py:587 (min_tiling = 60 on the reference's 16-aligned grid)
+constexpr float kGainThreshold = 0.03f;  // get_best_config.py:606-616 (time_diff_threshold)
+
+struct Layer { int out = 0, in = 0; std::vector<float> w, b; };
+struct Model {
+    std::vector<float> mean, std;
+    std::vector<Layer> layers;
+    bool ok = false;
+};
+
+struct Cand { int m1, n1, stages, splitk, policy; };
+
+static std::mutex g_mu;
+static Model g_model;
+static bool g_tried_default = false;
+
+static bool parse(const std::string &path, Model &m)
+{
+    std::ifstream in(path);
+    if (!in.is_open()) return false;
+    std::string tag;
+    int version = 0, nf = 0, nl = 0;
+    if (!(in >> tag >> version) || tag != "dga-predictor" || version != 1) return false;
+    if (!(in >> tag >> nf) || tag != "features" || nf != kFeatures) return false;
+    std::string rest;
+    std::getline(in, rest);  // feature names (informative)
+    if (!(in >> tag) || tag != "mean") return false;
+    m.mean.resize(nf);
+    for (float &v : m.mean) if (!(in >> v)) return false;
+    if (!(in >> tag) || tag != "std") return false;
+    m.std.resize(nf);
+    for (float &v : m.std) if (!(in >> v) || v == 0.f) return false;
+    if (!(in >> tag >> nl) || tag != "layers" || nl < 1 || nl > 16) return false;
+    int prev = nf;
+    for (int l = 0; l < nl; ++l) {
+        Layer L;
+        if (!(in >> tag >> L.out >> L.in) || tag != "layer" || L.in != prev || L.out < 1 || L.out > 4096) return false;
+        L.w.resize(static_cast<size_t>(L.out) * L.in);
+        L.b.resize(L.out);
+        for (float &v : L.w) if (!(in >> v)) return false;
+        for (float &v : L.b) if (!(in >> v)) return false;
+        prev = L.out;
+        m.layers.push_back(std::move(L));
+    }
+    if (prev != 1) return false;
+    m.ok = true;
+    return true;
+}
+
+static std::string default_path()
+{
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void *>(&dga_predictor_loaded), &info) && info.dli_fname) {
+        std::string dir(info.dli_fname);
+        const size_t slash = dir.rfind('/');
+        dir = slash == std::string::npos ? "." : dir.substr(0, slash);
+        return dir + "/tuned/predictor_mi355x.txt";
+    }
+    return "tuned/predictor_mi355x.txt";
+}
+
+// the model in use; loads tuned/predictor_mi355x.txt next to the library on first use unless $DGA_NO_PREDICTOR is set
+static const Model *model()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_model.ok && !g_tried_default) {
+        g_tried_default = true;
+        const char *off = std::getenv("DGA_NO_PREDICTOR");
+        if (!(off && *off && *off != '0')) {
+            Model m;
+            if (parse(default_path(), m)) g_model = std::move(m);
+        }
+    }
+    return g_model.ok ? &g_model : nullptr;
+}
+
+static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// LDS bytes of one stage (dga_device_common.hpp GemmCfg with 256 DMA threads; the 8-wave tile gives the same figure)
+static inline uint32_t stage_bytes(uint32_t m1, uint32_t n1)
+{
+    return std::max(m1, 32u) * 128 + n1 * 128 + ((m1 + 8 + 255) / 256) * 256 * 4;
+}
+
+// One candidate -> the 14 inputs.  Must match harness/train_predictor.py feature_row() exactly.
+static void feature_row(uint32_t m, uint32_t n, uint32_t k, const Cand &c, float *f)
+{
+    const uint32_t tm = cdiv(m, c.m1), tn = cdiv(n, c.n1);
+    const uint64_t tiles = static_cast<uint64_t>(tm) * tn * c.splitk;
+    const uint32_t waves = (c.m1 == 256 && c.n1 == 256) ? 8 : 4;
+    const uint32_t lds = stage_bytes(c.m1, c.n1) * (c.stages == 3 ? 3 : 2);
+    const uint32_t wg_per_cu = std::max(1u, std::min(160u * 1024u / lds, 2048u / (waves * 64)));
+    const uint64_t rounds = (tiles + 256ull * wg_per_cu - 1) / (256ull * wg_per_cu);
+    const uint32_t kb = cdiv(k, 128), kbps = cdiv(kb, c.splitk);
+    f[0] = std::log2(static_cast<float>(m)); f[1] = std::log2(static_cast<float>(n)); f[2] = std::log2(static_cast<float>(k));
+    f[3] = std::log2(static_cast<float>(c.m1)); f[4] = std::log2(static_cast<float>(c.n1));
+    f[5] = c.stages == 3 ? 1.f : 0.f;
+    f[6] = std::log2(static_cast<float>(c.splitk));
+    f[7] = c.policy == 1 ? 1.f : 0.f; f[8] = c.policy == 2 ? 1.f : 0.f;
+    f[9] = std::log2(static_cast<float>(tiles)); f[10] = std::log2(static_cast<float>(rounds));
+    f[11] = std::log2(static_cast<float>(kbps));
+    f[12] = static_cast<float>(m) / (static_cast<float>(tm) * c.m1);
+    f[13] = static_cast<float>(n) / (static_cast<float>(tn) * c.n1);
+}
+
+static float forward(const Model &mo, const float *f)
+{
+    std::vector<float> h(kFeatures), t;
+    for (int i = 0; i < kFeatures; ++i) h[i] = (f[i] - mo.mean[i]) / mo.std[i];
+    for (size_t l = 0; l < mo.layers.size(); ++l) {
+        const Layer &L = mo.layers[l];
+        t.assign(L.out, 0.f);
+        for (int o = 0; o < L.out; ++o) {
+            float acc = 0.f;
+            const float *w = &L.w[static_cast<size_t>(o) * L.in];
+            for (int i = 0; i < L.in; ++i) acc += w[i] * h[i];
+            acc += L.b[o];
+            t[o] = (l + 1 < mo.layers.size()) ? std::max(acc, 0.f) : acc;
+        }
+        h.swap(t);
+    }
+    return std::exp(h[0]);  // the model is trained on log(microseconds)
+}
+
+static bool has_variant(int bm, int bn)
+{
+    for (int i = 0; i < variant_count(); ++i) {
+        int vm, vn, wm, wn, lds;
+        variant_info(i, &vm, &vn, &wm, &wn, &lds);
+        if (vm == bm && vn == bn) return true;
+    }
+    return false;
+}
+
+// the list harness/sweep.py candidates() times (tiles x stages x split-K x schedule, one raster per candidate)
+static std::vector<Cand> candidates(uint32_t m, uint32_t n, uint32_t k)
+{
+    static const int tiles[][2] = {{256, 256}, {128, 256}, {256, 128}, {128, 128}, {64, 256}, {64, 128}, {32, 256}, {32, 128}, {16, 256}, {16, 128}};
+    std::vector<Cand> out;
+    const uint32_t kb = cdiv(k, 128);
+    for (const auto &t : tiles) {
+        const uint32_t bm = t[0], bn = t[1];
+        if (!has_variant(bm, bn)) continue;
+        if (bm >= 2 * std::max(m, 16u) && bm > 16) continue;  // a tile twice the problem is pointless
+        const uint64_t blocks = static_cast<uint64_t>(cdiv(m, bm)) * cdiv(n, bn);
+        const bool three = (bm == 128 && bn == 256) || (bm == 128 && bn == 128) || (bm == 64 && bn == 256);
+        const bool sched = (bm == 256 && bn == 256);
+        for (int st = 2; st <= (three ? 3 : 2); ++st)
+            for (int sk : {1, 2, 4, 8, 16}) {
+                if (sk > 1 && !(blocks * sk <= 1024 && kb / sk >= 4 && blocks < 192)) continue;
+                for (int pol = 0; pol <= ((sched && sk == 1) ? 2 : 0); ++pol) out.push_back(Cand{(int)bm, (int)bn, st, sk, pol});
+            }
+    }
+    return out;
+}
+
+static uint8_t raster_for(uint32_t m, uint32_t n, const Cand &c)
+{
+    const uint32_t tiles_m = cdiv(m, c.m1);
+    const uint32_t per_xcd = std::max<uint32_t>(1, static_cast<uint32_t>((static_cast<uint64_t>(tiles_m) * cdiv(n, c.n1) * c.splitk) / 8));
+    uint32_t gm = 1;
+    while ((gm * 2) * (gm * 2) <= per_xcd * 2 && gm * 2 <= tiles_m) gm *= 2;
+    return static_cast<uint8_t>(std::min<uint32_t>(gm, 255));
+}
+
+static bool eligible(const dga_problem_t &p)
+{
+    // what the training sweep covers: the dense NT fp8 problem with 16-byte-chunk K
+    return p.dtype == DGA_DT_FP8_E4M3FN && (p.groups <= 1) && !(p.flags & DGA_PROBLEM_CONTIGUOUS_M) && p.m > 0 &&
+           p.n > 0 && p.k >= 128 && (p.k % 16) == 0;
+}
+
+}  // namespace predictor
+}  // namespace dga
+
+using namespace dga::predictor;
+
+extern "C" {
+
+int dga_predictor_load(const char *path)
+{
+    Model m;
+    const std::string p = (path && *path) ? std::string(path) : default_path();
+    if (!parse(p, m)) return DGA_E_IO;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_model = std::move(m);
+    g_tried_default = true;
+    return DGA_OK;
+}
+
+void dga_predictor_unload(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_model = Model{};
+    g_tried_default = true;  // stay unloaded until dga_predictor_load()
+}
+
+int dga_predictor_loaded(void) { return model() != nullptr; }
+
+int dga_predict_time_us(const dga_problem_t *problem, const dga_tiling_t *tiling, float *us)
+{
+    if (!problem || !tiling || !us) return DGA_E_NULL;
+    const Model *mo = model();
+    if (!mo) return DGA_E_IO;
+    if (!tiling->m1 || !tiling->n1 || !problem->m || !problem->n || !problem->k) return DGA_E_SHAPE;
+    const Cand c{tiling->m1, tiling->n1, tiling->stages == 3 ? 3 : 2, std::max<int>(1, tiling->splitkFactor), tiling->dispatchPolicyTag};
+    float f[kFeatures];
+    feature_row(problem->m, problem->n, problem->k, c, f);
+    *us = forward(*mo, f);
+    return DGA_OK;
+}
+
+// SelectKernelWithPredictor (select_kernel.cpp:380-388, commented out in the reference): native tiling first, then
+// the model's greedy pick over the candidate list unless a fallback applies.
+int dga_select_kernel_with_predictor(const dga_problem_t *problem, dga_tiling_t *out, float *predicted_us, float *native_us)
+{
+    if (!problem || !out) return DGA_E_NULL;
+    int rc = dga_select_kernel(problem, nullptr, out);
+    if (rc != DGA_OK) return rc;
+    if (predicted_us) *predicted_us = 0.f;
+    if (native_us) *native_us = 0.f;
+    const Model *mo = model();
+    if (!mo || !eligible(*problem) || out->blockDim == 0) return DGA_OK;
+    float f[kFeatures];
+    const Cand native{out->m1, out->n1, out->stages == 3 ? 3 : 2, std::max<int>(1, out->splitkFactor), out->dispatchPolicyTag};
+    feature_row(problem->m, problem->n, problem->k, native, f);
+    const float t_native = forward(*mo, f);
+    if (native_us) *native_us = t_native;
+    if (predicted_us) *predicted_us = t_native;
+    const std::vector<Cand> cands = candidates(problem->m, problem->n, problem->k);
+    if (static_cast<int>(cands.size()) < kMinCandidates) return DGA_OK;  // fallback 1: too few candidates
+    float best = 0.f;
+    const Cand *pick = nullptr;
+    for (const Cand &c : cands) {
+        feature_row(problem->m, problem->n, problem->k, c, f);
+        const float t = forward(*mo, f);
+        if (!pick || t < best) { best = t; pick = &c; }
+    }
+    if (!pick || !(best <= (1.f - kGainThreshold) * t_native)) return DGA_OK;  // fallback 2: gain below the threshold
+    out->m1 = static_cast<uint16_t>(pick->m1); out->n1 = static_cast<uint16_t>(pick->n1); out->k1 = 128;
+    out->stages = static_cast<uint8_t>(pick->stages);
+    out->dispatchPolicyTag = static_cast<uint8_t>(pick->policy);
+    out->splitkFactor = static_cast<uint16_t>(pick->splitk);
+    if (pick->splitk > 1) {  // no empty split (the launcher applies the same rule)
+        const uint32_t kb = cdiv(problem->k, 128), per = cdiv(kb, pick->splitk);
+        out->splitkFactor = static_cast<uint16_t>(cdiv(kb, per));
+    }
+    const uint64_t blocks = static_cast<uint64_t>(cdiv(problem->m, pick->m1)) * cdiv(problem->n, pick->n1);
+    out->kernelSerial = out->splitkFactor > 1 ? DGA_KERNEL_STREAMK
+                        : (blocks <= 256 && problem->k <= 128) ? DGA_KERNEL_SMALL : DGA_KERNEL_COMMON;
+    out->blockDim = static_cast<uint32_t>(blocks) * out->splitkFactor;
+    out->swizzleOffset = raster_for(problem->m, problem->n, *pick);
+    out->wavesM = out->wavesN = 0;  // first build of that tile size (the one the sweep timed)
+    for (int i = 0; i < dga::variant_count(); ++i) {
+        int vm, vn, wm, wn, lds;
+        dga::variant_info(i, &vm, &vn, &wm, &wn, &lds);
+        if (vm == pick->m1 && vn == pick->n1) {
+            out->wavesM = static_cast<uint8_t>(wm); out->wavesN = static_cast<uint8_t>(wn);
+            out->ldsBytes = static_cast<uint32_t>(lds) / 2 * pick->stages;
+            break;
+        }
+    }
+    if (predicted_us) *predicted_us = best;
+    return DGA_OK;
+}
+
+}  // extern "C"

@@ -638,7 +638,8 @@ int dga_tiling(const dga_problem_t *problem, dga_tiling_t *out)
         }
         return DGA_OK;
     }
-    int rc = dga_select_kernel(problem, nullptr, out);
+    // cache miss: the learned predictor where it applies (it starts from, and falls back to, the heuristic)
+    int rc = dga_select_kernel_with_predictor(problem, out, nullptr, nullptr);
     if (rc != DGA_OK) return rc;
     Cache::instance().put(*out);
     return DGA_OK;

@@ -44,7 +44,35 @@ THREE_STAGE = {(128, 256), (128, 128), (64, 256)}   # tiles that also have a 3-s
 PINGPONG = {(256, 256)}                               # ... ping-pong / continuous schedules (dispatchPolicyTag 1 / 2)
 
 
-def candidates(m, n, k):
+def heuristic_raster(m, n, bm, bn, splitk=1, xcds=8):
+    """The raster group select_mi355x derives for a tile (dga_tiling.cpp): the largest power of two whose square
+    fits twice an XCD's share of the grid."""
+    tiles_m = -(-m // bm)
+    per_xcd = max(1, (tiles_m * -(-n // bn) * splitk) // xcds)
+    gm = 1
+    while (gm * 2) * (gm * 2) <= per_xcd * 2 and gm * 2 <= tiles_m:
+        gm *= 2
+    return min(gm, 255)
+
+
+def grid_shapes(count, seed=0, max_mnk=2 ** 39):
+    """Random shapes for the predictor's training set: M log-uniform in [8, 8192], N and K multiples of 128 in
+    [512, 16384] (log-uniform), M*N*K bounded so that one launch stays under a millisecond."""
+    import random
+    rng = random.Random(seed)
+    out = []
+    while len(out) < count:
+        m = int(round(2 ** rng.uniform(3, 13)))
+        if rng.random() < 0.5:
+            m = max(8, (m + 15) // 16 * 16)
+        n = max(512, int(round(2 ** rng.uniform(9, 14))) // 128 * 128)
+        k = max(512, int(round(2 ** rng.uniform(9, 14))) // 128 * 128)
+        if m * n * k <= max_mnk and [m, n, k] not in out:
+            out.append([m, n, k])
+    return out
+
+
+def candidates(m, n, k, rasters=None):
     out = []
     kb = -(-k // 128)
     for bm, bn in TILES:
@@ -52,13 +80,14 @@ def candidates(m, n, k):
             continue
         blocks = -(-m // bm) * -(-n // bn)
         splits = [1] + [s for s in (2, 4, 8, 16) if blocks * s <= 1024 and kb // s >= 4 and blocks < 192]
-        for r in RASTERS:
+        for r in (RASTERS if rasters is None else [0]):
             if r > max(1, -(-m // bm)):
                 continue
             for st in ([2, 3] if (bm, bn) in THREE_STAGE else [2]):
                 for sk in splits:
                     for pol in ([0, 1, 2] if (bm, bn) in PINGPONG and sk == 1 else [0]):
-                        out.append({"m1": bm, "n1": bn, "raster": r, "stages": st, "splitk": sk, "policy": pol})
+                        rr = r if rasters is None else heuristic_raster(m, n, bm, bn, sk)
+                        out.append({"m1": bm, "n1": bn, "raster": rr, "stages": st, "splitk": sk, "policy": pol})
     return out
 
 
@@ -100,10 +129,10 @@ def time_us(fn, warm=3, iters=10):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
-def benchmark_shape(shape, out_dir: Path, rank=0, num_processes=1, iters=10):
+def benchmark_shape(shape, out_dir: Path, rank=0, num_processes=1, iters=10, rasters=None):
     import deepgemm_ascend_amd as dga
     m, n, k = shape
-    cands = candidates(m, n, k)
+    cands = candidates(m, n, k, rasters)
     per = -(-len(cands) // num_processes)
     lo, hi = rank * per, min(len(cands), (rank + 1) * per)
     res_path = out_dir / f"shape_{m}_{n}_{k}_rank_{rank}.jsonl"
@@ -150,13 +179,19 @@ def main(argv=None):
     ap.add_argument("--shapes", nargs="*", default=None, help="M,N,K ...")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--cache-csv", default=None, help="append winners to this tiling-cache CSV")
+    ap.add_argument("--grid", type=int, default=0, help="sweep this many random shapes (predictor training set)")
+    ap.add_argument("--grid-seed", type=int, default=0)
+    ap.add_argument("--heuristic-raster", action="store_true",
+                    help="one raster per candidate (the heuristic's) instead of the raster sweep")
     a = ap.parse_args(argv)
     torch.cuda.set_device(a.rank % max(1, torch.cuda.device_count()))
     out_dir = Path(a.out); out_dir.mkdir(parents=True, exist_ok=True)
     shapes = [[int(x) for x in s.split(",")] for s in a.shapes] if a.shapes else SHAPE_GROUP
+    if a.grid:
+        shapes = grid_shapes(a.grid, a.grid_seed)
     winners = []
     for shape in shapes:
-        best = benchmark_shape(shape, out_dir, a.rank, a.num_processes, a.iters)
+        best = benchmark_shape(shape, out_dir, a.rank, a.num_processes, a.iters, [0] if a.heuristic_raster else None)
         if best:
             us, p = best
             m, n, k = shape

@@ -122,6 +122,22 @@ int dga_select_kernel(const dga_problem_t *problem, const dga_platform_t *platfo
 void dga_platform_mi355x(dga_platform_t *out);
 void dga_platform_ascend910b(dga_platform_t *out, uint32_t core_num /*24 C++ default, 20 Python default*/);
 
+/* Learned predictor (get_best_config/get_best_config.py:166-670 TilingPredictor + model.py TimePredictMLP; C++ hook
+ * op_tiling/predictor.cpp:107-157, SelectKernelWithPredictor select_kernel.cpp:380-388).  The weights file is the
+ * text export of harness/train_predictor.py; tuned/predictor_mi355x.txt next to the library is loaded on first use
+ * unless $DGA_NO_PREDICTOR is set.  dga_tiling() consults it on a cache miss for dense fp8 problems.
+ *   dga_predictor_load(NULL) = the default file; DGA_E_IO if the file is missing or malformed.
+ *   dga_select_kernel_with_predictor: native tiling (dga_select_kernel) unless the model's greedy pick over the
+ *   compiled candidates promises >= 3 % over it and there are >= 4 candidates (the reference's two fallbacks,
+ *   get_best_config.py:587-621); *predicted_us / *native_us = the model's times for the result / the native tiling
+ *   (0 when no model is loaded or the problem is outside what the model covers). */
+int dga_predictor_load(const char *path);
+void dga_predictor_unload(void);
+int dga_predictor_loaded(void);
+int dga_predict_time_us(const dga_problem_t *problem, const dga_tiling_t *tiling, float *us);
+int dga_select_kernel_with_predictor(const dga_problem_t *problem, dga_tiling_t *out, float *predicted_us,
+                                     float *native_us);
+
 /* Tiling cache control (TilingCache, cache.cpp:69-100; CSV::Document, csv.cpp:31-140). */
 int dga_tiling_cache_open(const char *csv_path);  /* NULL/"" = memory only */
 int dga_tiling_cache_clear(void);

@@ -1,0 +1,41 @@
+"""On-device validation of the learned predictor on shapes it has not seen: time the heuristic's tiling and the
+predictor's tiling back to back (interleaved rounds), check both against the device fp32 golden."""
+import json, sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+import deepgemm_ascend_amd as dga
+from deepgemm_ascend_amd.harness import sweep
+
+out_path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/predictor_validation.json"
+shapes = sweep.grid_shapes(60, seed=4242) + [[1024, 18432, 7168], [512, 7168, 2048], [2048, 7168, 4096], [256, 4096, 7168]]
+rows = []
+for (m, n, k) in shapes:
+    a, sfa, b, sfb, golden = sweep.gen_data(m, n, k)
+    out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    native = dga.select_kernel(m, n, k)
+    pred, pred_us, native_us = dga.select_kernel_with_predictor(m, n, k)
+    key = lambda t: (t.m1, t.n1, t.stages, t.splitkFactor, t.dispatchPolicyTag)
+    res = {"shape": [m, n, k], "native": key(native), "predicted": key(pred), "model_us": [round(pred_us, 2), round(native_us, 2)]}
+    times = {"native": [], "predicted": []}
+    for name, t in (("native", native), ("predicted", pred)):
+        fn = lambda t=t: dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, tiling_=t)
+        fn(); torch.cuda.synchronize()
+        ok, diff = sweep.is_correct(golden, out)
+        res[name + "_ok"] = bool(ok)
+    for rnd in range(3):
+        for name, t in (("native", native), ("predicted", pred)):
+            fn = lambda t=t: dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, tiling_=t)
+            times[name].append(sweep.time_us(fn, warm=3, iters=20))
+    res["native_us"] = round(min(times["native"]), 2); res["predicted_us"] = round(min(times["predicted"]), 2)
+    rows.append(res)
+    print(json.dumps(res), flush=True)
+import math
+changed = [r for r in rows if r["native"] != r["predicted"]]
+ratio = [r["predicted_us"] / r["native_us"] for r in changed]
+summary = {"shapes": len(rows), "changed": len(changed), "all_correct": all(r["native_ok"] and r["predicted_ok"] for r in rows),
+           "geomean_time_ratio_changed": round(math.exp(sum(math.log(x) for x in ratio) / max(1, len(ratio))), 4),
+           "geomean_time_ratio_all": round(math.exp(sum(math.log(r["predicted_us"] / r["native_us"]) for r in rows) / len(rows)), 4),
+           "worst": round(max(ratio), 4) if ratio else None, "best": round(min(ratio), 4) if ratio else None}
+print(json.dumps(summary))
+Path(out_path).write_text(json.dumps({"summary": summary, "rows": rows}, indent=1) + "\n")

@@ -240,3 +240,16 @@ def test_hip_graph_capture_and_replay(dga, oracle):
     assert (out == 0).all()          # capture does not execute
     g.replay(); torch.cuda.synchronize()
     _check(oracle, out.view(torch.int16).cpu().numpy().view(np.uint16), a, sfa, b, sfb)
+
+
+@pytest.mark.parametrize("m,n,k", [(233, 1408, 5120), (1920, 512, 12928), (48, 3328, 512), (3789, 1280, 2176)])
+def test_predictor_picks_run_and_match_the_oracle(dga, oracle, m, n, k):
+    """Whatever the learned predictor selects must be a launchable build with the same parity as any other tiling."""
+    dga.predictor_load(None)
+    t, _, _ = dga.select_kernel_with_predictor(m, n, k)
+    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=m + n)
+    out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    dga.gemm_fp8_fp8_bf16_nt((torch.from_numpy(a).cuda(), torch.from_numpy(sfa).cuda()),
+                             (torch.from_numpy(b).cuda(), torch.from_numpy(sfb).cuda()), out, tiling_=t, sync=True)
+    want = oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, threads=8)
+    oracle.assert_parity(out.view(torch.int16).cpu().numpy().view(np.uint16), want, a, sfa, b, sfb)

@@ -1,0 +1,115 @@
+"""Learned tiling predictor: the C++ evaluation of the shipped weights equals the numpy
+statement of the exported model, the reference's two fallbacks hold (get_best_config.py:587-621), and every pick is a
+member of the compiled candidate list."""
+import math
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+WEIGHTS = ROOT / "deepgemm_ascend_amd" / "tuned" / "predictor_mi355x.txt"
+
+
+def _read_weights(path):
+    toks = path.read_text().split("\n")
+    assert toks[0] == "dga-predictor 1"
+    nf = int(toks[1].split()[1])
+    mean = np.array(toks[2].split()[1:], np.float32); std = np.array(toks[3].split()[1:], np.float32)
+    nl = int(toks[4].split()[1])
+    layers, i = [], 5
+    for _ in range(nl):
+        _, o, inn = toks[i].split(); o, inn = int(o), int(inn); i += 1
+        w = np.array([toks[i + r].split() for r in range(o)], np.float32); i += o
+        b = np.array(toks[i].split(), np.float32); i += 1
+        layers.append((w, b))
+    assert mean.size == nf and layers[0][0].shape[1] == nf
+    return layers, mean, std
+
+
+@pytest.fixture()
+def predictor(dga):
+    dga.predictor_load(None)
+    yield dga
+    dga.predictor_load(None)
+
+
+SHAPES = [(4096, 4096, 4096), (8, 7168, 18432), (233, 13440, 5120), (1920, 512, 12928), (3789, 5760, 2176),
+          (64, 2048, 7168), (512, 1024, 1024), (8192, 8192, 2048)]
+
+
+def test_cxx_forward_equals_numpy(predictor):
+    from deepgemm_ascend_amd.harness import train_predictor as tp, sweep
+    layers, mean, std = _read_weights(WEIGHTS)
+    for (m, n, k) in SHAPES:
+        for p in sweep.candidates(m, n, k, [0]):
+            t = predictor.select_kernel(m, n, k)
+            t.m1, t.n1, t.stages, t.splitkFactor, t.dispatchPolicyTag = p["m1"], p["n1"], p["stages"], p["splitk"], p["policy"]
+            got = predictor.predict_time_us(m, n, k, t)
+            want = float(np.exp(tp.forward_folded(layers, mean, std, np.array([tp.feature_row(m, n, k, p)], np.float32))[0]))
+            assert math.isclose(got, want, rel_tol=2e-4), (m, n, k, p, got, want)
+
+
+def test_pick_is_native_or_a_candidate_with_the_promised_gain(predictor):
+    from deepgemm_ascend_amd.harness import sweep
+    changed = 0
+    for (m, n, k) in SHAPES + [(m, n, k) for m, n, k in sweep.grid_shapes(40, seed=5)]:
+        native = predictor.select_kernel(m, n, k)
+        t, pred_us, native_us = predictor.select_kernel_with_predictor(m, n, k)
+        key = lambda x: (x.m1, x.n1, x.stages, x.splitkFactor, x.dispatchPolicyTag)
+        if key(t) == key(native):
+            assert pred_us == pytest.approx(native_us)
+            continue
+        changed += 1
+        cands = {(p["m1"], p["n1"], p["stages"], p["splitk"], p["policy"]) for p in sweep.candidates(m, n, k, [0])}
+        kb = -(-k // 128)
+        assert any(c[:3] == key(t)[:3] and c[4] == key(t)[4] and -(-kb // -(-kb // c[3])) == t.splitkFactor for c in cands), key(t)
+        assert len(cands) >= 4
+        assert pred_us <= 0.97 * native_us * (1 + 1e-5)
+        assert t.blockDim == -(-m // t.m1) * -(-n // t.n1) * t.splitkFactor
+        assert t.kernelSerial == (4 if t.splitkFactor > 1 else t.kernelSerial)
+        assert predictor.predict_time_us(m, n, k, t) == pytest.approx(pred_us, rel=1e-4) or t.splitkFactor > 1
+    assert changed > 0, "the predictor never departed from the heuristic on 48 shapes"
+
+
+def test_fallbacks_and_unload(predictor, tmp_path):
+    m, n, k = 233, 13440, 5120
+    native = predictor.select_kernel(m, n, k)
+    predictor.predictor_unload()
+    assert not predictor.predictor_loaded()
+    t, a, b = predictor.select_kernel_with_predictor(m, n, k)
+    assert (t.m1, t.n1, t.stages, t.splitkFactor) == (native.m1, native.n1, native.stages, native.splitkFactor) and a == b == 0.0
+    # a model whose output does not depend on the candidate can never promise 3 %: native tiling
+    flat = tmp_path / "flat.txt"
+    lines = ["dga-predictor 1", "features 14 " + " ".join(f"f{i}" for i in range(14)),
+             "mean " + " ".join(["0.0"] * 14), "std " + " ".join(["1.0"] * 14), "layers 1", "layer 1 14",
+             " ".join(["0.0"] * 14), "3.0"]
+    flat.write_text("\n".join(lines) + "\n")
+    predictor.predictor_load(str(flat))
+    t, a, b = predictor.select_kernel_with_predictor(m, n, k)
+    assert (t.m1, t.n1, t.stages, t.splitkFactor) == (native.m1, native.n1, native.stages, native.splitkFactor)
+    assert a == pytest.approx(math.exp(3.0)) and b == pytest.approx(math.exp(3.0))
+    # grouped / contiguous / odd-K problems are outside the model: native
+    for bad in (dict(m=64, n=4096, k=1921),):
+        t2, a2, _ = predictor.select_kernel_with_predictor(**bad)
+        nat = predictor.select_kernel(**bad)
+        assert (t2.m1, t2.n1) == (nat.m1, nat.n1) and a2 == 0.0
+
+
+def test_malformed_weights_are_rejected(predictor, tmp_path):
+    bad = tmp_path / "bad.txt"
+    bad.write_text("dga-predictor 1\nfeatures 6 a b c d e f\n")
+    with pytest.raises(predictor.DGAError):
+        predictor.predictor_load(str(bad))
+    with pytest.raises(predictor.DGAError):
+        predictor.predictor_load(str(tmp_path / "missing.txt"))
+    assert predictor.predictor_loaded()  # a failed load leaves the model in use untouched
+
+
+def test_tiling_consults_the_predictor_on_a_cache_miss(predictor):
+    """dga_tiling = cache -> predictor -> heuristic; the swept table still wins for its shapes."""
+    m, n, k = 1928, 640, 12928  # a shape no other test asks for (the in-memory cache is process-wide)
+    t_pred, _, _ = predictor.select_kernel_with_predictor(m, n, k)
+    t = predictor.tiling(m, n, k)
+    assert (t.m1, t.n1, t.stages, t.splitkFactor, t.dispatchPolicyTag) == \
+           (t_pred.m1, t_pred.n1, t_pred.stages, t_pred.splitkFactor, t_pred.dispatchPolicyTag)
