@@ -21,6 +21,7 @@ import time
 from dataclasses import dataclass
 from typing import Callable, Optional
 
+import numpy as np
 import torch
 
 
@@ -73,6 +74,7 @@ class ExpertShardedGroupedGemm:
         self.masked_m = torch.zeros((self.Gl,), dtype=torch.int32, device=device)
         self.b = None
         self.sfb = None
+        self._pinned = None
 
     def set_weights(self, b: torch.Tensor, sfb: torch.Tensor):
         assert tuple(b.shape) == (self.Gl, self.n, self.k) and tuple(sfb.shape) == (self.Gl, self.nb, self.kb)
@@ -85,41 +87,56 @@ class ExpertShardedGroupedGemm:
     def dispatch(self, tok_q: torch.Tensor, tok_sf: torch.Tensor, expert_ids: torch.Tensor) -> RouteState:
         """tok_q [T,K] u8, tok_sf [T,KB] f32, expert_ids [T] int64 (global expert of each token)."""
         T = tok_q.shape[0]
-        order = torch.argsort(expert_ids, stable=True).contiguous()
         counts = torch.bincount(expert_ids, minlength=self.G).to(torch.int64)        # [G]
         if self.world > 1:
             flat = torch.empty((self.world * self.G,), dtype=torch.int64, device=counts.device)
             self.dist.all_gather_into_tensor(flat, counts)
-            allc = flat.view(self.world, self.G)
         else:
-            allc = counts[None, :]
-        mine = allc[:, self.rank * self.Gl:(self.rank + 1) * self.Gl]                # [world, Gl] rows I receive
-        send_splits = counts.view(self.world, self.Gl).sum(1).tolist()
-        recv_splits = mine.sum(1).tolist()
+            flat = counts
+        # The one host synchronisation of the exchange: the count matrix (world x G int64) comes to the host, where
+        # the split lists that all_to_all_single needs anyway, the per-expert row counts and the slot of every
+        # arriving row are derived with numpy (a few microseconds) instead of a dozen small device launches.  The
+        # copy is asynchronous into pinned memory; the sort and the packing below do not depend on it and run meanwhile.
+        if flat.is_cuda:
+            if self._pinned is None or self._pinned.numel() != flat.numel():
+                self._pinned = torch.empty((flat.numel(),), dtype=torch.int64, pin_memory=True)
+            self._pinned.copy_(flat, non_blocking=True)
+            landed = torch.cuda.Event()
+            landed.record()
+        else:
+            landed = None
+        order = torch.argsort(expert_ids, stable=True).contiguous()
         # one byte row per token: K fp8 bytes followed by KB fp32 scales, gathered in expert order
         payload = torch.empty((T, self.row_bytes), dtype=torch.uint8, device=tok_q.device)
         _rows(payload, tok_q, src_index=order, row_bytes=self.k)
         _rows(payload, tok_sf.view(torch.uint8), src_index=order, row_bytes=4 * self.kb, dst_off=self.k)
+        if landed is not None:
+            landed.synchronize()
+            allc = self._pinned.numpy().reshape(self.world, self.G).copy()
+        else:
+            allc = flat.numpy().reshape(self.world, self.G)
+        mine = allc[:, self.rank * self.Gl:(self.rank + 1) * self.Gl]                 # [world, Gl] rows I receive
+        send_splits = allc[self.rank].reshape(self.world, self.Gl).sum(1).tolist()
+        recv_splits = mine.sum(1).tolist()
+        masked = mine.sum(0)                                                          # [Gl]
+        if masked.size and int(masked.max()) > self.m_max:
+            raise ValueError(f"an expert received {int(masked.max())} rows > m_max {self.m_max}")
         total = int(sum(recv_splits))
+        # slot of every received row: source-major, expert-minor arrival order -> [g, row] masked layout
+        start = (np.cumsum(mine, 0) - mine) + (np.arange(self.Gl, dtype=np.int64) * self.m_max)[None, :]
+        flat_cnt = mine.reshape(-1)
+        seg_begin = np.cumsum(flat_cnt) - flat_cnt
+        dest_np = np.repeat(start.reshape(-1) - seg_begin, flat_cnt) + np.arange(total, dtype=np.int64)
+        dest = torch.from_numpy(dest_np).to(tok_q.device, non_blocking=True)
+        self.masked_m.copy_(torch.from_numpy(masked.astype(np.int32)), non_blocking=True)
         if self.world > 1:
             recv = torch.empty((total, self.row_bytes), dtype=torch.uint8, device=tok_q.device)
             self.dist.all_to_all_single(recv, payload, recv_splits, send_splits)
         else:
             recv = payload
-        # slot of every received row: source-major, expert-minor arrival order -> [g, row] masked layout
-        masked = mine.sum(0)                                                          # [Gl]
-        if int(masked.max().item() if masked.numel() else 0) > self.m_max:
-            raise ValueError(f"an expert received {int(masked.max())} rows > m_max {self.m_max}")
-        start = (torch.cumsum(mine, 0) - mine) + (torch.arange(self.Gl, device=mine.device) * self.m_max)[None, :]
-        flat_cnt = mine.reshape(-1)
-        flat_start = start.reshape(-1)
-        seg_begin = torch.cumsum(flat_cnt, 0) - flat_cnt
-        idx = torch.arange(total, device=mine.device)
-        dest = (torch.repeat_interleave(flat_start - seg_begin, flat_cnt) + idx).contiguous()
         _rows(self.a.view(self.Gl * self.m_max, self.k), recv, dst_index=dest, row_bytes=self.k)
         _rows(self.sfa.view(self.Gl * self.m_max, self.kb).view(torch.uint8), recv, dst_index=dest,
               row_bytes=4 * self.kb, src_off=self.k)
-        self.masked_m.copy_(masked.to(torch.int32))
         return RouteState(order, dest, send_splits, recv_splits, T)
 
     # ------------------------------------------------------------------ compute
