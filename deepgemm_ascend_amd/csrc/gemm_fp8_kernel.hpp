@@ -572,7 +572,6 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
                 part[i % RING] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
                     bf[nt & 1], af[mt], v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                // refill DMA: head part of block kb+1 (stage s^1 is free since the previous barrier) ...
 #ifndef DGA_ABL_NODMA
                 // refill DMA: head part of block kb+1 (stage s^1 is free since the previous barrier) on the first
                 // HEAD_STEPS steps, tail part of block kb+2 into THIS stage on the TM steps behind the barrier.

@@ -132,3 +132,21 @@ def test_contiguous_bad_index_is_ignored(dga, oracle):
     bad = m_indices.copy(); bad[128:] = 7
     _, got = _run(dga, a, sfa, b, sfb, bad, n)
     assert (got[128:] == SENTINEL).all() and (got[:128] != SENTINEL).any()
+
+
+def test_contiguous_degenerate_shapes(dga, oracle):
+    """m_sum = 0, G = 0 and K = 0 (valid rows become zeros, padding rows stay untouched)."""
+    e = lambda *s: torch.empty(s, dtype=torch.uint8, device="cuda")
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device="cuda")
+    out = torch.empty((0, 128), dtype=torch.bfloat16, device="cuda")
+    dga.m_grouped_gemm_fp8_fp8_bf16_nt_contiguous((e(0, 256), f(0, 2)), (e(2, 128, 256), f(2, 1, 2)), out,
+                                                  torch.empty((0,), dtype=torch.int32, device="cuda"), sync=True)
+    idx = torch.tensor([0] * 100 + [-1] * 28, dtype=torch.int32, device="cuda")
+    init = np.full((128, 128), SENTINEL, np.uint16)
+    out = torch.from_numpy(init.view(np.int16)).cuda().view(torch.bfloat16)
+    dga.m_grouped_gemm_fp8_fp8_bf16_nt_contiguous((e(128, 0), f(128, 0)), (e(1, 128, 0), f(1, 1, 0)), out, idx, sync=True)
+    got = _bits(out)
+    assert (got[:100] == 0).all() and (got[100:] == SENTINEL).all()
+    out2 = torch.from_numpy(init.view(np.int16)).cuda().view(torch.bfloat16)
+    dga.m_grouped_gemm_fp8_fp8_bf16_nt_contiguous((e(128, 256), f(128, 2)), (e(0, 128, 256), f(0, 1, 2)), out2, idx, sync=True)
+    assert (_bits(out2) == SENTINEL).all()

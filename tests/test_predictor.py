@@ -113,3 +113,19 @@ def test_tiling_consults_the_predictor_on_a_cache_miss(predictor):
     t = predictor.tiling(m, n, k)
     assert (t.m1, t.n1, t.stages, t.splitkFactor, t.dispatchPolicyTag) == \
            (t_pred.m1, t_pred.n1, t_pred.stages, t_pred.splitkFactor, t_pred.dispatchPolicyTag)
+
+
+def test_training_export_round_trips_into_the_cxx_loader(predictor, tmp_path):
+    """harness/train_predictor.py on a small slice of the committed sweep records: the exported text file loads in the
+    C++ evaluator and reproduces the numpy forward of the folded model."""
+    from deepgemm_ascend_amd.harness import train_predictor as tp
+    out = tmp_path / "p.txt"
+    tp.main(["--train", str(ROOT / "profiles" / "r01_sweep"), "--out", str(out), "--epochs", "60"])
+    layers, mean, std = _read_weights(out)
+    predictor.predictor_load(str(out))
+    m, n, k = 1024, 4096, 7168
+    t = predictor.select_kernel(m, n, k)
+    p = {"m1": t.m1, "n1": t.n1, "stages": t.stages, "splitk": t.splitkFactor, "policy": t.dispatchPolicyTag}
+    want = float(np.exp(tp.forward_folded(layers, mean, std, np.array([tp.feature_row(m, n, k, p)], np.float32))[0]))
+    assert math.isclose(predictor.predict_time_us(m, n, k, t), want, rel_tol=2e-4)
+    assert (tmp_path / "p.report.json").exists()
