@@ -166,7 +166,9 @@ def main():
     ap.add_argument("--workload", default="dense_4096", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grouped", action="store_true")
-    ap.add_argument("--no-widen", action="store_true")
+    ap.add_argument("--widen", action="store_true",
+                    help="also time the rows either side of the hot path (contiguous-grouped layout, quantiser); off by "
+                         "default so that the default command's kernel statistics hold the headline kernels only")
     ap.add_argument("--groups", type=int, default=256)
     ap.add_argument("--grouped-mask", default="full", choices=["full", "random"])
     ap.add_argument("--cpu-budget", type=float, default=15.0)
@@ -250,7 +252,7 @@ def main():
         if isinstance(grouped.get("roofline"), dict) and world == 1 and args.groups == 256 and args.grouped_mask == "full":
             grouped["roofline"]["traffic"] = pmc_traffic("grouped")
         res["grouped"] = grouped
-    if rank == 0 and world == 1 and not args.no_widen:
+    if rank == 0 and world == 1 and args.widen:
         try:
             res["widen"] = widen_leg()
         except Exception as e:
