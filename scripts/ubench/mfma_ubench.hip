@@ -7,6 +7,7 @@
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <int MODE>  // 0: MFMA only (accumulate chain x4 indep), 1: MFMA(C=0) + 4 FMA pipelined lag 3, 2: 32x32x64 variant
 __global__ void __launch_bounds__(512) k(const int *seed, float *out, int iters)
@@ -16,6 +17,8 @@ __global__ void __launch_bounds__(512) k(const int *seed, float *out, int iters)
     v4f acc[16];
     for (int i = 0; i < 16; ++i) acc[i] = v4f{0, 0, 0, 0};
     float s = 1.0001f;
+    v2f acc2[32];
+    for (int i = 0; i < 32; ++i) acc2[i] = v2f{0, 0};
     if (MODE == 2) {   // 32x32x64 form, MFMA only, 4 independent accumulators (same flops per wave-iteration as 16 x 16x16x128)
         v16f a32[4];
         for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) a32[i][j] = 0.f;
@@ -47,7 +50,14 @@ __global__ void __launch_bounds__(512) k(const int *seed, float *out, int iters)
                     part[i & 3] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, v4f{0, 0, 0, 0}, 0, 0, 0, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (i >= 3) {
+                if (MODE == 3 && i >= 3) {   // two v_pk_fma_f32 instead of four v_fma_f32 (accumulators kept as register pairs)
+                    const int j = i - 3;
+                    const v2f sv = v2f{s, s};
+                    const v2f plo = __builtin_shufflevector(part[j & 3], part[j & 3], 0, 1);
+                    const v2f phi = __builtin_shufflevector(part[j & 3], part[j & 3], 2, 3);
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc2[2 * j]) : "v"(plo), "v"(sv));
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc2[2 * j + 1]) : "v"(phi), "v"(sv));
+                } else if (i >= 3) {
                     const int j = i - 3;
                     acc[j].x = __builtin_fmaf(part[j & 3].x, s, acc[j].x);
                     acc[j].y = __builtin_fmaf(part[j & 3].y, s, acc[j].y);
@@ -60,6 +70,7 @@ __global__ void __launch_bounds__(512) k(const int *seed, float *out, int iters)
     }
     float r = 0;
     for (int i = 0; i < 16; ++i) r += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
+    if (MODE == 3) for (int i = 0; i < 32; ++i) r += acc2[i].x + acc2[i].y;
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
@@ -84,17 +95,18 @@ int main(int argc, char **argv)
     hipMemcpy(seed, h.data(), 4096 * 4, hipMemcpyHostToDevice);
     printf("operands: %s\n", randomise ? "random e4m3 bytes" : "constant 0x38");
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 3; ++mode)
+    for (int mode = 0; mode < 4; ++mode)
         for (int threads : {256, 512}) {
             for (int rep = 0; rep < 3; ++rep) {
                 hipEventRecord(e0);
                 if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(threads), 0, 0, seed, out, iters);
                 else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(threads), 0, 0, seed, out, iters);
-                else hipLaunchKernelGGL(k<2>, dim3(256), dim3(threads), 0, 0, seed, out, iters);
+                else if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(threads), 0, 0, seed, out, iters);
+                else hipLaunchKernelGGL(k<3>, dim3(256), dim3(threads), 0, 0, seed, out, iters);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 double flops = 2.0 * 16 * 16 * 128 * 16.0 * iters * (threads / 64) * 256;
-                if (rep == 2) printf("mode %d (%s) waves/SIMD %d: %.3f ms  %.0f TFLOP/s\n", mode, mode == 1 ? "MFMA+4FMA lag3" : mode == 2 ? "32x32x64 MFMA only" : "MFMA only", threads / 256, ms, flops / ms / 1e9);
+                if (rep == 2) printf("mode %d (%s) waves/SIMD %d: %.3f ms  %.0f TFLOP/s\n", mode, mode == 1 ? "MFMA+4FMA lag3" : mode == 2 ? "32x32x64 MFMA only" : mode == 3 ? "MFMA+2 pk_fma lag3" : "MFMA only", threads / 256, ms, flops / ms / 1e9);
             }
         }
     return 0;
