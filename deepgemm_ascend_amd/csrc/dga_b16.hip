@@ -155,8 +155,9 @@ static int launch_b16(const void *x, const void *y, float *z, int batch, int m, 
         const size_t yt_bytes = (static_cast<size_t>(batch) * n * kp * 2 + 255) & ~size_t(255);
         const bool x_in_place = (k % 64 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
         dim3 tg((n + 63) / 64, static_cast<unsigned>(kp / 64), batch);
+        const int y_vec = (n % 8 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
         hipLaunchKernelGGL(transpose_b16_kernel, tg, dim3(256), 0, stream, static_cast<const uint16_t *>(y), yt, k, n,
-                           static_cast<int>(kp), static_cast<int64_t>(k) * n, static_cast<int64_t>(n) * kp);
+                           static_cast<int>(kp), static_cast<int64_t>(k) * n, static_cast<int64_t>(n) * kp, y_vec);
         const uint16_t *xs = static_cast<const uint16_t *>(x);
         if (!x_in_place) {
             uint16_t *xp = reinterpret_cast<uint16_t *>(ws + yt_bytes);

@@ -164,23 +164,47 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
     }
 }
 
-// y [K][N] (16-bit) -> yT [N][kp], kp = K rounded up to 64, zero filled: 64 x 64 tiles through LDS, coalesced both ways.
+// y [K][N] (16-bit) -> yT [N][kp], kp = K rounded up to 64, zero filled: 64 x 64 tiles through LDS.  Both global
+// sides move 16 bytes per lane on full 128-byte row segments (8 lanes per row); the transposition happens in the LDS
+// reads (eight 16-bit reads of one column, conflict-free on the 66-element pitch).  `vec` = N % 8 == 0 and both bases
+// 16-byte aligned; otherwise the loads fall back to element accesses.
 __global__ void __launch_bounds__(256) transpose_b16_kernel(const uint16_t *y, uint16_t *yt, int k, int n, int kp,
-                                                            int64_t y_bs, int64_t yt_bs)
+                                                            int64_t y_bs, int64_t yt_bs, int vec)
 {
-    __shared__ uint16_t tile[64][66];
+    constexpr int PITCH = 66;
+    __shared__ __attribute__((aligned(16))) uint16_t tile[64 * PITCH];
     const uint16_t *src = y + (int64_t)blockIdx.z * y_bs;
     uint16_t *dst = yt + (int64_t)blockIdx.z * yt_bs;
     const int k0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int r = ty; r < 64; r += 4) {
-        const int kk = k0 + r, nn = n0 + tx;
-        tile[r][tx] = (kk < k && nn < n) ? src[(int64_t)kk * n + nn] : (uint16_t)0;
+    const int t = threadIdx.x, r8 = t >> 3, c8 = (t & 7) * 8;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int kk = k0 + r8 + it * 32, nn = n0 + c8;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        if (kk < k) {
+            const uint16_t *row = src + (int64_t)kk * n;
+            if (vec && nn + 8 <= n) {
+                const v4i q = *(const v4i *)(row + nn);
+                w[0] = (uint32_t)q.x; w[1] = (uint32_t)q.y; w[2] = (uint32_t)q.z; w[3] = (uint32_t)q.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (nn + j < n) w[j >> 1] |= (uint32_t)row[nn + j] << (16 * (j & 1));
+            }
+        }
+        uint32_t *lw = (uint32_t *)(tile + (r8 + it * 32) * PITCH + c8);  // 4-byte aligned (PITCH and c8 are even)
+        lw[0] = w[0]; lw[1] = w[1]; lw[2] = w[2]; lw[3] = w[3];
     }
     __syncthreads();
-    for (int r = ty; r < 64; r += 4) {
-        const int nn = n0 + r, kk = k0 + tx;
-        if (nn < n && kk < kp) dst[(int64_t)nn * kp + kk] = tile[tx][r];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int nl = r8 + it * 32, nn = n0 + nl, kk = k0 + c8;
+        if (nn >= n || kk >= kp) continue;
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            w[j] = (uint32_t)tile[(c8 + 2 * j) * PITCH + nl] | ((uint32_t)tile[(c8 + 2 * j + 1) * PITCH + nl] << 16);
+        *(v4i *)(dst + (int64_t)nn * kp + kk) = v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};  // kp % 64 == 0, base 256-B aligned
     }
 }
 
