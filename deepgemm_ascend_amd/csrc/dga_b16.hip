@@ -10,6 +10,7 @@
 //   * without one (the plain C entry points): each lane gathers its B fragment straight from global memory
 //     (8 two-byte loads down a column) -- no LDS, no transposition pass; correct, slow.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstdint>
 #include <mutex>
 
@@ -120,10 +121,10 @@ static size_t b16_workspace_bytes(int batch, int m, int n, int k, const void *x)
     return bytes + 256;
 }
 
-template <class Cfg, bool BF16>
+template <class Cfg, bool BF16, int PP = 0>
 static int launch_tiled(const B16Params &p, int batch, hipStream_t stream)
 {
-    auto kfn = gemm_b16_nt_f32_kernel<Cfg, BF16>;
+    auto kfn = gemm_b16_nt_f32_kernel<Cfg, BF16, PP>;
     constexpr int lds = 2 * (Cfg::A_BYTES + Cfg::B_BYTES);
     static std::once_flag once[64];
     static hipError_t attr_err[64];
@@ -181,6 +182,9 @@ static int launch_b16(const void *x, const void *y, float *z, int batch, int m, 
         p.tiles_n = (n + bn - 1) / bn;
         p.raster_group = p.tiles_m >= 8 ? 8 : (p.tiles_m >= 4 ? 4 : 1);
         const bool bf = dtype == DGA_DT_BF16;
+        static const int plain = [] { const char *e = std::getenv("DGA_B16_PLAIN"); return e ? std::atoi(e) : 0; }();
+        if (big && !plain) return bf ? launch_tiled<GemmCfg<256, 256, 4, 2>, true, 2>(p, batch, stream)
+                                     : launch_tiled<GemmCfg<256, 256, 4, 2>, false, 2>(p, batch, stream);
         if (big) return bf ? launch_tiled<GemmCfg<256, 256, 4, 2>, true>(p, batch, stream)
                            : launch_tiled<GemmCfg<256, 256, 4, 2>, false>(p, batch, stream);
         return bf ? launch_tiled<GemmCfg<128, 128, 2, 2>, true>(p, batch, stream)

@@ -36,7 +36,10 @@ __device__ __forceinline__ v4f mfma_b16(v4i a, v4i b, v4f c)
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8f16, a), __builtin_bit_cast(v8f16, b), c, 0, 0, 0);
 }
 
-template <class Cfg, bool BF16>
+// PP = 0: one barrier per k step in front of the fragment reads (every tile).
+// PP = 2: continuous pipeline (256x256, 8 waves), the 16-bit form of the fp8 kernel's schedule: the k-step boundary
+//         disappears from the MFMA stream (fragments of the next step are read under the last MFMAs of this one).
+template <class Cfg, bool BF16, int PP = 0>
 __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Params p)
 {
     constexpr int BM = Cfg::kBM, BN = Cfg::kBN, WN = Cfg::kWN;
@@ -102,6 +105,70 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
         for (int j = 0; j < TN; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
 
     const int KS = p.k / 64;
+    if constexpr (PP == 2) {
+        // ---- continuous pipeline.  One k step = STEPS single MFMAs, ordered (n-tile, k half, m-tile) so that the two
+        // MFMAs that chain through one accumulator are TM steps apart.  Stage s = ks & 1.
+        //   * B fragments rotate through two register sets (next n-tile read at the n-tile's first step); the rotation
+        //     continues into the next k step;
+        //   * step SB = first step of the last n-tile: vmcnt(0) + the ONE barrier.  Passing it means stage s^1 has landed
+        //     everywhere and nobody reads stage s any more (its last read, the last n-tile's B fragment, was issued an
+        //     n-tile earlier);
+        //   * during the last n-tile every A fragment half is reloaded IN PLACE from stage s^1 right behind its last
+        //     MFMA, and the next step's first B fragment is read: the next k step finds its operands in registers;
+        //   * refill of stage s (k step ks + 2): TAIL_DMA wave-instructions on the steps behind the barrier, the rest on
+        //     the first HEAD_STEPS steps of the next k step -- every batch has more than half a k step to land.
+        constexpr int STEPS = TN * 2 * TM, SB = (TN - 1) * 2 * TM;
+        constexpr int TAIL_DMA = NL / 2, HEAD_STEPS = (STEPS * 9) / 32;
+        static_assert(BM == 256 && BN == 256 && Cfg::kWM == 4 && WN == 2, "continuous schedule: 256x256, 8 waves");
+        auto barrier = [&]() {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        v4i af[TM][2], bf[2][2];
+#pragma unroll
+        for (int idx = 0; idx < NL; ++idx) issue_one(idx, 0, 0);
+#pragma unroll
+        for (int idx = 0; idx < TAIL_DMA; ++idx) issue_one(idx, 1, 1);
+        wait_vmcnt<TAIL_DMA>();
+        barrier();
+        bf[0][0] = *(const v4i *)(smem + b_off0);
+        bf[0][1] = *(const v4i *)(smem + b_off1);
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            af[mt][0] = *(const v4i *)(smem + a_off0 + mt * 2048);
+            af[mt][1] = *(const v4i *)(smem + a_off1 + mt * 2048);
+        }
+        for (int ks = 0; ks < KS; ++ks) {
+            const uint8_t *st = smem + (ks & 1) * STAGE;
+            const uint8_t *sn = smem + ((ks & 1) ^ 1) * STAGE;
+#pragma unroll
+            for (int i = 0; i < STEPS; ++i) {
+                const int nt = i / (2 * TM), h = (i / TM) & 1, mt = i % TM;
+                if (i == SB) {
+                    wait_vmcnt<0>();
+                    barrier();
+                }
+                acc[mt][nt] = mfma_b16<BF16>(bf[nt & 1][h], af[mt][h], acc[mt][nt]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i < HEAD_STEPS) {   // head part of k step ks + 1's refill (stage s^1 is free since the previous barrier)
+#pragma unroll
+                    for (int j = (i * (NL - TAIL_DMA)) / HEAD_STEPS; j < ((i + 1) * (NL - TAIL_DMA)) / HEAD_STEPS; ++j)
+                        issue_one(TAIL_DMA + j, (ks & 1) ^ 1, ks + 1);
+                }
+                if (i > SB && i <= SB + TAIL_DMA) issue_one(i - SB - 1, ks & 1, ks + 2);  // tail part of ks + 2 into this stage
+                if (h == 0 && mt == 0) {  // next n-tile's B fragment (wraps into the next k step)
+                    const uint8_t *src = nt + 1 < TN ? st : sn;
+                    const int nn = nt + 1 < TN ? nt + 1 : 0;
+                    const int boff = (nn >> 1) * 4096 + (nn & 1) * 512;
+                    bf[(nt + 1) & 1][0] = *(const v4i *)(src + b_off0 + boff);
+                    bf[(nt + 1) & 1][1] = *(const v4i *)(src + b_off1 + boff);
+                }
+                if (nt == TN - 1) af[mt][h] = *(const v4i *)(sn + (h ? a_off1 : a_off0) + mt * 2048);  // in-place reload
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        wait_vmcnt<0>();
+    } else {
 #pragma unroll
     for (int idx = 0; idx < NL; ++idx) issue_one(idx, 0, 0);
     for (int ks = 0; ks < KS; ++ks) {
@@ -140,6 +207,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
         }
     }
     wait_vmcnt<0>();
+    }
 
     // epilogue: lane owns row m, 4 consecutive n per 16x16 tile (same n permutation as the fp8 kernel)
     const int m_row = m0 + wm * (BM / Cfg::kWM) + li;
