@@ -10,7 +10,9 @@
 //   * without one (the plain C entry points): each lane gathers its B fragment straight from global memory
 //     (8 two-byte loads down a column) -- no LDS, no transposition pass; correct, slow.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <cstdint>
 #include <mutex>
 
@@ -111,6 +113,31 @@ __global__ void __launch_bounds__(256) mmad_nn_f32_kernel(const B16DirectParams 
         }
 }
 
+// Tile and split-K of the tiled path (shared by the workspace size and the launch).  The largest tile that still gives
+// every CU a workgroup; when even the shortest tile leaves most CUs idle (the reference's benchmark list,
+// framework/benchmark/benchmark.py:24-44, is mostly M = 8..128 against N, K in the thousands: the y stream is the cost),
+// K is cut so that every CU pulls on that stream, with fp32 slabs combined by a second kernel (as in the fp8 operator).
+struct B16Plan { int bm, bn, splitk, ks_per_split; };
+static B16Plan b16_plan(int batch, int m, int n, int k)
+{
+    const int ks_n = (k + 63) / 64;
+    auto tiles_of = [&](int bm, int bn) { return static_cast<int64_t>(batch) * ((m + bm - 1) / bm) * ((n + bn - 1) / bn); };
+    B16Plan pl{128, 128, 1, ks_n};
+    if (tiles_of(256, 256) >= 192) { pl.bm = 256; pl.bn = 256; return pl; }
+    if (tiles_of(128, 128) < 192 && m <= 64) pl.bm = m > 32 ? 64 : (m > 16 ? 32 : 16);
+    const int64_t tiles = tiles_of(pl.bm, pl.bn);
+    if (tiles * 4 <= 256 * 3 && ks_n >= 16) {
+        int s = static_cast<int>(std::min<int64_t>({512 / tiles, ks_n / 8, 16}));
+        // slab write + read stays below half of the operand read
+        while (s > 1 && static_cast<int64_t>(s) * batch * m * n * 8 * 2 > static_cast<int64_t>(batch) * (m + n) * k * 2) --s;
+        if (s > 1) {
+            pl.ks_per_split = (ks_n + s - 1) / s;
+            pl.splitk = (ks_n + pl.ks_per_split - 1) / pl.ks_per_split;
+        }
+    }
+    return pl;
+}
+
 static size_t b16_workspace_bytes(int batch, int m, int n, int k, const void *x)
 {
     if (batch <= 0 || m <= 0 || n <= 0 || k <= 0) return 0;
@@ -118,6 +145,8 @@ static size_t b16_workspace_bytes(int batch, int m, int n, int k, const void *x)
     size_t bytes = ((static_cast<size_t>(batch) * n * kp * 2 + 255) & ~size_t(255));       // yT
     const bool x_in_place = (k % 64 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     if (!x_in_place) bytes += ((static_cast<size_t>(batch) * m * kp * 2 + 255) & ~size_t(255));  // padded x
+    const B16Plan pl = b16_plan(batch, m, n, k);
+    if (pl.splitk > 1) bytes += ((static_cast<size_t>(pl.splitk) * batch * m * n * 4 + 255) & ~size_t(255));  // fp32 slabs
     return bytes + 256;
 }
 
@@ -134,7 +163,8 @@ static int launch_tiled(const B16Params &p, int batch, hipStream_t stream)
         attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     });
     if (record_hip(attr_err[dev]) != DGA_OK) return DGA_E_HIP;
-    hipLaunchKernelGGL(kfn, dim3(static_cast<unsigned>(batch) * p.tiles_m * p.tiles_n), dim3(Cfg::NT), lds, stream, p);
+    hipLaunchKernelGGL(kfn, dim3(static_cast<unsigned>(batch) * p.tiles_m * p.tiles_n * (p.splitk > 1 ? p.splitk : 1)),
+                       dim3(Cfg::NT), lds, stream, p);
     return record_hip(hipGetLastError());
 }
 
@@ -176,19 +206,36 @@ static int launch_b16(const void *x, const void *y, float *z, int batch, int m, 
         p.x_bs = static_cast<int64_t>(m) * p.ldx;
         p.y_bs = static_cast<int64_t>(n) * kp;
         p.z_bs = static_cast<int64_t>(m) * n;
-        const bool big = static_cast<int64_t>(batch) * ((m + 255) / 256) * ((n + 255) / 256) >= 192;
-        const int bm = big ? 256 : 128, bn = big ? 256 : 128;
-        p.tiles_m = (m + bm - 1) / bm;
-        p.tiles_n = (n + bn - 1) / bn;
-        p.raster_group = p.tiles_m >= 8 ? 8 : (p.tiles_m >= 4 ? 4 : 1);
-        const bool bf = dtype == DGA_DT_BF16;
         static const int plain = [] { const char *e = std::getenv("DGA_B16_PLAIN"); return e ? std::atoi(e) : 0; }();
-        if (big && !plain) return bf ? launch_tiled<GemmCfg<256, 256, 4, 2>, true, 2>(p, batch, stream)
-                                     : launch_tiled<GemmCfg<256, 256, 4, 2>, false, 2>(p, batch, stream);
-        if (big) return bf ? launch_tiled<GemmCfg<256, 256, 4, 2>, true>(p, batch, stream)
-                           : launch_tiled<GemmCfg<256, 256, 4, 2>, false>(p, batch, stream);
-        return bf ? launch_tiled<GemmCfg<128, 128, 2, 2>, true>(p, batch, stream)
-                  : launch_tiled<GemmCfg<128, 128, 2, 2>, false>(p, batch, stream);
+        const bool bf = dtype == DGA_DT_BF16;
+        const B16Plan pl = b16_plan(batch, m, n, k);
+        p.batch = batch;
+        p.splitk = pl.splitk;
+        p.ks_per_split = pl.ks_per_split;
+        size_t slab_at = yt_bytes;
+        if (!x_in_place) slab_at += (static_cast<size_t>(batch) * m * kp * 2 + 255) & ~size_t(255);
+        p.partial = pl.splitk > 1 ? reinterpret_cast<float *>(ws + slab_at) : nullptr;
+        auto go = [&](auto cfg, auto pp) -> int {
+            using Cfg = decltype(cfg);
+            constexpr int PPv = decltype(pp)::value;
+            p.tiles_m = (m + Cfg::kBM - 1) / Cfg::kBM;
+            p.tiles_n = (n + Cfg::kBN - 1) / Cfg::kBN;
+            p.raster_group = p.tiles_m >= 8 ? 8 : (p.tiles_m >= 4 ? 4 : 1);
+            return bf ? launch_tiled<Cfg, true, PPv>(p, batch, stream) : launch_tiled<Cfg, false, PPv>(p, batch, stream);
+        };
+        using P0 = std::integral_constant<int, 0>;
+        using P2 = std::integral_constant<int, 2>;
+        int rc;
+        if (pl.bm == 256) rc = plain ? go(GemmCfg<256, 256, 4, 2>{}, P0{}) : go(GemmCfg<256, 256, 4, 2>{}, P2{});
+        else if (pl.bm == 128) rc = go(GemmCfg<128, 128, 2, 2>{}, P0{});
+        else if (pl.bm == 64) rc = go(GemmCfg<64, 128, 1, 4>{}, P0{});
+        else if (pl.bm == 32) rc = go(GemmCfg<32, 128, 1, 4>{}, P0{});
+        else rc = go(GemmCfg<16, 128, 1, 4>{}, P0{});
+        if (rc != DGA_OK || pl.splitk <= 1) return rc;
+        const int64_t total = static_cast<int64_t>(batch) * m * n;
+        hipLaunchKernelGGL(splitk_reduce_f32_kernel, dim3(static_cast<unsigned>((total / 4 + 255) / 256 + 1)), dim3(256), 0,
+                           stream, p.partial, z, total, pl.splitk);
+        return record_hip(hipGetLastError());
     }
     // no workspace: fragments gathered straight from global memory (correct, slow)
     B16DirectParams p{};

@@ -25,6 +25,10 @@ struct B16Params {
     int64_t ldx, ldy;
     int64_t x_bs, y_bs, z_bs;
     int tiles_m, tiles_n, raster_group;
+    int batch;           // z / x / yt matrices
+    int splitk;          // > 1: the grid is splitk x batch x tiles (split-major); split s covers k steps [s*ks_per_split, +)
+    int ks_per_split;    //      and writes its fp32 partial tile to slab s of `partial` ([splitk][batch][m][n])
+    float *partial;
 };
 
 template <bool BF16>
@@ -58,6 +62,8 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     const int per_batch = p.tiles_m * p.tiles_n;
+    const int split = p.splitk > 1 ? tile / (per_batch * p.batch) : 0;
+    tile -= split * per_batch * p.batch;
     const int bi = tile / per_batch;
     const int t_in = tile - bi * per_batch;
     int tm, tn;
@@ -70,7 +76,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
     const int m0 = tm * BM, n0 = tn * BN;
     const uint8_t *X = (const uint8_t *)(p.x + (int64_t)bi * p.x_bs);
     const uint8_t *Y = (const uint8_t *)(p.yt + (int64_t)bi * p.y_bs);
-    float *Z = p.z + (int64_t)bi * p.z_bs;
+    float *Z = (p.splitk > 1 ? p.partial + (int64_t)split * p.batch * p.z_bs : p.z) + (int64_t)bi * p.z_bs;
     const int64_t ldxb = p.ldx * 2, ldyb = p.ldy * 2;  // row strides in bytes
 
     const int dtid = tid & (DNT - 1);
@@ -169,10 +175,12 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
         }
         wait_vmcnt<0>();
     } else {
+    const int ks_begin = p.splitk > 1 ? split * p.ks_per_split : 0;
+    const int ks_end = p.splitk > 1 ? min(KS, ks_begin + p.ks_per_split) : KS;
 #pragma unroll
-    for (int idx = 0; idx < NL; ++idx) issue_one(idx, 0, 0);
-    for (int ks = 0; ks < KS; ++ks) {
-        const int stage = ks & 1;
+    for (int idx = 0; idx < NL; ++idx) issue_one(idx, 0, ks_begin);
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
+        const int stage = (ks - ks_begin) & 1;
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -273,6 +281,24 @@ __global__ void __launch_bounds__(256) transpose_b16_kernel(const uint16_t *y, u
         for (int j = 0; j < 4; ++j)
             w[j] = (uint32_t)tile[(c8 + 2 * j) * PITCH + nl] | ((uint32_t)tile[(c8 + 2 * j + 1) * PITCH + nl] << 16);
         *(v4i *)(dst + (int64_t)nn * kp + kk) = v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};  // kp % 64 == 0, base 256-B aligned
+    }
+}
+
+// split-K combine of the 16-bit path: z = sum_s slab[s] in fp32, s ascending (deterministic)
+__global__ void __launch_bounds__(256) splitk_reduce_f32_kernel(const float *partial, float *z, int64_t total, int splitk)
+{
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= total) return;
+    if (i + 4 <= total && ((total & 3) == 0) && ((((uintptr_t)z) & 15) == 0)) {
+        v4f a = *(const v4f *)(partial + i);
+        for (int s = 1; s < splitk; ++s) a += *(const v4f *)(partial + (int64_t)s * total + i);
+        *(v4f *)(z + i) = a;
+    } else {
+        for (int q = 0; q < 4 && i + q < total; ++q) {
+            float a = partial[i + q];
+            for (int s = 1; s < splitk; ++s) a += partial[(int64_t)s * total + i + q];
+            z[i + q] = a;
+        }
     }
 }
 
