@@ -150,10 +150,10 @@ static size_t b16_workspace_bytes(int batch, int m, int n, int k, const void *x)
     return bytes + 256;
 }
 
-template <class Cfg, bool BF16, int PP = 0>
+template <class Cfg, bool BF16, int PP = 0, bool NN = false>
 static int launch_tiled(const B16Params &p, int batch, hipStream_t stream)
 {
-    auto kfn = gemm_b16_nt_f32_kernel<Cfg, BF16, PP>;
+    auto kfn = gemm_b16_nt_f32_kernel<Cfg, BF16, PP, NN>;
     constexpr int lds = 2 * (Cfg::A_BYTES + Cfg::B_BYTES);
     static std::once_flag once[64];
     static hipError_t attr_err[64];
@@ -178,37 +178,45 @@ static int launch_b16(const void *x, const void *y, float *z, int batch, int m, 
     const size_t need = b16_workspace_bytes(batch, m, n, k, x);
     if (workspace && workspace_bytes < need) return DGA_E_WORKSPACE;
     const size_t kp = (static_cast<size_t>(k) + 63) / 64 * 64;
-    if (workspace && k > 0 && kp * 257 * 2 < 0x7FFFFFFFull) {
-        // tiled path: transpose y into the workspace (the re-layout the reference does on the way into L1,
-        // generate_code.hpp:250-260), pad x if its rows are not whole 128-byte k steps, then the LDS-DMA kernel
+    // y read where it lies ([K][N], transposing LDS reads) when the 16-byte DMA chunks line up; otherwise y is first
+    // transposed into the workspace (the re-layout the reference does on the way into L1, generate_code.hpp:250-260)
+    static const int no_direct = [] { const char *e = std::getenv("DGA_B16_TRANSPOSE"); return e ? std::atoi(e) : 0; }();
+    const bool direct = !no_direct && k > 0 && (k % 64 == 0) && (n % 8 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (static_cast<int64_t>(k) * n * 2 < 0x7FFFFFFFll) &&
+                        (static_cast<int64_t>(k) * 257 * 2 < 0x7FFFFFFFll);
+    if ((workspace || direct) && k > 0 && kp * 257 * 2 < 0x7FFFFFFFull) {
         uint8_t *ws = static_cast<uint8_t *>(workspace);
         uint16_t *yt = reinterpret_cast<uint16_t *>(ws);
         const size_t yt_bytes = (static_cast<size_t>(batch) * n * kp * 2 + 255) & ~size_t(255);
         const bool x_in_place = (k % 64 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-        dim3 tg((n + 63) / 64, static_cast<unsigned>(kp / 64), batch);
-        const int y_vec = (n % 8 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-        hipLaunchKernelGGL(transpose_b16_kernel, tg, dim3(256), 0, stream, static_cast<const uint16_t *>(y), yt, k, n,
-                           static_cast<int>(kp), static_cast<int64_t>(k) * n, static_cast<int64_t>(n) * kp, y_vec);
         const uint16_t *xs = static_cast<const uint16_t *>(x);
-        if (!x_in_place) {
-            uint16_t *xp = reinterpret_cast<uint16_t *>(ws + yt_bytes);
-            const int64_t rows = static_cast<int64_t>(batch) * m;
-            hipLaunchKernelGGL(pad_rows_b16_kernel, dim3(static_cast<unsigned>((rows * kp + 255) / 256)), dim3(256), 0, stream,
-                               xs, xp, rows, k, static_cast<int>(kp));
-            xs = xp;
+        if (!direct) {
+            dim3 tg((n + 63) / 64, static_cast<unsigned>(kp / 64), batch);
+            const int y_vec = (n % 8 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+            hipLaunchKernelGGL(transpose_b16_kernel, tg, dim3(256), 0, stream, static_cast<const uint16_t *>(y), yt, k, n,
+                               static_cast<int>(kp), static_cast<int64_t>(k) * n, static_cast<int64_t>(n) * kp, y_vec);
+            if (!x_in_place) {
+                uint16_t *xp = reinterpret_cast<uint16_t *>(ws + yt_bytes);
+                const int64_t rows = static_cast<int64_t>(batch) * m;
+                hipLaunchKernelGGL(pad_rows_b16_kernel, dim3(static_cast<unsigned>((rows * kp + 255) / 256)), dim3(256), 0, stream,
+                                   xs, xp, rows, k, static_cast<int>(kp));
+                xs = xp;
+            }
+            if (record_hip(hipGetLastError()) != DGA_OK) return DGA_E_HIP;
         }
-        if (record_hip(hipGetLastError()) != DGA_OK) return DGA_E_HIP;
         B16Params p{};
-        p.x = xs; p.yt = yt; p.z = z;
+        p.x = xs; p.z = z;
+        p.yt = direct ? static_cast<const uint16_t *>(y) : yt;
         p.m = m; p.n = n; p.k = static_cast<int>(kp);
         p.ldx = x_in_place ? k : static_cast<int64_t>(kp);
-        p.ldy = static_cast<int64_t>(kp);
+        p.ldy = direct ? static_cast<int64_t>(n) : static_cast<int64_t>(kp);
         p.x_bs = static_cast<int64_t>(m) * p.ldx;
-        p.y_bs = static_cast<int64_t>(n) * kp;
+        p.y_bs = direct ? static_cast<int64_t>(k) * n : static_cast<int64_t>(n) * kp;
         p.z_bs = static_cast<int64_t>(m) * n;
         static const int plain = [] { const char *e = std::getenv("DGA_B16_PLAIN"); return e ? std::atoi(e) : 0; }();
         const bool bf = dtype == DGA_DT_BF16;
-        const B16Plan pl = b16_plan(batch, m, n, k);
+        B16Plan pl = b16_plan(batch, m, n, k);
+        if (!workspace) { pl.splitk = 1; pl.ks_per_split = static_cast<int>(kp / 64); }  // no room for the slabs
         p.batch = batch;
         p.splitk = pl.splitk;
         p.ks_per_split = pl.ks_per_split;
@@ -221,6 +229,8 @@ static int launch_b16(const void *x, const void *y, float *z, int batch, int m, 
             p.tiles_m = (m + Cfg::kBM - 1) / Cfg::kBM;
             p.tiles_n = (n + Cfg::kBN - 1) / Cfg::kBN;
             p.raster_group = p.tiles_m >= 8 ? 8 : (p.tiles_m >= 4 ? 4 : 1);
+            if (direct)
+                return bf ? launch_tiled<Cfg, true, PPv, true>(p, batch, stream) : launch_tiled<Cfg, false, PPv, true>(p, batch, stream);
             return bf ? launch_tiled<Cfg, true, PPv>(p, batch, stream) : launch_tiled<Cfg, false, PPv>(p, batch, stream);
         };
         using P0 = std::integral_constant<int, 0>;

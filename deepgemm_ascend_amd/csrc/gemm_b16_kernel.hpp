@@ -15,6 +15,7 @@
 namespace dga {
 
 typedef __bf16 v8bf16 __attribute__((ext_vector_type(8)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 typedef _Float16 v8f16 __attribute__((ext_vector_type(8)));
 
 struct B16Params {
@@ -43,7 +44,17 @@ __device__ __forceinline__ v4f mfma_b16(v4i a, v4i b, v4f c)
 // PP = 0: one barrier per k step in front of the fragment reads (every tile).
 // PP = 2: continuous pipeline (256x256, 8 waves), the 16-bit form of the fp8 kernel's schedule: the k-step boundary
 //         disappears from the MFMA stream (fragments of the next step are read under the last MFMAs of this one).
-template <class Cfg, bool BF16, int PP = 0>
+// NN = false: the y operand comes transposed (yT [N][Kp], K-contiguous rows, written by transpose_b16_kernel).
+// NN = true:  y is read where it lies, [K][N] with N contiguous -- no pre-pass, no workspace.  The LDS image of the
+//             tile is then [64 k rows][BN columns] and the MFMA operand (8 consecutive k of one n per lane) is produced
+//             by the hardware transposing read ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of
+//             row q / columns 4p..4p+3 of a 4 x 16 block and lane i receives column i.  Group g takes rows 8g+q (+4 for
+//             the second read), so an operand is two reads.  Rows are BN*2 bytes (a multiple of the 256-byte bank row),
+//             so the 16-byte chunk c of row k is stored at chunk c ^ 2*h(k), h(k) = (k&3) | ((k>>3)&1)<<2: the 8 rows
+//             a 32-lane half touches then fall into 8 different 32-byte groups of one bank row (conflict-free).  The
+//             n index of MFMA row i is simply 16*nt + i here (the fp32 stores need no pairing of n-tiles).
+//             Requires K % 64 == 0, N % 8 == 0 and 16-byte aligned bases (the host falls back to NN = false otherwise).
+template <class Cfg, bool BF16, int PP = 0, bool NN = false>
 __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Params p)
 {
     constexpr int BM = Cfg::kBM, BN = Cfg::kBN, WN = Cfg::kWN;
@@ -85,16 +96,26 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
 #pragma unroll
     for (int it = 0; it < Cfg::A_ITERS; ++it)
         a_voff[it] = (uint32_t)min((it * DNT + dtid) >> 3, p.m - 1 - m0) * (uint32_t)ldxb + a_col;
+    constexpr int CPR = BN / 8;  // NN: 16-byte chunks per LDS row of the y tile
 #pragma unroll
-    for (int it = 0; it < Cfg::B_ITERS; ++it)
-        b_voff[it] = (uint32_t)min((it * DNT + dtid) >> 3, p.n - 1 - n0) * (uint32_t)ldyb + b_col;
+    for (int it = 0; it < Cfg::B_ITERS; ++it) {
+        if constexpr (NN) {
+            const int cid = it * DNT + dtid, kr = cid / CPR, cs = cid % CPR;
+            const int c = cs ^ (2 * ((kr & 3) | (((kr >> 3) & 1) << 2)));  // swizzle on the source side
+            b_voff[it] = (uint32_t)kr * (uint32_t)ldyb + (uint32_t)c * 16u;
+        } else {
+            b_voff[it] = (uint32_t)min((it * DNT + dtid) >> 3, p.n - 1 - n0) * (uint32_t)ldyb + b_col;
+        }
+    }
     const v4i a_rsrc = make_rsrc(X + (int64_t)m0 * ldxb, (int64_t)(p.m - m0) * ldxb);
-    const v4i b_rsrc = make_rsrc(Y + (int64_t)n0 * ldyb, (int64_t)(p.n - n0) * ldyb);
+    const v4i b_rsrc = NN ? make_rsrc(Y + (int64_t)n0 * 2, (int64_t)p.k * ldyb - (int64_t)n0 * 2)
+                          : make_rsrc(Y + (int64_t)n0 * ldyb, (int64_t)(p.n - n0) * ldyb);
+    const uint32_t b_kstep = NN ? (uint32_t)(64 * ldyb) : 128u;  // bytes one k step advances in the y operand
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
     auto issue_one = [&](int idx, int stage, int ks) {
         const uint32_t sa = lds0 + stage * STAGE + wave * 1024;
         if (idx < Cfg::A_ITERS) dma16(a_voff[idx], a_rsrc, (uint32_t)(ks * 128), sa + idx * DNT * 16);
-        else dma16(b_voff[idx - Cfg::A_ITERS], b_rsrc, (uint32_t)(ks * 128), sa + Cfg::A_BYTES + (idx - Cfg::A_ITERS) * DNT * 16);
+        else dma16(b_voff[idx - Cfg::A_ITERS], b_rsrc, (uint32_t)ks * b_kstep, sa + Cfg::A_BYTES + (idx - Cfg::A_ITERS) * DNT * 16);
     };
 
     const int li = lane & 15, kg = lane >> 4;
@@ -103,6 +124,26 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
     const int b_row = wn * (BN / WN) + 8 * (li >> 2) + (li & 3);
     const int b_off0 = Cfg::A_BYTES + b_row * 128 + ((kg ^ swz_b(b_row)) * 16);
     const int b_off1 = Cfg::A_BYTES + b_row * 128 + (((kg + 4) ^ swz_b(b_row)) * 16);
+    // NN: lane = 16g + 4q + p supplies row 8g + q, columns (wave's n base) + 16 nt + 4p; chunk swizzle h = q | (g&1)<<2
+    const int tq = (lane >> 2) & 3, tp = lane & 3;
+    const int nn_h = tq | ((kg & 1) << 2);
+    const int nn_base = Cfg::A_BYTES + (8 * kg + tq) * (BN * 2) + (tp >> 1) * 16 + 8 * (tp & 1);
+    const int nn_cb = wn * (BN / WN) / 16;  // the wave's first 32-byte chunk pair (n-tile nt is pair nn_cb + nt)
+    // operand of n-tile nt, k half h (k = 32h .. 32h+31 of the step) out of stage `st`
+    auto load_b = [&](const uint8_t *st, int nt, int h) -> v4i {
+        if constexpr (NN) {
+            typedef short v4s __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) v4s *lds_v4s;
+            const uint8_t *a0 = st + nn_base + (((nn_cb + nt) ^ nn_h) << 5) + h * 32 * (BN * 2);
+            const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(a0));
+            const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(a0 + 4 * (BN * 2)));
+            const v2i l2 = __builtin_bit_cast(v2i, lo), h2 = __builtin_bit_cast(v2i, hi);
+            return v4i{l2.x, l2.y, h2.x, h2.y};
+        } else {
+            const int boff = (nt >> 1) * 4096 + (nt & 1) * 512;
+            return *(const v4i *)(st + (h ? b_off1 : b_off0) + boff);
+        }
+    };
 
     v4f acc[TM][TN];
 #pragma unroll
@@ -137,8 +178,8 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
         for (int idx = 0; idx < TAIL_DMA; ++idx) issue_one(idx, 1, 1);
         wait_vmcnt<TAIL_DMA>();
         barrier();
-        bf[0][0] = *(const v4i *)(smem + b_off0);
-        bf[0][1] = *(const v4i *)(smem + b_off1);
+        bf[0][0] = load_b(smem, 0, 0);
+        bf[0][1] = load_b(smem, 0, 1);
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt) {
             af[mt][0] = *(const v4i *)(smem + a_off0 + mt * 2048);
@@ -165,9 +206,8 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
                 if (h == 0 && mt == 0) {  // next n-tile's B fragment (wraps into the next k step)
                     const uint8_t *src = nt + 1 < TN ? st : sn;
                     const int nn = nt + 1 < TN ? nt + 1 : 0;
-                    const int boff = (nn >> 1) * 4096 + (nn & 1) * 512;
-                    bf[(nt + 1) & 1][0] = *(const v4i *)(src + b_off0 + boff);
-                    bf[(nt + 1) & 1][1] = *(const v4i *)(src + b_off1 + boff);
+                    bf[(nt + 1) & 1][0] = load_b(src, nn, 0);
+                    bf[(nt + 1) & 1][1] = load_b(src, nn, 1);
                 }
                 if (nt == TN - 1) af[mt][h] = *(const v4i *)(sn + (h ? a_off1 : a_off0) + mt * 2048);  // in-place reload
                 __builtin_amdgcn_sched_barrier(0);
@@ -186,8 +226,8 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
         asm volatile("" ::: "memory");
         const uint8_t *st = smem + stage * STAGE;
         v4i af[TM][2], bf[2][2];
-        bf[0][0] = *(const v4i *)(st + b_off0);
-        bf[0][1] = *(const v4i *)(st + b_off1);
+        bf[0][0] = load_b(st, 0, 0);
+        bf[0][1] = load_b(st, 0, 1);
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt) {
             af[mt][0] = *(const v4i *)(st + a_off0 + mt * 2048);
@@ -206,9 +246,8 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
                     issue_one(idx, stage ^ 1, ks + 1);  // past the last k step: reads the tile's following bytes, unused
             }
             if (nt + 1 < TN) {
-                const int boff = ((nt + 1) >> 1) * 4096 + ((nt + 1) & 1) * 512;
-                bf[(nt + 1) & 1][0] = *(const v4i *)(st + b_off0 + boff);
-                bf[(nt + 1) & 1][1] = *(const v4i *)(st + b_off1 + boff);
+                bf[(nt + 1) & 1][0] = load_b(st, nt + 1, 0);
+                bf[(nt + 1) & 1][1] = load_b(st, nt + 1, 1);
             }
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) acc[mt][nt] = mfma_b16<BF16>(bf[nt & 1][1], af[mt][1], acc[mt][nt]);
@@ -219,7 +258,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
 
     // epilogue: lane owns row m, 4 consecutive n per 16x16 tile (same n permutation as the fp8 kernel)
     const int m_row = m0 + wm * (BM / Cfg::kWM) + li;
-    const int n_base = n0 + wn * (BN / WN) + 8 * kg;
+    const int n_base = n0 + wn * (BN / WN) + (NN ? 4 : 8) * kg;
     const bool v_ok = ((p.n & 3) == 0) && ((((uintptr_t)Z) & 15) == 0);
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
@@ -228,7 +267,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
         float *zr = Z + (int64_t)m * p.n;
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt) {
-            const int n = n_base + 32 * (nt >> 1) + 4 * (nt & 1);
+            const int n = NN ? n_base + 16 * nt : n_base + 32 * (nt >> 1) + 4 * (nt & 1);
             if (v_ok && n + 4 <= p.n) {
                 *(v4f *)(zr + n) = acc[mt][nt];
             } else {
