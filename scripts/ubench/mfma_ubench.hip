@@ -34,6 +34,33 @@ __global__ void __launch_bounds__(512) k(const int *seed, float *out, int iters)
         out[blockIdx.x * blockDim.x + threadIdx.x] = r;
         return;
     }
+    if (MODE == 4) {   // 32x32x64: two chained MFMAs per 128-wide scale block (C = 0, then C = part) + 16 promotion FMAs, lag 1 block
+        v16f acc32[4], part32[2];
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc32[i][j] = 0.f;
+        for (int j = 0; j < 16; ++j) { part32[0][j] = 0.f; part32[1][j] = 0.f; }
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4 + 1; ++i) {
+                if (i < 4) {
+                    asm volatile("" : "+v"(a));
+                    v16f z16; for (int j = 0; j < 16; ++j) z16[j] = 0.f;
+                    v16f t = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, z16, 0, 0, 0, 0, 0, 0);
+                    part32[i & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b, a, t, 0, 0, 0, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (i >= 1) {
+                    const int j = i - 1;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc32[j][q] = __builtin_fmaf(part32[j & 1][q], s, acc32[j][q]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        float r = 0;
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) r += acc32[i][j];
+        out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+        return;
+    }
     if (MODE == 0) {
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -95,18 +122,19 @@ int main(int argc, char **argv)
     hipMemcpy(seed, h.data(), 4096 * 4, hipMemcpyHostToDevice);
     printf("operands: %s\n", randomise ? "random e4m3 bytes" : "constant 0x38");
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 4; ++mode)
+    for (int mode = 0; mode < 5; ++mode)
         for (int threads : {256, 512}) {
             for (int rep = 0; rep < 3; ++rep) {
                 hipEventRecord(e0);
                 if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(threads), 0, 0, seed, out, iters);
                 else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(threads), 0, 0, seed, out, iters);
                 else if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(threads), 0, 0, seed, out, iters);
-                else hipLaunchKernelGGL(k<3>, dim3(256), dim3(threads), 0, 0, seed, out, iters);
+                else if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(256), dim3(threads), 0, 0, seed, out, iters);
+                else hipLaunchKernelGGL(k<4>, dim3(256), dim3(threads), 0, 0, seed, out, iters);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 double flops = 2.0 * 16 * 16 * 128 * 16.0 * iters * (threads / 64) * 256;
-                if (rep == 2) printf("mode %d (%s) waves/SIMD %d: %.3f ms  %.0f TFLOP/s\n", mode, mode == 1 ? "MFMA+4FMA lag3" : mode == 2 ? "32x32x64 MFMA only" : mode == 3 ? "MFMA+2 pk_fma lag3" : "MFMA only", threads / 256, ms, flops / ms / 1e9);
+                if (rep == 2) printf("mode %d (%s) waves/SIMD %d: %.3f ms  %.0f TFLOP/s\n", mode, mode == 1 ? "MFMA+4FMA lag3" : mode == 2 ? "32x32x64 MFMA only" : mode == 3 ? "MFMA+2 pk_fma lag3" : mode == 4 ? "32x32x64 x2 + 16 FMA" : "MFMA only", threads / 256, ms, flops / ms / 1e9);
             }
         }
     return 0;
