@@ -348,6 +348,18 @@ def per_block_cast_to_fp8(x: torch.Tensor):
     return _cast("dga_cast_to_fp8_128x128", x, 128)
 
 
+def route_tokens(expert_ids: torch.Tensor, groups: int):
+    """(counts int64 [groups], pos int64 [T]): pos[t] = slot of token t in the expert-sorted order (dga_route_tokens)."""
+    _require(expert_ids.dtype == torch.int64 and expert_ids.dim() == 1 and expert_ids.is_contiguous(), "expert_ids int64 [T]")
+    counts = torch.empty((groups,), dtype=torch.int64, device=expert_ids.device)
+    pos = torch.empty((expert_ids.numel(),), dtype=torch.int64, device=expert_ids.device)
+    with _device_guard(expert_ids):
+        rc = _lib.lib().dga_route_tokens(expert_ids.data_ptr(), expert_ids.numel(), groups, counts.data_ptr(), pos.data_ptr(),
+                                         _stream_ptr(expert_ids))
+        _lib.check(rc, "route_tokens")
+    return counts, pos
+
+
 def copy_rows(dst: torch.Tensor, src: torch.Tensor, dst_index: Optional[torch.Tensor] = None,
               src_index: Optional[torch.Tensor] = None, rows: Optional[int] = None, row_bytes: Optional[int] = None,
               dst_byte_offset: int = 0, src_byte_offset: int = 0) -> None:

@@ -22,6 +22,7 @@ __global__ void __launch_bounds__(256) copy_rows_kernel(uint8_t *dst, int64_t ds
     const int part = blockIdx.x % parts;
     if (r >= rows) return;
     const int64_t dr = dst_index ? dst_index[r] : r, sr = src_index ? src_index[r] : r;
+    if (dr < 0 || sr < 0) return;  // a negative index marks a row that takes no part (dga_route_tokens: id out of range)
     uint8_t *d = dst + dr * dst_stride;
     const uint8_t *s = src + sr * src_stride;
     if (VEC) {
@@ -33,7 +34,59 @@ __global__ void __launch_bounds__(256) copy_rows_kernel(uint8_t *dst, int64_t ds
     }
 }
 
+// ---- token routing for the dispatch (one pass of atomics instead of a device sort + histogram) ------------------
+// rank[t] = how many tokens of the same expert were counted before token t (arrival order of the atomics: the order
+// inside an expert's segment is unspecified, which the exchange does not care about -- dispatch and combine use the
+// same table); counts[g] = tokens of expert g.
+__global__ void __launch_bounds__(256) route_rank_kernel(const int64_t *ids, int64_t tokens, int groups,
+                                                         unsigned long long *counts, int64_t *pos)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= tokens) return;
+    const int64_t e = ids[t];
+    pos[t] = (e >= 0 && e < groups) ? (int64_t)atomicAdd(counts + e, 1ull) : -1;
+}
+
+// pos[t] = (exclusive prefix sum of counts)[ids[t]] + rank[t].  Every block rebuilds the prefix sums in LDS (groups is
+// a few hundred at most), so the two steps need no third launch.
+__global__ void __launch_bounds__(256) route_pos_kernel(const int64_t *ids, int64_t tokens, int groups,
+                                                        const unsigned long long *counts, int64_t *pos)
+{
+    extern __shared__ long long off[];  // [groups] exclusive offsets, then [256] per-thread partial sums
+    long long *partial = off + groups;
+    const int per = (groups + 255) / 256, g0 = threadIdx.x * per, g1 = min(groups, g0 + per);
+    long long sum = 0;
+    for (int g = g0; g < g1; ++g) sum += (long long)counts[g];
+    partial[threadIdx.x] = sum;
+    __syncthreads();
+    long long base = 0;
+    for (int i = 0; i < (int)threadIdx.x; ++i) base += partial[i];
+    for (int g = g0; g < g1; ++g) { off[g] = base; base += (long long)counts[g]; }
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= tokens) return;
+    const int64_t e = ids[t];
+    if (e >= 0 && e < groups) pos[t] += off[e];
+}
+
 }  // namespace dga
+
+extern "C" int dga_route_tokens(const int64_t *expert_ids, int64_t tokens, int groups, int64_t *counts, int64_t *pos,
+                                void *stream)
+{
+    if (tokens < 0 || groups < 0 || groups > 4096) return DGA_E_SHAPE;
+    if (groups > 0 && !counts) return DGA_E_NULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (groups > 0 && dga::record_hip(hipMemsetAsync(counts, 0, sizeof(int64_t) * groups, st)) != DGA_OK) return DGA_E_HIP;
+    if (tokens == 0) return DGA_OK;
+    if (!expert_ids || !pos) return DGA_E_NULL;
+    const unsigned grid = static_cast<unsigned>((tokens + 255) / 256);
+    hipLaunchKernelGGL(dga::route_rank_kernel, dim3(grid), dim3(256), 0, st, expert_ids, tokens, groups,
+                       reinterpret_cast<unsigned long long *>(counts), pos);
+    hipLaunchKernelGGL(dga::route_pos_kernel, dim3(grid), dim3(256), sizeof(long long) * (groups + 256), st, expert_ids,
+                       tokens, groups, reinterpret_cast<const unsigned long long *>(counts), pos);
+    return dga::record_hip(hipGetLastError());
+}
 
 extern "C" int dga_copy_rows(void *dst, int64_t dst_row_stride, const int64_t *dst_index, const void *src,
                              int64_t src_row_stride, const int64_t *src_index, int64_t row_bytes, int64_t rows,

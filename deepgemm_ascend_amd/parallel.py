@@ -27,11 +27,12 @@ import torch
 
 @dataclass
 class RouteState:
-    order: torch.Tensor        # permutation that sorts my tokens by expert
+    order: torch.Tensor        # scatter=False: permutation that sorts my tokens by expert; scatter=True: slot of every token
     dest: torch.Tensor         # slot (g_local * m_max + row) of every received row
     send_splits: list
     recv_splits: list
     tokens: int
+    scatter: bool = False      # device path: `order` is pos (token -> slot in expert-sorted order, dga_route_tokens)
 
 
 def _default_compute(a, sfa, b, sfb, out, masked_m, expected_m):
@@ -75,6 +76,8 @@ class ExpertShardedGroupedGemm:
         self.b = None
         self.sfb = None
         self._pinned = None
+        self._stage = [None, None]
+        self._stage_i = 0
 
     def set_weights(self, b: torch.Tensor, sfb: torch.Tensor):
         assert tuple(b.shape) == (self.Gl, self.n, self.k) and tuple(sfb.shape) == (self.Gl, self.nb, self.kb)
@@ -87,7 +90,15 @@ class ExpertShardedGroupedGemm:
     def dispatch(self, tok_q: torch.Tensor, tok_sf: torch.Tensor, expert_ids: torch.Tensor) -> RouteState:
         """tok_q [T,K] u8, tok_sf [T,KB] f32, expert_ids [T] int64 (global expert of each token)."""
         T = tok_q.shape[0]
-        counts = torch.bincount(expert_ids, minlength=self.G).to(torch.int64)        # [G]
+        scatter = tok_q.is_cuda
+        if scatter:
+            # one pass of atomics: counts and the slot of every token in the expert-sorted order (no device sort, no
+            # histogram with its hidden host sync)
+            from . import api
+            counts, order = api.route_tokens(expert_ids.contiguous(), self.G)
+        else:
+            counts = torch.bincount(expert_ids, minlength=self.G).to(torch.int64)        # [G]
+            order = None
         if self.world > 1:
             flat = torch.empty((self.world * self.G,), dtype=torch.int64, device=counts.device)
             self.dist.all_gather_into_tensor(flat, counts)
@@ -105,11 +116,15 @@ class ExpertShardedGroupedGemm:
             landed.record()
         else:
             landed = None
-        order = torch.argsort(expert_ids, stable=True).contiguous()
-        # one byte row per token: K fp8 bytes followed by KB fp32 scales, gathered in expert order
+        # one byte row per token: K fp8 bytes followed by KB fp32 scales, in expert order
         payload = torch.empty((T, self.row_bytes), dtype=torch.uint8, device=tok_q.device)
-        _rows(payload, tok_q, src_index=order, row_bytes=self.k)
-        _rows(payload, tok_sf.view(torch.uint8), src_index=order, row_bytes=4 * self.kb, dst_off=self.k)
+        if scatter:
+            _rows(payload, tok_q, dst_index=order, row_bytes=self.k)
+            _rows(payload, tok_sf.view(torch.uint8), dst_index=order, row_bytes=4 * self.kb, dst_off=self.k)
+        else:
+            order = torch.argsort(expert_ids, stable=True).contiguous()
+            _rows(payload, tok_q, src_index=order, row_bytes=self.k)
+            _rows(payload, tok_sf.view(torch.uint8), src_index=order, row_bytes=4 * self.kb, dst_off=self.k)
         if landed is not None:
             landed.synchronize()
             allc = self._pinned.numpy().reshape(self.world, self.G).copy()
@@ -127,8 +142,25 @@ class ExpertShardedGroupedGemm:
         flat_cnt = mine.reshape(-1)
         seg_begin = np.cumsum(flat_cnt) - flat_cnt
         dest_np = np.repeat(start.reshape(-1) - seg_begin, flat_cnt) + np.arange(total, dtype=np.int64)
-        dest = torch.from_numpy(dest_np).to(tok_q.device, non_blocking=True)
-        self.masked_m.copy_(torch.from_numpy(masked.astype(np.int32)), non_blocking=True)
+        if tok_q.is_cuda:
+            # staged through pinned memory so that the two uploads are asynchronous (a pageable source makes the copy a
+            # blocking staging copy); a fresh buffer pair per call while the previous one may still be in flight
+            slot = self._stage[self._stage_i]
+            self._stage_i ^= 1
+            if slot is None or slot[0].numel() < total:
+                slot = (torch.empty((max(total, 1024),), dtype=torch.int64, pin_memory=True),
+                        torch.empty((self.Gl,), dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+                self._stage[self._stage_i ^ 1] = slot
+            else:
+                slot[2].synchronize()   # the uploads that used this slot two calls ago
+            slot[0][:total].numpy()[:] = dest_np
+            slot[1].numpy()[:] = masked
+            dest = slot[0][:total].to(tok_q.device, non_blocking=True)
+            self.masked_m.copy_(slot[1], non_blocking=True)
+            slot[2].record()
+        else:
+            dest = torch.from_numpy(dest_np)
+            self.masked_m.copy_(torch.from_numpy(masked.astype(np.int32)))
         if self.world > 1:
             recv = torch.empty((total, self.row_bytes), dtype=torch.uint8, device=tok_q.device)
             self.dist.all_to_all_single(recv, payload, recv_splits, send_splits)
@@ -137,7 +169,7 @@ class ExpertShardedGroupedGemm:
         _rows(self.a.view(self.Gl * self.m_max, self.k), recv, dst_index=dest, row_bytes=self.k)
         _rows(self.sfa.view(self.Gl * self.m_max, self.kb).view(torch.uint8), recv, dst_index=dest,
               row_bytes=4 * self.kb, src_off=self.k)
-        return RouteState(order, dest, send_splits, recv_splits, T)
+        return RouteState(order, dest, send_splits, recv_splits, T, scatter)
 
     # ------------------------------------------------------------------ compute
     def run_local(self, expected_m: int = 0):
@@ -155,7 +187,10 @@ class ExpertShardedGroupedGemm:
         else:
             back = rows
         res = torch.empty_like(back)
-        _rows(res.view(torch.uint8), back.view(torch.uint8), dst_index=st.order, row_bytes=2 * self.n)
+        if st.scatter:
+            _rows(res.view(torch.uint8), back.view(torch.uint8), src_index=st.order, row_bytes=2 * self.n)
+        else:
+            _rows(res.view(torch.uint8), back.view(torch.uint8), dst_index=st.order, row_bytes=2 * self.n)
         return res
 
     def forward(self, tok_q, tok_sf, expert_ids, expected_m: int = 0) -> torch.Tensor:

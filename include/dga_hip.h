@@ -225,6 +225,12 @@ int dga_run_mmad_bench_ws(const void *x, const void *y, float *z, int m, int n, 
 
 /* ---- expert sharding helper (the reference has no routing or collective of any kind) ------- */
 
+/* Token routing for the dispatch: counts[g] = number of t with expert_ids[t] == g (int64, zeroed here) and pos[t] =
+ * position of token t in the expert-sorted order (an expert's tokens are contiguous, their relative order is
+ * unspecified; ids outside [0, groups) get pos -1 and are not counted).  One pass of atomics in place of a device sort
+ * and a histogram.  No reference counterpart (row 8(e)). */
+int dga_route_tokens(const int64_t *expert_ids, int64_t tokens, int groups, int64_t *counts, int64_t *pos, void *stream);
+
 /* Indexed row copy on the device: for r in [0, rows):
  *   dst[(dst_index ? dst_index[r] : r) * dst_row_stride .. +row_bytes) = src[(src_index ? src_index[r] : r) * src_row_stride ..)
  * (strides in bytes; index arrays are device int64).  Packs token rows for the dispatch all-to-all, scatters the

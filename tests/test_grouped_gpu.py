@@ -143,3 +143,21 @@ def test_config4_full_size(dga, oracle):
         t = dga.tiling(r, N, K); t.m1, t.n1, t.stages, t.splitkFactor, t.kernelSerial, t.wavesM, t.wavesN = 128, 256, 3, 1, 0, 2, 2
         dga.gemm_fp8_fp8_bf16_nt((a[e, :r].contiguous(), sfa[e, :r].contiguous()), (b[e], sfb[e]), dense, tiling_=t, sync=True)
         assert torch.equal(dense, out[e, :r])
+
+
+def test_route_tokens(dga):
+    """dga_route_tokens: counts = histogram, pos = a permutation that sorts the tokens by expert; out-of-range ids -> -1."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for T, G in ((0, 8), (1, 1), (5000, 37), (32768, 256)):
+        ids = torch.randint(0, G, (T,), device="cuda", generator=g)
+        counts, pos = dga.route_tokens(ids, G)
+        torch.cuda.synchronize()
+        assert torch.equal(counts, torch.bincount(ids, minlength=G))
+        if T:
+            assert torch.equal(torch.sort(pos).values, torch.arange(T, device="cuda"))
+            by_slot = torch.empty_like(ids); by_slot[pos] = ids
+            assert (by_slot[1:] >= by_slot[:-1]).all()
+    ids = torch.tensor([3, -1, 0, 9, 3], device="cuda")
+    counts, pos = dga.route_tokens(ids, 4)
+    assert counts.tolist() == [1, 0, 0, 2] and pos[1].item() == -1 and pos[3].item() == -1
+    assert sorted(pos[[0, 2, 4]].tolist()) == [0, 1, 2] and pos[2].item() == 0
