@@ -1,0 +1,89 @@
+"""Randomised parity sweep: shapes, masks and layouts drawn from a seeded generator, every result checked against the
+oracle.  Whatever tiling dga_tiling() returns for the shape (swept table, learned predictor or heuristic; split-K,
+padding pass, K tails) is what runs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(t):
+    return t.view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+def _shapes(seed, count):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        m = int(rng.choice([1, 7, 16, 33, 64, 100, 128, 200, 257, 512, 700]))
+        n = int(rng.choice([16, 128, 136, 256, 384, 520, 1024, 1536]))
+        k = int(rng.choice([16, 128, 144, 256, 512, 1000, 1024, 1921, 2048, 4096]))
+        out.append((m, n, k))
+    return out
+
+
+@pytest.mark.parametrize("m,n,k", _shapes(2026, 28))
+def test_dense_random_shapes(dga, oracle, m, n, k):
+    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=m * 31 + n * 7 + k)
+    out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    dga.gemm_fp8_fp8_bf16_nt((torch.from_numpy(a).cuda(), torch.from_numpy(sfa).cuda()),
+                             (torch.from_numpy(b).cuda(), torch.from_numpy(sfb).cuda()), out, sync=True)
+    want = oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, threads=8)
+    if m * n >= 2048:
+        oracle.assert_parity(_bits(out), want, a, sfa, b, sfb)
+    else:   # too few elements for the fraction criterion: the per-element envelope only
+        rep = oracle.parity_report(_bits(out), want, a, sfa, b, sfb)
+        assert rep["nan_positions_equal"] and rep["worst_excess_over_S"] <= oracle.MFMA_ALIGN_EPS, rep
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_grouped_random_masks(dga, oracle, seed):
+    rng = np.random.default_rng(100 + seed)
+    g = int(rng.integers(1, 9)); mmax = int(rng.choice([8, 48, 128, 130])); n = int(rng.choice([128, 256, 392])); k = int(rng.choice([128, 384, 1040]))
+    masks = rng.integers(0, mmax + 1, size=g).astype(np.int32)
+    A, SFA, B, SFB = [], [], [], []
+    for i in range(g):
+        a, sfa, b, sfb = oracle.make_inputs(mmax, n, k, seed=seed * 50 + i)
+        A.append(a); SFA.append(sfa); B.append(b); SFB.append(sfb)
+    a, sfa, b, sfb = np.stack(A), np.stack(SFA), np.stack(B), np.stack(SFB)
+    init = np.full((g, mmax, n), 0x7FC1, np.uint16)
+    out = torch.from_numpy(init.view(np.int16)).cuda().view(torch.bfloat16)
+    dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((torch.from_numpy(a).cuda(), torch.from_numpy(sfa).cuda()),
+                                              (torch.from_numpy(b).cuda(), torch.from_numpy(sfb).cuda()), out,
+                                              torch.from_numpy(masks).cuda(), expected_m=int(masks.max()), sync=True)
+    got = _bits(out)
+    want = oracle.m_grouped_gemm_fp8_fp8_bf16_nt_masked(a, sfa, b, sfb, init, masks, threads=8)
+    for i in range(g):
+        mm = int(masks[i])
+        assert (got[i, mm:] == 0x7FC1).all()
+        if mm * n >= 2048:
+            oracle.assert_parity(got[i, :mm], want[i, :mm], a[i, :mm], sfa[i, :mm], b[i], sfb[i])
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_contiguous_random_segments(dga, oracle, seed):
+    rng = np.random.default_rng(200 + seed)
+    g = int(rng.integers(1, 7)); n = int(rng.choice([128, 256, 520])); k = int(rng.choice([128, 640, 1000]))
+    counts = [int(c) for c in rng.integers(0, 700, size=g)]
+    idx = []
+    for gi, c in enumerate(counts):
+        idx += [gi] * c + [-1] * (-(-c // 128) * 128 - c)
+    if not idx:
+        idx = [-1] * 128
+    idx = np.array(idx, np.int32)
+    a, sfa, _, _ = oracle.make_inputs(idx.size, 8, k, seed=seed)
+    bs = [oracle.make_inputs(8, n, k, seed=seed * 9 + i + 1)[2:] for i in range(g)]
+    b = np.stack([x[0] for x in bs]); sfb = np.stack([x[1] for x in bs])
+    init = np.full((idx.size, n), 0x7FC1, np.uint16)
+    out = torch.from_numpy(init.view(np.int16)).cuda().view(torch.bfloat16)
+    dga.m_grouped_gemm_fp8_fp8_bf16_nt_contiguous((torch.from_numpy(a).cuda(), torch.from_numpy(sfa).cuda()),
+                                                  (torch.from_numpy(b).cuda(), torch.from_numpy(sfb).cuda()), out,
+                                                  torch.from_numpy(idx).cuda(), sync=True)
+    got = _bits(out)
+    want = oracle.m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(a, sfa, b, sfb, init, idx, threads=8)
+    assert (got[idx < 0] == 0x7FC1).all()
+    for gi in range(g):
+        rows = np.nonzero(idx == gi)[0]
+        if rows.size * n >= 2048:
+            oracle.assert_parity(got[rows], want[rows], a[rows], sfa[rows], b[gi], sfb[gi])
