@@ -46,7 +46,8 @@ static int launch_one(const GemmParams &p, hipStream_t stream)
                                             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     });
     DGA_HIP_TRY(attr_err[dev]);
-    unsigned grid = static_cast<unsigned>(p.groups) * p.tiles_m * p.tiles_n;
+    unsigned grid = p.launch_tiles > 0 ? static_cast<unsigned>(p.launch_tiles)
+                                       : static_cast<unsigned>(p.groups) * p.tiles_m * p.tiles_n;
     if (p.m_indices && Cfg::kBM > DGA_CONTIGUOUS_M_ALIGNMENT) grid *= 2;  // pass-1 copies for straddling tiles
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p);
     DGA_HIP_TRY(hipGetLastError());
@@ -234,9 +235,34 @@ static int run_fp8(const void *a, const float *sfa, const void *b, const float *
     }
     static const int pp_env = [] { const char *e = std::getenv("DGA_PINGPONG"); return e ? std::atoi(e) : -1; }();
     const int policy = pp_env >= 0 ? pp_env : tiling->dispatchPolicyTag;
-    if (policy == 1 && v->launch_pp) return v->launch_pp(p, stream);
-    if (policy == 2 && v->launch_cont) return v->launch_cont(p, stream);
-    return v->launch(p, stream);
+    auto launch_main = [&](const GemmParams &q) -> int {
+        if (policy == 1 && v->launch_pp) return v->launch_pp(q, stream);
+        if (policy == 2 && v->launch_cont) return v->launch_cont(q, stream);
+        return v->launch(q, stream);
+    };
+
+    // ---- tail in quarter tiles (kernelSerial 5): the whole waves of 256x256 tiles run as they are; the last partial wave
+    //      is covered by 128x128 tiles (four per parent tile) in a second launch, so that it occupies four times as many
+    //      CUs for a fraction of a round -- the purpose of the reference's Stream-K handler (select_kernel.cpp:303-331,
+    //      wave quantisation) without partial sums: every output still comes from one accumulation in k order, the
+    //      bytes are those of a single launch.
+    if (tiling->kernelSerial == DGA_KERNEL_STREAMK_TAIL && groups == 1 && !masked_m && !m_indices && v->bm == 256 && v->bn == 256) {
+        const int tiles = p.tiles_m * p.tiles_n, cus = 256;
+        const int tail = tiles % cus, main_tiles = tiles - tail;
+        const Variant *vq = find_variant(128, 128, 0, 0, 3);
+        if (tail > 0 && main_tiles > 0 && vq) {
+            GemmParams pm = p;
+            pm.launch_tiles = main_tiles;
+            int rc = launch_main(pm);
+            if (rc != DGA_OK) return rc;
+            GemmParams pt = p;  // tiles_m / tiles_n / raster_group stay those of the parent raster
+            pt.tail_begin = main_tiles;
+            pt.tail_sub = 2;
+            pt.launch_tiles = tail * 4;
+            return vq->launch(pt, stream);
+        }
+    }
+    return launch_main(p);
 }
 
 }  // namespace dga

@@ -248,6 +248,7 @@ int dga_select_kernel_with_predictor(const dga_problem_t *problem, dga_tiling_t 
     if (native_us) *native_us = 0.f;
     const Model *mo = model();
     if (!mo || !eligible(*problem) || out->blockDim == 0) return DGA_OK;
+    if (out->kernelSerial == DGA_KERNEL_STREAMK_TAIL) return DGA_OK;  // outside the candidate space the model was trained on
     float f[kFeatures];
     const Cand native{out->m1, out->n1, out->stages == 3 ? 3 : 2, std::max<int>(1, out->splitkFactor), out->dispatchPolicyTag};
     feature_row(problem->m, problem->n, problem->k, native, f);
@@ -288,6 +289,7 @@ int dga_select_kernel_with_predictor(const dga_problem_t *problem, dga_tiling_t 
         }
     }
     if (predicted_us) *predicted_us = best;
+    dga::apply_tail_split(*out, 256);  // the model picks the tile; a small last wave of 256x256 tiles is still cut along K
     return DGA_OK;
 }
 

@@ -282,6 +282,24 @@ static double tile_cycles_per_kblock(const MenuEntry &e)
     return std::max({mfma, lds, dma}) + 200.0;                // + barrier/issue overhead per k block
 }
 
+}  // namespace tiling
+
+// Tail in quarter tiles (kernelSerial 5): more than one wave of 256x256 tiles with a small remainder -- the remainder would
+// cost a whole extra round at 1/8..1/4 occupancy; covered by 128x128 tiles (second launch) it occupies four times the
+// CUs for about half a round.  Applied to a dense tiling whatever chose the tile (heuristic or predictor).
+void apply_tail_split(dga_tiling_t &t, uint32_t cus)
+{
+    if (t.splitkFactor > 1 || t.m1 != 256 || t.n1 != 256 || t.groups > 1 || t.contiguous || !cus) return;
+    const uint64_t blocks = static_cast<uint64_t>((t.m + 255) / 256) * ((t.n + 255) / 256);
+    if (blocks <= cus) return;
+    const uint32_t tail = static_cast<uint32_t>(blocks % cus);
+    if (tail == 0 || tail * 4 > cus) return;
+    t.kernelSerial = DGA_KERNEL_STREAMK_TAIL;
+    t.blockDim = static_cast<uint32_t>(blocks - tail) + tail * 4;
+}
+
+namespace tiling {
+
 void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, uint32_t expected_m,
                    bool contiguous = false)
 {
@@ -314,7 +332,12 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
         const uint32_t wg_per_cu = std::max<uint64_t>(1, std::min<uint64_t>(pf.l1Size / e.lds, 2048 / (e.wm * e.wn * 64)));
         const uint64_t tiles = static_cast<uint64_t>(groups) * ceil_div(m_eff, e.bm) * ceil_div(t.n, e.bn);
         const uint64_t slots = static_cast<uint64_t>(pf.coreNum) * wg_per_cu;
-        const double rounds = std::ceil(static_cast<double>(tiles) / slots);
+        double rounds = std::ceil(static_cast<double>(tiles) / slots);
+        // 256x256: a small last partial wave is cut along K (apply_tail_split) and costs a fraction of a round
+        if (groups == 1 && !contiguous && e.bm == 256 && e.bn == 256 && tiles > pf.coreNum) {
+            const uint64_t tail = tiles % pf.coreNum;
+            if (tail > 0 && tail * 4 <= pf.coreNum) rounds = static_cast<double>(tiles / pf.coreNum) + 0.5;
+        }
         // co-resident workgroups share the CU's MFMA pipes
         const double share = std::min<double>(wg_per_cu, std::ceil(static_cast<double>(tiles) / pf.coreNum));
         double cost = rounds * share * kb * tile_cycles_per_kblock(e);
@@ -355,6 +378,7 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
             t.blockDim = static_cast<uint32_t>(blocks) * t.splitkFactor;
         }
     }
+    if (groups == 1 && !contiguous) apply_tail_split(t, pf.coreNum);
     // raster: walk `swizzleOffset` tile-rows together so that an XCD's slice of the grid
     // (blocks/8 consecutive tiles) is a near-square patch sharing A and B panels in its L2.
     const uint32_t per_xcd = std::max<uint32_t>(1, static_cast<uint32_t>(blocks / std::max(1u, pf.xcdNum)));

@@ -45,6 +45,9 @@ struct GemmParams {
     int xcd_remap;               // 1: contiguous tile chunk per XCD (blocks b, b+8, ... share an XCD)
     float *partial;              // split-K: fp32 slabs [splitk][m][n] in the caller's workspace (dense only)
     int splitk, kb_per_split;    // splitk > 1: block -> (split, tile); split s covers k blocks [s*kb_per_split, +kb_per_split)
+    int launch_tiles;            // > 0: grid size of this launch (the first launch_tiles tiles of the raster); 0: all tiles
+    int tail_begin, tail_sub;    // tail_sub = 2: this launch's tiles are QUARTER tiles (2 x 2 per parent) of the parent
+                                 // raster's tiles [tail_begin, ...); tiles_m / tiles_n then hold the PARENT raster
     unsigned long long *stamps;  // diagnostic builds only (-DDGA_STAMPS): per-wave segment cycle sums
 };
 
@@ -124,6 +127,8 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
     const int g = p.splitk > 1 ? 0 : tile / tiles_per_group;
     int t_in = tile - (p.splitk > 1 ? split : g) * tiles_per_group;
     int tm, tn;
+    const int sub = p.tail_sub ? (t_in & 3) : 0;
+    if (p.tail_sub) t_in = p.tail_begin + (t_in >> 2);
     {
         const int gm = p.raster_group;
         const int per = gm * p.tiles_n;
@@ -134,9 +139,14 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         tm = first + loc % rows;
         tn = loc / rows;
     }
+    if (p.tail_sub) {  // quarter tile (sub & 1, sub >> 1) of parent tile (tm, tn)
+        tm = 2 * tm + (sub & 1);
+        tn = 2 * tn + (sub >> 1);
+    }
     const int M = p.masked_m ? min(p.masked_m[g], p.m) : p.m;
     const int m0 = tm * BM, n0 = tn * BN;
     if (m0 >= M) return;  // empty expert / fully masked tile: nothing read, nothing written
+    if (p.tail_sub && n0 >= p.n) return;  // a quarter tile beyond the matrix edge
     // contiguous-grouped layout: one A/out matrix, the B group comes from the index of the tile's first row (the
     // layout contract aligns group segments to the tile height); padding tiles (index -1) do nothing
     //   A tile taller than the alignment (256 rows = two 128-row blocks) may hold two groups: pass 0 computes the

@@ -88,6 +88,9 @@ def candidates(m, n, k, rasters=None):
                     for pol in ([0, 1, 2] if (bm, bn) in PINGPONG and sk == 1 else [0]):
                         rr = r if rasters is None else heuristic_raster(m, n, bm, bn, sk)
                         out.append({"m1": bm, "n1": bn, "raster": rr, "stages": st, "splitk": sk, "policy": pol})
+                        # 256x256, more than one wave of tiles with a small remainder: also with the quarter-tile tail
+                        if (bm, bn) == (256, 256) and sk == 1 and blocks > 256 and 0 < blocks % 256 <= 64:
+                            out.append({"m1": bm, "n1": bn, "raster": rr, "stages": st, "splitk": sk, "policy": pol, "tail": 1})
     return out
 
 
@@ -158,7 +161,7 @@ def benchmark_shape(shape, out_dir: Path, rank=0, num_processes=1, iters=10, ras
         t = dga.tiling(m, n, k)
         t.m1, t.n1, t.swizzleOffset = p["m1"], p["n1"], p["raster"]
         t.stages, t.wavesM, t.wavesN, t.dispatchPolicyTag = p["stages"], 0, 0, p["policy"]
-        t.splitkFactor = p["splitk"]; t.kernelSerial = 4 if p["splitk"] > 1 else 0
+        t.splitkFactor = p["splitk"]; t.kernelSerial = 5 if p.get("tail") else (4 if p["splitk"] > 1 else 0)
         fn = lambda: dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, tiling_=t)
         fn(); torch.cuda.synchronize()
         ok, diff = is_correct(golden, out)
@@ -205,7 +208,7 @@ def main(argv=None):
                         "splitkFactor,stages,swizzleOffset,wavesM,wavesN,dispatchPolicyTag\n")
             for (m, n, k), p in winners:
                 blocks = -(-m // p["m1"]) * -(-n // p["n1"]) * p["splitk"]
-                f.write(f"{m},{n},{k},{p['m1']},{p['n1']},128,{4 if p['splitk'] > 1 else 0},0,0,0,{blocks},"
+                f.write(f"{m},{n},{k},{p['m1']},{p['n1']},128,{5 if p.get('tail') else (4 if p['splitk'] > 1 else 0)},0,0,0,{blocks},"
                         f"{p['splitk']},{p['stages']},{p['raster']},0,0,{p['policy']}\n")
 
 

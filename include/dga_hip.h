@@ -46,7 +46,8 @@ enum { DGA_PADDING_NONE = 0, DGA_PADDING_ND = 1, DGA_PADDING_BLOCK_ND = 2, DGA_P
 /* kernelSerial menu, same numbering as the reference
  * (op_kernel/kernel/kernel_utils.h:31-37, select_kernel.cpp:270-331):
  *   0 Common, 1 Small, 2 PaddingCommon (never chosen on CDNA4), 4 StreamK/split-K. */
-enum { DGA_KERNEL_COMMON = 0, DGA_KERNEL_SMALL = 1, DGA_KERNEL_PADDING_COMMON = 2, DGA_KERNEL_STREAMK = 4 };
+enum { DGA_KERNEL_COMMON = 0, DGA_KERNEL_SMALL = 1, DGA_KERNEL_PADDING_COMMON = 2, DGA_KERNEL_STREAMK = 4,
+       DGA_KERNEL_STREAMK_TAIL = 5 /* whole waves of 256x256 tiles, the last partial wave covered by 128x128 tiles */ };
 
 /* Platform description: the CDNA4 retarget of PlatformInfo
  * (op_tiling/platform_info.h:16-41; Python mirror get_best_config/tiling_calculator.py:25-30).

@@ -253,3 +253,25 @@ def test_predictor_picks_run_and_match_the_oracle(dga, oracle, m, n, k):
                              (torch.from_numpy(b).cuda(), torch.from_numpy(sfb).cuda()), out, tiling_=t, sync=True)
     want = oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, threads=8)
     oracle.assert_parity(out.view(torch.int16).cpu().numpy().view(np.uint16), want, a, sfa, b, sfb)
+
+
+@pytest.mark.parametrize("m,n,k", [(4352, 4096, 128), (4300, 4100, 256), (4352, 4352, 144)])
+def test_quarter_tile_tail(dga, oracle, m, n, k):
+    """kernelSerial 5: whole waves of 256x256 tiles + the last partial wave in 128x128 tiles (second launch).  Same bytes
+    as a single launch over all tiles; parity against the oracle on a sample of rows (incl. the tail region)."""
+    import os
+    t = dga.select_kernel(m, n, k)
+    assert (t.m1, t.n1, t.kernelSerial) == (256, 256, 5), t.as_dict()
+    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=k)
+    ta, tsfa, tb, tsfb = [torch.from_numpy(x).cuda() for x in (a, sfa, b, sfb)]
+    out = torch.zeros((m, n), dtype=torch.bfloat16, device="cuda")
+    dga.gemm_fp8_fp8_bf16_nt((ta, tsfa), (tb, tsfb), out, tiling_=t, sync=True)
+    t0 = dga.select_kernel(m, n, k)
+    t0.kernelSerial = 0
+    ref = torch.zeros_like(out)
+    dga.gemm_fp8_fp8_bf16_nt((ta, tsfa), (tb, tsfb), ref, tiling_=t0, sync=True)
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    rows = np.r_[0:64, m - 300:m]   # the head and the rows the tail tiles cover
+    want = oracle.gemm_fp8_fp8_bf16_nt(a[rows], sfa[rows], b, sfb, threads=8)
+    oracle.assert_parity(out[torch.from_numpy(rows).cuda()].view(torch.int16).cpu().numpy().view(np.uint16), want,
+                         a[rows], sfa[rows], b, sfb)

@@ -62,12 +62,19 @@ def test_mi355x_selection_is_launchable(dga):
         t = dga.select_kernel(*shape)
         assert (t.m1, t.n1) in menu and t.k1 == 128
         assert t.ldsBytes <= pf.l1Size and t.m1 * t.n1 * 4 <= pf.l0CSize
-        assert t.blockDim == -(-shape[0] // t.m1) * -(-shape[1] // t.n1) * max(1, t.splitkFactor)
+        tiles = -(-shape[0] // t.m1) * -(-shape[1] // t.n1)
+        if t.kernelSerial == 5:   # whole waves of 256x256 tiles + the last partial wave in quarter tiles
+            assert (t.m1, t.n1, t.splitkFactor) == (256, 256, 1) and 0 < tiles % 256 <= 64
+            assert t.blockDim == tiles - tiles % 256 + 4 * (tiles % 256)
+        else:
+            assert t.blockDim == tiles * max(1, t.splitkFactor)
         assert (t.kernelSerial == 4) == (t.splitkFactor > 1)
         assert (t.paddingTagA, t.paddingTagB, t.paddingTagC) == (0, 0, 0)
         assert t.swizzleOffset >= 1
     t = dga.select_kernel(4096, 4096, 4096)
     assert (t.m1, t.n1, t.blockDim) == (256, 256, 256)   # one full wave of the 256 CUs
+    tq = dga.select_kernel(1024, 18432, 7168)             # 288 tiles: one wave + 32 tiles in quarter tiles
+    assert (tq.m1, tq.n1, tq.kernelSerial, tq.blockDim) == (256, 256, 5, 256 + 32 * 4)
     tg = dga.select_kernel(128, 2048, 7168, groups=256, expected_m=128)
     assert tg.groups == 256 and tg.m1 == 128 and tg.blockDim == 256 * (2048 // tg.n1)
     assert dga.select_kernel(0, 128, 128).blockDim == 0
