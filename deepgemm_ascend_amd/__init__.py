@@ -10,6 +10,7 @@ from .api import (  # noqa: F401
     CONFIG_FIELDS,
     bbit_params,
     bench_params_fill,
+    catlass_dynamic_matmul,
     copy_rows,
     gemm_fp8_fp8_bf16_nt,
     get_bench_config,

@@ -91,6 +91,9 @@ SIGNATURES = {
                                                               c_void_p, c_size_t, c_void_p]),
     "dga_cast_to_fp8_1x128": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "dga_cast_to_fp8_128x128": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "dga_catlass_dynamic_matmul_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dga_catlass_dynamic_matmul": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
+                                           c_void_p]),
     "dga_get_best_config": (c_int, [c_uint32] * 4 + [POINTER(c_uint32)]),
     "dga_get_bench_config": (c_int, [c_uint32] * 9 + [POINTER(c_uint32)]),
     "dga_bench_params_fill": (c_int, [c_uint32] * 3 + [POINTER(c_int32)]),

@@ -283,6 +283,35 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_masked(lhs, rhs, out: torch.Tensor, masked_m:
             torch.cuda.current_stream(out.device).synchronize()
 
 
+def catlass_dynamic_matmul(self_: torch.Tensor, mat2: torch.Tensor, out: torch.Tensor, sync: bool = False) -> None:
+    """The aclnn operator CatlassDynamicMatmul in its own dtypes: out[M,N] = self[M,K] @ mat2[K,N], all fp16 or all bf16.
+    mat2 is the logical [K,N] matrix in column-major storage, i.e. the transposed view of a contiguous [N,K] tensor
+    (`b.t()`), the operator's only layout (catlass_dynamic_matmul_tiling.cpp:83-84)."""
+    _require(self_.dim() == 2 and mat2.dim() == 2 and out.dim() == 2, "rank must be 2")
+    m, k = self_.shape
+    k2, n = mat2.shape
+    _require(k == k2, "self dimk is not equal with mat2 dimk")
+    _require(self_.dtype in (torch.float16, torch.bfloat16) and mat2.dtype == self_.dtype and out.dtype == self_.dtype,
+             "self, mat2 and out must share one 16-bit dtype")
+    _require(tuple(out.shape) == (m, n) and out.is_contiguous() and self_.is_contiguous(), "self / out must be contiguous")
+    _require(n == 0 or k == 0 or (mat2.stride(0) == 1 and mat2.stride(1) == k) or (k == 1 and mat2.stride(1) == 1) or
+             (n == 1 and mat2.stride(0) == 1), "mat2 must be the transposed view of a contiguous [N,K] tensor (NT)")
+    dt = _lib.DT_BF16 if self_.dtype == torch.bfloat16 else _lib.DT_FP16
+    with _device_guard(self_, mat2, out):
+        need = _lib.lib().dga_catlass_dynamic_matmul_workspace_bytes(m, n, k, self_.data_ptr(), mat2.data_ptr())
+        key = ("op16", out.device.index)
+        ws = _WORKSPACES.get(key)
+        if need and (ws is None or ws.numel() < need):
+            ws = torch.empty((need,), dtype=torch.uint8, device=out.device)
+            _WORKSPACES[key] = ws
+        rc = _lib.lib().dga_catlass_dynamic_matmul(self_.data_ptr(), mat2.data_ptr(), out.data_ptr(), m, n, k, dt,
+                                                   ws.data_ptr() if need else None, ws.numel() if need else 0,
+                                                   _stream_ptr(out))
+        _lib.check(rc, "catlass_dynamic_matmul")
+        if sync:
+            torch.cuda.current_stream(out.device).synchronize()
+
+
 def get_m_alignment_for_contiguous_layout() -> int:
     """Row alignment of the group segments in the contiguous-grouped layout (upstream DeepGEMM's name)."""
     return _lib.CONTIGUOUS_M_ALIGNMENT

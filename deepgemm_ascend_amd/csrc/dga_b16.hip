@@ -150,10 +150,10 @@ static size_t b16_workspace_bytes(int batch, int m, int n, int k, const void *x)
     return bytes + 256;
 }
 
-template <class Cfg, bool BF16, int PP = 0, bool NN = false>
+template <class Cfg, bool BF16, int PP = 0, bool NN = false, bool OUT16 = false>
 static int launch_tiled(const B16Params &p, int batch, hipStream_t stream)
 {
-    auto kfn = gemm_b16_nt_f32_kernel<Cfg, BF16, PP, NN>;
+    auto kfn = gemm_b16_nt_f32_kernel<Cfg, BF16, PP, NN, OUT16>;
     constexpr int lds = 2 * (Cfg::A_BYTES + Cfg::B_BYTES);
     static std::once_flag once[64];
     static hipError_t attr_err[64];
@@ -264,9 +264,107 @@ static int launch_b16(const void *x, const void *y, float *z, int batch, int m, 
     return record_hip(hipGetLastError());
 }
 
+// ---- the aclnn operator in its own dtypes: out[M,N] (16-bit) = self[M,K] . mat2, mat2 stored [N,K] (NT) -----------------
+static size_t b16_nt_workspace_bytes(int m, int n, int k, const void *a, const void *b)
+{
+    if (m <= 0 || n <= 0 || k <= 0) return 0;
+    const size_t kp = (static_cast<size_t>(k) + 63) / 64 * 64;
+    const bool in_place = (k % 64 == 0) && (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0);
+    size_t bytes = 0;
+    if (!in_place) bytes += ((static_cast<size_t>(m) * kp * 2 + 255) & ~size_t(255)) + ((static_cast<size_t>(n) * kp * 2 + 255) & ~size_t(255));
+    const B16Plan pl = b16_plan(1, m, n, k);
+    if (pl.splitk > 1) bytes += (static_cast<size_t>(pl.splitk) * m * n * 4 + 255) & ~size_t(255);
+    return bytes ? bytes + 256 : 0;
+}
+
+static int launch_b16_nt(const void *a, const void *b, void *out, int m, int n, int k, int dtype, void *workspace,
+                         size_t workspace_bytes, hipStream_t stream)
+{
+    if (m < 0 || n < 0 || k < 0) return DGA_E_SHAPE;
+    if (dtype != DGA_DT_BF16 && dtype != DGA_DT_FP16) return DGA_E_DTYPE;
+    if (m == 0 || n == 0) return DGA_OK;
+    if (!out || ((!a || !b) && k != 0)) return DGA_E_NULL;
+    if (workspace && workspace_bytes < b16_nt_workspace_bytes(m, n, k, a, b)) return DGA_E_WORKSPACE;
+    const bool bf = dtype == DGA_DT_BF16;
+    const size_t kp = (static_cast<size_t>(k) + 63) / 64 * 64;
+    const bool in_place = (k % 64 == 0) && (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0);
+    if (k == 0 || (!in_place && !workspace) || kp * 257 * 2 >= 0x7FFFFFFFull) {
+        // nothing to pad into (or K = 0: zeros): element-wise kernel
+        dim3 grid((n + 15) / 16, (m + 15) / 16);
+        if (bf) hipLaunchKernelGGL(gemm_b16_nt_generic_kernel<true>, grid, dim3(256), 0, stream, static_cast<const uint16_t *>(a),
+                                   static_cast<const uint16_t *>(b), static_cast<uint16_t *>(out), m, n, k);
+        else hipLaunchKernelGGL(gemm_b16_nt_generic_kernel<false>, grid, dim3(256), 0, stream, static_cast<const uint16_t *>(a),
+                                static_cast<const uint16_t *>(b), static_cast<uint16_t *>(out), m, n, k);
+        return record_hip(hipGetLastError());
+    }
+    uint8_t *ws = static_cast<uint8_t *>(workspace);
+    size_t at = 0;
+    const uint16_t *as = static_cast<const uint16_t *>(a), *bs = static_cast<const uint16_t *>(b);
+    if (!in_place) {  // rows zero-padded to whole 128-byte k steps (the PaddingCommon variant's role)
+        uint16_t *ap = reinterpret_cast<uint16_t *>(ws);
+        at = (static_cast<size_t>(m) * kp * 2 + 255) & ~size_t(255);
+        uint16_t *bp = reinterpret_cast<uint16_t *>(ws + at);
+        at += (static_cast<size_t>(n) * kp * 2 + 255) & ~size_t(255);
+        hipLaunchKernelGGL(pad_rows_b16_kernel, dim3(static_cast<unsigned>((static_cast<int64_t>(m) * kp + 255) / 256)), dim3(256), 0,
+                           stream, as, ap, static_cast<int64_t>(m), k, static_cast<int>(kp));
+        hipLaunchKernelGGL(pad_rows_b16_kernel, dim3(static_cast<unsigned>((static_cast<int64_t>(n) * kp + 255) / 256)), dim3(256), 0,
+                           stream, bs, bp, static_cast<int64_t>(n), k, static_cast<int>(kp));
+        if (record_hip(hipGetLastError()) != DGA_OK) return DGA_E_HIP;
+        as = ap; bs = bp;
+    }
+    B16Params p{};
+    p.x = as; p.yt = bs; p.z = nullptr; p.z16 = static_cast<uint16_t *>(out);
+    p.m = m; p.n = n; p.k = static_cast<int>(kp);
+    p.ldx = in_place ? k : static_cast<int64_t>(kp);
+    p.ldy = p.ldx;
+    p.x_bs = static_cast<int64_t>(m) * p.ldx;
+    p.y_bs = static_cast<int64_t>(n) * p.ldy;
+    p.z_bs = static_cast<int64_t>(m) * n;
+    p.batch = 1;
+    B16Plan pl = b16_plan(1, m, n, k);
+    if (!workspace) { pl.splitk = 1; pl.ks_per_split = static_cast<int>(kp / 64); }
+    p.splitk = pl.splitk;
+    p.ks_per_split = pl.ks_per_split;
+    p.partial = pl.splitk > 1 ? reinterpret_cast<float *>(ws + at) : nullptr;
+    auto go = [&](auto cfg, auto pp) -> int {
+        using Cfg = decltype(cfg);
+        constexpr int PPv = decltype(pp)::value;
+        p.tiles_m = (m + Cfg::kBM - 1) / Cfg::kBM;
+        p.tiles_n = (n + Cfg::kBN - 1) / Cfg::kBN;
+        p.raster_group = p.tiles_m >= 8 ? 8 : (p.tiles_m >= 4 ? 4 : 1);
+        return bf ? launch_tiled<Cfg, true, PPv, false, true>(p, 1, stream) : launch_tiled<Cfg, false, PPv, false, true>(p, 1, stream);
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P2 = std::integral_constant<int, 2>;
+    int rc;
+    if (pl.bm == 256) rc = go(GemmCfg<256, 256, 4, 2>{}, P2{});
+    else if (pl.bm == 128) rc = go(GemmCfg<128, 128, 2, 2>{}, P0{});
+    else if (pl.bm == 64) rc = go(GemmCfg<64, 128, 1, 4>{}, P0{});
+    else if (pl.bm == 32) rc = go(GemmCfg<32, 128, 1, 4>{}, P0{});
+    else rc = go(GemmCfg<16, 128, 1, 4>{}, P0{});
+    if (rc != DGA_OK || pl.splitk <= 1) return rc;
+    const int64_t total = static_cast<int64_t>(m) * n;
+    if (bf) hipLaunchKernelGGL(splitk_reduce_16_kernel<true>, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, stream,
+                               p.partial, p.z16, total, pl.splitk);
+    else hipLaunchKernelGGL(splitk_reduce_16_kernel<false>, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, stream,
+                            p.partial, p.z16, total, pl.splitk);
+    return record_hip(hipGetLastError());
+}
+
 }  // namespace dga
 
 extern "C" {
+
+size_t dga_catlass_dynamic_matmul_workspace_bytes(int m, int n, int k, const void *self, const void *mat2)
+{
+    return dga::b16_nt_workspace_bytes(m, n, k, self, mat2);
+}
+
+int dga_catlass_dynamic_matmul(const void *self, const void *mat2, void *out, int m, int n, int k, int dtype,
+                               void *workspace, size_t workspace_bytes, void *stream)
+{
+    return dga::launch_b16_nt(self, mat2, out, m, n, k, dtype, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
 
 size_t dga_mmad_workspace_bytes(int batch, int m, int n, int k, const void *x)
 {

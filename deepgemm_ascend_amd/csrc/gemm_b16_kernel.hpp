@@ -30,6 +30,7 @@ struct B16Params {
     int splitk;          // > 1: the grid is splitk x batch x tiles (split-major); split s covers k steps [s*ks_per_split, +)
     int ks_per_split;    //      and writes its fp32 partial tile to slab s of `partial` ([splitk][batch][m][n])
     float *partial;
+    uint16_t *z16;       // OUT16 builds: the output in the inputs' 16-bit type ([batch][m][n]); z is unused then
 };
 
 template <bool BF16>
@@ -54,9 +55,13 @@ __device__ __forceinline__ v4f mfma_b16(v4i a, v4i b, v4f c)
 //             a 32-lane half touches then fall into 8 different 32-byte groups of one bank row (conflict-free).  The
 //             n index of MFMA row i is simply 16*nt + i here (the fp32 stores need no pairing of n-tiles).
 //             Requires K % 64 == 0, N % 8 == 0 and 16-byte aligned bases (the host falls back to NN = false otherwise).
-template <class Cfg, bool BF16, int PP = 0, bool NN = false>
+// OUT16 = true: the result is rounded (RNE) to the inputs' 16-bit type and stored with 16-byte rows segments (two
+//             n-tiles = 8 consecutive n per lane, as in the fp8 kernel) -- the dtype contract of the aclnn operator
+//             (catlass_dynamic_matmul.cpp:37-46: out dtype = input dtype).  NT (NN = false) only.
+template <class Cfg, bool BF16, int PP = 0, bool NN = false, bool OUT16 = false>
 __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Params p)
 {
+    static_assert(!(OUT16 && NN), "16-bit output is built for the NT operand layout");
     constexpr int BM = Cfg::kBM, BN = Cfg::kBN, WN = Cfg::kWN;
     constexpr int NT = Cfg::NT, TM = Cfg::TM, TN = Cfg::TN, DNT = Cfg::DNT;
     constexpr int STAGE = Cfg::A_BYTES + Cfg::B_BYTES;  // no scale slots
@@ -259,6 +264,43 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
     // epilogue: lane owns row m, 4 consecutive n per 16x16 tile (same n permutation as the fp8 kernel)
     const int m_row = m0 + wm * (BM / Cfg::kWM) + li;
     const int n_base = n0 + wn * (BN / WN) + (NN ? 4 : 8) * kg;
+    if (OUT16 && p.splitk <= 1) {
+        uint16_t *Z16 = p.z16 + (int64_t)bi * p.z_bs;
+        const bool v16_ok = ((p.n & 7) == 0) && ((((uintptr_t)Z16) & 15) == 0);
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            const int m = m_row + mt * 16;
+            if (m >= p.m) continue;
+            uint16_t *zr = Z16 + (int64_t)m * p.n;
+#pragma unroll
+            for (int j = 0; j < TN / 2; ++j) {
+                const int n = n_base + 32 * j;
+                const v4f lo = acc[mt][2 * j], hi = acc[mt][2 * j + 1];
+                v4i pk;
+                if constexpr (BF16) {
+                    pk = v4i{__builtin_bit_cast(int, __builtin_convertvector(v2f{lo.x, lo.y}, v2bf)),
+                             __builtin_bit_cast(int, __builtin_convertvector(v2f{lo.z, lo.w}, v2bf)),
+                             __builtin_bit_cast(int, __builtin_convertvector(v2f{hi.x, hi.y}, v2bf)),
+                             __builtin_bit_cast(int, __builtin_convertvector(v2f{hi.z, hi.w}, v2bf))};
+                } else {
+                    typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+                    pk = v4i{__builtin_bit_cast(int, v2h{(_Float16)lo.x, (_Float16)lo.y}),
+                             __builtin_bit_cast(int, v2h{(_Float16)lo.z, (_Float16)lo.w}),
+                             __builtin_bit_cast(int, v2h{(_Float16)hi.x, (_Float16)hi.y}),
+                             __builtin_bit_cast(int, v2h{(_Float16)hi.z, (_Float16)hi.w})};
+                }
+                if (v16_ok && n + 8 <= p.n) {
+                    *(v4i *)(zr + n) = pk;
+                } else {
+                    const uint16_t *e = (const uint16_t *)&pk;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (n + q < p.n) zr[n + q] = e[q];
+                }
+            }
+        }
+        return;
+    }
     const bool v_ok = ((p.n & 3) == 0) && ((((uintptr_t)Z) & 15) == 0);
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
@@ -338,6 +380,46 @@ __global__ void __launch_bounds__(256) splitk_reduce_f32_kernel(const float *par
             for (int s = 1; s < splitk; ++s) a += partial[(int64_t)s * total + i + q];
             z[i + q] = a;
         }
+    }
+}
+
+// split-K combine with 16-bit output (the operator's dtype contract): out = round16( sum_s slab[s] ), s ascending
+template <bool BF16>
+__global__ void __launch_bounds__(256) splitk_reduce_16_kernel(const float *partial, uint16_t *z, int64_t total, int splitk)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    float a = partial[i];
+    for (int s = 1; s < splitk; ++s) a += partial[(int64_t)s * total + i];
+    if constexpr (BF16) {
+        const v2bf h = __builtin_convertvector(v2f{a, 0.f}, v2bf);
+        z[i] = (uint16_t)(__builtin_bit_cast(uint32_t, h) & 0xFFFFu);
+    } else {
+        z[i] = __builtin_bit_cast(uint16_t, (_Float16)a);
+    }
+}
+
+// element-wise 16-bit NT GEMM (any K, any alignment; fp32 running sum in k order): the route of last resort of the
+// operator entry when there is no workspace to pad into
+template <bool BF16>
+__global__ void __launch_bounds__(256) gemm_b16_nt_generic_kernel(const uint16_t *a, const uint16_t *b, uint16_t *out, int m,
+                                                                  int n, int k)
+{
+    const int col = blockIdx.x * 16 + (threadIdx.x & 15), row = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (row >= m || col >= n) return;
+    const uint16_t *ar = a + (int64_t)row * k, *br = b + (int64_t)col * k;
+    float acc = 0.f;
+    for (int i = 0; i < k; ++i) {
+        float x, y;
+        if constexpr (BF16) { x = __uint_as_float((uint32_t)ar[i] << 16); y = __uint_as_float((uint32_t)br[i] << 16); }
+        else { x = (float)__builtin_bit_cast(_Float16, ar[i]); y = (float)__builtin_bit_cast(_Float16, br[i]); }
+        acc = __builtin_fmaf(x, y, acc);
+    }
+    if constexpr (BF16) {
+        const v2bf h = __builtin_convertvector(v2f{acc, 0.f}, v2bf);
+        out[(int64_t)row * n + col] = (uint16_t)(__builtin_bit_cast(uint32_t, h) & 0xFFFFu);
+    } else {
+        out[(int64_t)row * n + col] = __builtin_bit_cast(uint16_t, (_Float16)acc);
     }
 }
 

@@ -170,6 +170,16 @@ int dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked(const void *a, const float *sfa, c
                                               int k, int expected_m, const dga_tiling_t *tiling, void *workspace,
                                               size_t workspace_bytes, void *stream);
 
+/* The aclnn operator in its own dtypes (CatlassDynamicMatmul, op_host/catlass_dynamic_matmul.cpp:50-80; device entry
+ * op_kernel/catlass_dynamic_matmul.cpp:16-45): out[M,N] = self[M,K] . mat2, self row-major, mat2 logical [K,N] stored
+ * column-major = physical [N,K] (NT, catlass_dynamic_matmul_tiling.cpp:83-84), all three of `dtype` (DGA_DT_FP16 or
+ * DGA_DT_BF16; fp32 accumulate, one RNE rounding at the end).  workspace: dga_catlass_dynamic_matmul_workspace_bytes()
+ * (padded operand copies when K % 64 != 0 or a base is not 16-byte aligned; split-K slabs for small M); NULL is legal
+ * (single pass, element-wise kernel for unaligned shapes). */
+size_t dga_catlass_dynamic_matmul_workspace_bytes(int m, int n, int k, const void *self, const void *mat2);
+int dga_catlass_dynamic_matmul(const void *self, const void *mat2, void *out, int m, int n, int k, int dtype,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
 /* m_grouped_gemm_fp8_fp8_bf16_nt_contiguous: the prefill-side MoE layout.
  *   a [m_sum,K], sfa [m_sum,KB], b [G,N,K], sfb [G,NB,KB], out [m_sum,N], m_indices device int32[m_sum].
  * Row r is multiplied with b[m_indices[r]]; rows with m_indices[r] < 0 are padding and are not written.

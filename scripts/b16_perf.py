@@ -15,3 +15,14 @@ for (m, n, k) in [(4096, 4096, 4096), (8192, 8192, 8192), (1024, 4096, 7168), (1
     ref = (x[0].float() @ y[0].float())
     err = ((z[0] - ref).abs().max() / ref.abs().max()).item()
     print(f"run_mmad_rtc bf16 {m}x{n}x{k}: {us:.1f} us (incl. transpose + sync)  {2*m*n*k/us/1e6:.0f} TFLOP/s  rel err {err:.2e}", flush=True)
+for (m, n, k) in [(4096, 4096, 4096), (8192, 8192, 8192), (4096, 2048, 7168), (128, 4096, 7168)]:
+    a = torch.randn((m, k), device="cuda").to(torch.bfloat16); b = torch.randn((n, k), device="cuda").to(torch.bfloat16)
+    out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    for _ in range(5): dga.catlass_dynamic_matmul(a, b.t(), out)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): dga.catlass_dynamic_matmul(a, b.t(), out)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 50
+    print(f"catlass_dynamic_matmul bf16 NT {m}x{n}x{k}: {us:.1f} us  {2*m*n*k/us/1e6:.0f} TFLOP/s", flush=True)
