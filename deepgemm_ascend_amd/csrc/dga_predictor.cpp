@@ -13,6 +13,7 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <fstream>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -38,7 +39,7 @@ struct Model {
 struct Cand { int m1, n1, stages, splitk, policy; };
 
 static std::mutex g_mu;
-static Model g_model;
+static std::shared_ptr<const Model> g_model;  // replaced as a whole: a reader keeps the instance it started with
 static bool g_tried_default = false;
 
 static bool parse(const std::string &path, Model &m)
@@ -87,18 +88,18 @@ static std::string default_path()
 }
 
 // the model in use; loads tuned/predictor_mi355x.txt next to the library on first use unless $DGA_NO_PREDICTOR is set
-static const Model *model()
+static std::shared_ptr<const Model> model()
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_model.ok && !g_tried_default) {
+    if (!g_model && !g_tried_default) {
         g_tried_default = true;
         const char *off = std::getenv("DGA_NO_PREDICTOR");
         if (!(off && *off && *off != '0')) {
-            Model m;
-            if (parse(default_path(), m)) g_model = std::move(m);
+            auto m = std::make_shared<Model>();
+            if (parse(default_path(), *m)) g_model = std::move(m);
         }
     }
-    return g_model.ok ? &g_model : nullptr;
+    return g_model;
 }
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
@@ -206,9 +207,9 @@ extern "C" {
 
 int dga_predictor_load(const char *path)
 {
-    Model m;
+    auto m = std::make_shared<Model>();
     const std::string p = (path && *path) ? std::string(path) : default_path();
-    if (!parse(p, m)) return DGA_E_IO;
+    if (!parse(p, *m)) return DGA_E_IO;
     std::lock_guard<std::mutex> lk(g_mu);
     g_model = std::move(m);
     g_tried_default = true;
@@ -218,7 +219,7 @@ int dga_predictor_load(const char *path)
 void dga_predictor_unload(void)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    g_model = Model{};
+    g_model.reset();
     g_tried_default = true;  // stay unloaded until dga_predictor_load()
 }
 
@@ -227,7 +228,7 @@ int dga_predictor_loaded(void) { return model() != nullptr; }
 int dga_predict_time_us(const dga_problem_t *problem, const dga_tiling_t *tiling, float *us)
 {
     if (!problem || !tiling || !us) return DGA_E_NULL;
-    const Model *mo = model();
+    const std::shared_ptr<const Model> mo = model();
     if (!mo) return DGA_E_IO;
     if (!tiling->m1 || !tiling->n1 || !problem->m || !problem->n || !problem->k) return DGA_E_SHAPE;
     const Cand c{tiling->m1, tiling->n1, tiling->stages == 3 ? 3 : 2, std::max<int>(1, tiling->splitkFactor), tiling->dispatchPolicyTag};
@@ -246,7 +247,7 @@ int dga_select_kernel_with_predictor(const dga_problem_t *problem, dga_tiling_t 
     if (rc != DGA_OK) return rc;
     if (predicted_us) *predicted_us = 0.f;
     if (native_us) *native_us = 0.f;
-    const Model *mo = model();
+    const std::shared_ptr<const Model> mo = model();
     if (!mo || !eligible(*problem) || out->blockDim == 0) return DGA_OK;
     if (out->kernelSerial == DGA_KERNEL_STREAMK_TAIL) return DGA_OK;  // outside the candidate space the model was trained on
     float f[kFeatures];
