@@ -457,8 +457,8 @@ public:
         std::lock_guard<std::mutex> lk(mu_);
         return static_cast<int>(data_.size());
     }
-    bool last_hit_had_cdna4_columns() const { return has_cdna4_; }
-    bool get(dga_tiling_t &t)
+    // *swept = the entry carries the CDNA4 columns of a sweep (complete as it stands)
+    bool get(dga_tiling_t &t, bool *swept)
     {
         std::lock_guard<std::mutex> lk(mu_);
         auto it = data_.find(std::make_tuple(t.m, t.n, t.k, t.groups));
@@ -470,7 +470,7 @@ public:
         t.stages = static_cast<uint8_t>(e.stages); t.wavesM = static_cast<uint8_t>(e.waves_m);
         t.wavesN = static_cast<uint8_t>(e.waves_n); t.dispatchPolicyTag = static_cast<uint8_t>(e.policy);
         if (e.raster) t.swizzleOffset = static_cast<uint8_t>(e.raster);
-        has_cdna4_ = e.stages != 0;
+        *swept = e.stages != 0;
         return true;
     }
     void put(const dga_tiling_t &t)
@@ -530,7 +530,6 @@ private:
         return out;
     }
     std::mutex mu_;
-    bool has_cdna4_ = false;
     std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, Entry> data_;
     std::string path_;
 };
@@ -644,8 +643,9 @@ int dga_tiling(const dga_problem_t *problem, dga_tiling_t *out)
     if (!problem || !out) return DGA_E_NULL;
     init_params(*problem, *out);
     if (out->contiguous) return dga_select_kernel(problem, nullptr, out);  // the (m,n,k) cache holds dense tilings
-    if (Cache::instance().get(*out)) {
-        if (Cache::instance().last_hit_had_cdna4_columns()) {  // a swept entry is complete: use it as it stands
+    bool swept = false;
+    if (Cache::instance().get(*out, &swept)) {
+        if (swept) {  // a swept entry is complete: use it as it stands
             complete_from_menu(*out);
             return DGA_OK;
         }
