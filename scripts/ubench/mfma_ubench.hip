@@ -124,7 +124,8 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int mode = 0; mode < 5; ++mode)
         for (int threads : {256, 512}) {
-            for (int rep = 0; rep < 3; ++rep) {
+            const int reps = argc > 2 ? atoi(argv[2]) : 3;   // argv[2]: launches per mode; the LAST one is reported (300+ = sustained clocks)
+            for (int rep = 0; rep < reps; ++rep) {
                 hipEventRecord(e0);
                 if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(threads), 0, 0, seed, out, iters);
                 else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(threads), 0, 0, seed, out, iters);
@@ -134,7 +135,7 @@ int main(int argc, char **argv)
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 double flops = 2.0 * 16 * 16 * 128 * 16.0 * iters * (threads / 64) * 256;
-                if (rep == 2) printf("mode %d (%s) waves/SIMD %d: %.3f ms  %.0f TFLOP/s\n", mode, mode == 1 ? "MFMA+4FMA lag3" : mode == 2 ? "32x32x64 MFMA only" : mode == 3 ? "MFMA+2 pk_fma lag3" : mode == 4 ? "32x32x64 x2 + 16 FMA" : "MFMA only", threads / 256, ms, flops / ms / 1e9);
+                if (rep == reps - 1) printf("mode %d (%s) waves/SIMD %d: %.3f ms  %.0f TFLOP/s\n", mode, mode == 1 ? "MFMA+4FMA lag3" : mode == 2 ? "32x32x64 MFMA only" : mode == 3 ? "MFMA+2 pk_fma lag3" : mode == 4 ? "32x32x64 x2 + 16 FMA" : "MFMA only", threads / 256, ms, flops / ms / 1e9);
             }
         }
     return 0;
