@@ -58,6 +58,10 @@ def load_records(dirs):
                 r = json.loads(line)
                 if r["negative"] or r["time"] <= 0 or r["time"] > 1e8:
                     continue
+                # outside the model's candidate space: the quarter-tile tail is a post-pass on the model's pick
+                # (apply_tail_split), K % 16 != 0 goes through the padding pass
+                if r["parameters"].get("tail") or r["K"] % 16:
+                    continue
                 rows.append(r)
     return rows
 

@@ -58,17 +58,25 @@ def test_pick_is_native_or_a_candidate_with_the_promised_gain(predictor):
         t, pred_us, native_us = predictor.select_kernel_with_predictor(m, n, k)
         key = lambda x: (x.m1, x.n1, x.stages, x.splitkFactor, x.dispatchPolicyTag)
         if key(t) == key(native):
-            assert pred_us == pytest.approx(native_us)
+            # either a fallback (same time) or a pick that differed from the native tiling only in the 256x256 schedule
+            assert pred_us <= native_us * (1 + 1e-5)
             continue
         changed += 1
         cands = {(p["m1"], p["n1"], p["stages"], p["splitk"], p["policy"]) for p in sweep.candidates(m, n, k, [0])}
         kb = -(-k // 128)
-        assert any(c[:3] == key(t)[:3] and c[4] == key(t)[4] and -(-kb // -(-kb // c[3])) == t.splitkFactor for c in cands), key(t)
+        # (the 256x256 tile always runs the continuous schedule, whatever schedule the model's pick carried)
+        assert any(c[:3] == key(t)[:3] and (c[4] == key(t)[4] or key(t)[:2] == (256, 256)) and
+                   -(-kb // -(-kb // c[3])) == t.splitkFactor for c in cands), key(t)
         assert len(cands) >= 4
         assert pred_us <= 0.97 * native_us * (1 + 1e-5)
-        assert t.blockDim == -(-m // t.m1) * -(-n // t.n1) * t.splitkFactor
-        assert t.kernelSerial == (4 if t.splitkFactor > 1 else t.kernelSerial)
-        assert predictor.predict_time_us(m, n, k, t) == pytest.approx(pred_us, rel=1e-4) or t.splitkFactor > 1
+        tiles = -(-m // t.m1) * -(-n // t.n1)
+        if t.kernelSerial == 5:
+            assert t.blockDim == tiles - tiles % 256 + 4 * (tiles % 256)
+        else:
+            assert t.blockDim == tiles * t.splitkFactor
+        assert (t.kernelSerial == 4) == (t.splitkFactor > 1)
+        if (t.m1, t.n1) == (256, 256):
+            assert t.dispatchPolicyTag == 2 or t.splitkFactor > 1
     assert changed > 0, "the predictor never departed from the heuristic on 48 shapes"
 
 
