@@ -10,6 +10,7 @@ int record_hip(hipError_t e);
 // compiled fp8 kernel menu (dga_launch.hip)
 int variant_count();
 void variant_info(int i, int *bm, int *bn, int *wm, int *wn, int *lds);
+int variant_stages(int i);
 // dense 256x256 tilings: turn a small last partial wave into a K-split tail (dga_tiling.cpp)
 void apply_tail_split(dga_tiling_t &t, uint32_t cus);
 }  // namespace dga

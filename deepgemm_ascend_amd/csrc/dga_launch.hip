@@ -84,15 +84,20 @@ static const Variant kVariants[] = {
     DGA_VARIANT_C(128, 128, 2, 2), DGA_VARIANT_C(64, 256, 1, 4),  DGA_VARIANT(64, 128, 1, 4),
     DGA_VARIANT_C(128, 256, 2, 4),  // 8 waves on a 128x256 tile: two waves per SIMD cover each other's DMA stalls
     // three LDS stages (two refills in flight) for the HBM-bound grouped / small-M shapes
+    // (8 waves first: a tiling that names no wave layout -- a swept CSV row, the predictor -- gets this build; the selector
+    //  names 2x2 explicitly for the masked grouped stream)
+    Variant{128, 256, 2, 4, &launch_cfg<GemmCfg<128, 256, 2, 4, 3>, 0>, GemmCfg<128, 256, 2, 4, 3>::LDS_BYTES, nullptr, nullptr, 3},
     Variant{128, 256, 2, 2, &launch_cfg<GemmCfg<128, 256, 2, 2, 3>, 0>, GemmCfg<128, 256, 2, 2, 3>::LDS_BYTES, nullptr, nullptr, 3},
     Variant{128, 128, 2, 2, &launch_cfg<GemmCfg<128, 128, 2, 2, 3>, 0>, GemmCfg<128, 128, 2, 2, 3>::LDS_BYTES, nullptr, nullptr, 3},
     Variant{64, 256, 1, 4, &launch_cfg<GemmCfg<64, 256, 1, 4, 3>, 0>, GemmCfg<64, 256, 1, 4, 3>::LDS_BYTES, nullptr, nullptr, 3},
+
     DGA_VARIANT(32, 256, 1, 4),  DGA_VARIANT(32, 128, 1, 4),  DGA_VARIANT(16, 256, 1, 4),
     DGA_VARIANT(16, 128, 1, 4),
 };
 static constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int variant_count() { return kNumVariants; }
+int variant_stages(int i) { return kVariants[i].stages; }
 void variant_info(int i, int *bm, int *bn, int *wm, int *wn, int *lds)
 {
     *bm = kVariants[i].bm; *bn = kVariants[i].bn; *wm = kVariants[i].wm; *wn = kVariants[i].wn;

@@ -358,6 +358,10 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
     if ((pick.bm == 128 && pick.bn == 256 && pick.wm == 2 && pick.wn == 2) || (pick.bm == 128 && pick.bn == 128) ||
         (pick.bm == 64 && pick.bn == 256))
         t.stages = 3;
+    // 128x256 with three stages has two builds: 4 waves (2x2) and 8 waves (2x4, two per SIMD).  The masked grouped
+    // stream (HBM-bound) is 3 % faster on 4 waves, everything compute-bound 3-14 % faster on 8 (4096x2048x7168: 66.8 ->
+    // 61.8 us; scripts/steady_ab.py, scripts/contig_ab.py).
+    if (pick.bm == 128 && pick.bn == 256 && t.stages == 3 && groups == 1) { t.wavesM = 2; t.wavesN = 4; }
     const uint32_t tiles_m = ceil_div(t.m, t.m1), tiles_n = ceil_div(t.n, t.n1);
     const uint64_t blocks = static_cast<uint64_t>(groups) * tiles_m * tiles_n;
     t.blockDim = static_cast<uint32_t>(blocks) * ((contiguous && t.m1 > DGA_CONTIGUOUS_M_ALIGNMENT) ? 2 : 1);
@@ -554,11 +558,15 @@ int init_params(const dga_problem_t &p, dga_tiling_t &t)
 // fill the CDNA4-only fields of a tiling that came from the cache / CSV (which stores m1,n1 only)
 void complete_from_menu(dga_tiling_t &t)
 {
-    for (const MenuEntry &e : menu())
-        if (e.bm == t.m1 && e.bn == t.n1) {
-            if (!t.wavesM) { t.wavesM = e.wm; t.wavesN = e.wn; }
-            if (!t.stages) t.stages = 2;
-            t.ldsBytes = e.lds;
+    if (!t.stages) t.stages = 2;
+    // first build of that tile size with that stage count (the launcher's own preference order), else any build of it
+    for (int pass = 0; pass < 2; ++pass)
+        for (int i = 0; i < variant_count(); ++i) {
+            int bm, bn, wm, wn, lds;
+            variant_info(i, &bm, &bn, &wm, &wn, &lds);
+            if (bm != t.m1 || bn != t.n1 || (pass == 0 && variant_stages(i) != (t.stages == 3 ? 3 : 2))) continue;
+            if (!t.wavesM) { t.wavesM = static_cast<uint8_t>(wm); t.wavesN = static_cast<uint8_t>(wn); }
+            t.ldsBytes = static_cast<uint32_t>(lds);
             return;
         }
 }

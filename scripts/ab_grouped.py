@@ -18,7 +18,7 @@ for mask_name, masked in {"full": torch.full((G,), MMAX, dtype=torch.int32, devi
     alg = active * N * K + rows * (K + 4 * (K // 128) + 2 * N)
     variants = {}
     for name, (tile, waves, pp, st) in {"128x256 4w": ((128, 256), (2, 2), 0, 2), "128x256 4w 3st": ((128, 256), (2, 2), 0, 3),
-                                    "128x256 8w": ((128, 256), (2, 4), 0, 2),
+                                    "128x256 8w": ((128, 256), (2, 4), 0, 2), "128x256 8w 3st": ((128, 256), (2, 4), 0, 3),
                                     "128x128 4w": ((128, 128), (2, 2), 0, 2), "128x128 4w 3st": ((128, 128), (2, 2), 0, 3),
                                     "64x256 4w 3st": ((64, 256), (1, 4), 0, 3)}.items():
         t = dga.tiling(MMAX, N, K, groups=G, expected_m=MMAX)

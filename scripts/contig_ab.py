@@ -18,9 +18,9 @@ for groups, per, n, k in ((8, 1024, 4096, 7168), (8, 1024, 7168, 2048), (16, 512
         idx[i, :per] = i
     idx = idx.reshape(-1).contiguous()
     outs = {}
-    for name, (bm, bn, st, pol) in {"128x256": (128, 256, 3, 0), "256x256": (256, 256, 2, 2)}.items():
+    for name, (bm, bn, st, pol, wm, wn) in {"128x256": (128, 256, 3, 0, 2, 2), "128x256 8w": (128, 256, 3, 0, 2, 4), "256x256": (256, 256, 2, 2, 0, 0)}.items():
         t = dga.tiling(msum, n, k, groups=groups, contiguous=True)
-        t.m1, t.n1, t.stages, t.dispatchPolicyTag, t.wavesM, t.wavesN = bm, bn, st, pol, 0, 0
+        t.m1, t.n1, t.stages, t.dispatchPolicyTag, t.wavesM, t.wavesN = bm, bn, st, pol, wm, wn
         out = torch.zeros((msum, n), dtype=torch.bfloat16, device="cuda")
         fn = lambda: dga.m_grouped_gemm_fp8_fp8_bf16_nt_contiguous((a, sfa), (b, sfb), out, idx, tiling_=t)
         timeit(fn, iters=10, warm=5)

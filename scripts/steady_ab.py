@@ -28,7 +28,7 @@ for (m, n, k) in shapes:
     out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
     for name, (bm, bn, wm, wn, st, pol) in {"256x256 plain": (256, 256, 4, 2, 2, 0), "256x256 ping-pong": (256, 256, 4, 2, 2, 1),
                                              "256x256 continuous": (256, 256, 4, 2, 2, 2), "128x256 st3": (128, 256, 2, 2, 3, 0),
-                                             "128x256 st2": (128, 256, 2, 2, 2, 0), "128x256 8 waves": (128, 256, 2, 4, 2, 0),
+                                             "128x256 st2": (128, 256, 2, 2, 2, 0), "128x256 8 waves": (128, 256, 2, 4, 2, 0), "128x256 8 waves st3": (128, 256, 2, 4, 3, 0), "128x256 cont": (128, 256, 2, 2, 2, 2), "128x256 8 waves cont": (128, 256, 2, 4, 2, 2),
                                              "256x128": (256, 128, 4, 1, 2, 0), "128x128 st3": (128, 128, 2, 2, 3, 0)}.items():
         t = dga.tiling(m, n, k)
         t.m1, t.n1, t.wavesM, t.wavesN, t.stages, t.dispatchPolicyTag, t.kernelSerial, t.splitkFactor = bm, bn, wm, wn, st, pol, 0, 1
