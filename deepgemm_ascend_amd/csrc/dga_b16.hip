@@ -124,6 +124,7 @@ static B16Plan b16_plan(int batch, int m, int n, int k)
     auto tiles_of = [&](int bm, int bn) { return static_cast<int64_t>(batch) * ((m + bm - 1) / bm) * ((n + bn - 1) / bn); };
     B16Plan pl{128, 128, 1, ks_n};
     if (tiles_of(256, 256) >= 192) { pl.bm = 256; pl.bn = 256; return pl; }
+    if (tiles_of(128, 256) >= 192) { pl.bm = 128; pl.bn = 256; return pl; }   // 8 waves, three LDS stages
     if (tiles_of(128, 128) < 192 && m <= 64) pl.bm = m > 32 ? 64 : (m > 16 ? 32 : 16);
     const int64_t tiles = tiles_of(pl.bm, pl.bn);
     if (tiles * 4 <= 256 * 3 && ks_n >= 16) {
@@ -154,7 +155,7 @@ template <class Cfg, bool BF16, int PP = 0, bool NN = false, bool OUT16 = false>
 static int launch_tiled(const B16Params &p, int batch, hipStream_t stream)
 {
     auto kfn = gemm_b16_nt_f32_kernel<Cfg, BF16, PP, NN, OUT16>;
-    constexpr int lds = 2 * (Cfg::A_BYTES + Cfg::B_BYTES);
+    constexpr int lds = (PP == 2 ? 2 : Cfg::STAGES) * (Cfg::A_BYTES + Cfg::B_BYTES);
     static std::once_flag once[64];
     static hipError_t attr_err[64];
     int dev = 0;
@@ -237,7 +238,9 @@ static int launch_b16(const void *x, const void *y, float *z, int batch, int m, 
         using P2 = std::integral_constant<int, 2>;
         int rc;
         if (pl.bm == 256) rc = plain ? go(GemmCfg<256, 256, 4, 2>{}, P0{}) : go(GemmCfg<256, 256, 4, 2>{}, P2{});
-        else if (pl.bm == 128) rc = go(GemmCfg<128, 128, 2, 2>{}, P0{});
+        else if (pl.bm == 128 && pl.bn == 256) rc = go(GemmCfg<128, 256, 2, 4, 3>{}, P0{});
+        else if (pl.bm == 128 && pl.bn == 256) rc = go(GemmCfg<128, 256, 2, 4, 3>{}, P0{});
+    else if (pl.bm == 128) rc = go(GemmCfg<128, 128, 2, 2>{}, P0{});
         else if (pl.bm == 64) rc = go(GemmCfg<64, 128, 1, 4>{}, P0{});
         else if (pl.bm == 32) rc = go(GemmCfg<32, 128, 1, 4>{}, P0{});
         else rc = go(GemmCfg<16, 128, 1, 4>{}, P0{});
@@ -338,6 +341,7 @@ static int launch_b16_nt(const void *a, const void *b, void *out, int m, int n, 
     using P2 = std::integral_constant<int, 2>;
     int rc;
     if (pl.bm == 256) rc = go(GemmCfg<256, 256, 4, 2>{}, P2{});
+    else if (pl.bm == 128 && pl.bn == 256) rc = go(GemmCfg<128, 256, 2, 4, 3>{}, P0{});
     else if (pl.bm == 128) rc = go(GemmCfg<128, 128, 2, 2>{}, P0{});
     else if (pl.bm == 64) rc = go(GemmCfg<64, 128, 1, 4>{}, P0{});
     else if (pl.bm == 32) rc = go(GemmCfg<32, 128, 1, 4>{}, P0{});

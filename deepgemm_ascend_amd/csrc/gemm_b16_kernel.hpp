@@ -222,11 +222,15 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
     } else {
     const int ks_begin = p.splitk > 1 ? split * p.ks_per_split : 0;
     const int ks_end = p.splitk > 1 ? min(KS, ks_begin + p.ks_per_split) : KS;
+    // STG LDS stages (Cfg::STAGES; 3 for the 128x256 8-wave build: two refills in flight)
+    constexpr int STG = Cfg::STAGES;
 #pragma unroll
-    for (int idx = 0; idx < NL; ++idx) issue_one(idx, 0, ks_begin);
+    for (int d = 0; d < STG - 1; ++d)
+#pragma unroll
+        for (int idx = 0; idx < NL; ++idx) issue_one(idx, d, ks_begin + d);
+    int stage = 0, fill = STG - 1;
     for (int ks = ks_begin; ks < ks_end; ++ks) {
-        const int stage = (ks - ks_begin) & 1;
-        wait_vmcnt<0>();
+        wait_vmcnt<(STG - 2) * NL>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const uint8_t *st = smem + stage * STAGE;
@@ -248,7 +252,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
             if (nt < ISSUE_NT) {
 #pragma unroll
                 for (int idx = (nt * NL) / ISSUE_NT; idx < ((nt + 1) * NL) / ISSUE_NT; ++idx)
-                    issue_one(idx, stage ^ 1, ks + 1);  // past the last k step: reads the tile's following bytes, unused
+                    issue_one(idx, fill, ks + STG - 1);  // past the last k step: reads the tile's following bytes, unused
             }
             if (nt + 1 < TN) {
                 bf[(nt + 1) & 1][0] = load_b(st, nt + 1, 0);
@@ -257,6 +261,8 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) acc[mt][nt] = mfma_b16<BF16>(bf[nt & 1][1], af[mt][1], acc[mt][nt]);
         }
+        stage = stage + 1 == STG ? 0 : stage + 1;
+        fill = fill + 1 == STG ? 0 : fill + 1;
     }
     wait_vmcnt<0>();
     }

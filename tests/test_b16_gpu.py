@@ -52,7 +52,7 @@ def test_run_mmad_custom_is_a_noop(dga):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("batch,m,n,k", [(1, 1024, 1024, 1024), (2, 300, 520, 200), (1, 4096, 512, 136), (3, 64, 64, 64),
                                           (1, 8, 1024, 4096), (1, 40, 640, 2048), (2, 20, 384, 1100), (1, 128, 512, 8192),
-                                          (1, 2048, 2048, 512)])   # short tiles + split-K, 256x256 continuous schedule
+                                          (1, 2048, 2048, 512), (1, 4096, 2048, 192), (1, 4000, 2000, 200)])   # short tiles + split-K, 256x256 continuous, 128x256 3-stage
 def test_tiled_16bit_path(dga, oracle, dtype, batch, m, n, k):
     """The workspace (tiled MFMA) path of run_mmad_rtc: transposing pre-pass + LDS-DMA kernel, all tails."""
     rng = np.random.default_rng(m + n + k)

@@ -19,6 +19,7 @@ def _case(dtype, m, n, k, seed):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("m,n,k", [(128, 128, 128), (1024, 1024, 1024), (2048, 2048, 512),   # in place, 128^2 / 256^2 tiles
+                                   (4096, 2048, 192), (4000, 2000, 72),                        # 128x256, 8 waves, three stages
                                    (300, 520, 200), (257, 129, 100),                          # padded copies, ragged edges
                                    (8, 1024, 4096), (40, 640, 2048), (128, 512, 8192),        # short tiles + split-K
                                    (1, 16, 64), (5, 7, 3)])
