@@ -12,6 +12,7 @@ from .api import (  # noqa: F401
     bench_params_fill,
     catlass_dynamic_matmul,
     copy_rows,
+    copy_rows2,
     gemm_fp8_fp8_bf16_nt,
     get_bench_config,
     get_best_config,

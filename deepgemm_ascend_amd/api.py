@@ -408,6 +408,23 @@ def copy_rows(dst: torch.Tensor, src: torch.Tensor, dst_index: Optional[torch.Te
         _lib.check(rc, "copy_rows")
 
 
+def copy_rows2(dst0, src0, bytes0, dst1, src1, bytes1, dst_index=None, src_index=None, rows=None,
+               dst0_off=0, src0_off=0, dst1_off=0, src1_off=0) -> None:
+    """Two indexed row copies with shared indices in one launch (dga_copy_rows2); tensors are 2-D row tensors viewed as
+    bytes, *_off are byte offsets inside a row."""
+    for t in (dst0, src0, dst1, src1):
+        _require(t.dim() == 2 and t.stride(1) == 1, "2-D row tensors")
+    n = rows if rows is not None else (dst_index.numel() if dst_index is not None else
+                                       src_index.numel() if src_index is not None else src0.shape[0])
+    rs = lambda t: t.stride(0) * t.element_size()
+    with _device_guard(dst0, src0, dst1, src1):
+        rc = _lib.lib().dga_copy_rows2(dst0.data_ptr() + dst0_off, rs(dst0), src0.data_ptr() + src0_off, rs(src0), bytes0,
+                                       dst1.data_ptr() + dst1_off, rs(dst1), src1.data_ptr() + src1_off, rs(src1), bytes1,
+                                       dst_index.data_ptr() if dst_index is not None else None,
+                                       src_index.data_ptr() if src_index is not None else None, n, _stream_ptr(dst0))
+        _lib.check(rc, "copy_rows2")
+
+
 # ----------------------------------------------------------------------------- the framework's 16-bit entry points
 
 def _dt16(t: torch.Tensor) -> int:

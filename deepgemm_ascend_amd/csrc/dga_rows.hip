@@ -34,6 +34,30 @@ __global__ void __launch_bounds__(256) copy_rows_kernel(uint8_t *dst, int64_t ds
     }
 }
 
+// Two row streams with shared indices in one launch (the dispatch packs K fp8 bytes and K/128 fp32 scales of a token into
+// one payload row, and unpacks them again on the receiving side): stream 1 rides in the same workgroups.
+__global__ void __launch_bounds__(256) copy_rows2_kernel(uint8_t *d0, int64_t d0_stride, const uint8_t *s0, int64_t s0_stride,
+                                                         int64_t bytes0, uint8_t *d1, int64_t d1_stride, const uint8_t *s1,
+                                                         int64_t s1_stride, int64_t bytes1, const int64_t *dst_index,
+                                                         const int64_t *src_index, int64_t rows, int parts, int vec)
+{
+    const int64_t r = blockIdx.x / parts;
+    const int part = blockIdx.x % parts;
+    if (r >= rows) return;
+    const int64_t dr = dst_index ? dst_index[r] : r, sr = src_index ? src_index[r] : r;
+    if (dr < 0 || sr < 0) return;
+    auto run = [&](uint8_t *d, const uint8_t *s, int64_t bytes) {
+        if (vec) {
+            for (int64_t c = part * 256 + threadIdx.x; c < bytes / 16; c += 256 * parts)
+                *(v4i *)(d + c * 16) = *(const v4i *)(s + c * 16);
+        } else {
+            for (int64_t c = part * 256 + threadIdx.x; c < bytes; c += 256 * parts) d[c] = s[c];
+        }
+    };
+    run(d0 + dr * d0_stride, s0 + sr * s0_stride, bytes0);
+    run(d1 + dr * d1_stride, s1 + sr * s1_stride, bytes1);
+}
+
 // ---- token routing for the dispatch (one pass of atomics instead of a device sort + histogram) ------------------
 // rank[t] = how many tokens of the same expert were counted before token t (arrival order of the atomics: the order
 // inside an expert's segment is unspecified, which the exchange does not care about -- dispatch and combine use the
@@ -85,6 +109,29 @@ extern "C" int dga_route_tokens(const int64_t *expert_ids, int64_t tokens, int g
                        reinterpret_cast<unsigned long long *>(counts), pos);
     hipLaunchKernelGGL(dga::route_pos_kernel, dim3(grid), dim3(256), sizeof(long long) * (groups + 256), st, expert_ids,
                        tokens, groups, reinterpret_cast<const unsigned long long *>(counts), pos);
+    return dga::record_hip(hipGetLastError());
+}
+
+extern "C" int dga_copy_rows2(void *dst0, int64_t dst0_row_stride, const void *src0, int64_t src0_row_stride, int64_t row_bytes0,
+                              void *dst1, int64_t dst1_row_stride, const void *src1, int64_t src1_row_stride, int64_t row_bytes1,
+                              const int64_t *dst_index, const int64_t *src_index, int64_t rows, void *stream)
+{
+    if (rows < 0 || row_bytes0 < 0 || row_bytes1 < 0) return DGA_E_SHAPE;
+    if (rows == 0 || (row_bytes0 == 0 && row_bytes1 == 0)) return DGA_OK;
+    if ((row_bytes0 && (!dst0 || !src0)) || (row_bytes1 && (!dst1 || !src1))) return DGA_E_NULL;
+    const int vec = ((reinterpret_cast<uintptr_t>(dst0) | reinterpret_cast<uintptr_t>(src0) | reinterpret_cast<uintptr_t>(dst1) |
+                      reinterpret_cast<uintptr_t>(src1) | dst0_row_stride | src0_row_stride | dst1_row_stride |
+                      src1_row_stride | row_bytes0 | row_bytes1) & 15) == 0;
+    const int64_t big = row_bytes0 > row_bytes1 ? row_bytes0 : row_bytes1;
+    int parts = static_cast<int>((big / (vec ? 16 : 1) + 256 * 4 - 1) / (256 * 4));
+    if (parts < 1) parts = 1;
+    if (parts > 64) parts = 64;
+    if (rows * parts > 0x7FFFFFFFll) return DGA_E_RANGE;
+    hipLaunchKernelGGL(dga::copy_rows2_kernel, dim3(static_cast<unsigned>(rows * parts)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<uint8_t *>(dst0), dst0_row_stride,
+                       static_cast<const uint8_t *>(src0), src0_row_stride, row_bytes0, static_cast<uint8_t *>(dst1),
+                       dst1_row_stride, static_cast<const uint8_t *>(src1), src1_row_stride, row_bytes1, dst_index, src_index,
+                       rows, parts, vec);
     return dga::record_hip(hipGetLastError());
 }
 

@@ -119,8 +119,9 @@ class ExpertShardedGroupedGemm:
         # one byte row per token: K fp8 bytes followed by KB fp32 scales, in expert order
         payload = torch.empty((T, self.row_bytes), dtype=torch.uint8, device=tok_q.device)
         if scatter:
-            _rows(payload, tok_q, dst_index=order, row_bytes=self.k)
-            _rows(payload, tok_sf.view(torch.uint8), dst_index=order, row_bytes=4 * self.kb, dst_off=self.k)
+            from . import api
+            api.copy_rows2(payload, tok_q, self.k, payload, tok_sf.view(torch.uint8), 4 * self.kb, dst_index=order,
+                           dst1_off=self.k)
         else:
             order = torch.argsort(expert_ids, stable=True).contiguous()
             _rows(payload, tok_q, src_index=order, row_bytes=self.k)
@@ -166,9 +167,14 @@ class ExpertShardedGroupedGemm:
             self.dist.all_to_all_single(recv, payload, recv_splits, send_splits)
         else:
             recv = payload
-        _rows(self.a.view(self.Gl * self.m_max, self.k), recv, dst_index=dest, row_bytes=self.k)
-        _rows(self.sfa.view(self.Gl * self.m_max, self.kb).view(torch.uint8), recv, dst_index=dest,
-              row_bytes=4 * self.kb, src_off=self.k)
+        if scatter:
+            api.copy_rows2(self.a.view(self.Gl * self.m_max, self.k), recv, self.k,
+                           self.sfa.view(self.Gl * self.m_max, self.kb).view(torch.uint8), recv, 4 * self.kb,
+                           dst_index=dest, src1_off=self.k)
+        else:
+            _rows(self.a.view(self.Gl * self.m_max, self.k), recv, dst_index=dest, row_bytes=self.k)
+            _rows(self.sfa.view(self.Gl * self.m_max, self.kb).view(torch.uint8), recv, dst_index=dest,
+                  row_bytes=4 * self.kb, src_off=self.k)
         return RouteState(order, dest, send_splits, recv_splits, T, scatter)
 
     # ------------------------------------------------------------------ compute

@@ -248,6 +248,11 @@ int dga_route_tokens(const int64_t *expert_ids, int64_t tokens, int groups, int6
  * received rows into the masked [G, m_max, K] layout, and the reverse for the combine. */
 int dga_copy_rows(void *dst, int64_t dst_row_stride, const int64_t *dst_index, const void *src, int64_t src_row_stride,
                   const int64_t *src_index, int64_t row_bytes, int64_t rows, void *stream);
+/* Two row streams with shared indices in one launch: dst0[di] = src0[si] (row_bytes0) and dst1[di] = src1[si]
+ * (row_bytes1) -- the dispatch's pack (fp8 bytes + scales -> one payload row) and unpack. */
+int dga_copy_rows2(void *dst0, int64_t dst0_row_stride, const void *src0, int64_t src0_row_stride, int64_t row_bytes0,
+                   void *dst1, int64_t dst1_row_stride, const void *src1, int64_t src1_row_stride, int64_t row_bytes1,
+                   const int64_t *dst_index, const int64_t *src_index, int64_t rows, void *stream);
 
 /* ---- misc -------------------------------------------------------------------------------- */
 const char *dga_status_string(int status);

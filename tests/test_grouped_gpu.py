@@ -161,3 +161,22 @@ def test_route_tokens(dga):
     counts, pos = dga.route_tokens(ids, 4)
     assert counts.tolist() == [1, 0, 0, 2] and pos[1].item() == -1 and pos[3].item() == -1
     assert sorted(pos[[0, 2, 4]].tolist()) == [0, 1, 2] and pos[2].item() == 0
+
+
+def test_copy_rows2(dga):
+    """dga_copy_rows2: two row streams with shared indices, byte offsets inside rows, negative index = skip."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rows, k, kb = 300, 256, 2
+    q = torch.randint(0, 256, (rows, k), dtype=torch.uint8, device="cuda", generator=g)
+    sf = torch.rand((rows, kb), device="cuda", generator=g)
+    perm = torch.randperm(rows, device="cuda", generator=g)
+    payload = torch.zeros((rows, k + 4 * kb), dtype=torch.uint8, device="cuda")
+    dga.copy_rows2(payload, q, k, payload, sf.view(torch.uint8), 4 * kb, dst_index=perm, dst1_off=k)
+    torch.cuda.synchronize()
+    assert torch.equal(payload[perm][:, :k], q)
+    assert torch.equal(payload[perm][:, k:].contiguous().view(torch.float32), sf)
+    a = torch.zeros((rows, k), dtype=torch.uint8, device="cuda"); s2 = torch.zeros((rows, kb), device="cuda")
+    idx = perm.clone(); idx[:7] = -1
+    dga.copy_rows2(a, payload, k, s2.view(torch.uint8), payload, 4 * kb, src_index=idx, src1_off=k)
+    torch.cuda.synchronize()
+    assert torch.equal(a[7:], q[7:]) and torch.equal(s2[7:], sf[7:]) and (a[:7] == 0).all() and (s2[:7] == 0).all()
