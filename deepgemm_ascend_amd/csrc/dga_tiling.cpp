@@ -303,7 +303,12 @@ namespace tiling {
 void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, uint32_t expected_m,
                    bool contiguous = false)
 {
-    const uint32_t m_eff = (groups > 1 && expected_m) ? std::min(expected_m, t.m) : t.m;
+    // Grouped masked-M: the tile height covers m_max (the rows allocated per group), not expected_m.  masked_m[g] may
+    // exceed the hint, and every extra tile row of a group streams that group's whole B again, while rows beyond
+    // masked_m cost nothing but skipped waves: at G = 256 x (128, 7168, 2048) with 0..32 rows per group the 128-row tile
+    // streams 5.7 TB/s where a 16-row tile (the hint's choice) reaches 2.8 (scripts/grouped_decode_perf.py).
+    (void)expected_m;
+    const uint32_t m_eff = t.m;
     const uint32_t kb = ceil_div(std::max(t.k, 1u), 128);
     double best = 1e300;
     MenuEntry pick{};

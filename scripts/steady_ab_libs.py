@@ -5,7 +5,8 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
 import bench
-m = n = k = 4096
+import os
+m, n, k = (int(v) for v in os.environ.get('DGA_AB_SHAPE', '4096,4096,4096').split(','))
 a, sfa, b, sfb = bench.make_dense_inputs(m, n, k, seed=0)
 out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
