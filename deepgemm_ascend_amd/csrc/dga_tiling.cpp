@@ -366,7 +366,9 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
     // 128x256 with three stages has two builds: 4 waves (2x2) and 8 waves (2x4, two per SIMD).  The masked grouped
     // stream (HBM-bound) is 3 % faster on 4 waves, everything compute-bound 3-14 % faster on 8 (4096x2048x7168: 66.8 ->
     // 61.8 us; scripts/steady_ab.py, scripts/contig_ab.py).
-    if (pick.bm == 128 && pick.bn == 256 && t.stages == 3 && groups == 1) { t.wavesM = 2; t.wavesN = 4; }
+    // (the contiguous layout with one 128-row block per group is the same HBM-bound stream as the masked layout: 4 waves)
+    const bool weight_stream = groups > 1 || (contiguous && t.m / std::max(1u, t.groups) <= DGA_CONTIGUOUS_M_ALIGNMENT);
+    if (pick.bm == 128 && pick.bn == 256 && t.stages == 3 && !weight_stream) { t.wavesM = 2; t.wavesN = 4; }
     const uint32_t tiles_m = ceil_div(t.m, t.m1), tiles_n = ceil_div(t.n, t.n1);
     const uint64_t blocks = static_cast<uint64_t>(groups) * tiles_m * tiles_n;
     t.blockDim = static_cast<uint32_t>(blocks) * ((contiguous && t.m1 > DGA_CONTIGUOUS_M_ALIGNMENT) ? 2 : 1);
@@ -393,6 +395,13 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
     const uint32_t per_xcd = std::max<uint32_t>(1, static_cast<uint32_t>(blocks / std::max(1u, pf.xcdNum)));
     uint32_t gm = 1;
     while ((gm * 2) * (gm * 2) <= per_xcd * 2 && gm * 2 <= tiles_m) gm *= 2;
+    // contiguous-grouped layout: tile rows of different groups share no B panel, so a band should not be taller than a
+    // group (one 128-row block per group: walk along N, the group's tiles then share its A panel and stream its B once:
+    // 933 -> 826 us at 256 groups x 128 rows; scripts/contig_stream.py)
+    if (contiguous) {
+        const uint32_t rows_per_group = std::max(1u, t.m / std::max(1u, t.groups) / std::max<uint32_t>(1, t.m1));
+        while (gm > 1 && gm > rows_per_group) gm /= 2;
+    }
     t.swizzleOffset = static_cast<uint8_t>(std::min<uint32_t>(gm, 255));
 }
 
