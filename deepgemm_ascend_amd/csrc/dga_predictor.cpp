@@ -184,10 +184,15 @@ static std::vector<Cand> candidates(uint32_t m, uint32_t n, uint32_t k)
 
 static uint8_t raster_for(uint32_t m, uint32_t n, const Cand &c)
 {
+    // as select_mi355x: a near-square patch of the tiles an XCD runs at the same time
     const uint32_t tiles_m = cdiv(m, c.m1);
-    const uint32_t per_xcd = std::max<uint32_t>(1, static_cast<uint32_t>((static_cast<uint64_t>(tiles_m) * cdiv(n, c.n1) * c.splitk) / 8));
+    const uint32_t waves = (c.m1 == 256 && c.n1 == 256) ? 8 : 4;
+    const uint32_t lds = stage_bytes(c.m1, c.n1) * (c.stages == 3 ? 3 : 2);
+    const uint32_t wg_per_cu = std::max(1u, std::min(160u * 1024u / lds, 2048u / (waves * 64)));
+    const uint64_t per_xcd = std::max<uint64_t>(1, (static_cast<uint64_t>(tiles_m) * cdiv(n, c.n1) * c.splitk) / 8);
+    const uint32_t conc = static_cast<uint32_t>(std::min<uint64_t>(per_xcd, 32ull * wg_per_cu));
     uint32_t gm = 1;
-    while ((gm * 2) * (gm * 2) <= per_xcd * 2 && gm * 2 <= tiles_m) gm *= 2;
+    while ((gm * 2) * (gm * 2) <= conc && gm * 2 <= tiles_m) gm *= 2;
     return static_cast<uint8_t>(std::min<uint32_t>(gm, 255));
 }
 

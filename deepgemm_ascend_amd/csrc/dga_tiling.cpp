@@ -390,11 +390,15 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
         }
     }
     if (groups == 1 && !contiguous) apply_tail_split(t, pf.coreNum);
-    // raster: walk `swizzleOffset` tile-rows together so that an XCD's slice of the grid
-    // (blocks/8 consecutive tiles) is a near-square patch sharing A and B panels in its L2.
-    const uint32_t per_xcd = std::max<uint32_t>(1, static_cast<uint32_t>(blocks / std::max(1u, pf.xcdNum)));
+    // raster: walk `swizzleOffset` tile-rows together so that the tiles an XCD runs AT THE SAME TIME (its CUs x
+    // workgroups per CU, consecutive in the raster) are a near-square patch sharing A and B panels in its L2.  (Sizing
+    // the patch by the XCD's whole share of the grid instead gave 8 / 16 where the sweep finds 4: 8192^3 472 -> 440 us.)
+    const uint32_t lds_pick = static_cast<uint32_t>(pick.lds) / 2 * t.stages;
+    const uint32_t wpc = std::max<uint32_t>(1, std::min<uint32_t>(pf.l1Size / std::max(1u, lds_pick), 2048 / (pick.wm * pick.wn * 64)));
+    const uint32_t per_xcd = std::max<uint32_t>(1, static_cast<uint32_t>(static_cast<uint64_t>(t.blockDim) / std::max(1u, pf.xcdNum)));
+    const uint32_t conc = std::min<uint32_t>(per_xcd, pf.coreNum / std::max(1u, pf.xcdNum) * wpc);
     uint32_t gm = 1;
-    while ((gm * 2) * (gm * 2) <= per_xcd * 2 && gm * 2 <= tiles_m) gm *= 2;
+    while ((gm * 2) * (gm * 2) <= conc && gm * 2 <= tiles_m) gm *= 2;
     // contiguous-grouped layout: tile rows of different groups share no B panel, so a band should not be taller than a
     // group (one 128-row block per group: walk along N, the group's tiles then share its A panel and stream its B once:
     // 933 -> 826 us at 256 groups x 128 rows; scripts/contig_stream.py)

@@ -44,13 +44,16 @@ THREE_STAGE = {(128, 256), (128, 128), (64, 256)}   # tiles that also have a 3-s
 PINGPONG = {(256, 256)}                               # ... ping-pong / continuous schedules (dispatchPolicyTag 1 / 2)
 
 
-def heuristic_raster(m, n, bm, bn, splitk=1, xcds=8):
-    """The raster group select_mi355x derives for a tile (dga_tiling.cpp): the largest power of two whose square
-    fits twice an XCD's share of the grid."""
+def heuristic_raster(m, n, bm, bn, splitk=1, xcds=8, stages=2):
+    """The raster group select_mi355x derives for a tile (dga_tiling.cpp): the largest power of two whose square fits
+    the tiles an XCD runs AT THE SAME TIME (its 32 CUs x workgroups per CU), so that those form a near-square patch."""
     tiles_m = -(-m // bm)
-    per_xcd = max(1, (tiles_m * -(-n // bn) * splitk) // xcds)
+    lds = (max(bm, 32) * 128 + bn * 128 + ((bm + 8 + 255) // 256) * 256 * 4) * (3 if stages == 3 else 2)
+    waves = 8 if (bm, bn) == (256, 256) else 4
+    wg_per_cu = max(1, min(160 * 1024 // lds, 2048 // (waves * 64)))
+    conc = min(max(1, (tiles_m * -(-n // bn) * splitk) // xcds), 32 * wg_per_cu)
     gm = 1
-    while (gm * 2) * (gm * 2) <= per_xcd * 2 and gm * 2 <= tiles_m:
+    while (gm * 2) * (gm * 2) <= conc and gm * 2 <= tiles_m:
         gm *= 2
     return min(gm, 255)
 
@@ -86,7 +89,7 @@ def candidates(m, n, k, rasters=None):
             for st in ([2, 3] if (bm, bn) in THREE_STAGE else [2]):
                 for sk in splits:
                     for pol in ([0, 1, 2] if (bm, bn) in PINGPONG and sk == 1 else [0]):
-                        rr = r if rasters is None else heuristic_raster(m, n, bm, bn, sk)
+                        rr = r if rasters is None else heuristic_raster(m, n, bm, bn, sk, stages=st)
                         out.append({"m1": bm, "n1": bn, "raster": rr, "stages": st, "splitk": sk, "policy": pol})
                         # 256x256, more than one wave of tiles with a small remainder: also with the quarter-tile tail
                         if (bm, bn) == (256, 256) and sk == 1 and blocks > 256 and 0 < blocks % 256 <= 64:
