@@ -117,6 +117,14 @@ __global__ void __launch_bounds__(256) mmad_nn_f32_kernel(const B16DirectParams 
 // every CU a workgroup; when even the shortest tile leaves most CUs idle (the reference's benchmark list,
 // framework/benchmark/benchmark.py:24-44, is mostly M = 8..128 against N, K in the thousands: the y stream is the cost),
 // K is cut so that every CU pulls on that stream, with fp32 slabs combined by a second kernel (as in the fp8 operator).
+// raster group: a near-square patch of the tiles an XCD runs at the same time (one per CU here: 32 -> 4 rows x 8 columns)
+static int b16_raster(int tiles_m)
+{
+    static const int forced = [] { const char *e = std::getenv("DGA_B16_RASTER"); return e ? std::atoi(e) : 0; }();
+    if (forced > 0) return forced;
+    return tiles_m >= 4 ? 4 : (tiles_m >= 2 ? 2 : 1);
+}
+
 struct B16Plan { int bm, bn, splitk, ks_per_split; };
 static B16Plan b16_plan(int batch, int m, int n, int k)
 {
@@ -229,7 +237,7 @@ static int launch_b16(const void *x, const void *y, float *z, int batch, int m, 
             constexpr int PPv = decltype(pp)::value;
             p.tiles_m = (m + Cfg::kBM - 1) / Cfg::kBM;
             p.tiles_n = (n + Cfg::kBN - 1) / Cfg::kBN;
-            p.raster_group = p.tiles_m >= 8 ? 8 : (p.tiles_m >= 4 ? 4 : 1);
+            p.raster_group = b16_raster(p.tiles_m);
             if (direct)
                 return bf ? launch_tiled<Cfg, true, PPv, true>(p, batch, stream) : launch_tiled<Cfg, false, PPv, true>(p, batch, stream);
             return bf ? launch_tiled<Cfg, true, PPv>(p, batch, stream) : launch_tiled<Cfg, false, PPv>(p, batch, stream);
@@ -334,7 +342,7 @@ static int launch_b16_nt(const void *a, const void *b, void *out, int m, int n, 
         constexpr int PPv = decltype(pp)::value;
         p.tiles_m = (m + Cfg::kBM - 1) / Cfg::kBM;
         p.tiles_n = (n + Cfg::kBN - 1) / Cfg::kBN;
-        p.raster_group = p.tiles_m >= 8 ? 8 : (p.tiles_m >= 4 ? 4 : 1);
+        p.raster_group = b16_raster(p.tiles_m);
         return bf ? launch_tiled<Cfg, true, PPv, false, true>(p, 1, stream) : launch_tiled<Cfg, false, PPv, false, true>(p, 1, stream);
     };
     using P0 = std::integral_constant<int, 0>;
