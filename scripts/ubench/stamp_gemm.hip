@@ -33,7 +33,8 @@ int main(int argc, char **argv)
     auto kfn = pp == 2 ? gemm_fp8_blockscaled_nt_kernel<Cfg, 2, false> : pp ? gemm_fp8_blockscaled_nt_kernel<Cfg, 1, false> : gemm_fp8_blockscaled_nt_kernel<Cfg, 0, false>;
     hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, 0, p);
+    const int warm = argc > 5 ? atoi(argv[5]) : 5;   // 4000+ = sustained clocks (the default 5 is inside the ramp after idle)
+    for (int i = 0; i < warm; ++i) hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, 0, p);
     hipEventRecord(e0);
     for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, 0, p);
     hipEventRecord(e1); hipEventSynchronize(e1);
