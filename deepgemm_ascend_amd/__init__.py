@@ -14,6 +14,7 @@ from .api import (  # noqa: F401
     copy_rows,
     copy_rows2,
     gemm_fp8_fp8_bf16_nt,
+    gemm_fp8_loop_clock,
     get_bench_config,
     get_best_config,
     infer_dtype,

@@ -46,32 +46,49 @@ def _fp8_bytes(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-_WORKSPACES = {}
+_WORKSPACES = {}   # (kind, device index, stream handle) -> uint8 tensor
+_RETIRED = []      # outgrown buffers: a HIP graph captured earlier may still hold their address, so they stay alive
+
+
+def _scratch(kind: str, device, need: int) -> Tuple[Optional[int], int]:
+    """Device scratch, one grow-only buffer per (kind, device, stream): two GEMMs issued on different streams never
+    share split-K slabs or padded operand copies, and the capture stream of a HIP graph has a buffer of its own.  A
+    buffer that has to grow is replaced, not freed (a captured graph may replay into the old one); growth is geometric
+    so that few are ever retired.  The callee never allocates (the op runtime hands the workspace in)."""
+    if need == 0:
+        return None, 0
+    dev = torch.device(device)
+    key = (kind, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < need:
+        if buf is not None:
+            _RETIRED.append(buf)
+            need = max(need, buf.numel() * 3 // 2)
+        buf = torch.empty((need,), dtype=torch.uint8, device=dev)
+        _WORKSPACES[key] = buf
+    return buf.data_ptr(), buf.numel()
 
 
 def _workspace(t: Tiling, device) -> Tuple[Optional[int], int]:
-    """Device scratch for split-K slabs / odd-K padding, sized by dga_workspace_bytes and kept per device
-    (grow-only).  The callee never allocates (the op runtime hands the workspace in)."""
-    need = workspace_bytes(t)
-    if need == 0:
-        return None, 0
-    buf = _WORKSPACES.get(device)
-    if buf is None or buf.numel() < need:
-        buf = torch.empty((need,), dtype=torch.uint8, device=device)
-        _WORKSPACES[device] = buf
-    return buf.data_ptr(), buf.numel()
+    """Split-K slabs / odd-K padding of the fp8 kernels, sized by dga_workspace_bytes."""
+    return _scratch("fp8", device, workspace_bytes(t))
 
 
 def _mmad_workspace(batch, m, n, k, x) -> Tuple[Optional[int], int]:
-    need = int(_lib.lib().dga_mmad_workspace_bytes(batch, m, n, k, x.data_ptr()))
-    if need == 0:
-        return None, 0
-    key = ("mmad", x.device)
-    buf = _WORKSPACES.get(key)
-    if buf is None or buf.numel() < need:
-        buf = torch.empty((need,), dtype=torch.uint8, device=x.device)
-        _WORKSPACES[key] = buf
-    return buf.data_ptr(), buf.numel()
+    return _scratch("mmad", x.device, int(_lib.lib().dga_mmad_workspace_bytes(batch, m, n, k, x.data_ptr())))
+
+
+POLICY_PLAIN, POLICY_PINGPONG, POLICY_CONTINUOUS, POLICY_STRICT = 0, 1, 2, 3
+
+
+def _with_policy(t: Tiling, strict: bool) -> Tiling:
+    """strict=True: a copy of the tiling with dispatchPolicyTag = DGA_POLICY_STRICT (the exact-arithmetic kernel)."""
+    if not strict or t.dispatchPolicyTag == POLICY_STRICT:
+        return t
+    c = Tiling()
+    ctypes.memmove(ctypes.byref(c), ctypes.byref(t), ctypes.sizeof(Tiling))
+    c.dispatchPolicyTag = POLICY_STRICT
+    return c
 
 
 def _device_guard(*ts: torch.Tensor):
@@ -221,8 +238,13 @@ def bench_params_fill(m: int, n: int, k: int, params6: Sequence[int]) -> list:
 # ----------------------------------------------------------------------------- the hot path
 
 def gemm_fp8_fp8_bf16_nt(lhs: Tuple[torch.Tensor, torch.Tensor], rhs: Tuple[torch.Tensor, torch.Tensor],
-                         out: torch.Tensor, tiling_: Optional[Tiling] = None, sync: bool = False) -> None:
+                         out: torch.Tensor, tiling_: Optional[Tiling] = None, sync: bool = False,
+                         strict: bool = False) -> None:
     """out[M,N] (bf16, written in place) = (A[M,K] fp8, sfa[M,ceil(K/128)]) x (B[N,K] fp8, sfb[ceil(N/128),ceil(K/128)])^T.
+
+    strict=True runs the exact-arithmetic kernel (dispatchPolicyTag 3): fp32 products and sums in the reference CPU
+    path's own order, bit-identical to the oracle, at the fp32 matrix rate.  The default fp8-MFMA path is ~30x faster
+    and differs from it on cancellation-dominated outputs (README.md, "Numerics").
 
     Asynchronous on the current stream (the reference syncs on every call, gemm.hpp:110;
     pass sync=True for that behaviour)."""
@@ -244,6 +266,7 @@ def gemm_fp8_fp8_bf16_nt(lhs: Tuple[torch.Tensor, torch.Tensor], rhs: Tuple[torc
     with _device_guard(a, b, sfa, sfb, out):
         if tiling_ is None:
             tiling_ = tiling(m, n, k)
+        tiling_ = _with_policy(tiling_, strict)
         ws_ptr, ws_bytes = _workspace(tiling_, out.device)
         rc = _lib.lib().dga_gemm_fp8_fp8_bf16_nt(a.data_ptr(), sfa.data_ptr(), b.data_ptr(), sfb.data_ptr(),
                                                  out.data_ptr(), m, n, k, ctypes.byref(tiling_), ws_ptr, ws_bytes,
@@ -253,8 +276,30 @@ def gemm_fp8_fp8_bf16_nt(lhs: Tuple[torch.Tensor, torch.Tensor], rhs: Tuple[torc
             torch.cuda.current_stream(out.device).synchronize()
 
 
+def gemm_fp8_loop_clock(lhs, rhs, out: torch.Tensor, tiling_: Optional[Tiling] = None, launches: int = 50):
+    """(clock_mhz, loop_us): the shader clock the chip holds inside the main loop of the dense kernel `tiling_` selects,
+    and that loop's duration, from the loop-clock build (dga_gemm_fp8_loop_clock; a diagnostic: it synchronises)."""
+    a, sfa = lhs
+    b, sfb = rhs
+    a = _fp8_bytes(a); b = _fp8_bytes(b)
+    m, k = a.shape
+    n = b.shape[0]
+    with _device_guard(a, b, sfa, sfb, out):
+        if tiling_ is None:
+            tiling_ = tiling(m, n, k)
+        tiles = -(-m // max(1, tiling_.m1)) * -(-n // max(1, tiling_.n1))
+        ws_ptr, ws_bytes = _scratch("clock", out.device, tiles * 128)
+        mhz, us = ctypes.c_float(0), ctypes.c_float(0)
+        rc = _lib.lib().dga_gemm_fp8_loop_clock(a.data_ptr(), sfa.data_ptr(), b.data_ptr(), sfb.data_ptr(), out.data_ptr(),
+                                                m, n, k, ctypes.byref(tiling_), ws_ptr, ws_bytes, int(launches),
+                                                _stream_ptr(out), ctypes.byref(mhz), ctypes.byref(us))
+        _lib.check(rc, "gemm_fp8_loop_clock")
+    return mhz.value, us.value
+
+
 def m_grouped_gemm_fp8_fp8_bf16_nt_masked(lhs, rhs, out: torch.Tensor, masked_m: torch.Tensor, expected_m: int,
-                                          tiling_: Optional[Tiling] = None, sync: bool = False) -> None:
+                                          tiling_: Optional[Tiling] = None, sync: bool = False,
+                                          strict: bool = False) -> None:
     """Grouped masked-M GEMM: a [G,Mmax,K], sfa [G,Mmax,KB], b [G,N,K], sfb [G,NB,KB], out [G,Mmax,N] bf16;
     only rows < masked_m[g] of out[g] are written (upstream DeepGEMM's convention)."""
     a, sfa = lhs
@@ -274,6 +319,7 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_masked(lhs, rhs, out: torch.Tensor, masked_m:
     with _device_guard(a, b, sfa, sfb, out, masked_m):
         if tiling_ is None:
             tiling_ = tiling(mmax, n, k, groups=g, expected_m=int(expected_m))
+        tiling_ = _with_policy(tiling_, strict)
         ws_ptr, ws_bytes = _workspace(tiling_, out.device)
         rc = _lib.lib().dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked(
             a.data_ptr(), sfa.data_ptr(), b.data_ptr(), sfb.data_ptr(), out.data_ptr(), masked_m.data_ptr(),
@@ -298,15 +344,10 @@ def catlass_dynamic_matmul(self_: torch.Tensor, mat2: torch.Tensor, out: torch.T
              (n == 1 and mat2.stride(0) == 1), "mat2 must be the transposed view of a contiguous [N,K] tensor (NT)")
     dt = _lib.DT_BF16 if self_.dtype == torch.bfloat16 else _lib.DT_FP16
     with _device_guard(self_, mat2, out):
-        need = _lib.lib().dga_catlass_dynamic_matmul_workspace_bytes(m, n, k, self_.data_ptr(), mat2.data_ptr())
-        key = ("op16", out.device.index)
-        ws = _WORKSPACES.get(key)
-        if need and (ws is None or ws.numel() < need):
-            ws = torch.empty((need,), dtype=torch.uint8, device=out.device)
-            _WORKSPACES[key] = ws
+        need = int(_lib.lib().dga_catlass_dynamic_matmul_workspace_bytes(m, n, k, self_.data_ptr(), mat2.data_ptr()))
+        ws_ptr, ws_bytes = _scratch("op16", out.device, need)
         rc = _lib.lib().dga_catlass_dynamic_matmul(self_.data_ptr(), mat2.data_ptr(), out.data_ptr(), m, n, k, dt,
-                                                   ws.data_ptr() if need else None, ws.numel() if need else 0,
-                                                   _stream_ptr(out))
+                                                   ws_ptr, ws_bytes, _stream_ptr(out))
         _lib.check(rc, "catlass_dynamic_matmul")
         if sync:
             torch.cuda.current_stream(out.device).synchronize()
@@ -318,7 +359,8 @@ def get_m_alignment_for_contiguous_layout() -> int:
 
 
 def m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(lhs, rhs, out: torch.Tensor, m_indices: torch.Tensor,
-                                              tiling_: Optional[Tiling] = None, sync: bool = False) -> None:
+                                              tiling_: Optional[Tiling] = None, sync: bool = False,
+                                              strict: bool = False) -> None:
     """Contiguous-grouped GEMM (the prefill-side MoE layout): a [Msum,K], sfa [Msum,KB], b [G,N,K], sfb [G,NB,KB],
     out [Msum,N] bf16, m_indices int32 [Msum].  Row r is multiplied with b[m_indices[r]]; rows with a negative index
     are padding and stay untouched.  Group segments start at multiples of get_m_alignment_for_contiguous_layout()
@@ -340,6 +382,7 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(lhs, rhs, out: torch.Tensor, m_ind
     with _device_guard(a, b, sfa, sfb, out, m_indices):
         if tiling_ is None:
             tiling_ = tiling(msum, n, k, groups=g, contiguous=True)
+        tiling_ = _with_policy(tiling_, strict)
         ws_ptr, ws_bytes = _workspace(tiling_, out.device)
         rc = _lib.lib().dga_m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(
             a.data_ptr(), sfa.data_ptr(), b.data_ptr(), sfb.data_ptr(), out.data_ptr(), m_indices.data_ptr(),

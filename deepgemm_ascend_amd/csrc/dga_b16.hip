@@ -131,12 +131,14 @@ static B16Plan b16_plan(int batch, int m, int n, int k)
     const int ks_n = (k + 63) / 64;
     auto tiles_of = [&](int bm, int bn) { return static_cast<int64_t>(batch) * ((m + bm - 1) / bm) * ((n + bn - 1) / bn); };
     B16Plan pl{128, 128, 1, ks_n};
-    if (tiles_of(256, 256) >= 192) { pl.bm = 256; pl.bn = 256; return pl; }
-    if (tiles_of(128, 256) >= 192) { pl.bm = 128; pl.bn = 256; return pl; }   // 8 waves, three LDS stages
-    if (tiles_of(128, 128) < 192 && m <= 64) pl.bm = m > 32 ? 64 : (m > 16 ? 32 : 16);
+    const int64_t cus = device_cus();            // 256 on a whole MI355X; fewer under a compute-partition mode
+    const int64_t fill = cus * 3 / 4;            // "the big tile fills the chip": three quarters of the CUs
+    if (tiles_of(256, 256) >= fill) { pl.bm = 256; pl.bn = 256; return pl; }
+    if (tiles_of(128, 256) >= fill) { pl.bm = 128; pl.bn = 256; return pl; }   // 8 waves, three LDS stages
+    if (tiles_of(128, 128) < fill && m <= 64) pl.bm = m > 32 ? 64 : (m > 16 ? 32 : 16);
     const int64_t tiles = tiles_of(pl.bm, pl.bn);
-    if (tiles * 4 <= 256 * 3 && ks_n >= 16) {
-        int s = static_cast<int>(std::min<int64_t>({512 / tiles, ks_n / 8, 16}));
+    if (tiles * 4 <= cus * 3 && ks_n >= 16) {
+        int s = static_cast<int>(std::min<int64_t>({2 * cus / tiles, ks_n / 8, 16}));
         // slab write + read stays below half of the operand read
         while (s > 1 && static_cast<int64_t>(s) * batch * m * n * 8 * 2 > static_cast<int64_t>(batch) * (m + n) * k * 2) --s;
         if (s > 1) {
@@ -247,8 +249,7 @@ static int launch_b16(const void *x, const void *y, float *z, int batch, int m, 
         int rc;
         if (pl.bm == 256) rc = plain ? go(GemmCfg<256, 256, 4, 2>{}, P0{}) : go(GemmCfg<256, 256, 4, 2>{}, P2{});
         else if (pl.bm == 128 && pl.bn == 256) rc = go(GemmCfg<128, 256, 2, 4, 3>{}, P0{});
-        else if (pl.bm == 128 && pl.bn == 256) rc = go(GemmCfg<128, 256, 2, 4, 3>{}, P0{});
-    else if (pl.bm == 128) rc = go(GemmCfg<128, 128, 2, 2>{}, P0{});
+        else if (pl.bm == 128) rc = go(GemmCfg<128, 128, 2, 2>{}, P0{});
         else if (pl.bm == 64) rc = go(GemmCfg<64, 128, 1, 4>{}, P0{});
         else if (pl.bm == 32) rc = go(GemmCfg<32, 128, 1, 4>{}, P0{});
         else rc = go(GemmCfg<16, 128, 1, 4>{}, P0{});

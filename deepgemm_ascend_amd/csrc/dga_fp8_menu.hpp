@@ -1,0 +1,37 @@
+// The compiled menu of fp8 tile-kernel builds, shared between the launcher (dga_launch.hip, which only takes the
+// addresses of the launch functions) and the translation units that instantiate the kernels
+// (dga_launch_menu_{a,b,c}.hip -- split so that `make -j` compiles the menu in parallel).  This is the AOT replacement
+// of the reference's per-shape cmake-subprocess JIT (/root/reference/deep_gemm_ascend/framework/csrc/jit/compiler.hpp:26-93).
+#pragma once
+#include "dga_internal.hpp"
+#include "gemm_fp8_kernel.hpp"
+
+namespace dga {
+
+// Launch one build on `stream`: grid from p (launch_tiles / groups x tiles), LDS attribute set once per device.
+// K % 128 != 0 takes the instantiation with the per-lane beyond-K test in its DMA slots.  CLK: the loop-clock
+// diagnostic build (K % 128 == 0 only).
+template <class Cfg, int PP, bool CLK = false>
+int launch_cfg(const GemmParams &p, hipStream_t stream);
+
+// X(BM, BN, WM, WN, STAGES, PP)
+#define DGA_MENU_A(X) X(256, 256, 4, 2, 2, 0) X(256, 256, 4, 2, 2, 1) X(256, 256, 4, 2, 2, 2)
+#define DGA_MENU_B(X)                                                                                              \
+    X(128, 256, 2, 2, 2, 2) X(256, 128, 4, 1, 2, 2) X(128, 128, 2, 2, 2, 2) X(64, 256, 1, 4, 2, 2) X(128, 256, 2, 4, 2, 2)
+#define DGA_MENU_C(X)                                                                                              \
+    X(128, 256, 2, 2, 2, 0) X(256, 128, 4, 1, 2, 0) X(128, 128, 2, 2, 2, 0) X(64, 256, 1, 4, 2, 0) X(64, 128, 1, 4, 2, 0) \
+    X(128, 256, 2, 4, 2, 0) X(128, 256, 2, 4, 3, 0) X(128, 256, 2, 2, 3, 0) X(128, 128, 2, 2, 3, 0) X(64, 256, 1, 4, 3, 0) \
+    X(32, 256, 1, 4, 2, 0) X(32, 128, 1, 4, 2, 0) X(16, 256, 1, 4, 2, 0) X(16, 128, 1, 4, 2, 0)
+// loop-clock builds: the kernels of BASELINE configs[1] and configs[2]
+#define DGA_MENU_CLK(X) X(256, 256, 4, 2, 2, 2) X(128, 256, 2, 4, 3, 0)
+
+#define DGA_MENU_EXTERN(BM, BN, WM, WN, ST, PP) \
+    extern template int launch_cfg<GemmCfg<BM, BN, WM, WN, ST>, PP, false>(const GemmParams &, hipStream_t);
+#define DGA_MENU_EXTERN_CLK(BM, BN, WM, WN, ST, PP) \
+    extern template int launch_cfg<GemmCfg<BM, BN, WM, WN, ST>, PP, true>(const GemmParams &, hipStream_t);
+DGA_MENU_A(DGA_MENU_EXTERN)
+DGA_MENU_B(DGA_MENU_EXTERN)
+DGA_MENU_C(DGA_MENU_EXTERN)
+DGA_MENU_CLK(DGA_MENU_EXTERN_CLK)
+
+}  // namespace dga

@@ -7,6 +7,13 @@
 
 namespace dga {
 int record_hip(hipError_t e);
+// CUs of the current device (cached); the MI355X constant 256 when no device is visible (host-only tiling calls)
+uint32_t device_cus();
+// the fp8 launcher behind the three C-ABI GEMM entry points (dga_launch.hip); clock_stamps: see dga_diag.hip
+int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, void *out, const int32_t *masked_m,
+            const int32_t *m_indices, int b_groups, int groups, int m, int n, int k, int expected_m,
+            const dga_tiling_t *tiling, void *workspace, size_t workspace_bytes, hipStream_t stream,
+            unsigned long long *clock_stamps);
 // compiled fp8 kernel menu (dga_launch.hip)
 int variant_count();
 void variant_info(int i, int *bm, int *bn, int *wm, int *wn, int *lds);

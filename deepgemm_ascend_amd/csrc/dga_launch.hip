@@ -13,7 +13,9 @@
 
 #include "dga_hip.h"
 #include "dga_internal.hpp"
-#include "gemm_fp8_kernel.hpp"
+#include "dga_fp8_menu.hpp"
+#include "gemm_fp8_aux_kernels.hpp"
+#include "gemm_fp8_strict_kernel.hpp"
 
 namespace dga {
 
@@ -26,40 +28,21 @@ int record_hip(hipError_t e)
     }
     return DGA_OK;
 }
+uint32_t device_cus()
+{
+    static std::atomic<uint32_t> cache[64];
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (const uint32_t v = cache[dev].load()) return v;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+    cache[dev].store(static_cast<uint32_t>(n));
+    return static_cast<uint32_t>(n);
+}
 #define DGA_HIP_TRY(expr)                     \
     do {                                      \
         int _rc = dga::record_hip((expr));    \
         if (_rc != DGA_OK) return _rc;        \
     } while (0)
-
-template <class Cfg, int PP, bool KTAIL>
-static int launch_one(const GemmParams &p, hipStream_t stream)
-{
-    auto kfn = gemm_fp8_blockscaled_nt_kernel<Cfg, PP, KTAIL>;
-    static std::once_flag once[64];
-    static hipError_t attr_err[64];
-    int dev = 0;
-    DGA_HIP_TRY(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) return DGA_E_HIP;
-    std::call_once(once[dev], [&] {
-        attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-    });
-    DGA_HIP_TRY(attr_err[dev]);
-    unsigned grid = p.launch_tiles > 0 ? static_cast<unsigned>(p.launch_tiles)
-                                       : static_cast<unsigned>(p.groups) * p.tiles_m * p.tiles_n;
-    if (p.m_indices && Cfg::kBM > DGA_CONTIGUOUS_M_ALIGNMENT) grid *= 2;  // pass-1 copies for straddling tiles
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p);
-    DGA_HIP_TRY(hipGetLastError());
-    return DGA_OK;
-}
-
-// K % 128 != 0 takes the instantiation with the per-lane beyond-K test in its DMA slots
-template <class Cfg, int PP>
-static int launch_cfg(const GemmParams &p, hipStream_t stream)
-{
-    return (p.k % 128) ? launch_one<Cfg, PP, true>(p, stream) : launch_one<Cfg, PP, false>(p, stream);
-}
 
 struct Variant {
     int bm, bn, wm, wn;
@@ -115,12 +98,22 @@ static const Variant *find_variant(int bm, int bn, int wm, int wn, int stages)
     return wm ? find_variant(bm, bn, 0, 0, 2) : nullptr;
 }
 
+// the loop-clock build of a variant (dga_gemm_fp8_loop_clock), where one is compiled (DGA_MENU_CLK)
+static int (*find_clock_build(const Variant *v, int policy))(const GemmParams &, hipStream_t)
+{
+    if (v->bm == 256 && v->bn == 256 && policy == DGA_POLICY_CONTINUOUS) return &launch_cfg<GemmCfg<256, 256, 4, 2, 2>, 2, true>;
+    if (v->bm == 128 && v->bn == 256 && v->wm == 2 && v->wn == 4 && v->stages == 3) return &launch_cfg<GemmCfg<128, 256, 2, 4, 3>, 0, true>;
+    return nullptr;
+}
+
 // m_indices != nullptr: contiguous-grouped layout -- one A/out matrix of m rows (groups == 1 on that side), b_groups
 // B matrices picked per row block by m_indices.  Otherwise b_groups == groups.
-static int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, void *out,
-                   const int32_t *masked_m, const int32_t *m_indices, int b_groups, int groups, int m, int n, int k,
-                   int expected_m, const dga_tiling_t *tiling, void *workspace, size_t workspace_bytes,
-                   hipStream_t stream)
+// clock_stamps != nullptr (dga_gemm_fp8_loop_clock only): run the loop-clock build of the chosen variant, two words per
+// wave go to clock_stamps.
+int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, void *out,
+            const int32_t *masked_m, const int32_t *m_indices, int b_groups, int groups, int m, int n, int k,
+            int expected_m, const dga_tiling_t *tiling, void *workspace, size_t workspace_bytes,
+            hipStream_t stream, unsigned long long *clock_stamps)
 {
     if (m < 0 || n < 0 || k < 0 || groups < 0 || b_groups < 0) return DGA_E_SHAPE;
     if (groups == 0 || m == 0 || n == 0) return DGA_OK;  // empty problem: nothing to write
@@ -167,6 +160,24 @@ static int run_fp8(const void *a, const float *sfa, const void *b, const float *
     p.sfb_gs = static_cast<int64_t>(p.nb_n) * p.kb_n;
     p.groups = groups;
     p.splitk = 1;
+    p.stamps = clock_stamps;
+
+    // ---- strict policy: the exact-arithmetic kernel takes every shape as it is (no workspace, no padding pass)
+    static const int strict_env = [] { const char *e = std::getenv("DGA_STRICT"); return e ? std::atoi(e) : 0; }();
+    if (clock_stamps && (tiling->dispatchPolicyTag == DGA_POLICY_STRICT || strict_env || (k % 16) != 0)) return DGA_E_TILING;
+    if (tiling->dispatchPolicyTag == DGA_POLICY_STRICT || strict_env) {
+        const int bm = m > 64 ? 128 : (m > 32 ? 64 : 32);
+        p.tiles_m = (m + bm - 1) / bm;
+        p.tiles_n = (n + 127) / 128;
+        const int64_t blocks = static_cast<int64_t>(groups) * p.tiles_m * p.tiles_n;
+        if (blocks > 0x7FFFFFFFll) return DGA_E_SHAPE;
+        const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+        if (bm == 128) hipLaunchKernelGGL(gemm_fp8_strict_nt_kernel<4>, grid, block, 0, stream, p);
+        else if (bm == 64) hipLaunchKernelGGL(gemm_fp8_strict_nt_kernel<2>, grid, block, 0, stream, p);
+        else hipLaunchKernelGGL(gemm_fp8_strict_nt_kernel<1>, grid, block, 0, stream, p);
+        DGA_HIP_TRY(hipGetLastError());
+        return DGA_OK;
+    }
 
     // ---- workspace carve: [padded A | padded B] (K % 16 != 0), then [split-K slabs]
     uint8_t *ws = static_cast<uint8_t *>(workspace);
@@ -217,6 +228,7 @@ static int run_fp8(const void *a, const float *sfa, const void *b, const float *
     p.xcd_remap = xcd_remap;
 
     // ---- split-K (kernelSerial 4): partial fp32 slabs + combine; dense only
+    if (clock_stamps && (tiling->splitkFactor > 1 || tiling->kernelSerial == DGA_KERNEL_STREAMK_TAIL)) return DGA_E_TILING;
     if (tiling->splitkFactor > 1 && groups == 1 && !masked_m && !m_indices) {
         int s = tiling->splitkFactor;
         const int kbps = (p.kb_n + s - 1) / s;
@@ -241,6 +253,10 @@ static int run_fp8(const void *a, const float *sfa, const void *b, const float *
     static const int pp_env = [] { const char *e = std::getenv("DGA_PINGPONG"); return e ? std::atoi(e) : -1; }();
     const int policy = pp_env >= 0 ? pp_env : tiling->dispatchPolicyTag;
     auto launch_main = [&](const GemmParams &q) -> int {
+        if (q.stamps) {
+            auto clk = find_clock_build(v, policy == 2 && v->launch_cont ? 2 : 0);
+            return clk ? clk(q, stream) : DGA_E_TILING;
+        }
         if (policy == 1 && v->launch_pp) return v->launch_pp(q, stream);
         if (policy == 2 && v->launch_cont) return v->launch_cont(q, stream);
         return v->launch(q, stream);
@@ -252,7 +268,7 @@ static int run_fp8(const void *a, const float *sfa, const void *b, const float *
     //      wave quantisation) without partial sums: every output still comes from one accumulation in k order, the
     //      bytes are those of a single launch.
     if (tiling->kernelSerial == DGA_KERNEL_STREAMK_TAIL && groups == 1 && !masked_m && !m_indices && v->bm == 256 && v->bn == 256) {
-        const int tiles = p.tiles_m * p.tiles_n, cus = 256;
+        const int tiles = p.tiles_m * p.tiles_n, cus = static_cast<int>(device_cus());
         const int tail = tiles % cus, main_tiles = tiles - tail;
         const Variant *vq = find_variant(128, 128, 0, 0, 3);
         if (tail > 0 && main_tiles > 0 && vq) {
@@ -279,7 +295,7 @@ int dga_gemm_fp8_fp8_bf16_nt(const void *a, const float *sfa, const void *b, con
                              void *stream)
 {
     return dga::run_fp8(a, sfa, b, sfb, out, nullptr, nullptr, 1, 1, m, n, k, 0, tiling, workspace, workspace_bytes,
-                        static_cast<hipStream_t>(stream));
+                        static_cast<hipStream_t>(stream), nullptr);
 }
 
 int dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked(const void *a, const float *sfa, const void *b, const float *sfb,
@@ -289,7 +305,7 @@ int dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked(const void *a, const float *sfa, c
 {
     if (groups > 0 && m_max > 0 && !masked_m) return DGA_E_NULL;
     return dga::run_fp8(a, sfa, b, sfb, out, masked_m, nullptr, groups, groups, m_max, n, k, expected_m, tiling,
-                        workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+                        workspace, workspace_bytes, static_cast<hipStream_t>(stream), nullptr);
 }
 
 int dga_m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(const void *a, const float *sfa, const void *b, const float *sfb,
@@ -301,7 +317,7 @@ int dga_m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(const void *a, const float *sf
     if (m_sum > 0 && n > 0 && groups > 0 && !m_indices) return DGA_E_NULL;
     if (groups == 0) return DGA_OK;  // no B matrices: every row is a padding row
     return dga::run_fp8(a, sfa, b, sfb, out, nullptr, m_indices, groups, 1, m_sum, n, k, 0, tiling, workspace,
-                        workspace_bytes, static_cast<hipStream_t>(stream));
+                        workspace_bytes, static_cast<hipStream_t>(stream), nullptr);
 }
 
 int dga_last_hip_error(void) { return dga::g_last_hip_error.load(); }

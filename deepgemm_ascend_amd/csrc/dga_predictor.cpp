@@ -283,21 +283,23 @@ int dga_select_kernel_with_predictor(const dga_problem_t *problem, dga_tiling_t 
     }
     const uint64_t blocks = static_cast<uint64_t>(cdiv(problem->m, pick->m1)) * cdiv(problem->n, pick->n1);
     out->kernelSerial = out->splitkFactor > 1 ? DGA_KERNEL_STREAMK
-                        : (blocks <= 256 && problem->k <= 128) ? DGA_KERNEL_SMALL : DGA_KERNEL_COMMON;
+                        : (blocks <= dga::device_cus() && problem->k <= 128) ? DGA_KERNEL_SMALL : DGA_KERNEL_COMMON;
     out->blockDim = static_cast<uint32_t>(blocks) * out->splitkFactor;
     out->swizzleOffset = raster_for(problem->m, problem->n, *pick);
-    out->wavesM = out->wavesN = 0;  // first build of that tile size (the one the sweep timed)
-    for (int i = 0; i < dga::variant_count(); ++i) {
-        int vm, vn, wm, wn, lds;
-        dga::variant_info(i, &vm, &vn, &wm, &wn, &lds);
-        if (vm == pick->m1 && vn == pick->n1) {
+    // the build the sweep timed for this (tile, stage count): the menu's first entry with that tile AND that stage count
+    // (what a tiling that names no wave grid resolves to in the launcher); the tile's first entry only if none matches
+    out->wavesM = out->wavesN = 0;
+    for (int pass = 0; pass < 2 && !out->wavesM; ++pass)
+        for (int i = 0; i < dga::variant_count(); ++i) {
+            int vm, vn, wm, wn, lds;
+            dga::variant_info(i, &vm, &vn, &wm, &wn, &lds);
+            if (vm != pick->m1 || vn != pick->n1 || (pass == 0 && dga::variant_stages(i) != pick->stages)) continue;
             out->wavesM = static_cast<uint8_t>(wm); out->wavesN = static_cast<uint8_t>(wn);
-            out->ldsBytes = static_cast<uint32_t>(lds) / 2 * pick->stages;
+            out->ldsBytes = static_cast<uint32_t>(lds);
             break;
         }
-    }
     if (predicted_us) *predicted_us = best;
-    dga::apply_tail_split(*out, 256);  // the model picks the tile; a small last wave of 256x256 tiles is still cut along K
+    dga::apply_tail_split(*out, dga::device_cus());  // the model picks the tile; a small last wave of 256x256 tiles is still cut along K
     return DGA_OK;
 }
 

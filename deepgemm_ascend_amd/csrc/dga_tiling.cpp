@@ -287,6 +287,23 @@ static double tile_cycles_per_kblock(const MenuEntry &e)
 // Tail in quarter tiles (kernelSerial 5): more than one wave of 256x256 tiles with a small remainder -- the remainder would
 // cost a whole extra round at 1/8..1/4 occupancy; covered by 128x128 tiles (second launch) it occupies four times the
 // CUs for about half a round.  Applied to a dense tiling whatever chose the tile (heuristic or predictor).
+// LDS bytes of the compiled build a tiling resolves to: exact (tile, stages, wave grid) match, else the menu's first
+// build of that tile and stage count, else of that tile
+static uint32_t menu_lds_bytes(const dga_tiling_t &t)
+{
+    const int stages = t.stages == 3 ? 3 : 2;
+    for (int pass = 0; pass < 3; ++pass)
+        for (int i = 0; i < variant_count(); ++i) {
+            int bm, bn, wm, wn, lds;
+            variant_info(i, &bm, &bn, &wm, &wn, &lds);
+            if (bm != t.m1 || bn != t.n1) continue;
+            if (pass < 2 && variant_stages(i) != stages) continue;
+            if (pass == 0 && t.wavesM && (wm != t.wavesM || wn != t.wavesN)) continue;
+            return static_cast<uint32_t>(lds);
+        }
+    return t.ldsBytes;
+}
+
 void apply_tail_split(dga_tiling_t &t, uint32_t cus)
 {
     if (t.splitkFactor > 1 || t.m1 != 256 || t.n1 != 256 || t.groups > 1 || t.contiguous || !cus) return;
@@ -407,12 +424,18 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
         while (gm > 1 && gm > rows_per_group) gm /= 2;
     }
     t.swizzleOffset = static_cast<uint8_t>(std::min<uint32_t>(gm, 255));
+    t.ldsBytes = menu_lds_bytes(t);   // of the build that will run (stage count and wave grid are settled by now)
 }
 
 // ---- CSV-backed (m,n,k)-keyed cache ---------------------------------------------------------
 static const char *kCsvHead[] = {"m", "n", "k", "m1", "n1", "k1", "kernelSerial",
                                  "paddingTagA", "paddingTagB", "paddingTagC", "blockDim"};
 constexpr int kCsvCols = 11;
+// CDNA4 columns behind the reference's eleven (csv.cpp:23-26): a file that has them round-trips a tiling completely
+// (split-K factor, LDS stages, raster group, wave grid, schedule); a reference-format file is still read and appended
+// to in its own format.
+static const char *kCsvExt[] = {"splitkFactor", "stages", "swizzleOffset", "wavesM", "wavesN", "dispatchPolicyTag"};
+constexpr int kCsvExtCols = 6;
 
 class Cache {
 public:
@@ -426,6 +449,7 @@ public:
         std::lock_guard<std::mutex> lk(mu_);
         data_.clear();
         path_.clear();
+        ext_ = false;
         if (!path || !*path) return DGA_OK;
         std::ifstream in(path);
         std::string line;
@@ -438,6 +462,8 @@ public:
             for (size_t i = 0; i < head.size(); ++i) col[head[i]] = i;
             for (const char *h : kCsvHead)
                 if (!col.count(h)) return DGA_E_IO;
+            ext_ = true;
+            for (const char *h : kCsvExt) ext_ = ext_ && col.count(h);
             while (std::getline(in, line)) {
                 if (line.empty()) continue;
                 const auto cells = split(line);
@@ -464,7 +490,9 @@ public:
             std::ofstream out(path);
             if (!out.is_open()) return DGA_E_IO;
             for (int i = 0; i < kCsvCols; ++i) out << (i ? "," : "") << kCsvHead[i];
+            for (int i = 0; i < kCsvExtCols; ++i) out << "," << kCsvExt[i];
             out << "\n";
+            ext_ = true;
         }
         path_ = path;
         return DGA_OK;
@@ -506,10 +534,16 @@ public:
         data_[key] = e;
         if (!path_.empty() && t.groups <= 1) {  // the CSV schema has no group column: dense rows only
             std::ofstream out(path_, std::ios::app);
-            if (out.is_open())
+            if (out.is_open()) {
                 out << t.m << ',' << t.n << ',' << t.k << ',' << t.m1 << ',' << t.n1 << ',' << t.k1 << ','
                     << unsigned(t.kernelSerial) << ',' << unsigned(t.paddingTagA) << ',' << unsigned(t.paddingTagB)
-                    << ',' << unsigned(t.paddingTagC) << ',' << t.blockDim << "\n";
+                    << ',' << unsigned(t.paddingTagC) << ',' << t.blockDim;
+                if (ext_)
+                    out << ',' << unsigned(t.splitkFactor) << ',' << unsigned(t.stages ? t.stages : 2) << ','
+                        << unsigned(t.swizzleOffset) << ',' << unsigned(t.wavesM) << ',' << unsigned(t.wavesN) << ','
+                        << unsigned(t.dispatchPolicyTag);
+                out << "\n";
+            }
         }
     }
 
@@ -554,6 +588,7 @@ private:
     std::mutex mu_;
     std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, Entry> data_;
     std::string path_;
+    bool ext_ = false;   // the open file's header has the CDNA4 columns
 };
 
 // TilingParams ctor (tiling_params.h:45-65): strides from the layouts, swizzle defaults.
@@ -584,7 +619,7 @@ void complete_from_menu(dga_tiling_t &t)
             variant_info(i, &bm, &bn, &wm, &wn, &lds);
             if (bm != t.m1 || bn != t.n1 || (pass == 0 && variant_stages(i) != (t.stages == 3 ? 3 : 2))) continue;
             if (!t.wavesM) { t.wavesM = static_cast<uint8_t>(wm); t.wavesN = static_cast<uint8_t>(wn); }
-            t.ldsBytes = static_cast<uint32_t>(lds);
+            t.ldsBytes = menu_lds_bytes(t);
             return;
         }
 }
@@ -650,7 +685,13 @@ int dga_select_kernel(const dga_problem_t *problem, const dga_platform_t *platfo
         problem->layoutTagC != DGA_LAYOUT_ROW_MAJOR)
         return DGA_E_SHAPE;  // the operator is NT (catlass_dynamic_matmul_tiling.cpp:83-84)
     dga_platform_t pf;
-    if (platform) pf = *platform; else dga_platform_mi355x(&pf);
+    if (platform) {
+        pf = *platform;
+    } else {  // the device this call runs on: a compute-partition mode exposes fewer CUs than the whole chip
+        dga_platform_mi355x(&pf);
+        pf.coreNum = dga::device_cus();
+        pf.xcdNum = std::max<uint32_t>(2, pf.coreNum / 32);   // (1 would select the Ascend replay below)
+    }
     if (!pf.coreNum) return DGA_E_RANGE;
     init_params(*problem, *out);
     if (problem->m == 0 || problem->n == 0) { out->blockDim = 0; return DGA_OK; }

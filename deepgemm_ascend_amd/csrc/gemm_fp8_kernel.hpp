@@ -48,7 +48,8 @@ struct GemmParams {
     int launch_tiles;            // > 0: grid size of this launch (the first launch_tiles tiles of the raster); 0: all tiles
     int tail_begin, tail_sub;    // tail_sub = 2: this launch's tiles are QUARTER tiles (2 x 2 per parent) of the parent
                                  // raster's tiles [tail_begin, ...); tiles_m / tiles_n then hold the PARENT raster
-    unsigned long long *stamps;  // diagnostic builds only (-DDGA_STAMPS): per-wave segment cycle sums
+    unsigned long long *stamps;  // diagnostics only: per-wave segment cycle sums (-DDGA_STAMPS builds, 8 words per wave) or the
+                                 // loop clock of the CLK = true instantiations (2 words per wave); nullptr in product calls
 };
 
 // In-kernel stamps (diagnostic build only; cdna_hip_programming.md section 7 "In-kernel stamps").
@@ -90,12 +91,39 @@ struct GemmParams {
 #endif
 
 
+// Clock of the main loop (MI355X_MICROARCH.md "DVFS give-back" item 6): shader ticks / 100 MHz real-time ticks, stamped
+// once in front of and once behind the k loop.  Compiled in only in the CLK = true instantiations, which the
+// dga_gemm_fp8_loop_clock() diagnostic launches; the product kernels (CLK = false) carry no stamp.  The two words per
+// wave go to a buffer nothing else reads.
+template <bool ON>
+struct LoopClock {
+    unsigned long long t = 0, rt = 0;
+    __device__ __forceinline__ void tick()
+    {
+        if constexpr (ON) {
+            unsigned long long c0, c1;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(c1)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            t = c0 - t;
+            rt = c1 - rt;
+        }
+    }
+    __device__ __forceinline__ void flush(unsigned long long *dst, int slot, int lane) const
+    {
+        if constexpr (ON) {
+            if (dst && lane == 0) { dst[2 * slot] = t; dst[2 * slot + 1] = rt; }
+        }
+    }
+};
+
 // PP = 0: every wave runs the same k-block loop (one barrier per k block).
 // PP = 1 ("ping-pong", 256x256 tile with 8 waves only): the second-dispatched half of the workgroup runs half a k
 //         block behind the first, so one half's LDS fragment burst always overlaps the other half's MFMAs.
-template <class Cfg, int PP, bool KTAIL>
+template <class Cfg, int PP, bool KTAIL, bool CLK = false>
 __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const GemmParams p)
 {
+    LoopClock<CLK> loop_clock;
     constexpr int BM = Cfg::kBM, BN = Cfg::kBN, WN = Cfg::kWN;
     constexpr int NT = Cfg::NT, TM = Cfg::TM, TN = Cfg::TN;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -533,6 +561,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         const int KB = p.kb_n;
         DGA_STAMP_DECL
         DGA_STAMP_CLOCK(6, 7);
+        loop_clock.tick();
         auto barrier = [&]() {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -658,6 +687,8 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         wait_vmcnt<0>();
         DGA_STAMP_CLOCK(6, 7);
         DGA_STAMP_FLUSH();
+        loop_clock.tick();
+        loop_clock.flush(p.stamps, blockIdx.x * (NT / 64) + wave, lane);
         epilogue(acc);
     } else {
         v4f acc[TM][TN];
@@ -680,6 +711,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
             for (int idx = 0; idx < Cfg::LOADS_PER_STAGE; ++idx) issue_one(idx, d, kb_begin + d);
         DGA_STAMP_START();
         DGA_STAMP_CLOCK(6, 7);   // slots 6/7: shader-clock and 100 MHz real-time ticks across the main loop
+        loop_clock.tick();
         int stage = 0, fill = STG - 1;   // stage being consumed / stage being refilled (with k block kb + STG - 1)
         const bool wave_has_rows = m0 + wm * (BM / Cfg::kWM) < M;  // wave-uniform (wm comes from readfirstlane)
         for (int kb = kb_begin; kb < kb_end; ++kb) {
@@ -782,96 +814,10 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         }
         DGA_STAMP_CLOCK(6, 7);
         DGA_STAMP_FLUSH();
+        loop_clock.tick();
+        loop_clock.flush(p.stamps, blockIdx.x * (NT / 64) + wave, lane);
         epilogue(acc);
     }
-}
-
-// Generic kernel: any K (also K % 16 != 0), any strides.  One thread per output
-// element, fp32 running sums in the oracle's order.  Used only where the LDS-DMA
-// kernel's 16-byte chunking does not apply.
-__device__ __forceinline__ float e4m3fn_to_f32(uint8_t v)
-{
-    const uint32_t e = (v >> 3) & 15u, mnt = v & 7u;
-    float r;
-    if (e == 0) r = (float)mnt * 0.001953125f;  // subnormal: mnt/8 * 2^-6
-    else if (e == 15u && mnt == 7u) r = __builtin_nanf("");
-    else r = __uint_as_float(((e + 120u) << 23) | (mnt << 20));
-    return (v & 0x80) ? -r : r;
-}
-
-__global__ void __launch_bounds__(256) gemm_fp8_blockscaled_nt_generic_kernel(const GemmParams p)
-{
-    __shared__ float lut[256];
-    lut[threadIdx.x] = e4m3fn_to_f32((uint8_t)threadIdx.x);
-    __syncthreads();
-    const int g = blockIdx.z;
-    const int M = p.masked_m ? min(p.masked_m[g], p.m) : p.m;
-    const int n = blockIdx.x * 16 + (threadIdx.x & 15);
-    const int m = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (m >= M || n >= p.n) return;
-    int bg = g;
-    if (p.m_indices) {  // contiguous-grouped: per-row B group
-        bg = p.m_indices[m];
-        if (bg < 0 || bg >= p.b_groups) return;
-    }
-    const uint8_t *ar = p.a + (int64_t)g * p.a_gs + (int64_t)m * p.lda;
-    const uint8_t *br = p.b + (int64_t)bg * p.b_gs + (int64_t)n * p.ldb;
-    const float *sa = p.sfa + (int64_t)g * p.sfa_gs + (int64_t)m * p.kb_n;
-    const float *sb = p.sfb + (int64_t)bg * p.sfb_gs + (int64_t)(n / 128) * p.kb_n;
-    float acc = 0.f;
-    for (int kb = 0; kb < p.kb_n; ++kb) {
-        const int k0 = kb * 128, k1 = min(p.k, k0 + 128);
-        float part = 0.f;
-        for (int k = k0; k < k1; ++k) part += lut[ar[k]] * lut[br[k]];
-        acc += part * (sa[kb] * sb[kb]);
-    }
-    const v2bf h = __builtin_convertvector(v2f{acc, 0.f}, v2bf);
-    p.out[(int64_t)g * p.c_gs + (int64_t)m * p.ldc + n] = (uint16_t)(__builtin_bit_cast(uint32_t, h) & 0xFFFFu);
-}
-
-// split-K combine: out[m][n] = bf16( sum_s slab[s][m][n] ), s ascending (= k ascending; deterministic).  The fp32
-// counterpart of the reference's StreamkReduceAdd (op_kernel/kernel/padding_streamk_matmul_kernel.h:96-98).
-__global__ void __launch_bounds__(256) splitk_reduce_bf16_kernel(const float *partial, uint16_t *out, int64_t mn,
-                                                                 int splitk)
-{
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
-    if (i >= mn) return;
-    if (((mn & 7) == 0) && ((((uintptr_t)out) & 15) == 0)) {
-        v4f a0 = *(const v4f *)(partial + i), a1 = *(const v4f *)(partial + i + 4);
-        for (int s = 1; s < splitk; ++s) {
-            a0 += *(const v4f *)(partial + (int64_t)s * mn + i);
-            a1 += *(const v4f *)(partial + (int64_t)s * mn + i + 4);
-        }
-        const v2bf h0 = __builtin_convertvector(v2f{a0.x, a0.y}, v2bf), h1 = __builtin_convertvector(v2f{a0.z, a0.w}, v2bf);
-        const v2bf h2 = __builtin_convertvector(v2f{a1.x, a1.y}, v2bf), h3 = __builtin_convertvector(v2f{a1.z, a1.w}, v2bf);
-        *(v4i *)(out + i) = v4i{__builtin_bit_cast(int, h0), __builtin_bit_cast(int, h1), __builtin_bit_cast(int, h2),
-                               __builtin_bit_cast(int, h3)};
-    } else {
-        for (int q = 0; q < 8 && i + q < mn; ++q) {
-            float acc = partial[i + q];
-            for (int s = 1; s < splitk; ++s) acc += partial[(int64_t)s * mn + i + q];
-            const v2bf h = __builtin_convertvector(v2f{acc, 0.f}, v2bf);
-            out[i + q] = (uint16_t)(__builtin_bit_cast(uint32_t, h) & 0xFFFFu);
-        }
-    }
-}
-
-// K not a multiple of 16: rows cannot be cut into aligned 16-byte DMA chunks.  Re-lay the operand once into the
-// workspace with its rows padded (zero-filled) to a multiple of 128 -- the CDNA4 reading of the reference's
-// PaddingCommon variant (op_kernel/kernel/padding_common_matmul_kernel.h:33-107: a re-layout pass on the vector
-// cores in front of the matmul) -- and run the LDS-DMA kernel on that.
-__global__ void __launch_bounds__(256) pad_rows_kernel(const uint8_t *src, uint8_t *dst, int64_t rows, int k, int kp)
-{
-    const int64_t chunk = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one 16-byte output chunk per thread
-    const int cpr = kp / 16;
-    const int64_t r = chunk / cpr;
-    if (r >= rows) return;
-    const int c0 = (int)(chunk - r * cpr) * 16;
-    const uint8_t *s = src + r * k + c0;
-    uint8_t v[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = (c0 + j < k) ? s[j] : (uint8_t)0;
-    *(v4i *)(dst + r * kp + c0) = *(const v4i *)v;
 }
 
 }  // namespace dga

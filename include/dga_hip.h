@@ -49,6 +49,14 @@ enum { DGA_PADDING_NONE = 0, DGA_PADDING_ND = 1, DGA_PADDING_BLOCK_ND = 2, DGA_P
 enum { DGA_KERNEL_COMMON = 0, DGA_KERNEL_SMALL = 1, DGA_KERNEL_PADDING_COMMON = 2, DGA_KERNEL_STREAMK = 4,
        DGA_KERNEL_STREAMK_TAIL = 5 /* whole waves of 256x256 tiles, the last partial wave covered by 128x128 tiles */ };
 
+/* dispatchPolicyTag of the fp8 tile kernels (the reference's field selects a catlass dispatch policy,
+ * op_tiling/tiling_params.h:19-66; here it selects the main-loop schedule or the exact-arithmetic kernel):
+ *   0 plain (one barrier per k block), 1 ping-pong, 2 continuous pipeline -- the same results, bit for bit;
+ *   3 strict: fp32-input MFMA chain in the reference CPU path's own order (fp32 products, fp32 running sum, k ascending:
+ *     framework/tests/test.py:37) -- bit-identical to the oracle, any shape, at the fp32 matrix rate (1/32 of the fp8
+ *     rate).  $DGA_STRICT=1 forces it for every fp8 call of the process. */
+enum { DGA_POLICY_PLAIN = 0, DGA_POLICY_PINGPONG = 1, DGA_POLICY_CONTINUOUS = 2, DGA_POLICY_STRICT = 3 };
+
 /* Platform description: the CDNA4 retarget of PlatformInfo
  * (op_tiling/platform_info.h:16-41; Python mirror get_best_config/tiling_calculator.py:25-30).
  * The same struct carries the Ascend numbers when the reference's own arithmetic is
@@ -253,6 +261,19 @@ int dga_copy_rows(void *dst, int64_t dst_row_stride, const int64_t *dst_index, c
 int dga_copy_rows2(void *dst0, int64_t dst0_row_stride, const void *src0, int64_t src0_row_stride, int64_t row_bytes0,
                    void *dst1, int64_t dst1_row_stride, const void *src1, int64_t src1_row_stride, int64_t row_bytes1,
                    const int64_t *dst_index, const int64_t *src_index, int64_t rows, void *stream);
+
+/* ---- diagnostics ------------------------------------------------------------------------- */
+
+/* The shader clock held inside the dense kernel's main loop ("record the measured clock" beside the
+ * vendor peak).  Runs `launches` back-to-back launches of the loop-clock build of the kernel `tiling` selects -- the
+ * product kernel plus one s_memtime / s_memrealtime pair either side of the k loop -- synchronises `stream`, and returns
+ * the median over waves of shader ticks / 100 MHz ticks (clock_mhz) and of the loop's duration (loop_us, nullable).
+ * Compiled for the kernels of BASELINE configs[1] / [2] (256x256 continuous, 128x256 8-wave 3-stage); other tilings,
+ * split-K, K % 128 != 0: DGA_E_TILING.  scratch: device memory, 16 bytes per wave (128 per tile).  The reference times
+ * with msprof from outside (framework/benchmark/benchmark.py:400-418) and has no counterpart. */
+int dga_gemm_fp8_loop_clock(const void *a, const float *sfa, const void *b, const float *sfb, void *out, int m, int n,
+                            int k, const dga_tiling_t *tiling, void *scratch, size_t scratch_bytes, int launches,
+                            void *stream, float *clock_mhz, float *loop_us);
 
 /* ---- misc -------------------------------------------------------------------------------- */
 const char *dga_status_string(int status);

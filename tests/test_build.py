@@ -11,8 +11,13 @@ ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "deepgemm_ascend_amd" / "csrc"
 
 
-@pytest.mark.parametrize("unit,min_kernels,tile_kernel", [("dga_launch.hip", 40, "gemm_fp8_blockscaled_nt_kernel"),
-                                                          ("dga_b16.hip", 20, "gemm_b16_nt_f32_kernel")])
+@pytest.mark.parametrize("unit,min_kernels,tile_kernel", [
+    ("dga_launch.hip", 6, "gemm_fp8_strict_nt_kernel"),          # strict x 3, element-wise, split-K combine, padding
+    ("dga_launch_menu_a.hip", 6, "gemm_fp8_blockscaled_nt_kernel"),
+    ("dga_launch_menu_b.hip", 10, "gemm_fp8_blockscaled_nt_kernel"),
+    ("dga_launch_menu_c.hip", 28, "gemm_fp8_blockscaled_nt_kernel"),
+    ("dga_diag.hip", 2, "gemm_fp8_blockscaled_nt_kernel"),
+    ("dga_b16.hip", 20, "gemm_b16_nt_f32_kernel")])
 def test_no_kernel_spills_or_scratch(unit, min_kernels, tile_kernel):
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT / 'include'}", f"-I{CSRC}",
            "-fno-slp-vectorize", "-x", "hip", "--cuda-device-only", "-S", "-o", "/dev/null",

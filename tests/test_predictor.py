@@ -80,6 +80,37 @@ def test_pick_is_native_or_a_candidate_with_the_promised_gain(predictor):
     assert changed > 0, "the predictor never departed from the heuristic on 48 shapes"
 
 
+def test_picks_resolve_to_the_build_the_sweep_timed(predictor, tmp_path):
+    """The sweep times a candidate with wavesM = wavesN = 0, i.e. the menu's first build of that tile AND stage count
+    (what a swept CSV row resolves to).  A predictor pick must name that same build, not the tile's first entry of
+    another stage count (128x256 / 3 stages: the 8-wave 2x4 build, not the 4-wave 2x2 one)."""
+    from deepgemm_ascend_amd.harness import sweep
+    seen = set()
+    try:
+        for i, (m, n, k) in enumerate(SHAPES + [(512, 4096, 7168)] + list(sweep.grid_shapes(60, seed=11))):
+            t, _, _ = predictor.select_kernel_with_predictor(m, n, k)
+            native = predictor.select_kernel(m, n, k)
+            if (t.m1, t.n1, t.stages, t.splitkFactor) == (native.m1, native.n1, native.stages, native.splitkFactor):
+                continue
+            # a swept row with the pick's tile / stages and no wave grid, read back through the cache
+            path = tmp_path / f"row{i}.csv"
+            path.write_text("m,n,k,m1,n1,k1,kernelSerial,paddingTagA,paddingTagB,paddingTagC,blockDim,"
+                            "splitkFactor,stages,swizzleOffset,wavesM,wavesN,dispatchPolicyTag\n"
+                            f"{m},{n},{k},{t.m1},{t.n1},128,{t.kernelSerial},0,0,0,{t.blockDim},{t.splitkFactor},"
+                            f"{t.stages},{t.swizzleOffset},0,0,{t.dispatchPolicyTag}\n")
+            predictor.tiling_cache_open(str(path))
+            swept = predictor.tiling(m, n, k)
+            assert (t.wavesM, t.wavesN, t.ldsBytes) == (swept.wavesM, swept.wavesN, swept.ldsBytes), (m, n, k, t.as_dict())
+            seen.add((t.m1, t.n1, t.stages))
+    finally:
+        predictor.tiling_cache_open(None)
+        predictor.tiling_cache_clear()
+    assert (128, 256, 3) in seen or len(seen) >= 3
+    t, _, _ = predictor.select_kernel_with_predictor(512, 4096, 7168)
+    if (t.m1, t.n1, t.stages) == (128, 256, 3):
+        assert (t.wavesM, t.wavesN) == (2, 4)
+
+
 def test_fallbacks_and_unload(predictor, tmp_path):
     m, n, k = 233, 13440, 5120
     native = predictor.select_kernel(m, n, k)

@@ -121,9 +121,43 @@ def test_tiling_cache_creates_header_for_new_file(dga, tmp_path):
     path = tmp_path / "new.csv"
     try:
         dga.tiling_cache_open(str(path))
-        assert path.read_text() == "m,n,k,m1,n1,k1,kernelSerial,paddingTagA,paddingTagB,paddingTagC,blockDim\n"
+        # the reference's eleven columns (csv.cpp:23-26) first, the CDNA4 columns behind them
+        assert path.read_text() == ("m,n,k,m1,n1,k1,kernelSerial,paddingTagA,paddingTagB,paddingTagC,blockDim,"
+                                    "splitkFactor,stages,swizzleOffset,wavesM,wavesN,dispatchPolicyTag\n")
         dga.tiling(256, 256, 256)
         assert len(path.read_text().strip().splitlines()) == 2
+    finally:
+        dga.tiling_cache_open(None)
+        dga.tiling_cache_clear()
+
+
+@pytest.mark.parametrize("m,n,k", [(64, 7168, 18432), (8, 18432, 7168), (1024, 18432, 7168), (4096, 4096, 4096),
+                                   (512, 4096, 7168), (4096, 2048, 7168)])
+def test_tiling_round_trips_through_a_new_cache_file(dga, tmp_path, m, n, k):
+    """tiling -> CSV row -> a fresh cache (= the next process) -> the identical dga_tiling_t: split-K factor, stages,
+    wave grid, raster and schedule survive a restart, so the same shape runs the same kernel."""
+    path = tmp_path / "rt.csv"
+    try:
+        dga.tiling_cache_open(str(path))
+        first = dga.tiling(m, n, k).as_dict()
+        dga.tiling_cache_open(str(path))          # drops the in-memory map, re-reads the file
+        assert dga.tiling_cache_size() == 1
+        again = dga.tiling(m, n, k).as_dict()
+        assert again == first
+    finally:
+        dga.tiling_cache_open(None)
+        dga.tiling_cache_clear()
+
+
+def test_reference_format_file_keeps_its_format(dga, tmp_path):
+    """A file that carries only the reference's eleven columns is appended to in that format."""
+    path = tmp_path / "ref.csv"
+    path.write_text("m,n,k,m1,n1,k1,kernelSerial,paddingTagA,paddingTagB,paddingTagC,blockDim\n")
+    try:
+        dga.tiling_cache_open(str(path))
+        dga.tiling(64, 7168, 18432)
+        rows = path.read_text().strip().splitlines()
+        assert len(rows) == 2 and len(rows[1].split(",")) == 11
     finally:
         dga.tiling_cache_open(None)
         dga.tiling_cache_clear()
