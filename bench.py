@@ -3,24 +3,32 @@
 
 Default workload = BASELINE.json configs[1]: 4096 x 4096 x 4096 fp8 block-scaled NT GEMM, bf16 out,
 per-1x128 A scales / per-128x128 B scales, 1 x MI355X.  One "step" = one pass of the hot path over one
-batch = one GEMM launch through the C ABI with inputs already resident in HBM.
+batch = one operator call through the C ABI (tiling lookup included, as the reference's op consults its cache on
+every call, select_kernel.cpp:371-378) with inputs already resident in HBM.
 
   python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+      N > 1 without WORLD_SIZE in the environment: this process starts N ranks (one per GPU, torch.distributed.run on
+      127.0.0.1) BEFORE it touches a GPU and exits with their status -- the reference's multi-card model is likewise N
+      processes, one per device (benchmark_msprof/main.cpp:24-26, framework/benchmark/benchmark.py:249-253).
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...     (what the driver runs)
 
-N > 1: the dense GEMM does not shard ("replicas only", DESIGN.md section e): every rank runs the same
+N > 1: the dense GEMM does not shard ("replicas only"): every rank runs the same
 problem, `value` = N x per-replica work / max-over-ranks time (weak scaling).  The path that does shard --
 the grouped masked-M GEMM with experts partitioned over ranks and an RCCL all-to-all each way -- is reported
 in the extra "grouped" object of the same JSON line (tok/s with and without the exchange).
 
-Extra objects: "roofline" (dominant kernel vs the dense fp8 MFMA peak), "cpu_baseline" (the CPU oracle timed
-on this box's host cores on a bounded row sample; rank 0, N = 1 only).
+Extra objects: "roofline" (dominant kernel vs the dense fp8 MFMA peak, with the clock measured inside the kernel's
+main loop), "parity" (every output of the timed kernel against the strict kernel, which tests pin bit for bit to the
+CPU oracle), "dsv3_prefill" (BASELINE configs[2], own roofline), "cpu_baseline" (the CPU oracle and the reference's
+numpy formula timed on this box's host cores on a bounded row sample; rank 0, N = 1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -28,10 +36,9 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-import torch  # noqa: E402
-
 PEAK_FP8_TFLOPS = 5000.0   # MI355X dense fp8 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md, chip table)
 PEAK_HBM_GBPS = 8000.0
+FP8_FLOP_PER_CLK_PER_CU = 8192.0   # peak_fp8 = CUs x clk x 8192
 
 WORKLOADS = {
     # name: (m, n, k)
@@ -40,7 +47,51 @@ WORKLOADS = {
 }
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="dense_4096", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-grouped", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-prefill", action="store_true")
+    ap.add_argument("--widen", action="store_true",
+                    help="also time the rows either side of the hot path (contiguous-grouped layout, quantiser); off by "
+                         "default so that the default command's kernel statistics hold the headline kernels only")
+    ap.add_argument("--groups", type=int, default=256)
+    ap.add_argument("--grouped-mask", default="full", choices=["full", "random"])
+    ap.add_argument("--capacity-factor", type=float, default=1.25,
+                    help="sharded grouped path: rows reserved per (chunk, peer) = this x the even share (parallel.py)")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
+                    help="untimed clock pre-warm in front of the W warmup steps: after idle the GPU needs a few hundred "
+                         "steps to reach its sustained clocks (20 warmup steps alone leave the first 200 timed steps 14 %% "
+                         "slow, scripts/warm_effect.py)")
+    ap.add_argument("--stub", action="store_true",
+                    help="no GPU: gloo backend, CPU tensors and a numpy stand-in for the step -- exercises the launcher, the "
+                         "rendezvous, the barrier / max-over-ranks timing and the JSON contract (tests/test_bench_launcher.py)")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args) -> int:
+    """--gpus N outside a torchrun environment: start the N ranks as children.  Nothing in this process has touched a
+    GPU (torch is not even imported yet), so no GPU-initialised process is ever re-executed."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+# --------------------------------------------------------------------------------------------------- inputs
+
 def _rand_fp8(shape, gen):
+    import torch
     x = torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda", generator=gen)
     return torch.where((x & 0x7F) == 0x7F, x & 0x80, x)  # no NaN encodings
 
@@ -48,6 +99,7 @@ def _rand_fp8(shape, gen):
 def make_dense_inputs(m, n, k, seed):
     """Synthetic data of the SURVEY.md 8(d) shape: fp32 ~ N(0,1), amax-scaled per 1x128 / 128x128, cast to
     e4m3fn.  Generated on the device (torch casts saturate identically to the oracle for |x| <= 448)."""
+    import torch
     g = torch.Generator(device="cuda").manual_seed(seed)
     xa = torch.randn((m, k), device="cuda", generator=g)
     xb = torch.randn((n, k), device="cuda", generator=g)
@@ -61,49 +113,107 @@ def make_dense_inputs(m, n, k, seed):
 
 
 def pmc_traffic(workload: str):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json: FETCH_SIZE and
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r0N_traffic.json: FETCH_SIZE and
     WRITE_SIZE collected in separate passes and corrected as MI355X_MICROARCH.md prescribes).  PMC counters cannot be
     read from inside this process, so this is the figure of the profiled run of the same kernel, not of this run."""
-    try:
-        d = json.loads((ROOT / "profiles" / "r01_traffic.json").read_text())
-        return int(d[workload]["traffic_bytes"])
-    except Exception:
-        return None
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            d = json.loads((ROOT / "profiles" / name).read_text())
+            return int(d[workload]["traffic_bytes"])
+        except Exception:
+            continue
+    return None
 
 
-def cpu_baseline(m, n, k, a, sfa, b, sfb, budget_s=15.0):
-    """The CPU oracle (oracle/dga_oracle.c, kind "port") on a bounded row sample of the same workload."""
+# --------------------------------------------------------------------------------------------------- legs
+
+def parity_vs_strict(dga, a, sfa, b, sfb, fast_out):
+    """Every output of the timed (fast, fp8-MFMA) kernel against the strict kernel on the same inputs.  The strict
+    kernel is the product's exact-arithmetic policy; tests/test_strict_gpu.py pins it bit for bit to the CPU oracle, so
+    these figures are the fast path's distance from the oracle over ALL elements.  S = sum |scaled products| comes from
+    the strict kernel run on |a|, |b|, |scales| (bf16-rounded, 2^-9 relative)."""
+    import torch
+    m, n = fast_out.shape
+    exact = torch.empty_like(fast_out)
+    s_abs = torch.empty_like(fast_out)
+    dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), exact, strict=True)
+    dga.gemm_fp8_fp8_bf16_nt((a & 0x7F, sfa.abs()), (b & 0x7F, sfb.abs()), s_abs, strict=True, sync=True)
+
+    def key(t):   # monotone integer map of bf16 bit patterns (+0 / -0 coincide)
+        v = t.view(torch.int16).to(torch.int32)
+        mag = v & 0x7FFF
+        return torch.where(v < 0, -mag, mag)
+    ulps = (key(fast_out) - key(exact)).abs()
+    f, e, s = fast_out.double(), exact.double(), s_abs.double()
+    ulp = torch.exp2(torch.floor(torch.log2(e.abs().clamp_min(2.0 ** -126))) - 7)
+    excess = ((f - e).abs() - 2 * ulp).clamp_min(0) / s.clamp_min(1e-300)
+    return {
+        "against": "strict policy (fp32-MFMA chain in the oracle's order; bit-identical to the CPU oracle in tests/test_strict_gpu.py)",
+        "elements": int(m * n), "max_ulp": int(ulps.max()), "frac_gt_2ulp": float((ulps > 2).double().mean()),
+        "worst_excess_over_S": float(excess.max()), "bar": "|d| <= 2 ulp_bf16 + 2^-15 * S (README.md, Numerics)",
+        "within_bar": bool(float(excess.max()) <= 2.0 ** -15 * 1.01),
+    }
+
+
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def cpu_baseline(m, n, k, a, sfa, b, sfb, gpu_out=None, budget_s=15.0):
+    """The CPU oracle (oracle/dga_oracle.c, kind "port") on a bounded row sample of the same workload: one warm-up,
+    median of >= 3 passes.  Beside it the reference's own CPU path restated -- np.matmul(f32, f32) on the dequantised
+    operands (/root/reference/deep_gemm_ascend/framework/benchmark/benchmark.py:362) -- as the BLAS-quality bound:
+    operands dequantised once outside the timed region, one sgemm over the full K, same protocol.  The oracle rows
+    computed here also check the timed GPU output (the oracle as checker)."""
     import numpy as np
     from oracle import oracle as O
     O.build()
     cores = max(1, min(os.cpu_count() or 1, 64))
     an = a.cpu().numpy(); bn = b.cpu().numpy(); san = sfa.cpu().numpy(); sbn = sfb.cpu().numpy()
     probe = min(m, cores)
+    O.gemm_fp8_fp8_bf16_nt(an[:probe], san[:probe], bn, sbn, threads=cores)          # warm-up (page-in, thread start)
     t0 = time.perf_counter()
     O.gemm_fp8_fp8_bf16_nt(an[:probe], san[:probe], bn, sbn, threads=cores)
     dt = max(time.perf_counter() - t0, 1e-4)
-    rows = int(min(m, max(cores, probe * budget_s / dt)))
-    rows -= rows % cores or 0
-    rows = max(rows, cores)
-    reps = 0
-    t0 = time.perf_counter()
-    while True:
-        O.gemm_fp8_fp8_bf16_nt(an[:rows], san[:rows], bn, sbn, threads=cores)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt >= 0.6 * budget_s or reps >= 50:
-            break
-    dt /= reps
-    # the reference's own CPU path restated: np.matmul(f32, f32) per 128-wide k block (BLAS), same rows
-    t1 = time.perf_counter()
-    O.np_gemm_fp8_fp8_bf16_nt(an[:min(rows, 512)], san[:min(rows, 512)], bn, sbn)
-    dt_blas = time.perf_counter() - t1
-    return {
-        "value": round(2.0 * rows * n * k / dt / 1e12, 6), "unit": "TFLOP/s", "cores": cores, "kind": "port",
-        "sample": f"first {rows} of {m} rows of A against all of B, {reps} passes of {dt:.2f} s each (scalar fp32-accumulate C oracle, one thread per core)",
-        "blas_value": round(2.0 * min(rows, 512) * n * k / dt_blas / 1e12, 6),
-        "blas_note": "reference golden formula np.matmul(f32,f32) per k block, numpy BLAS threads",
+    reps = 3
+    rows = int(min(m, max(cores, probe * (0.6 * budget_s / reps) / dt)))
+    rows = max(cores, rows - rows % cores)
+    times, want = [], None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        want = O.gemm_fp8_fp8_bf16_nt(an[:rows], san[:rows], bn, sbn, threads=cores)
+        times.append(time.perf_counter() - t0)
+    med = _median(times)
+    res = {
+        "value": round(2.0 * rows * n * k / med / 1e12, 6), "unit": "TFLOP/s", "cores": cores, "kind": "port",
+        "reps": reps, "median_s": round(med, 4),
+        "sample": f"first {rows} of {m} rows of A against all of B; 1 warm-up + {reps} passes, median {med:.2f} s (scalar "
+                  f"fp32-accumulate C oracle, one thread per core)",
     }
+    # the reference's golden formula on the dequantised operands, BLAS sgemm over the full K
+    tab = O.e4m3fn_table()
+    rb = min(m, 1024)
+    kb = k // 128
+    a_deq = (tab[an[:rb]].reshape(rb, kb, 128) * san[:rb, :, None]).reshape(rb, k).astype(np.float32)
+    b_deq = (tab[bn].reshape(n // 128, 128, kb, 128) * sbn[:, None, :, None]).reshape(n, k).astype(np.float32)
+    b_t = np.ascontiguousarray(b_deq.T)
+    np.matmul(a_deq, b_t)                                                            # warm-up
+    bt = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        np.matmul(a_deq, b_t)
+        bt.append(time.perf_counter() - t0)
+    bmed = _median(bt)
+    res.update({"blas_value": round(2.0 * rb * n * k / bmed / 1e12, 6), "blas_reps": 3, "blas_median_s": round(bmed, 4),
+                "blas_note": f"reference golden formula np.matmul(f32, f32) on operands dequantised once outside the timed "
+                             f"region, first {rb} rows, numpy BLAS threads"})
+    if gpu_out is not None:
+        got = gpu_out[:rows].view(__import__("torch").int16).cpu().numpy().view(np.uint16)
+        rep = O.parity_report(got, want, an[:rows], san[:rows], bn, sbn)
+        res["gpu_rows_vs_oracle"] = {"rows": rows, "max_ulp": rep["max_ulp"], "frac_gt_2ulp": rep["frac_gt_max_ulp"],
+                                     "worst_excess_over_S": rep["worst_excess_over_S"]}
+    return res
 
 
 def grouped_leg(args, rank, world, dist):
@@ -111,10 +221,11 @@ def grouped_leg(args, rank, world, dist):
     from deepgemm_ascend_amd import parallel
     return parallel.bench_grouped(rank, world, dist, steps=max(3, min(args.steps, 20)), warmup=3,
                                   groups_total=args.groups, m_max=128, n=2048, k=7168,
-                                  mask=args.grouped_mask)
+                                  mask=args.grouped_mask, capacity_factor=args.capacity_factor)
 
 
 def _time_us(fn, iters, warm):
+    import torch
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -127,9 +238,31 @@ def _time_us(fn, iters, warm):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
+def roofline_mfma(dga, a, sfa, b, sfb, out, t, m, n, k, kernel_us, cus):
+    """`roofline` object of a dense launch: achieved = 2MNK / average launch time; peak = the vendor dense fp8 figure;
+    clock_mhz = the shader clock measured inside the kernel's main loop right after the timed region (loop-clock build
+    of the same kernel); frac_at_measured_clock prices the same launch against CUs x clk x 8192."""
+    flops = 2.0 * m * n * k
+    achieved = flops / (kernel_us * 1e-6) / 1e12
+    r = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s",
+         "frac": round(achieved / PEAK_FP8_TFLOPS, 4), "traffic": None, "kernel_us": round(kernel_us, 3),
+         "algorithmic_bytes": m * k + n * k + 2 * m * n + 4 * (sfa.numel() + sfb.numel()),
+         "kernel": "gemm_fp8_blockscaled_nt_kernel", "tile": f"{t.m1}x{t.n1}x{t.k1}", "clock_mhz": None,
+         "frac_at_measured_clock": None}
+    try:
+        mhz, loop_us = dga.gemm_fp8_loop_clock((a, sfa), (b, sfb), out, tiling_=t, launches=100)
+        peak_clk = cus * mhz * 1e6 * FP8_FLOP_PER_CLK_PER_CU / 1e12
+        r.update({"clock_mhz": round(mhz, 1), "main_loop_us": round(loop_us, 2),
+                  "peak_at_measured_clock": round(peak_clk, 1), "frac_at_measured_clock": round(achieved / peak_clk, 4)})
+    except Exception as e:   # a tiling without a loop-clock build: the vendor-peak fraction stands alone
+        r["clock_note"] = repr(e)
+    return r
+
+
 def widen_leg():
     """The rows either side of the hot path, reported beside the headline metric:
     the contiguous-grouped (prefill MoE) layout and the activation quantiser that feeds the GEMM."""
+    import torch
     import deepgemm_ascend_amd as dga
     gen = torch.Generator(device="cuda").manual_seed(7)
     groups, per, n, k = 8, 1024, 4096, 7168
@@ -158,117 +291,168 @@ def widen_leg():
     return res
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="dense_4096", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-grouped", action="store_true")
-    ap.add_argument("--widen", action="store_true",
-                    help="also time the rows either side of the hot path (contiguous-grouped layout, quantiser); off by "
-                         "default so that the default command's kernel statistics hold the headline kernels only")
-    ap.add_argument("--groups", type=int, default=256)
-    ap.add_argument("--grouped-mask", default="full", choices=["full", "random"])
-    ap.add_argument("--cpu-budget", type=float, default=15.0)
-    ap.add_argument("--prewarm-ms", type=float, default=300.0,
-                    help="untimed clock pre-warm in front of the W warmup steps: after idle the GPU needs a few hundred "
-                         "steps to reach its sustained clocks (20 warmup steps alone leave the first 200 timed steps 14 %% "
-                         "slow, scripts/warm_effect.py)")
-    args = ap.parse_args()
+# --------------------------------------------------------------------------------------------------- main
 
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}: start it as `python bench.py --gpus {args.gpus}` "
+              f"(it spawns the ranks) or under torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
+        if args.stub:
+            backend = "gloo"
+            dist.init_process_group(backend)
+        else:
+            backend = "nccl"   # RCCL on ROCm
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+    elif not args.stub:
         torch.cuda.set_device(0)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    dev = "cpu" if args.stub else "cuda"
 
-    import deepgemm_ascend_amd as dga
-    dga.lib()  # fails loudly if libdga_hip.so is missing
+    def sync():
+        if not args.stub:
+            torch.cuda.synchronize()
 
     m, n, k = WORKLOADS[args.workload]
-    a, sfa, b, sfb = make_dense_inputs(m, n, k, seed=rank)
-    out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
-    t = dga.tiling(m, n, k)
+    dga = None
+    if args.stub:
+        import numpy as np
+        xs = np.ones((64, 64), np.float32)
+        t = None
 
-    def step():
-        dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, tiling_=t)
+        def step():
+            np.matmul(xs, xs)
+    else:
+        import deepgemm_ascend_amd as dga_mod
+        dga = dga_mod
+        dga.lib()  # fails loudly if libdga_hip.so is missing
+        a, sfa, b, sfb = make_dense_inputs(m, n, k, seed=rank)
+        out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+        t = dga.tiling(m, n, k)
+
+        def step():   # the operator call as a caller makes it: the tiling comes from the (m,n,k) cache on every call
+            dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out)
 
     t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:   # untimed: bring the clocks to their sustained state
+    while not args.stub and (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:   # untimed: sustained clocks
         for _ in range(50):
             step()
-        torch.cuda.synchronize()
+        sync()
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     # HIP events on the stream the kernel is launched on (torch's current stream)
-    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    if not args.stub:
+        ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
     t0 = time.perf_counter()
-    ev0.record()
     for _ in range(args.steps):
         step()
-    ev1.record()
-    torch.cuda.synchronize()
+    if not args.stub:
+        ev1.record()
+    sync()
+    t_local = time.perf_counter() - t0
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
-    kernel_us = ev0.elapsed_time(ev1) * 1e3 / args.steps
+    kernel_us = (ev0.elapsed_time(ev1) * 1e3 / args.steps) if not args.stub else t_local * 1e6 / args.steps
+    per_rank_us = [round(kernel_us, 3)]
     if dist:
-        tt = torch.tensor([elapsed, kernel_us], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed, kernel_us], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, kernel_us = float(tt[0]), float(tt[1])
+        elapsed = float(tt[0])
+        gathered = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([kernel_us], device=dev, dtype=torch.float64))
+        per_rank_us = [round(float(x), 3) for x in gathered]
+        kernel_us = float(tt[1])
 
     flops = 2.0 * m * n * k
     value = world * flops * args.steps / elapsed / 1e12
-    achieved = flops / (kernel_us * 1e-6) / 1e12
-    alg_bytes = m * k + n * k + 2 * m * n + 4 * (sfa.numel() + sfb.numel())
+    res = {
+        "metric": "fp8 TFLOPS + % MFMA peak, 4096^3 block-scaled GEMM; grouped-GEMM tok/s at 1/2/4/8 GPU",
+        "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": dist.get_world_size() if dist else 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "fp8_e4m3fn", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: gemm_fp8_fp8_bf16_nt M={m} N={n} K={k}, per-1x128 / per-128x128 f32 scales, bf16 out",
+                   "tile": f"{t.m1}x{t.n1}x{t.k1}" if t is not None else None,
+                   "parallelism": "replicas" if world > 1 else "single", "prewarm_ms": args.prewarm_ms,
+                   "backend": backend, "stub": bool(args.stub)},
+        "per_rank_kernel_us": per_rank_us,
+    }
+    if args.stub:
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
-    grouped = None
+    cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    res["roofline"] = roofline_mfma(dga, a, sfa, b, sfb, out, t, m, n, k, kernel_us, cus)
+    if args.workload == "dense_4096":
+        res["roofline"]["traffic"] = pmc_traffic("dense")
+
+    if rank == 0 and not args.no_parity:
+        try:
+            dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, sync=True)
+            res["parity"] = parity_vs_strict(dga, a, sfa, b, sfb, out)
+        except Exception as e:
+            res["parity"] = {"error": repr(e)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(m, n, k, a, sfa, b, sfb, gpu_out=out, budget_s=args.cpu_budget)
+
+    # BASELINE configs[2] beside the headline (every rank runs it: replicas, like the headline)
+    if not args.no_prefill and args.workload == "dense_4096":
+        try:
+            pm, pn, pk = WORKLOADS["dsv3_prefill"]
+            del a, b, out
+            pa, psfa, pb, psfb = make_dense_inputs(pm, pn, pk, seed=100 + rank)
+            pout = torch.empty((pm, pn), dtype=torch.bfloat16, device="cuda")
+            pt = dga.tiling(pm, pn, pk)
+            us = _time_us(lambda: dga.gemm_fp8_fp8_bf16_nt((pa, psfa), (pb, psfb), pout), max(50, min(args.steps, 400)), 200)
+            res["dsv3_prefill"] = {"workload": f"gemm_fp8_fp8_bf16_nt M={pm} N={pn} K={pk} (BASELINE configs[2])",
+                                   "value": round(2.0 * pm * pn * pk / us / 1e6, 2), "unit": "TFLOP/s",
+                                   "roofline": roofline_mfma(dga, pa, psfa, pb, psfb, pout, pt, pm, pn, pk, us, cus)}
+            res["dsv3_prefill"]["roofline"]["traffic"] = pmc_traffic("dsv3_prefill")
+            if rank == 0 and not args.no_parity:
+                dga.gemm_fp8_fp8_bf16_nt((pa, psfa), (pb, psfb), pout, sync=True)
+                res["dsv3_prefill"]["parity"] = parity_vs_strict(dga, pa, psfa, pb, psfb, pout)
+            del pa, pb, pout
+        except Exception as e:
+            res["dsv3_prefill"] = {"error": repr(e)}
+
     if not args.no_grouped:
         try:
             grouped = grouped_leg(args, rank, world, dist)
+            if isinstance(grouped.get("roofline"), dict) and world == 1 and args.groups == 256 and args.grouped_mask == "full":
+                grouped["roofline"]["traffic"] = pmc_traffic("grouped")
+            res["grouped"] = grouped
         except Exception as e:  # the primary metric must still be reported
-            grouped = {"error": repr(e)}
-
-    res = {
-        "metric": "fp8 TFLOPS + % MFMA peak, 4096^3 block-scaled GEMM; grouped-GEMM tok/s at 1/2/4/8 GPU",
-        "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "fp8_e4m3fn", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: gemm_fp8_fp8_bf16_nt M={m} N={n} K={k}, per-1x128 / per-128x128 f32 scales, bf16 out",
-                   "tile": f"{t.m1}x{t.n1}x{t.k1}", "parallelism": "replicas" if world > 1 else "single",
-                   "prewarm_ms": args.prewarm_ms},
-        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_FP8_TFLOPS, 4),
-                     "traffic": pmc_traffic("dense") if args.workload == "dense_4096" else None,
-                     "kernel_us": round(kernel_us, 3), "algorithmic_bytes": alg_bytes,
-                     "kernel": "gemm_fp8_blockscaled_nt_kernel"},
-    }
-    if grouped is not None:
-        if isinstance(grouped.get("roofline"), dict) and world == 1 and args.groups == 256 and args.grouped_mask == "full":
-            grouped["roofline"]["traffic"] = pmc_traffic("grouped")
-        res["grouped"] = grouped
+            res["grouped"] = {"error": repr(e)}
     if rank == 0 and world == 1 and args.widen:
         try:
             res["widen"] = widen_leg()
         except Exception as e:
             res["widen"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(m, n, k, a, sfa, b, sfb, budget_s=args.cpu_budget)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if dist:

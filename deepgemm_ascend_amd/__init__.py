@@ -26,6 +26,7 @@ from .api import (  # noqa: F401
     per_token_cast_to_fp8,
     platform_ascend910b,
     predict_time_us,
+    route_slots,
     route_tokens,
     predictor_load,
     predictor_loaded,

@@ -107,6 +107,8 @@ SIGNATURES = {
     "dga_run_mmad_bench_ws": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int32),
                                       c_void_p, c_size_t, c_void_p]),
     "dga_route_tokens": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "dga_route_slots": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
+                                c_void_p, c_int64, c_void_p, c_void_p]),
     "dga_copy_rows2": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                c_void_p, c_void_p, c_int64, c_void_p]),
     "dga_copy_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p]),

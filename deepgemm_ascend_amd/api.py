@@ -432,6 +432,23 @@ def route_tokens(expert_ids: torch.Tensor, groups: int):
     return counts, pos
 
 
+def route_slots(keys: torch.Tensor, key_stride_bytes: int, rows: int, buckets: int, cap: int, counts: torch.Tensor,
+                dest: torch.Tensor, overflow: torch.Tensor, key_div: int = 1, key_sub: int = 0, key_mul: int = 1,
+                zero_counts: bool = True, tags: Optional[torch.Tensor] = None, tag_stride_bytes: int = 0,
+                keys_byte_offset: int = 0, tags_byte_offset: int = 0) -> None:
+    """Capacity-bounded slot assignment on the device (dga_route_slots): dest[r] = bucket(key_r) * cap + next free slot,
+    -1 for unused rows and for rows of a full bucket (which also raises the sticky device flag `overflow`)."""
+    _require(counts.dtype == torch.int32 and counts.numel() >= buckets and counts.is_contiguous(), "counts int32[buckets]")
+    _require(dest.dtype == torch.int64 and dest.numel() >= rows and dest.is_contiguous(), "dest int64[rows]")
+    _require(overflow.dtype == torch.int32 and overflow.numel() >= 1, "overflow int32[1]")
+    with _device_guard(keys, counts, dest, overflow):
+        rc = _lib.lib().dga_route_slots(keys.data_ptr() + keys_byte_offset, key_stride_bytes, rows, key_div, key_sub, key_mul,
+                                        buckets, cap, counts.data_ptr(), 1 if zero_counts else 0, dest.data_ptr(),
+                                        (tags.data_ptr() + tags_byte_offset) if tags is not None else None,
+                                        tag_stride_bytes, overflow.data_ptr(), _stream_ptr(dest))
+        _lib.check(rc, "route_slots")
+
+
 def copy_rows(dst: torch.Tensor, src: torch.Tensor, dst_index: Optional[torch.Tensor] = None,
               src_index: Optional[torch.Tensor] = None, rows: Optional[int] = None, row_bytes: Optional[int] = None,
               dst_byte_offset: int = 0, src_byte_offset: int = 0) -> None:

@@ -93,7 +93,62 @@ __global__ void __launch_bounds__(256) route_pos_kernel(const int64_t *ids, int6
     if (e >= 0 && e < groups) pos[t] += off[e];
 }
 
+// ---- capacity-bounded slot assignment: the host-sync-free routing of the sharded forward --------------------------
+// Row r carries an int32 key (an expert id).  bucket(key) names a destination with room for `cap` rows; the row gets
+// the next free slot of its bucket by one atomic, dest[r] = bucket * cap + slot.  A key outside [0, key_div * key_mul)
+// (unused payload rows carry -1) gets dest -1 silently; a full bucket gets dest -1 and raises *overflow.
+//   key_sub == 0:  bucket = key / key_div                       tag = key % key_div
+//   key_sub  > 0:  bucket = ((key % key_div) / key_sub) * key_mul + key / key_div     (chunk-major, then rank)
+// Source side of the dispatch: key_div = experts per rank, bucket = (chunk, destination rank), cap = rows per pair and
+// chunk, tag (the expert's index on its owner) is written into the payload row's header.  Receiving side: key_div = 1,
+// bucket = local expert, cap = m_max, dest = slot in the masked [G_local, m_max] layout, counts = masked_m.
+__global__ void __launch_bounds__(256) route_slots_kernel(const uint8_t *keys, int64_t key_stride, int64_t rows, int key_div,
+                                                          int key_sub, int key_mul, int buckets, int cap, int32_t *counts,
+                                                          int64_t *dest, uint8_t *tags, int64_t tag_stride, int32_t *overflow)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const int key = *(const int32_t *)(keys + r * key_stride);
+    int64_t d = -1;
+    if (key >= 0) {
+        const int hi = key / key_div, lo = key - hi * key_div;
+        const int bucket = key_sub ? (lo / key_sub) * key_mul + hi : hi;
+        if (hi < (key_sub ? key_mul : buckets) && bucket < buckets) {
+            const int slot = atomicAdd(counts + bucket, 1);
+            if (slot < cap) {
+                d = (int64_t)bucket * cap + slot;
+                if (tags) *(int32_t *)(tags + d * tag_stride) = lo;
+            } else {
+                atomicSub(counts + bucket, 1);   // masked_m must not exceed m_max
+                atomicOr(overflow, 1);
+            }
+        }
+    }
+    dest[r] = d;
+}
+
 }  // namespace dga
+
+extern "C" int dga_route_slots(const void *keys, int64_t key_stride_bytes, int64_t rows, int key_div, int key_sub, int key_mul,
+                               int buckets, int cap, int32_t *counts, int zero_counts, int64_t *dest, void *tags,
+                               int64_t tag_stride_bytes, int32_t *overflow, void *stream)
+{
+    if (rows < 0 || key_div < 1 || key_sub < 0 || buckets < 0 || cap < 0 || key_stride_bytes < 4) return DGA_E_SHAPE;
+    if (key_sub > 0 && key_mul < 1) return DGA_E_SHAPE;
+    if (buckets > 0 && !counts) return DGA_E_NULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (zero_counts && buckets > 0 &&
+        dga::record_hip(hipMemsetAsync(counts, 0, sizeof(int32_t) * buckets, st)) != DGA_OK)
+        return DGA_E_HIP;
+    if (rows == 0) return DGA_OK;
+    if (!keys || !dest || !overflow) return DGA_E_NULL;
+    if ((reinterpret_cast<uintptr_t>(keys) | static_cast<uintptr_t>(key_stride_bytes)) & 3) return DGA_E_ALIGN;
+    if (tags && ((reinterpret_cast<uintptr_t>(tags) | static_cast<uintptr_t>(tag_stride_bytes)) & 3)) return DGA_E_ALIGN;
+    hipLaunchKernelGGL(dga::route_slots_kernel, dim3(static_cast<unsigned>((rows + 255) / 256)), dim3(256), 0, st,
+                       static_cast<const uint8_t *>(keys), key_stride_bytes, rows, key_div, key_sub, key_mul, buckets, cap,
+                       counts, dest, static_cast<uint8_t *>(tags), tag_stride_bytes, overflow);
+    return dga::record_hip(hipGetLastError());
+}
 
 extern "C" int dga_route_tokens(const int64_t *expert_ids, int64_t tokens, int groups, int64_t *counts, int64_t *pos,
                                 void *stream)

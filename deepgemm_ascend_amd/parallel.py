@@ -5,12 +5,20 @@ The reference has no collective of any kind ("multi-card" = rank-sliced independ
 framework/benchmark/benchmark.py:249-253); this module is new work for BASELINE.json configs[4].
 
 Partitioning: expert g lives on rank g // (G / world); its weights never move.  One exchange each way:
-  dispatch  all-to-all-v of token rows (fp8 [K] bytes + their fp32 [K/128] scales packed in one byte row)
-            from the token's home rank to the expert's rank -> masked layout [G_local, m_max, K]
-  compute   m_grouped_gemm_fp8_fp8_bf16_nt_masked with masked_m = received counts
-  combine   all-to-all-v of bf16 [N] rows back, restored to the original token order
-`torch.distributed` backend "nccl" is RCCL on ROCm; on MI355X's fully connected xGMI mesh every peer pair has
-its own link, so an all-to-all is per-link bound.  world == 1 skips the exchange.
+  dispatch  all-to-all of token rows (fp8 [K] bytes + fp32 [K/128] scales + a 4-byte header naming the expert on its
+            owner, packed in one byte row) from the token's home rank to the expert's rank -> masked layout [G_local, m_max, K]
+  compute   m_grouped_gemm_fp8_fp8_bf16_nt_masked with masked_m = rows received per expert (counted on the device)
+  combine   all-to-all of bf16 [N] rows back, restored to the original token order
+
+No host round trip: every shape is static.  A rank sends each peer a fixed-capacity slice (`pair capacity` rows per
+(expert chunk, destination rank); unused rows carry header -1) and the per-expert row counts are built on the
+receiving device by atomics (dga_route_slots), so nothing is read back and a whole forward captures into one HIP graph.
+The price is padding on the wire: capacity = capacity_factor x the even share (default: the provable bound, which
+never overflows before an expert itself does); a bucket that does overflow raises a sticky device flag that
+`check()` turns into an error.  The experts are processed in `chunks`: dispatch of chunk i+1, the grouped GEMM of
+chunk i and the combine of chunk i-1 run on three streams.  `torch.distributed` backend "nccl" is RCCL on ROCm; on
+MI355X's fully connected xGMI mesh every peer pair has its own link, so an all-to-all is per-link bound.
+world == 1 has no exchange: tokens are routed straight into the masked layout (one indexed copy in, one out).
 
 `compute` is injectable so that the routing can be covered by world_size-2 gloo tests on CPU with the oracle
 as the checker; the default is the HIP operator (no CPU fallback in the product path).
@@ -18,21 +26,10 @@ as the checker; the default is the HIP operator (no CPU fallback in the product 
 from __future__ import annotations
 
 import time
-from dataclasses import dataclass
 from typing import Callable, Optional
 
 import numpy as np
 import torch
-
-
-@dataclass
-class RouteState:
-    order: torch.Tensor        # scatter=False: permutation that sorts my tokens by expert; scatter=True: slot of every token
-    dest: torch.Tensor         # slot (g_local * m_max + row) of every received row
-    send_splits: list
-    recv_splits: list
-    tokens: int
-    scatter: bool = False      # device path: `order` is pos (token -> slot in expert-sorted order, dga_route_tokens)
 
 
 def _default_compute(a, sfa, b, sfb, out, masked_m, expected_m):
@@ -42,42 +39,97 @@ def _default_compute(a, sfa, b, sfb, out, masked_m, expected_m):
 
 def _rows(dst, src, dst_index=None, src_index=None, row_bytes=None, dst_off=0, src_off=0):
     """Indexed row copy on byte views: the HIP kernel (dga_copy_rows) for device tensors; torch indexing for the CPU
-    tensors of the gloo routing tests (where nothing in this module touches a GPU)."""
+    tensors of the gloo routing tests (where nothing in this module touches a GPU).  Negative indices are skipped."""
     if dst.is_cuda:
         from . import api
         api.copy_rows(dst, src, dst_index, src_index, row_bytes=row_bytes, dst_byte_offset=dst_off,
                       src_byte_offset=src_off)
         return
     rb = row_bytes if row_bytes is not None else min(dst.shape[1], src.shape[1])
-    s = src[:, src_off:src_off + rb] if src_index is None else src[src_index, src_off:src_off + rb]
-    if dst_index is None:
-        dst[:s.shape[0], dst_off:dst_off + rb] = s
-    else:
-        dst[dst_index, dst_off:dst_off + rb] = s
+    n = dst_index.numel() if dst_index is not None else (src_index.numel() if src_index is not None else src.shape[0])
+    di = dst_index if dst_index is not None else torch.arange(n)
+    si = src_index if src_index is not None else torch.arange(n)
+    ok = (di >= 0) & (si >= 0)
+    dst[di[ok], dst_off:dst_off + rb] = src[si[ok], src_off:src_off + rb]
+
+
+def _rows2(dst0, src0, bytes0, dst1, src1, bytes1, dst_index, dst1_off=0, src1_off=0):
+    """Two row streams with one index list (fp8 bytes and scales of a token): dga_copy_rows2 on the device."""
+    if dst0.is_cuda:
+        from . import api
+        api.copy_rows2(dst0, src0, bytes0, dst1, src1, bytes1, dst_index=dst_index, dst1_off=dst1_off, src1_off=src1_off)
+        return
+    _rows(dst0, src0, dst_index=dst_index, row_bytes=bytes0)
+    _rows(dst1, src1, dst_index=dst_index, row_bytes=bytes1, dst_off=dst1_off, src_off=src1_off)
+
+
+def _route_slots(keys, key_stride, key_off, rows, buckets, cap, counts, dest, overflow, key_div=1, key_sub=0, key_mul=1,
+                 zero_counts=True, tags=None, tag_stride=0, tag_off=0):
+    """dga_route_slots on the device; the same assignment in numpy for the CPU tensors of the gloo tests."""
+    if dest.is_cuda:
+        from . import api
+        api.route_slots(keys, key_stride, rows, buckets, cap, counts, dest, overflow, key_div=key_div, key_sub=key_sub,
+                        key_mul=key_mul, zero_counts=zero_counts, tags=tags, tag_stride_bytes=tag_stride,
+                        keys_byte_offset=key_off, tags_byte_offset=tag_off)
+        return
+    kb = keys.contiguous().view(torch.uint8).reshape(-1).numpy()
+    key = np.array([np.frombuffer(kb[key_off + r * key_stride: key_off + r * key_stride + 4].tobytes(), np.int32)[0]
+                    for r in range(rows)], np.int64)
+    cnt = counts.numpy()
+    if zero_counts:
+        cnt[:buckets] = 0
+    d = dest.numpy()
+    tg = tags.view(torch.uint8).reshape(-1).numpy() if tags is not None else None
+    for r in range(rows):
+        d[r] = -1
+        if key[r] < 0:
+            continue
+        hi, lo = divmod(int(key[r]), key_div)
+        bucket = (lo // key_sub) * key_mul + hi if key_sub else hi
+        if hi >= (key_mul if key_sub else buckets) or bucket >= buckets:
+            continue
+        if cnt[bucket] >= cap:
+            overflow[0] = 1
+            continue
+        d[r] = bucket * cap + cnt[bucket]
+        cnt[bucket] += 1
+        if tg is not None:
+            at = tag_off + int(d[r]) * tag_stride
+            tg[at:at + 4] = np.frombuffer(np.int32(lo).tobytes(), np.uint8)
 
 
 class ExpertShardedGroupedGemm:
     def __init__(self, rank: int, world: int, groups_total: int, m_max: int, n: int, k: int, device,
-                 dist=None, compute: Optional[Callable] = None):
+                 dist=None, compute: Optional[Callable] = None, chunks: Optional[int] = None,
+                 capacity_factor: Optional[float] = None, max_tokens: Optional[int] = None):
         assert groups_total % world == 0, "experts must divide evenly over ranks"
         self.rank, self.world, self.dist = rank, world, dist
         self.G, self.Gl = groups_total, groups_total // world
         self.m_max, self.n, self.k = m_max, n, k
         self.kb = (k + 127) // 128
         self.nb = (n + 127) // 128
-        self.row_bytes = k + 4 * self.kb
-        self.device = device
+        self.hdr = k + 4 * self.kb                      # byte offset of the 4-byte header in a payload row
+        self.row_bytes = (self.hdr + 4 + 15) // 16 * 16
+        self.device = torch.device(device)
         self.compute = compute or _default_compute
+        if chunks is None:
+            chunks = 2 if (world > 1 and self.Gl % 2 == 0 and self.Gl >= 8) else 1
+        assert self.Gl % chunks == 0, "chunks must divide the experts per rank"
+        self.chunks, self.Glc = chunks, self.Gl // chunks
+        self.capacity_factor = capacity_factor
+        # the largest number of tokens one rank brings to a forward: it sizes the exchange slices, so every rank must
+        # pass the same value (default: what a rank's own experts can hold)
+        self.max_tokens = int(max_tokens) if max_tokens is not None else self.Gl * m_max
         # resident buffers sized once (288 GB HBM: weights + masked activations stay put)
         self.a = torch.zeros((self.Gl, m_max, k), dtype=torch.uint8, device=device)
         self.sfa = torch.ones((self.Gl, m_max, self.kb), dtype=torch.float32, device=device)
         self.out = torch.zeros((self.Gl, m_max, n), dtype=torch.bfloat16, device=device)
         self.masked_m = torch.zeros((self.Gl,), dtype=torch.int32, device=device)
+        self.overflow = torch.zeros((1,), dtype=torch.int32, device=device)
         self.b = None
         self.sfb = None
-        self._pinned = None
-        self._stage = [None, None]
-        self._stage_i = 0
+        self._T = -1
+        self._side = None
 
     def set_weights(self, b: torch.Tensor, sfb: torch.Tensor):
         assert tuple(b.shape) == (self.Gl, self.n, self.k) and tuple(sfb.shape) == (self.Gl, self.nb, self.kb)
@@ -86,123 +138,160 @@ class ExpertShardedGroupedGemm:
     def owner(self, g):
         return g // self.Gl
 
-    # ------------------------------------------------------------------ dispatch
-    def dispatch(self, tok_q: torch.Tensor, tok_sf: torch.Tensor, expert_ids: torch.Tensor) -> RouteState:
-        """tok_q [T,K] u8, tok_sf [T,KB] f32, expert_ids [T] int64 (global expert of each token)."""
-        T = tok_q.shape[0]
-        scatter = tok_q.is_cuda
-        if scatter:
-            # one pass of atomics: counts and the slot of every token in the expert-sorted order (no device sort, no
-            # histogram with its hidden host sync)
-            from . import api
-            counts, order = api.route_tokens(expert_ids.contiguous(), self.G)
-        else:
-            counts = torch.bincount(expert_ids, minlength=self.G).to(torch.int64)        # [G]
-            order = None
-        if self.world > 1:
-            flat = torch.empty((self.world * self.G,), dtype=torch.int64, device=counts.device)
-            self.dist.all_gather_into_tensor(flat, counts)
-        else:
-            flat = counts
-        # The one host synchronisation of the exchange: the count matrix (world x G int64) comes to the host, where
-        # the split lists that all_to_all_single needs anyway, the per-expert row counts and the slot of every
-        # arriving row are derived with numpy (a few microseconds) instead of a dozen small device launches.  The
-        # copy is asynchronous into pinned memory; the sort and the packing below do not depend on it and run meanwhile.
-        if flat.is_cuda:
-            if self._pinned is None or self._pinned.numel() != flat.numel():
-                self._pinned = torch.empty((flat.numel(),), dtype=torch.int64, pin_memory=True)
-            self._pinned.copy_(flat, non_blocking=True)
-            landed = torch.cuda.Event()
-            landed.record()
-        else:
-            landed = None
-        # one byte row per token: K fp8 bytes followed by KB fp32 scales, in expert order
-        payload = torch.empty((T, self.row_bytes), dtype=torch.uint8, device=tok_q.device)
-        if scatter:
-            from . import api
-            api.copy_rows2(payload, tok_q, self.k, payload, tok_sf.view(torch.uint8), 4 * self.kb, dst_index=order,
-                           dst1_off=self.k)
-        else:
-            order = torch.argsort(expert_ids, stable=True).contiguous()
-            _rows(payload, tok_q, src_index=order, row_bytes=self.k)
-            _rows(payload, tok_sf.view(torch.uint8), src_index=order, row_bytes=4 * self.kb, dst_off=self.k)
-        if landed is not None:
-            landed.synchronize()
-            allc = self._pinned.numpy().reshape(self.world, self.G).copy()
-        else:
-            allc = flat.numpy().reshape(self.world, self.G)
-        mine = allc[:, self.rank * self.Gl:(self.rank + 1) * self.Gl]                 # [world, Gl] rows I receive
-        send_splits = allc[self.rank].reshape(self.world, self.Gl).sum(1).tolist()
-        recv_splits = mine.sum(1).tolist()
-        masked = mine.sum(0)                                                          # [Gl]
-        if masked.size and int(masked.max()) > self.m_max:
-            raise ValueError(f"an expert received {int(masked.max())} rows > m_max {self.m_max}")
-        total = int(sum(recv_splits))
-        # slot of every received row: source-major, expert-minor arrival order -> [g, row] masked layout
-        start = (np.cumsum(mine, 0) - mine) + (np.arange(self.Gl, dtype=np.int64) * self.m_max)[None, :]
-        flat_cnt = mine.reshape(-1)
-        seg_begin = np.cumsum(flat_cnt) - flat_cnt
-        dest_np = np.repeat(start.reshape(-1) - seg_begin, flat_cnt) + np.arange(total, dtype=np.int64)
-        if tok_q.is_cuda:
-            # staged through pinned memory so that the two uploads are asynchronous (a pageable source makes the copy a
-            # blocking staging copy); a fresh buffer pair per call while the previous one may still be in flight
-            slot = self._stage[self._stage_i]
-            self._stage_i ^= 1
-            if slot is None or slot[0].numel() < total:
-                slot = (torch.empty((max(total, 1024),), dtype=torch.int64, pin_memory=True),
-                        torch.empty((self.Gl,), dtype=torch.int32, pin_memory=True), torch.cuda.Event())
-                self._stage[self._stage_i ^ 1] = slot
-            else:
-                slot[2].synchronize()   # the uploads that used this slot two calls ago
-            slot[0][:total].numpy()[:] = dest_np
-            slot[1].numpy()[:] = masked
-            dest = slot[0][:total].to(tok_q.device, non_blocking=True)
-            self.masked_m.copy_(slot[1], non_blocking=True)
-            slot[2].record()
-        else:
-            dest = torch.from_numpy(dest_np)
-            self.masked_m.copy_(torch.from_numpy(masked.astype(np.int32)))
-        if self.world > 1:
-            recv = torch.empty((total, self.row_bytes), dtype=torch.uint8, device=tok_q.device)
-            self.dist.all_to_all_single(recv, payload, recv_splits, send_splits)
-        else:
-            recv = payload
-        if scatter:
-            api.copy_rows2(self.a.view(self.Gl * self.m_max, self.k), recv, self.k,
-                           self.sfa.view(self.Gl * self.m_max, self.kb).view(torch.uint8), recv, 4 * self.kb,
-                           dst_index=dest, src1_off=self.k)
-        else:
-            _rows(self.a.view(self.Gl * self.m_max, self.k), recv, dst_index=dest, row_bytes=self.k)
-            _rows(self.sfa.view(self.Gl * self.m_max, self.kb).view(torch.uint8), recv, dst_index=dest,
-                  row_bytes=4 * self.kb, src_off=self.k)
-        return RouteState(order, dest, send_splits, recv_splits, T, scatter)
+    def pair_capacity(self, tokens: int) -> int:
+        """Rows reserved per (expert chunk, destination rank).  The bound min(tokens, experts in the chunk x m_max) cannot
+        overflow before an expert does; capacity_factor trades that guarantee for less padding on the wire."""
+        bound = max(1, min(tokens, self.Glc * self.m_max))
+        if self.capacity_factor is None:
+            return bound
+        even = tokens / float(self.world * self.chunks)
+        return int(min(bound, max(16, -(-int(np.ceil(self.capacity_factor * even)) // 16) * 16)))
 
-    # ------------------------------------------------------------------ compute
+    def _ensure(self, tokens: int):
+        """Static exchange buffers, allocated once for max_tokens rows (the same size on every rank)."""
+        if tokens > self.max_tokens:
+            raise ValueError(f"{tokens} tokens on rank {self.rank} > max_tokens {self.max_tokens} the engine was built for")
+        if self._T >= 0:
+            return
+        dev, w, ch = self.device, self.world, self.chunks
+        self._T = self.max_tokens
+        self.slot = torch.empty((max(self.max_tokens, 1),), dtype=torch.int64, device=dev)
+        if w == 1:
+            return
+        C = self.C = self.pair_capacity(self.max_tokens)
+        rows = ch * w * C
+        self.pair_cnt = torch.zeros((ch * w,), dtype=torch.int32, device=dev)
+        self.send = torch.zeros((rows, self.row_bytes), dtype=torch.uint8, device=dev)
+        self.recv = torch.zeros((rows, self.row_bytes), dtype=torch.uint8, device=dev)
+        self.rdest = torch.empty((rows,), dtype=torch.int64, device=dev)
+        self.osend = torch.zeros((rows, self.n), dtype=torch.bfloat16, device=dev)
+        self.oback = torch.zeros((rows, self.n), dtype=torch.bfloat16, device=dev)
+        if dev.type == "cuda" and self._side is None:
+            self._side = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+
+    def check(self):
+        """Synchronises and raises if a capacity was exceeded since the last check (rows of a full bucket are dropped)."""
+        if int(self.overflow.item()):
+            self.overflow.zero_()
+            raise ValueError(f"capacity exceeded: an expert received more than m_max = {self.m_max} rows, or a "
+                             f"(chunk, rank) pair more than its {getattr(self, 'C', self.m_max)} reserved rows")
+
+    # ------------------------------------------------------------------ world 1: route straight into the masked layout
+    def _forward_local(self, tok_q, tok_sf, expert_ids, expected_m, marks):
+        T = tok_q.shape[0]
+        flat_a = self.a.view(self.Gl * self.m_max, self.k)
+        flat_sfa = self.sfa.view(self.Gl * self.m_max, self.kb).view(torch.uint8)
+        _route_slots(expert_ids, 8, 0, T, self.Gl, self.m_max, self.masked_m, self.slot, self.overflow)
+        marks("route")
+        _rows2(flat_a, tok_q, self.k, flat_sfa, tok_sf.view(torch.uint8), 4 * self.kb, self.slot[:T])
+        marks("pack")
+        self.compute(self.a, self.sfa, self.b, self.sfb, self.out, self.masked_m, expected_m or self.m_max)
+        marks("gemm")
+        res = torch.empty((T, self.n), dtype=self.out.dtype, device=self.out.device)
+        _rows(res.view(torch.uint8), self.out.view(self.Gl * self.m_max, self.n).view(torch.uint8), src_index=self.slot[:T],
+              row_bytes=2 * self.n)
+        marks("unpack")
+        return res
+
+    # ------------------------------------------------------------------ world > 1
+    def _forward_sharded(self, tok_q, tok_sf, expert_ids, expected_m, marks, overlap):
+        T, w, ch, C = tok_q.shape[0], self.world, self.chunks, self.C
+        per = w * C                                             # rows of one chunk's exchange
+        flat_a = self.a.view(self.Gl * self.m_max, self.k)
+        flat_sfa = self.sfa.view(self.Gl * self.m_max, self.kb).view(torch.uint8)
+        flat_out = self.out.view(self.Gl * self.m_max, self.n).view(torch.uint8)
+        cuda = tok_q.is_cuda
+        # ---- source side: slot of every token in its (chunk, destination) slice, header = expert index on its owner
+        self.send[:, self.hdr:self.hdr + 4] = 255              # every header -1: rows nobody fills are skipped by the receiver
+        _route_slots(expert_ids, 8, 0, T, ch * w, C, self.pair_cnt, self.slot, self.overflow, key_div=self.Gl,
+                     key_sub=self.Glc, key_mul=w, tags=self.send, tag_stride=self.row_bytes, tag_off=self.hdr)
+        marks("route")
+        _rows2(self.send, tok_q, self.k, self.send, tok_sf.view(torch.uint8), 4 * self.kb, self.slot[:T], dst1_off=self.k)
+        self.masked_m.zero_()
+        marks("pack")
+        main = torch.cuda.current_stream(self.device) if cuda else None
+        s_disp, s_comb = self._side if (cuda and overlap) else (main, main)
+        ev_d, ev_g, ev_c = [], [], []
+
+        def on(stream):
+            return torch.cuda.stream(stream) if cuda else _Null()
+
+        if cuda and overlap:
+            s_disp.wait_stream(main)
+        for c in range(ch):                                     # dispatch: exchange, then receive-side slots + scatter
+            with on(s_disp):
+                sl = slice(c * per, (c + 1) * per)
+                self.dist.all_to_all_single(self.recv[sl], self.send[sl])
+                _route_slots(self.recv[sl], self.row_bytes, self.hdr, per, self.Gl, self.m_max, self.masked_m,
+                             self.rdest[sl], self.overflow, zero_counts=False)
+                _rows2(flat_a, self.recv[sl], self.k, flat_sfa, self.recv[sl], 4 * self.kb, self.rdest[sl], src1_off=self.k)
+                if cuda and overlap:
+                    ev_d.append(torch.cuda.Event()); ev_d[-1].record(s_disp)
+        marks("dispatch")
+        for c in range(ch):                                     # grouped GEMM of the chunk's experts
+            if cuda and overlap:
+                main.wait_event(ev_d[c])
+            g0, g1 = c * self.Glc, (c + 1) * self.Glc
+            self.compute(self.a[g0:g1], self.sfa[g0:g1], self.b[g0:g1], self.sfb[g0:g1], self.out[g0:g1],
+                         self.masked_m[g0:g1], expected_m or self.m_max)
+            if cuda and overlap:
+                ev_g.append(torch.cuda.Event()); ev_g[-1].record(main)
+        marks("gemm")
+        for c in range(ch):                                     # combine: rows back in arrival order, exchange
+            with on(s_comb):
+                if cuda and overlap:
+                    s_comb.wait_event(ev_g[c])
+                sl = slice(c * per, (c + 1) * per)
+                _rows(self.osend[sl].view(torch.uint8), flat_out, src_index=self.rdest[sl], row_bytes=2 * self.n)
+                self.dist.all_to_all_single(self.oback[sl], self.osend[sl])
+                if cuda and overlap:
+                    ev_c.append(torch.cuda.Event()); ev_c[-1].record(s_comb)
+        if cuda and overlap:
+            for e in ev_c:
+                main.wait_event(e)
+        marks("combine")
+        res = torch.empty((T, self.n), dtype=self.out.dtype, device=self.out.device)
+        _rows(res.view(torch.uint8), self.oback.view(torch.uint8), src_index=self.slot[:T], row_bytes=2 * self.n)
+        marks("unpack")
+        return res
+
+    def forward(self, tok_q, tok_sf, expert_ids, expected_m: int = 0, phase_us: Optional[dict] = None) -> torch.Tensor:
+        """tok_q [T,K] u8, tok_sf [T,KB] f32, expert_ids [T] int64 (global expert of each token) -> bf16 [T,N] in token
+        order.  Asynchronous on the current stream; nothing is read back (call check() to learn of a capacity overflow).
+        phase_us: a dict that receives the device time of each phase (the phases then run back to back on one stream)."""
+        T = tok_q.shape[0]
+        assert expert_ids.dtype == torch.int64 and expert_ids.is_contiguous()
+        self._ensure(T)
+        cuda = tok_q.is_cuda
+        events = []
+
+        def marks(name):
+            if phase_us is not None and cuda:
+                e = torch.cuda.Event(enable_timing=True); e.record(); events.append((name, e))
+
+        marks("start")
+        if self.world == 1:
+            res = self._forward_local(tok_q, tok_sf, expert_ids, expected_m, marks)
+        else:
+            res = self._forward_sharded(tok_q, tok_sf, expert_ids, expected_m, marks, overlap=phase_us is None)
+        if phase_us is not None and cuda:
+            torch.cuda.synchronize()
+            for (_, e0), (name, e1) in zip(events[:-1], events[1:]):
+                phase_us[name] = phase_us.get(name, 0.0) + e0.elapsed_time(e1) * 1e3
+        if not cuda:
+            self.check()    # CPU tensors (the gloo tests): the flag is host memory, checking costs nothing
+        return res
+
     def run_local(self, expected_m: int = 0):
         self.compute(self.a, self.sfa, self.b, self.sfb, self.out, self.masked_m, expected_m or self.m_max)
 
-    # ------------------------------------------------------------------ combine
-    def combine(self, st: RouteState) -> torch.Tensor:
-        total = st.dest.numel()
-        rows = torch.empty((total, self.n), dtype=self.out.dtype, device=self.out.device)   # arrival order
-        _rows(rows.view(torch.uint8), self.out.view(self.Gl * self.m_max, self.n).view(torch.uint8), src_index=st.dest,
-              row_bytes=2 * self.n)
-        if self.world > 1:
-            back = torch.empty((st.tokens, self.n), dtype=self.out.dtype, device=rows.device)
-            self.dist.all_to_all_single(back, rows, st.send_splits, st.recv_splits)
-        else:
-            back = rows
-        res = torch.empty_like(back)
-        if st.scatter:
-            _rows(res.view(torch.uint8), back.view(torch.uint8), src_index=st.order, row_bytes=2 * self.n)
-        else:
-            _rows(res.view(torch.uint8), back.view(torch.uint8), dst_index=st.order, row_bytes=2 * self.n)
-        return res
 
-    def forward(self, tok_q, tok_sf, expert_ids, expected_m: int = 0) -> torch.Tensor:
-        st = self.dispatch(tok_q, tok_sf, expert_ids)
-        self.run_local(expected_m)
-        return self.combine(st)
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 # ---------------------------------------------------------------------- benchmark leg (called from bench.py)
@@ -212,11 +301,12 @@ def _rand_fp8(shape, gen, device):
     return torch.where((x & 0x7F) == 0x7F, x & 0x80, x)
 
 
-def bench_grouped(rank, world, dist, steps=10, warmup=3, groups_total=256, m_max=128, n=2048, k=7168, mask="full"):
+def bench_grouped(rank, world, dist, steps=10, warmup=3, groups_total=256, m_max=128, n=2048, k=7168, mask="full",
+                  capacity_factor=1.25):
     """BASELINE.json configs[3] (world 1) / configs[4] (world 8): G experts x (M<=128, K=7168, N=2048).
     Tokens are born uniformly on the ranks; `full` = every expert gets m_max rows, `random` = randint(0, m_max+1)."""
     dev = torch.device("cuda", torch.cuda.current_device())
-    eng = ExpertShardedGroupedGemm(rank, world, groups_total, m_max, n, k, dev, dist)
+    eng = ExpertShardedGroupedGemm(rank, world, groups_total, m_max, n, k, dev, dist, capacity_factor=capacity_factor)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     kb, nb = eng.kb, eng.nb
     eng.set_weights(_rand_fp8((eng.Gl, n, k), g, dev), torch.rand((eng.Gl, nb, kb), device=dev, generator=g) + 0.5)
@@ -230,7 +320,7 @@ def bench_grouped(rank, world, dist, steps=10, warmup=3, groups_total=256, m_max
     extra = per_expert % world
     mine = base + (rank < extra).to(torch.int64)
     expert_ids = torch.repeat_interleave(torch.arange(groups_total), mine).to(dev)
-    expert_ids = expert_ids[torch.randperm(expert_ids.numel(), device=dev, generator=g)]
+    expert_ids = expert_ids[torch.randperm(expert_ids.numel(), device=dev, generator=g)].contiguous()
     T = expert_ids.numel()
     tok_q = _rand_fp8((T, k), g, dev)
     tok_sf = torch.rand((T, kb), device=dev, generator=g) + 0.5
@@ -242,15 +332,38 @@ def bench_grouped(rank, world, dist, steps=10, warmup=3, groups_total=256, m_max
             dist.barrier()
             torch.cuda.synchronize()
 
-    # end to end: dispatch + GEMM + combine
+    # end to end: dispatch + GEMM + combine, eager launches
     for _ in range(warmup):
         eng.forward(tok_q, tok_sf, expert_ids)
     sync()
+    eng.check()
     t0 = time.perf_counter()
     for _ in range(steps):
         eng.forward(tok_q, tok_sf, expert_ids)
     sync()
     e2e = (time.perf_counter() - t0) / steps
+    # the same forward replayed from one HIP graph (possible because no phase reads anything back)
+    e2e_graph = None
+    if world == 1:
+        try:
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                eng.forward(tok_q, tok_sf, expert_ids)
+            for _ in range(warmup):
+                gr.replay()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                gr.replay()
+            sync()
+            e2e_graph = (time.perf_counter() - t0) / steps
+        except Exception:   # capture is an optimisation, never a requirement of the bench line
+            e2e_graph = None
+    # per-phase device time (phases back to back on one stream)
+    phases = {}
+    for _ in range(3):
+        eng.forward(tok_q, tok_sf, expert_ids, phase_us=phases)
+    phases = {kk: round(v / 3, 1) for kk, v in phases.items()}
     # GEMM only (activations already in the masked layout on the owning rank)
     ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
     sync()
@@ -262,6 +375,7 @@ def bench_grouped(rank, world, dist, steps=10, warmup=3, groups_total=256, m_max
     sync()
     gemm = (time.perf_counter() - t0) / steps
     kernel_us = ev0.elapsed_time(ev1) * 1e3 / steps
+    eng.check()
     if dist is not None and world > 1:
         tt = torch.tensor([e2e, gemm, kernel_us], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -270,15 +384,19 @@ def bench_grouped(rank, world, dist, steps=10, warmup=3, groups_total=256, m_max
     active = int((eng.masked_m > 0).sum().item())
     alg_bytes = active * n * k + rows_local * (k + 4 * kb + 2 * n) + eng.Gl * nb * kb * 4
     flops_local = 2.0 * n * k * rows_local
-    return {
+    res = {
         "workload": f"m_grouped_gemm_fp8_fp8_bf16_nt_masked G={groups_total} x (M<={m_max}, K={k}, N={n}), "
                     f"mask={mask}, {groups_total // world} experts/GPU",
         "n_gpus": world, "tokens": total_tokens,
         "tok_per_s_gemm_only": round(total_tokens / gemm, 1),
         "tok_per_s_with_alltoall": round(total_tokens / e2e, 1),
         "ms_gemm": round(gemm * 1e3, 4), "ms_end_to_end": round(e2e * 1e3, 4),
+        "ms_end_to_end_graph": round(e2e_graph * 1e3, 4) if e2e_graph else None,
+        "phase_us": phases, "chunks": eng.chunks,
+        "pair_capacity_rows": getattr(eng, "C", None), "capacity_factor": capacity_factor if world > 1 else None,
         "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (kernel_us * 1e-6) / 1e9, 1), "peak": 8000.0,
                      "unit": "GB/s", "frac": round(alg_bytes / (kernel_us * 1e-6) / 1e9 / 8000.0, 4),
                      "traffic": None, "kernel_us": round(kernel_us, 2), "algorithmic_bytes": alg_bytes,
                      "tflops": round(flops_local / (kernel_us * 1e-6) / 1e12, 1)},
     }
+    return res

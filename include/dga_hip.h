@@ -250,6 +250,20 @@ int dga_run_mmad_bench_ws(const void *x, const void *y, float *z, int m, int n, 
  * and a histogram.  No reference counterpart (row 8(e)). */
 int dga_route_tokens(const int64_t *expert_ids, int64_t tokens, int groups, int64_t *counts, int64_t *pos, void *stream);
 
+/* Capacity-bounded slot assignment, the routing step of the sharded forward that needs no host round trip (static
+ * shapes: the whole forward is capturable in a HIP graph).  Row r carries an int32 key at keys + r * key_stride_bytes
+ * (an expert id; negative = unused row).  hi = key / key_div, lo = key % key_div;
+ *   bucket = hi                                        (key_sub == 0)
+ *   bucket = (lo / key_sub) * key_mul + hi             (key_sub > 0: expert chunk, then destination rank)
+ * dest[r] = bucket * cap + (next free slot of the bucket, one atomic), or -1 for an unused row / an unknown bucket; a
+ * full bucket gives -1 and ORs 1 into *overflow (device int32, sticky -- the caller clears and inspects it).
+ * counts (device int32[buckets]) end as the rows placed per bucket (zeroed first when zero_counts != 0); tags != NULL:
+ * the int32 at tags + dest[r] * tag_stride_bytes receives lo (the payload header the receiving rank routes by).
+ * Slot order inside a bucket is the atomics' arrival order.  No reference counterpart (row 8(e)). */
+int dga_route_slots(const void *keys, int64_t key_stride_bytes, int64_t rows, int key_div, int key_sub, int key_mul,
+                    int buckets, int cap, int32_t *counts, int zero_counts, int64_t *dest, void *tags,
+                    int64_t tag_stride_bytes, int32_t *overflow, void *stream);
+
 /* Indexed row copy on the device: for r in [0, rows):
  *   dst[(dst_index ? dst_index[r] : r) * dst_row_stride .. +row_bytes) = src[(src_index ? src_index[r] : r) * src_row_stride ..)
  * (strides in bytes; index arrays are device int64).  Packs token rows for the dispatch all-to-all, scatters the

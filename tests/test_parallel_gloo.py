@@ -38,7 +38,7 @@ def _world_data():
     return b, sfb, toks
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, chunks=1, capacity_factor=None):
     sys.path.insert(0, str(ROOT))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -46,7 +46,8 @@ def _worker(rank, world, port, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from deepgemm_ascend_amd.parallel import ExpertShardedGroupedGemm
     b, sfb, toks = _world_data()
-    eng = ExpertShardedGroupedGemm(rank, world, G_TOTAL, M_MAX, N, K, torch.device("cpu"), dist, compute=_oracle_compute)
+    eng = ExpertShardedGroupedGemm(rank, world, G_TOTAL, M_MAX, N, K, torch.device("cpu"), dist, compute=_oracle_compute,
+                                   chunks=chunks, capacity_factor=capacity_factor, max_tokens=32)
     gl = G_TOTAL // world
     eng.set_weights(torch.from_numpy(b[rank * gl:(rank + 1) * gl]), torch.from_numpy(sfb[rank * gl:(rank + 1) * gl]))
     q, sf, ids = toks[rank]
@@ -56,7 +57,10 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_expert_sharded_grouped_gemm_world2():
+@pytest.mark.parametrize("chunks,capacity_factor", [(1, None), (2, None), (2, 3.0)])
+def test_expert_sharded_grouped_gemm_world2(chunks, capacity_factor):
+    """Static-shape exchange (fixed-capacity slices, header-routed rows, device-side counts), whole and in two expert
+    chunks, with the provable capacity and with a capacity factor: every token's row bit-equal to the oracle."""
     from oracle import oracle as O
     O.build()
     with socket.socket() as s:
@@ -64,7 +68,7 @@ def test_expert_sharded_grouped_gemm_world2():
         port = s.getsockname()[1]
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, ret, chunks, capacity_factor), nprocs=2, join=True)
     b, sfb, toks = _world_data()
     total = np.zeros(G_TOTAL, np.int64)
     for r in range(2):
@@ -95,7 +99,21 @@ def test_world1_is_exchange_free():
 
 
 def test_capacity_overflow_is_an_error():
+    """Five tokens for an expert with room for four: the device flag is raised, check() (forward() on CPU tensors) throws."""
     from deepgemm_ascend_amd.parallel import ExpertShardedGroupedGemm
-    eng = ExpertShardedGroupedGemm(0, 1, 2, 4, N, K, torch.device("cpu"), None, compute=_oracle_compute)
+    eng = ExpertShardedGroupedGemm(0, 1, 2, 4, N, K, torch.device("cpu"), None, compute=lambda *a: None)
+    eng.set_weights(torch.zeros((2, N, K), dtype=torch.uint8), torch.ones((2, 1, 2)))
     with pytest.raises(ValueError):
-        eng.dispatch(torch.zeros((5, K), dtype=torch.uint8), torch.ones((5, 2)), torch.zeros(5, dtype=torch.int64))
+        eng.forward(torch.zeros((5, K), dtype=torch.uint8), torch.ones((5, 2)), torch.zeros(5, dtype=torch.int64))
+    assert int(eng.masked_m[0]) == 4            # the rows that fitted are in place, masked_m never exceeds m_max
+    eng.forward(torch.zeros((4, K), dtype=torch.uint8), torch.ones((4, 2)), torch.zeros(4, dtype=torch.int64))  # flag was cleared
+
+
+def test_pair_capacity_rule():
+    from deepgemm_ascend_amd.parallel import ExpertShardedGroupedGemm
+    mk = lambda **kw: ExpertShardedGroupedGemm(0, 8, 256, 128, N, K, torch.device("cpu"), None, compute=lambda *a: None, **kw)
+    assert mk(chunks=1).pair_capacity(4096) == 4096               # provable bound: min(T, experts x m_max)
+    assert mk(chunks=2).pair_capacity(4096) == 2048
+    assert mk(chunks=2, capacity_factor=1.25).pair_capacity(4096) == 320   # 1.25 x 4096 / 16 buckets
+    assert mk(chunks=1, capacity_factor=1.25).pair_capacity(4096) == 640
+    assert mk(chunks=1, capacity_factor=100.0).pair_capacity(4096) == 4096
