@@ -22,6 +22,7 @@ from .api import (  # noqa: F401
     get_m_alignment_for_contiguous_layout,
     m_grouped_gemm_fp8_fp8_bf16_nt_contiguous,
     m_grouped_gemm_fp8_fp8_bf16_nt_masked,
+    m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed,
     per_block_cast_to_fp8,
     per_token_cast_to_fp8,
     platform_ascend910b,

@@ -108,7 +108,11 @@ SIGNATURES = {
                                       c_void_p, c_size_t, c_void_p]),
     "dga_route_tokens": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "dga_route_slots": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
-                                c_void_p, c_int64, c_void_p, c_void_p]),
+                                c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                                                  c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
+                                                                  c_int, c_int, c_int, c_int, POINTER(Tiling), c_void_p,
+                                                                  c_size_t, c_void_p]),
     "dga_copy_rows2": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                c_void_p, c_void_p, c_int64, c_void_p]),
     "dga_copy_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p]),

@@ -329,6 +329,41 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_masked(lhs, rhs, out: torch.Tensor, masked_m:
             torch.cuda.current_stream(out.device).synchronize()
 
 
+def m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(a_rows: torch.Tensor, sfa_src: torch.Tensor, sfa_byte_offset: int,
+                                                  sfa_ld: int, rhs, out_rows: torch.Tensor, row_index: torch.Tensor,
+                                                  masked_m: torch.Tensor, m_max: int, expected_m: int = 0,
+                                                  tiling_: Optional[Tiling] = None, sync: bool = False,
+                                                  strict: bool = False) -> None:
+    """Masked grouped GEMM on rows that stay where they are (dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed):
+    row r of group g is row row_index[g * m_max + r] of the flat byte rows `a_rows` [rows, lda] (first K bytes = fp8),
+    its 1x128 scales start at byte sfa_byte_offset of row row_index[...] of `sfa_src` viewed with sfa_ld floats per row
+    (the same payload rows, or a separate [rows, KB] float tensor with offset 0), and its result is written to that row
+    of `out_rows` [rows, ldc] bf16.  b [G,N,K], sfb [G,NB,KB]; only r < masked_m[g] is read or written."""
+    b, sfb = rhs
+    b = _fp8_bytes(b); a_rows = _fp8_bytes(a_rows)
+    _require(a_rows.dim() == 2 and a_rows.stride(1) == 1 and out_rows.dim() == 2 and out_rows.stride(1) == 1, "2-D row tensors")
+    g, n, k = b.shape
+    rows, lda = a_rows.shape[0], a_rows.stride(0)
+    kb, nb = (k + 127) // 128, (n + 127) // 128
+    _require(a_rows.shape[1] >= k and out_rows.shape[1] >= n and out_rows.dtype == torch.bfloat16, "row widths")
+    _require(out_rows.shape[0] >= rows, "out_rows must have a row for every source row")
+    _require(tuple(sfb.shape) == (g, nb, kb) and sfb.dtype == torch.float32, f"sfb must be [{g},{nb},{kb}] f32")
+    _require(row_index.dtype == torch.int64 and row_index.numel() >= g * m_max and row_index.is_contiguous(), "row_index int64[G*m_max]")
+    _require(masked_m.dtype == torch.int32 and tuple(masked_m.shape) == (g,), "masked_m must be int32 [G]")
+    _require(sfa_byte_offset % 4 == 0 and sfa_ld >= kb, "scale rows must be float-aligned")
+    with _device_guard(a_rows, b, sfb, out_rows, row_index, masked_m, sfa_src):
+        if tiling_ is None:
+            tiling_ = tiling(m_max, n, k, groups=g, expected_m=int(expected_m))
+        tiling_ = _with_policy(tiling_, strict)
+        rc = _lib.lib().dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(
+            a_rows.data_ptr(), lda, sfa_src.data_ptr() + sfa_byte_offset, sfa_ld, b.data_ptr(), sfb.data_ptr(),
+            out_rows.data_ptr(), out_rows.stride(0), row_index.data_ptr(), rows, masked_m.data_ptr(), g, m_max, n, k,
+            int(expected_m), ctypes.byref(tiling_), None, 0, _stream_ptr(out_rows))
+        _lib.check(rc, "m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed")
+        if sync:
+            torch.cuda.current_stream(out_rows.device).synchronize()
+
+
 def catlass_dynamic_matmul(self_: torch.Tensor, mat2: torch.Tensor, out: torch.Tensor, sync: bool = False) -> None:
     """The aclnn operator CatlassDynamicMatmul in its own dtypes: out[M,N] = self[M,K] @ mat2[K,N], all fp16 or all bf16.
     mat2 is the logical [K,N] matrix in column-major storage, i.e. the transposed view of a contiguous [N,K] tensor
@@ -435,9 +470,14 @@ def route_tokens(expert_ids: torch.Tensor, groups: int):
 def route_slots(keys: torch.Tensor, key_stride_bytes: int, rows: int, buckets: int, cap: int, counts: torch.Tensor,
                 dest: torch.Tensor, overflow: torch.Tensor, key_div: int = 1, key_sub: int = 0, key_mul: int = 1,
                 zero_counts: bool = True, tags: Optional[torch.Tensor] = None, tag_stride_bytes: int = 0,
-                keys_byte_offset: int = 0, tags_byte_offset: int = 0) -> None:
+                keys_byte_offset: int = 0, tags_byte_offset: int = 0, inverse: Optional[torch.Tensor] = None,
+                inverse_base: int = 0) -> None:
     """Capacity-bounded slot assignment on the device (dga_route_slots): dest[r] = bucket(key_r) * cap + next free slot,
-    -1 for unused rows and for rows of a full bucket (which also raises the sticky device flag `overflow`)."""
+    -1 for unused rows and for rows of a full bucket (which also raises the sticky device flag `overflow`);
+    inverse[dest[r]] = r + inverse_base (the slot -> row table of the indexed grouped GEMM)."""
+    if inverse is not None:
+        _require(inverse.dtype == torch.int64 and inverse.numel() >= buckets * cap and inverse.is_contiguous(),
+                 "inverse int64[buckets * cap]")
     _require(counts.dtype == torch.int32 and counts.numel() >= buckets and counts.is_contiguous(), "counts int32[buckets]")
     _require(dest.dtype == torch.int64 and dest.numel() >= rows and dest.is_contiguous(), "dest int64[rows]")
     _require(overflow.dtype == torch.int32 and overflow.numel() >= 1, "overflow int32[1]")
@@ -445,7 +485,8 @@ def route_slots(keys: torch.Tensor, key_stride_bytes: int, rows: int, buckets: i
         rc = _lib.lib().dga_route_slots(keys.data_ptr() + keys_byte_offset, key_stride_bytes, rows, key_div, key_sub, key_mul,
                                         buckets, cap, counts.data_ptr(), 1 if zero_counts else 0, dest.data_ptr(),
                                         (tags.data_ptr() + tags_byte_offset) if tags is not None else None,
-                                        tag_stride_bytes, overflow.data_ptr(), _stream_ptr(dest))
+                                        tag_stride_bytes, overflow.data_ptr(),
+                                        inverse.data_ptr() if inverse is not None else None, inverse_base, _stream_ptr(dest))
         _lib.check(rc, "route_slots")
 
 

@@ -28,7 +28,7 @@ extern "C" int dga_gemm_fp8_loop_clock(const void *a, const float *sfa, const vo
     if (int rc = dga::record_hip(hipMemsetAsync(scratch, 0, need, s))) return rc;
     for (int i = 0; i < launches; ++i) {                  // the last launch's stamps are the ones read back
         int rc = dga::run_fp8(a, sfa, b, sfb, out, nullptr, nullptr, 1, 1, m, n, k, 0, tiling, nullptr, 0, s,
-                              static_cast<unsigned long long *>(scratch));
+                              static_cast<unsigned long long *>(scratch), nullptr);
         if (rc != DGA_OK) return rc;
     }
     std::vector<unsigned long long> h(waves * 2);

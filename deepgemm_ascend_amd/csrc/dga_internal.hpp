@@ -9,11 +9,19 @@ namespace dga {
 int record_hip(hipError_t e);
 // CUs of the current device (cached); the MI355X constant 256 when no device is visible (host-only tiling calls)
 uint32_t device_cus();
-// the fp8 launcher behind the three C-ABI GEMM entry points (dga_launch.hip); clock_stamps: see dga_diag.hip
+// indexed masked-grouped form: flat row buffers + slot -> row table (dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed)
+struct Fp8Indexed {
+    const int64_t *row_index;   // device int64[groups * m_max]
+    int64_t lda;                // bytes between rows of the flat A source
+    int64_t sfa_ld;             // floats between rows of the scale source
+    int64_t ldc;                // bf16 elements between rows of the flat destination
+    int64_t rows;               // rows of the flat A source (bounds the buffer descriptor)
+};
+// the fp8 launcher behind the C-ABI GEMM entry points (dga_launch.hip); clock_stamps: see dga_diag.hip
 int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, void *out, const int32_t *masked_m,
             const int32_t *m_indices, int b_groups, int groups, int m, int n, int k, int expected_m,
             const dga_tiling_t *tiling, void *workspace, size_t workspace_bytes, hipStream_t stream,
-            unsigned long long *clock_stamps);
+            unsigned long long *clock_stamps, const Fp8Indexed *ix);
 // compiled fp8 kernel menu (dga_launch.hip)
 int variant_count();
 void variant_info(int i, int *bm, int *bn, int *wm, int *wn, int *lds);

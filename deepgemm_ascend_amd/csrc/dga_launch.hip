@@ -110,10 +110,11 @@ static int (*find_clock_build(const Variant *v, int policy))(const GemmParams &,
 // B matrices picked per row block by m_indices.  Otherwise b_groups == groups.
 // clock_stamps != nullptr (dga_gemm_fp8_loop_clock only): run the loop-clock build of the chosen variant, two words per
 // wave go to clock_stamps.
+// ix != nullptr: indexed masked-grouped form (a / sfa / out are flat row buffers addressed through ix->row_index).
 int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, void *out,
             const int32_t *masked_m, const int32_t *m_indices, int b_groups, int groups, int m, int n, int k,
             int expected_m, const dga_tiling_t *tiling, void *workspace, size_t workspace_bytes,
-            hipStream_t stream, unsigned long long *clock_stamps)
+            hipStream_t stream, unsigned long long *clock_stamps, const Fp8Indexed *ix)
 {
     if (m < 0 || n < 0 || k < 0 || groups < 0 || b_groups < 0) return DGA_E_SHAPE;
     if (groups == 0 || m == 0 || n == 0) return DGA_OK;  // empty problem: nothing to write
@@ -158,6 +159,16 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     p.c_gs = static_cast<int64_t>(m) * n;
     p.sfa_gs = static_cast<int64_t>(m) * p.kb_n;
     p.sfb_gs = static_cast<int64_t>(p.nb_n) * p.kb_n;
+    p.sfa_ld = p.kb_n;
+    if (ix) {  // one flat source / destination for every group, rows named by the index
+        if (!ix->row_index || ix->lda < k || ix->ldc < n || ix->sfa_ld < p.kb_n || ix->rows < 0) return DGA_E_SHAPE;
+        p.row_index = ix->row_index;
+        p.lda = ix->lda; p.ldc = ix->ldc; p.sfa_ld = ix->sfa_ld;
+        p.a_gs = p.c_gs = p.sfa_gs = 0;
+        p.a_bytes = ix->rows * ix->lda;
+        // the buffer descriptor addresses the source with 32-bit offsets (and marks "beyond K" with bit 31)
+        if (p.a_bytes >= 0x7FFFFFFFll) return DGA_E_RANGE;
+    }
     p.groups = groups;
     p.splitk = 1;
     p.stamps = clock_stamps;
@@ -188,7 +199,7 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
         ws_used = at + bytes;
         return ws + at;
     };
-    if (k > 0 && (k % 16) != 0) {
+    if (k > 0 && (k % 16) != 0 && !ix) {   // (indexed rows are read where they lie: odd K takes the element-wise kernel)
         const int kp = p.kb_n * 128;
         const int64_t rows_a = static_cast<int64_t>(groups) * m, rows_b = static_cast<int64_t>(b_groups) * n;
         uint8_t *pa = carve(static_cast<size_t>(rows_a) * kp);
@@ -211,7 +222,8 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
 
     // LDS-DMA kernel: 16-byte chunks (K % 16 == 0, 16-byte aligned bases) and 32-bit in-tile byte offsets
     const bool fast_ok = (k % 16 == 0) && k > 0 && ((reinterpret_cast<uintptr_t>(p.a) & 15) == 0) &&
-                         ((reinterpret_cast<uintptr_t>(p.b) & 15) == 0) && (static_cast<int64_t>(k) * 257 < 0x7FFFFFFFll);
+                         ((reinterpret_cast<uintptr_t>(p.b) & 15) == 0) && (p.lda % 16 == 0) &&
+                         (static_cast<int64_t>(p.lda) * 257 < 0x7FFFFFFFll);
     if (!fast_ok) {
         // K not a multiple of the 16-byte DMA chunk and no workspace to pad into (or k == 0): element-wise kernel
         dim3 grid((n + 15) / 16, (m + 15) / 16, groups);
@@ -295,7 +307,7 @@ int dga_gemm_fp8_fp8_bf16_nt(const void *a, const float *sfa, const void *b, con
                              void *stream)
 {
     return dga::run_fp8(a, sfa, b, sfb, out, nullptr, nullptr, 1, 1, m, n, k, 0, tiling, workspace, workspace_bytes,
-                        static_cast<hipStream_t>(stream), nullptr);
+                        static_cast<hipStream_t>(stream), nullptr, nullptr);
 }
 
 int dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked(const void *a, const float *sfa, const void *b, const float *sfb,
@@ -305,7 +317,7 @@ int dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked(const void *a, const float *sfa, c
 {
     if (groups > 0 && m_max > 0 && !masked_m) return DGA_E_NULL;
     return dga::run_fp8(a, sfa, b, sfb, out, masked_m, nullptr, groups, groups, m_max, n, k, expected_m, tiling,
-                        workspace, workspace_bytes, static_cast<hipStream_t>(stream), nullptr);
+                        workspace, workspace_bytes, static_cast<hipStream_t>(stream), nullptr, nullptr);
 }
 
 int dga_m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(const void *a, const float *sfa, const void *b, const float *sfb,
@@ -317,7 +329,20 @@ int dga_m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(const void *a, const float *sf
     if (m_sum > 0 && n > 0 && groups > 0 && !m_indices) return DGA_E_NULL;
     if (groups == 0) return DGA_OK;  // no B matrices: every row is a padding row
     return dga::run_fp8(a, sfa, b, sfb, out, nullptr, m_indices, groups, 1, m_sum, n, k, 0, tiling, workspace,
-                        workspace_bytes, static_cast<hipStream_t>(stream), nullptr);
+                        workspace_bytes, static_cast<hipStream_t>(stream), nullptr, nullptr);
+}
+
+int dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(const void *a, int64_t lda, const float *sfa, int64_t sfa_ld,
+                                                      const void *b, const float *sfb, void *out, int64_t ldc,
+                                                      const int64_t *row_index, int64_t rows, const int32_t *masked_m,
+                                                      int groups, int m_max, int n, int k, int expected_m,
+                                                      const dga_tiling_t *tiling, void *workspace, size_t workspace_bytes,
+                                                      void *stream)
+{
+    if (groups > 0 && m_max > 0 && (!masked_m || !row_index)) return DGA_E_NULL;
+    const dga::Fp8Indexed ix{row_index, lda, sfa_ld, ldc, rows};
+    return dga::run_fp8(a, sfa, b, sfb, out, masked_m, nullptr, groups, groups, m_max, n, k, expected_m, tiling,
+                        workspace, workspace_bytes, static_cast<hipStream_t>(stream), nullptr, &ix);
 }
 
 int dga_last_hip_error(void) { return dga::g_last_hip_error.load(); }

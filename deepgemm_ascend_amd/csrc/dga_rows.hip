@@ -101,10 +101,12 @@ __global__ void __launch_bounds__(256) route_pos_kernel(const int64_t *ids, int6
 //   key_sub  > 0:  bucket = ((key % key_div) / key_sub) * key_mul + key / key_div     (chunk-major, then rank)
 // Source side of the dispatch: key_div = experts per rank, bucket = (chunk, destination rank), cap = rows per pair and
 // chunk, tag (the expert's index on its owner) is written into the payload row's header.  Receiving side: key_div = 1,
-// bucket = local expert, cap = m_max, dest = slot in the masked [G_local, m_max] layout, counts = masked_m.
+// bucket = local expert, cap = m_max, dest = slot in the masked [G_local, m_max] layout, counts = masked_m;
+// inverse[dest] = r + inverse_base is the slot -> row table the indexed GEMM reads the rows through.
 __global__ void __launch_bounds__(256) route_slots_kernel(const uint8_t *keys, int64_t key_stride, int64_t rows, int key_div,
                                                           int key_sub, int key_mul, int buckets, int cap, int32_t *counts,
-                                                          int64_t *dest, uint8_t *tags, int64_t tag_stride, int32_t *overflow)
+                                                          int64_t *dest, uint8_t *tags, int64_t tag_stride, int32_t *overflow,
+                                                          int64_t *inverse, int64_t inverse_base)
 {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= rows) return;
@@ -118,6 +120,7 @@ __global__ void __launch_bounds__(256) route_slots_kernel(const uint8_t *keys, i
             if (slot < cap) {
                 d = (int64_t)bucket * cap + slot;
                 if (tags) *(int32_t *)(tags + d * tag_stride) = lo;
+                if (inverse) inverse[d] = r + inverse_base;
             } else {
                 atomicSub(counts + bucket, 1);   // masked_m must not exceed m_max
                 atomicOr(overflow, 1);
@@ -131,7 +134,8 @@ __global__ void __launch_bounds__(256) route_slots_kernel(const uint8_t *keys, i
 
 extern "C" int dga_route_slots(const void *keys, int64_t key_stride_bytes, int64_t rows, int key_div, int key_sub, int key_mul,
                                int buckets, int cap, int32_t *counts, int zero_counts, int64_t *dest, void *tags,
-                               int64_t tag_stride_bytes, int32_t *overflow, void *stream)
+                               int64_t tag_stride_bytes, int32_t *overflow, int64_t *inverse, int64_t inverse_base,
+                               void *stream)
 {
     if (rows < 0 || key_div < 1 || key_sub < 0 || buckets < 0 || cap < 0 || key_stride_bytes < 4) return DGA_E_SHAPE;
     if (key_sub > 0 && key_mul < 1) return DGA_E_SHAPE;
@@ -146,7 +150,7 @@ extern "C" int dga_route_slots(const void *keys, int64_t key_stride_bytes, int64
     if (tags && ((reinterpret_cast<uintptr_t>(tags) | static_cast<uintptr_t>(tag_stride_bytes)) & 3)) return DGA_E_ALIGN;
     hipLaunchKernelGGL(dga::route_slots_kernel, dim3(static_cast<unsigned>((rows + 255) / 256)), dim3(256), 0, st,
                        static_cast<const uint8_t *>(keys), key_stride_bytes, rows, key_div, key_sub, key_mul, buckets, cap,
-                       counts, dest, static_cast<uint8_t *>(tags), tag_stride_bytes, overflow);
+                       counts, dest, static_cast<uint8_t *>(tags), tag_stride_bytes, overflow, inverse, inverse_base);
     return dga::record_hip(hipGetLastError());
 }
 

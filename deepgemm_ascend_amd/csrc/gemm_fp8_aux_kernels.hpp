@@ -33,9 +33,10 @@ __global__ void __launch_bounds__(256) gemm_fp8_blockscaled_nt_generic_kernel(co
         bg = p.m_indices[m];
         if (bg < 0 || bg >= p.b_groups) return;
     }
-    const uint8_t *ar = p.a + (int64_t)g * p.a_gs + (int64_t)m * p.lda;
+    const int64_t mrow = p.row_index ? p.row_index[(int64_t)g * p.m + m] : (int64_t)m;   // indexed: row of the flat buffers
+    const uint8_t *ar = p.a + (int64_t)g * p.a_gs + mrow * p.lda;
     const uint8_t *br = p.b + (int64_t)bg * p.b_gs + (int64_t)n * p.ldb;
-    const float *sa = p.sfa + (int64_t)g * p.sfa_gs + (int64_t)m * p.kb_n;
+    const float *sa = p.sfa + (int64_t)g * p.sfa_gs + mrow * p.sfa_ld;
     const float *sb = p.sfb + (int64_t)bg * p.sfb_gs + (int64_t)(n / 128) * p.kb_n;
     float acc = 0.f;
     for (int kb = 0; kb < p.kb_n; ++kb) {
@@ -45,7 +46,7 @@ __global__ void __launch_bounds__(256) gemm_fp8_blockscaled_nt_generic_kernel(co
         acc += part * (sa[kb] * sb[kb]);
     }
     const v2bf h = __builtin_convertvector(v2f{acc, 0.f}, v2bf);
-    p.out[(int64_t)g * p.c_gs + (int64_t)m * p.ldc + n] = (uint16_t)(__builtin_bit_cast(uint32_t, h) & 0xFFFFu);
+    p.out[(int64_t)g * p.c_gs + mrow * p.ldc + n] = (uint16_t)(__builtin_bit_cast(uint32_t, h) & 0xFFFFu);
 }
 
 // split-K combine: out[m][n] = bf16( sum_s slab[s][m][n] ), s ascending (= k ascending; deterministic).  The fp32

@@ -34,6 +34,11 @@ struct GemmParams {
     uint16_t *out;         // [G][m_rows][ldc] bf16 bits
     const int32_t *masked_m;  // grouped: device int32[G]; dense: nullptr
     const int32_t *m_indices;  // contiguous-grouped: device int32[m], the B group of every row (-1 = skip); else nullptr
+    const int64_t *row_index;  // indexed masked-grouped: device int64[groups * m]; row r of group g is row row_index[g*m + r]
+                               // of ONE flat source / destination (a, sfa and out then have group stride 0): the kernel
+                               // gathers token rows where they lie and scatters the result rows in place of a pack / unpack
+    int64_t sfa_ld;            // floats between consecutive sfa rows (kb_n unless the scales ride inside payload rows)
+    int64_t a_bytes;           // indexed: byte extent of the flat A source (bounds the buffer descriptor)
     int b_groups;              // contiguous-grouped: number of B groups (bounds the device-side index)
     int m;                 // dense: M; grouped: m_max (rows allocated per group)
     int n, k, kb_n, nb_n;
@@ -196,6 +201,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
     const int kb_begin = p.splitk > 1 ? split * p.kb_per_split : 0;
     const int kb_end = p.splitk > 1 ? min(p.kb_n, kb_begin + p.kb_per_split) : p.kb_n;
 
+    const int64_t *ridx = p.row_index ? p.row_index + (int64_t)g * p.m : nullptr;   // slot -> row of the flat buffers
     const uint8_t *A = p.a + (int64_t)g * p.a_gs;
     const uint8_t *B = p.b + (int64_t)bg * p.b_gs;
     const float *SFA = p.sfa + (int64_t)g * p.sfa_gs;
@@ -217,14 +223,15 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
 #pragma unroll
     for (int it = 0; it < Cfg::A_ITERS; ++it) {
         const int row = (it * DNT + dtid) >> 3;
-        a_voff[it] = (uint32_t)min(row, M - 1 - m0) * (uint32_t)p.lda + a_col;
+        const int rr = min(row, M - 1 - m0);
+        a_voff[it] = (ridx ? (uint32_t)ridx[m0 + rr] : (uint32_t)rr) * (uint32_t)p.lda + a_col;
     }
 #pragma unroll
     for (int it = 0; it < Cfg::B_ITERS; ++it) {
         const int row = (it * DNT + dtid) >> 3;
         b_voff[it] = (uint32_t)min(row, p.n - 1 - n0) * (uint32_t)p.ldb + b_col;
     }
-    const v4i a_rsrc = make_rsrc(A + (int64_t)m0 * p.lda, (int64_t)(M - m0) * p.lda);
+    const v4i a_rsrc = ridx ? make_rsrc(A, p.a_bytes) : make_rsrc(A + (int64_t)m0 * p.lda, (int64_t)(M - m0) * p.lda);
     const v4i b_rsrc = make_rsrc(B + (int64_t)n0 * p.ldb, (int64_t)(p.n - n0) * p.ldb);
     // scale slots: [0,BM) = sfa rows of this tile, [BM, BM+8) = sfb blocks of this tile, rest = padding
     const float *sc_src[Cfg::SC_ITERS];
@@ -232,7 +239,8 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
     for (int it = 0; it < Cfg::SC_ITERS; ++it) {
         const int s = it * DNT + dtid;
         if (s < BM) {
-            sc_src[it] = SFA + (int64_t)min(m0 + s, M - 1) * p.kb_n;
+            const int mr = min(m0 + s, M - 1);
+            sc_src[it] = SFA + (ridx ? ridx[mr] : (int64_t)mr) * p.sfa_ld;
         } else {
             const int nb = min(n0 / 128 + min(s - BM, 7), p.nb_n - 1);
             sc_src[it] = SFB + (int64_t)nb * p.kb_n;
@@ -318,7 +326,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
             const int m = m_row + mt * 16;
             if (m >= M) continue;
             if (p.m_indices && p.m_indices[m] != bg) continue;  // a row of another group / a padding row: untouched
-            uint16_t *crow = C + (int64_t)m * p.ldc;
+            uint16_t *crow = C + (ridx ? ridx[m] : (int64_t)m) * p.ldc;
 #pragma unroll
             for (int j = 0; j < TN / 2; ++j) {
                 const int n = n_base + 32 * j;

@@ -58,6 +58,7 @@ __global__ void __launch_bounds__(256) gemm_fp8_strict_nt_kernel(const GemmParam
         bg = p.m_indices[m0];
         if (bg < 0 || bg >= p.b_groups) return;
     }
+    const int64_t *ridx = p.row_index ? p.row_index + (int64_t)g * p.m : nullptr;   // slot -> row of the flat buffers
     const uint8_t *A = p.a + (int64_t)g * p.a_gs;
     const uint8_t *B = p.b + (int64_t)bg * p.b_gs;
     const float *SFA = p.sfa + (int64_t)g * p.sfa_gs;
@@ -84,14 +85,18 @@ __global__ void __launch_bounds__(256) gemm_fp8_strict_nt_kernel(const GemmParam
 #pragma unroll
         for (int it = 0; it < A_CH; ++it) {
             const int c = it * 256 + tid, row = c >> 3, ch = c & 7;
-            ra[it] = fetch_chunk(A + (int64_t)(m0 + min(row, M - 1 - m0)) * p.lda, k0 + ch * 16);
+            const int mr = m0 + min(row, M - 1 - m0);
+            ra[it] = fetch_chunk(A + (ridx ? ridx[mr] : (int64_t)mr) * p.lda, k0 + ch * 16);
         }
 #pragma unroll
         for (int it = 0; it < B_CH; ++it) {
             const int c = it * 256 + tid, row = c >> 3, ch = c & 7;
             rb[it] = fetch_chunk(B + (int64_t)(n0 + min(row, p.n - 1 - n0)) * p.ldb, k0 + ch * 16);
         }
-        if (tid < BM) rs = SFA[(int64_t)min(m0 + tid, M - 1) * p.kb_n + kb];
+        if (tid < BM) {
+            const int mr = min(m0 + tid, M - 1);
+            rs = SFA[(ridx ? ridx[mr] : (int64_t)mr) * p.sfa_ld + kb];
+        }
         else if (tid == BM) rs = SFB[kb];   // BM <= 128 < 256 threads
     };
     auto stage = [&]() {
@@ -179,7 +184,7 @@ __global__ void __launch_bounds__(256) gemm_fp8_strict_nt_kernel(const GemmParam
         const int m = m0 + a_row + 16 * mt;
         if (m >= M) continue;
         if (p.m_indices && p.m_indices[m] != bg) continue;
-        uint16_t *crow = C + (int64_t)m * p.ldc;
+        uint16_t *crow = C + (ridx ? ridx[m] : (int64_t)m) * p.ldc;
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt) {
             const int n = n0 + wn * 64 + 16 * nt + 4 * q;

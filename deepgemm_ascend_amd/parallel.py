@@ -37,6 +37,11 @@ def _default_compute(a, sfa, b, sfb, out, masked_m, expected_m):
     api.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), out, masked_m, expected_m)
 
 
+def _default_compute_strict(a, sfa, b, sfb, out, masked_m, expected_m, strict):
+    from . import api
+    api.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), out, masked_m, expected_m, strict=strict)
+
+
 def _rows(dst, src, dst_index=None, src_index=None, row_bytes=None, dst_off=0, src_off=0):
     """Indexed row copy on byte views: the HIP kernel (dga_copy_rows) for device tensors; torch indexing for the CPU
     tensors of the gloo routing tests (where nothing in this module touches a GPU).  Negative indices are skipped."""
@@ -64,14 +69,15 @@ def _rows2(dst0, src0, bytes0, dst1, src1, bytes1, dst_index, dst1_off=0, src1_o
 
 
 def _route_slots(keys, key_stride, key_off, rows, buckets, cap, counts, dest, overflow, key_div=1, key_sub=0, key_mul=1,
-                 zero_counts=True, tags=None, tag_stride=0, tag_off=0):
+                 zero_counts=True, tags=None, tag_stride=0, tag_off=0, inverse=None, inverse_base=0):
     """dga_route_slots on the device; the same assignment in numpy for the CPU tensors of the gloo tests."""
     if dest.is_cuda:
         from . import api
         api.route_slots(keys, key_stride, rows, buckets, cap, counts, dest, overflow, key_div=key_div, key_sub=key_sub,
                         key_mul=key_mul, zero_counts=zero_counts, tags=tags, tag_stride_bytes=tag_stride,
-                        keys_byte_offset=key_off, tags_byte_offset=tag_off)
+                        keys_byte_offset=key_off, tags_byte_offset=tag_off, inverse=inverse, inverse_base=inverse_base)
         return
+    assert inverse is None, "the indexed GEMM is a device path"
     kb = keys.contiguous().view(torch.uint8).reshape(-1).numpy()
     key = np.array([np.frombuffer(kb[key_off + r * key_stride: key_off + r * key_stride + 4].tobytes(), np.int32)[0]
                     for r in range(rows)], np.int64)
@@ -101,7 +107,8 @@ def _route_slots(keys, key_stride, key_off, rows, buckets, cap, counts, dest, ov
 class ExpertShardedGroupedGemm:
     def __init__(self, rank: int, world: int, groups_total: int, m_max: int, n: int, k: int, device,
                  dist=None, compute: Optional[Callable] = None, chunks: Optional[int] = None,
-                 capacity_factor: Optional[float] = None, max_tokens: Optional[int] = None):
+                 capacity_factor: Optional[float] = None, max_tokens: Optional[int] = None, strict: bool = False,
+                 indexed: Optional[bool] = None):
         assert groups_total % world == 0, "experts must divide evenly over ranks"
         self.rank, self.world, self.dist = rank, world, dist
         self.G, self.Gl = groups_total, groups_total // world
@@ -111,7 +118,13 @@ class ExpertShardedGroupedGemm:
         self.hdr = k + 4 * self.kb                      # byte offset of the 4-byte header in a payload row
         self.row_bytes = (self.hdr + 4 + 15) // 16 * 16
         self.device = torch.device(device)
-        self.compute = compute or _default_compute
+        self.strict = strict
+        # indexed (device default): the grouped GEMM gathers token rows where they lie (the caller's tensors at world 1,
+        # the receive buffer otherwise) and scatters result rows straight into the buffer that travels back -- no
+        # pack / unpack copy either side of it.  An injected `compute` (the CPU tests) works on the packed masked layout.
+        self.indexed = (compute is None and self.device.type == "cuda") if indexed is None else bool(indexed)
+        assert not (self.indexed and compute is not None), "an injected compute takes the packed layout"
+        self.compute = compute or (lambda a, sfa, b, sfb, out, mm, em: _default_compute_strict(a, sfa, b, sfb, out, mm, em, strict))
         if chunks is None:
             chunks = 2 if (world > 1 and self.Gl % 2 == 0 and self.Gl >= 8) else 1
         assert self.Gl % chunks == 0, "chunks must divide the experts per rank"
@@ -156,7 +169,9 @@ class ExpertShardedGroupedGemm:
         dev, w, ch = self.device, self.world, self.chunks
         self._T = self.max_tokens
         self.slot = torch.empty((max(self.max_tokens, 1),), dtype=torch.int64, device=dev)
+        self.row_of_slot = torch.zeros((self.Gl * self.m_max,), dtype=torch.int64, device=dev) if self.indexed else None
         if w == 1:
+            self.indexed = self.indexed and self.max_tokens * self.k < 2 ** 31 - 1    # 32-bit offsets in the tile loads
             return
         C = self.C = self.pair_capacity(self.max_tokens)
         rows = ch * w * C
@@ -166,6 +181,7 @@ class ExpertShardedGroupedGemm:
         self.rdest = torch.empty((rows,), dtype=torch.int64, device=dev)
         self.osend = torch.zeros((rows, self.n), dtype=torch.bfloat16, device=dev)
         self.oback = torch.zeros((rows, self.n), dtype=torch.bfloat16, device=dev)
+        self.indexed = self.indexed and rows * self.row_bytes < 2 ** 31 - 1
         if dev.type == "cuda" and self._side is None:
             self._side = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
 
@@ -179,6 +195,17 @@ class ExpertShardedGroupedGemm:
     # ------------------------------------------------------------------ world 1: route straight into the masked layout
     def _forward_local(self, tok_q, tok_sf, expert_ids, expected_m, marks):
         T = tok_q.shape[0]
+        if self.indexed:
+            from . import api
+            _route_slots(expert_ids, 8, 0, T, self.Gl, self.m_max, self.masked_m, self.slot, self.overflow,
+                         inverse=self.row_of_slot)
+            marks("route")
+            res = torch.empty((T, self.n), dtype=self.out.dtype, device=self.out.device)
+            api.m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(tok_q, tok_sf, 0, self.kb, (self.b, self.sfb), res,
+                                                              self.row_of_slot, self.masked_m, self.m_max,
+                                                              expected_m or self.m_max, strict=self.strict)
+            marks("gemm")
+            return res
         flat_a = self.a.view(self.Gl * self.m_max, self.k)
         flat_sfa = self.sfa.view(self.Gl * self.m_max, self.kb).view(torch.uint8)
         _route_slots(expert_ids, 8, 0, T, self.Gl, self.m_max, self.masked_m, self.slot, self.overflow)
@@ -223,8 +250,11 @@ class ExpertShardedGroupedGemm:
                 sl = slice(c * per, (c + 1) * per)
                 self.dist.all_to_all_single(self.recv[sl], self.send[sl])
                 _route_slots(self.recv[sl], self.row_bytes, self.hdr, per, self.Gl, self.m_max, self.masked_m,
-                             self.rdest[sl], self.overflow, zero_counts=False)
-                _rows2(flat_a, self.recv[sl], self.k, flat_sfa, self.recv[sl], 4 * self.kb, self.rdest[sl], src1_off=self.k)
+                             self.rdest[sl], self.overflow, zero_counts=False, inverse=self.row_of_slot,
+                             inverse_base=c * per)
+                if not self.indexed:
+                    _rows2(flat_a, self.recv[sl], self.k, flat_sfa, self.recv[sl], 4 * self.kb, self.rdest[sl],
+                           src1_off=self.k)
                 if cuda and overlap:
                     ev_d.append(torch.cuda.Event()); ev_d[-1].record(s_disp)
         marks("dispatch")
@@ -232,8 +262,15 @@ class ExpertShardedGroupedGemm:
             if cuda and overlap:
                 main.wait_event(ev_d[c])
             g0, g1 = c * self.Glc, (c + 1) * self.Glc
-            self.compute(self.a[g0:g1], self.sfa[g0:g1], self.b[g0:g1], self.sfb[g0:g1], self.out[g0:g1],
-                         self.masked_m[g0:g1], expected_m or self.m_max)
+            if self.indexed:    # rows read from the receive buffer, results written into the buffer that travels back
+                from . import api
+                api.m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(
+                    self.recv, self.recv, self.k, self.row_bytes // 4, (self.b[g0:g1], self.sfb[g0:g1]), self.osend,
+                    self.row_of_slot[g0 * self.m_max:g1 * self.m_max], self.masked_m[g0:g1], self.m_max,
+                    expected_m or self.m_max, strict=self.strict)
+            else:
+                self.compute(self.a[g0:g1], self.sfa[g0:g1], self.b[g0:g1], self.sfb[g0:g1], self.out[g0:g1],
+                             self.masked_m[g0:g1], expected_m or self.m_max)
             if cuda and overlap:
                 ev_g.append(torch.cuda.Event()); ev_g[-1].record(main)
         marks("gemm")
@@ -242,7 +279,8 @@ class ExpertShardedGroupedGemm:
                 if cuda and overlap:
                     s_comb.wait_event(ev_g[c])
                 sl = slice(c * per, (c + 1) * per)
-                _rows(self.osend[sl].view(torch.uint8), flat_out, src_index=self.rdest[sl], row_bytes=2 * self.n)
+                if not self.indexed:
+                    _rows(self.osend[sl].view(torch.uint8), flat_out, src_index=self.rdest[sl], row_bytes=2 * self.n)
                 self.dist.all_to_all_single(self.oback[sl], self.osend[sl])
                 if cuda and overlap:
                     ev_c.append(torch.cuda.Event()); ev_c[-1].record(s_comb)
@@ -364,7 +402,12 @@ def bench_grouped(rank, world, dist, steps=10, warmup=3, groups_total=256, m_max
     for _ in range(3):
         eng.forward(tok_q, tok_sf, expert_ids, phase_us=phases)
     phases = {kk: round(v / 3, 1) for kk, v in phases.items()}
-    # GEMM only (activations already in the masked layout on the owning rank)
+    # GEMM only (activations already in the masked layout on the owning rank; random bytes there -- the indexed forward
+    # never fills that layout, and zeros would run at a higher clock than real data)
+    eng.a.copy_(_rand_fp8(tuple(eng.a.shape), g, dev))
+    eng.sfa.copy_(torch.rand(tuple(eng.sfa.shape), device=dev, generator=g) + 0.5)
+    for _ in range(warmup):
+        eng.run_local()
     ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
     sync()
     t0 = time.perf_counter()
@@ -392,7 +435,7 @@ def bench_grouped(rank, world, dist, steps=10, warmup=3, groups_total=256, m_max
         "tok_per_s_with_alltoall": round(total_tokens / e2e, 1),
         "ms_gemm": round(gemm * 1e3, 4), "ms_end_to_end": round(e2e * 1e3, 4),
         "ms_end_to_end_graph": round(e2e_graph * 1e3, 4) if e2e_graph else None,
-        "phase_us": phases, "chunks": eng.chunks,
+        "phase_us": phases, "chunks": eng.chunks, "indexed_rows": bool(eng.indexed),
         "pair_capacity_rows": getattr(eng, "C", None), "capacity_factor": capacity_factor if world > 1 else None,
         "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (kernel_us * 1e-6) / 1e9, 1), "peak": 8000.0,
                      "unit": "GB/s", "frac": round(alg_bytes / (kernel_us * 1e-6) / 1e9 / 8000.0, 4),

@@ -178,6 +178,20 @@ int dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked(const void *a, const float *sfa, c
                                               int k, int expected_m, const dga_tiling_t *tiling, void *workspace,
                                               size_t workspace_bytes, void *stream);
 
+/* The masked grouped GEMM on rows that stay where they are: instead of a packed [G, m_max, K] activation tensor, row r of
+ * group g is row row_index[g * m_max + r] of ONE flat source -- a (rows x lda bytes, lda % 16 == 0, rows * lda < 2 GiB),
+ * its scales at sfa + row * sfa_ld floats (they may ride inside the same payload rows) -- and its result goes to row
+ * row_index[g * m_max + r] of the flat destination out (ldc bf16 elements per row).  Only entries r < masked_m[g] of the
+ * table are read.  This removes the pack / unpack copies either side of the GEMM in the expert-sharded forward (the
+ * tokens are gathered by the kernel's own tile loads and scattered by its stores); dga_route_slots builds the table.
+ * K % 16 != 0 runs the element-wise kernel.  No reference counterpart (row 8(e)). */
+int dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(const void *a, int64_t lda, const float *sfa, int64_t sfa_ld,
+                                                      const void *b, const float *sfb, void *out, int64_t ldc,
+                                                      const int64_t *row_index, int64_t rows, const int32_t *masked_m,
+                                                      int groups, int m_max, int n, int k, int expected_m,
+                                                      const dga_tiling_t *tiling, void *workspace, size_t workspace_bytes,
+                                                      void *stream);
+
 /* The aclnn operator in its own dtypes (CatlassDynamicMatmul, op_host/catlass_dynamic_matmul.cpp:50-80; device entry
  * op_kernel/catlass_dynamic_matmul.cpp:16-45): out[M,N] = self[M,K] . mat2, self row-major, mat2 logical [K,N] stored
  * column-major = physical [N,K] (NT, catlass_dynamic_matmul_tiling.cpp:83-84), all three of `dtype` (DGA_DT_FP16 or
@@ -259,10 +273,12 @@ int dga_route_tokens(const int64_t *expert_ids, int64_t tokens, int groups, int6
  * full bucket gives -1 and ORs 1 into *overflow (device int32, sticky -- the caller clears and inspects it).
  * counts (device int32[buckets]) end as the rows placed per bucket (zeroed first when zero_counts != 0); tags != NULL:
  * the int32 at tags + dest[r] * tag_stride_bytes receives lo (the payload header the receiving rank routes by).
- * Slot order inside a bucket is the atomics' arrival order.  No reference counterpart (row 8(e)). */
+ * Slot order inside a bucket is the atomics' arrival order.  No reference counterpart (row 8(e)).
+ * inverse != NULL (device int64[buckets * cap]): inverse[dest[r]] = r + inverse_base, the slot -> row table of
+ * dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed. */
 int dga_route_slots(const void *keys, int64_t key_stride_bytes, int64_t rows, int key_div, int key_sub, int key_mul,
                     int buckets, int cap, int32_t *counts, int zero_counts, int64_t *dest, void *tags,
-                    int64_t tag_stride_bytes, int32_t *overflow, void *stream);
+                    int64_t tag_stride_bytes, int32_t *overflow, int64_t *inverse, int64_t inverse_base, void *stream);
 
 /* Indexed row copy on the device: for r in [0, rows):
  *   dst[(dst_index ? dst_index[r] : r) * dst_row_stride .. +row_bytes) = src[(src_index ? src_index[r] : r) * src_row_stride ..)

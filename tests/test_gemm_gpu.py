@@ -115,8 +115,8 @@ def test_empty_problem_is_a_noop(dga):
 
 
 def test_linearity_in_scales_full_size(dga, oracle):
-    """Size-independent property at BASELINE config 2 (4096^3): doubling sfa doubles the fp32 sum exactly,
-    so the bf16 outputs differ by exactly one exponent step; and a column-block of B scaled by 4 likewise."""
+    """Size-independent property at BASELINE config 2 (4096^3), arbitrary bit patterns: doubling sfa doubles the fp32
+    sum exactly, so the bf16 outputs differ by exactly one exponent step."""
     m = n = k = 4096
     g = torch.Generator(device="cuda").manual_seed(0)
     a = torch.randint(0, 256, (m, k), dtype=torch.uint8, device="cuda", generator=g)
@@ -130,12 +130,25 @@ def test_linearity_in_scales_full_size(dga, oracle):
     dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), o1)
     dga.gemm_fp8_fp8_bf16_nt((a, sfa * 2), (b, sfb), o2, sync=True)
     assert torch.equal(o1.float() * 2, o2.float())
-    # spot-check 64 rows against the oracle
-    rows = np.arange(0, m, 64)
-    an, bn = a.cpu().numpy(), b.cpu().numpy()
-    want = oracle.gemm_fp8_fp8_bf16_nt(an[rows], sfa.cpu().numpy()[rows], bn, sfb.cpu().numpy(), threads=16)
-    got = o1[torch.from_numpy(rows).cuda()].view(torch.int16).cpu().numpy().view(np.uint16)
-    oracle.assert_parity(got, want, an[rows], sfa.cpu().numpy()[rows], bn, sfb.cpu().numpy(), eps=2.0 ** -12, frac=1e-2)
+
+
+@pytest.mark.parametrize("workload", ["dense_4096", "dsv3_prefill"])
+def test_baseline_configs_on_their_own_recipe(dga, oracle, workload):
+    """BASELINE configs[1] (4096^3) and configs[2] (M=4096, K=7168, N=2048) on the inputs bench.py times -- amax-quantised
+    normal data -- against the CPU oracle: 256 sampled rows, every column, eps = 2^-15, at most 2e-3 beyond 2 ulp."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+    m, n, k = bench.WORKLOADS[workload]
+    a, sfa, b, sfb = bench.make_dense_inputs(m, n, k, seed=0)
+    out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, sync=True)
+    rows = np.arange(3, m, 16)[:256]
+    an, san, bn, sbn = a.cpu().numpy(), sfa.cpu().numpy(), b.cpu().numpy(), sfb.cpu().numpy()
+    want = oracle.gemm_fp8_fp8_bf16_nt(an[rows], san[rows], bn, sbn, threads=16)
+    got = out[torch.from_numpy(rows).cuda()].view(torch.int16).cpu().numpy().view(np.uint16)
+    oracle.assert_parity(got, want, an[rows], san[rows], bn, sbn, eps=2.0 ** -15, frac=2e-3)
 
 
 @pytest.mark.parametrize("m,n,k,split", [(8, 1024, 4096, 4), (64, 512, 2048, 3), (100, 300, 1536, 5), (16, 128, 1024, 8)])

@@ -12,7 +12,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-G_TOTAL, M_MAX, N, K = 8, 32, 256, 512
+G_TOTAL, M_MAX, N, K = 8, 64, 256, 512
 
 
 def _strict_compute(a, sfa, b, sfb, out, masked_m, expected_m):
@@ -46,11 +46,21 @@ def _bits(t):
     return t.view(torch.int16).cpu().numpy().view(np.uint16)
 
 
-def test_world1_eager_and_graph(dga, oracle):
+def _engine(rank, world, dist, indexed, **kw):
+    """indexed: the GEMM gathers / scatters rows itself (strict policy); packed: copies into the masked layout first."""
     from deepgemm_ascend_amd.parallel import ExpertShardedGroupedGemm
+    if indexed:
+        return ExpertShardedGroupedGemm(rank, world, G_TOTAL, M_MAX, N, K, "cuda", dist, strict=True, max_tokens=128, **kw)
+    return ExpertShardedGroupedGemm(rank, world, G_TOTAL, M_MAX, N, K, "cuda", dist, compute=_strict_compute,
+                                    max_tokens=128, **kw)
+
+
+@pytest.mark.parametrize("indexed", [True, False])
+def test_world1_eager_and_graph(dga, oracle, indexed):
     b, sfb, toks = _data(1)
     q, sf, ids = toks[0]
-    eng = ExpertShardedGroupedGemm(0, 1, G_TOTAL, M_MAX, N, K, "cuda", None, compute=_strict_compute, max_tokens=128)
+    eng = _engine(0, 1, None, indexed)
+    assert eng.indexed == indexed
     eng.set_weights(torch.from_numpy(b).cuda(), torch.from_numpy(sfb).cuda())
     tq, tsf, tid = torch.from_numpy(q).cuda(), torch.from_numpy(sf).cuda(), torch.from_numpy(ids).cuda()
     want = _want(oracle, q, sf, ids, b, sfb)
@@ -82,7 +92,7 @@ def test_phase_timings_are_reported(dga):
     eng.set_weights(torch.from_numpy(b).cuda(), torch.from_numpy(sfb).cuda())
     ph = {}
     eng.forward(torch.from_numpy(q).cuda(), torch.from_numpy(sf).cuda(), torch.from_numpy(ids).cuda(), phase_us=ph)
-    assert set(ph) == {"route", "pack", "gemm", "unpack"} and all(v >= 0 for v in ph.values())
+    assert set(ph) == {"route", "gemm"} and all(v >= 0 for v in ph.values())     # indexed: no pack / unpack phase
 
 
 class _FakeDist:
@@ -102,9 +112,9 @@ class _FakeDist:
         self.barrier.wait()
 
 
-@pytest.mark.parametrize("chunks,capacity_factor", [(1, None), (2, None), (2, 2.5)])
-def test_world2_emulated_on_one_device(dga, oracle, chunks, capacity_factor):
-    from deepgemm_ascend_amd.parallel import ExpertShardedGroupedGemm
+@pytest.mark.parametrize("chunks,capacity_factor,indexed", [(1, None, True), (2, None, True), (2, 2.5, True),
+                                                            (2, None, False)])
+def test_world2_emulated_on_one_device(dga, oracle, chunks, capacity_factor, indexed):
     world = 2
     b, sfb, toks = _data(world)
     gl = G_TOTAL // world
@@ -114,9 +124,8 @@ def test_world2_emulated_on_one_device(dga, oracle, chunks, capacity_factor):
     def run(rank):
         try:
             torch.cuda.set_device(0)
-            eng = ExpertShardedGroupedGemm(rank, world, G_TOTAL, M_MAX, N, K, "cuda", _FakeDist(rank, world, box, barrier),
-                                           compute=_strict_compute, chunks=chunks, capacity_factor=capacity_factor,
-                                           max_tokens=128)
+            eng = _engine(rank, world, _FakeDist(rank, world, box, barrier), indexed, chunks=chunks,
+                          capacity_factor=capacity_factor)
             eng.set_weights(torch.from_numpy(b[rank * gl:(rank + 1) * gl]).cuda(),
                             torch.from_numpy(sfb[rank * gl:(rank + 1) * gl]).cuda())
             q, sf, ids = toks[rank]
@@ -138,3 +147,46 @@ def test_world2_emulated_on_one_device(dga, oracle, chunks, capacity_factor):
         total += np.bincount(ids, minlength=G_TOTAL)
         assert np.array_equal(results[r][0], _want(oracle, q, sf, ids, b, sfb)), f"rank {r}"
     assert np.array_equal(np.concatenate([results[0][1], results[1][1]]), total.astype(np.int32))
+
+
+@pytest.mark.parametrize("strict", [False, True])
+def test_indexed_gemm_equals_packed_gemm(dga, strict):
+    """dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed on payload rows (fp8 bytes, scales and a header in one row,
+    rows in scrambled order, BASELINE configs[3] K and N) writes, bit for bit, what the packed masked call computes on
+    the same rows copied into the [G, m_max, K] layout; rows it does not own stay untouched."""
+    g, m_max, n, k = 6, 128, 2048, 7168
+    kb = k // 128
+    row_bytes = k + 4 * kb + 16
+    rng = np.random.default_rng(7)
+    masked = np.array([128, 0, 37, 128, 1, 100], np.int32)
+    rows = int(masked.sum()) + 11                                    # 11 rows belong to nobody
+    payload = rng.integers(0, 120, size=(rows, row_bytes), dtype=np.uint8)
+    sf = rng.uniform(0.5, 1.5, size=(rows, kb)).astype(np.float32)
+    payload[:, k:k + 4 * kb] = sf.view(np.uint8)
+    b = rng.integers(0, 120, size=(g, n, k), dtype=np.uint8)
+    sfb = rng.uniform(0.5, 1.5, size=(g, n // 128, kb)).astype(np.float32)
+    perm = rng.permutation(rows)
+    row_index = np.full((g, m_max), -1, np.int64)
+    at = 0
+    for i in range(g):
+        row_index[i, :masked[i]] = perm[at:at + masked[i]]
+        at += masked[i]
+    a_packed = np.zeros((g, m_max, k), np.uint8); sfa_packed = np.ones((g, m_max, kb), np.float32)
+    for i in range(g):
+        a_packed[i, :masked[i]] = payload[row_index[i, :masked[i]], :k]
+        sfa_packed[i, :masked[i]] = sf[row_index[i, :masked[i]]]
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    tb, tsfb, tm = dev(b), dev(sfb), dev(masked)
+    out_packed = torch.zeros((g, m_max, n), dtype=torch.bfloat16, device="cuda")
+    dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((dev(a_packed), dev(sfa_packed)), (tb, tsfb), out_packed, tm, 64, strict=strict)
+    tp = dev(payload)
+    out_rows = torch.full((rows, n), -5.0, dtype=torch.bfloat16, device="cuda")
+    dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(tp, tp, k, row_bytes // 4, (tb, tsfb), out_rows, dev(row_index.reshape(-1)),
+                                                      tm, m_max, 64, strict=strict, sync=True)
+    got, want = _bits(out_rows), _bits(out_packed)
+    owned = np.zeros(rows, bool)
+    for i in range(g):
+        idx = row_index[i, :masked[i]]
+        owned[idx] = True
+        assert np.array_equal(got[idx], want[i, :masked[i]]), f"group {i}"
+    assert (got[~owned] == _bits(torch.tensor([-5.0], dtype=torch.bfloat16))[0]).all()
