@@ -263,6 +263,9 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         const uint32_t sa = lds0 + stage * Cfg::STAGE_BYTES + wave * 1024;
         const int k0 = kb * 128;
         if (idx < Cfg::A_ITERS) {
+#ifdef DGA_ABL_NOADMA
+            return;   // diagnostic: the A tile is never fetched (whatever lies in the LDS is multiplied)
+#endif
             const int it = idx;
             uint32_t voff = a_voff[it];
             if constexpr (KTAIL) voff = (k0 + a_col < p.k) ? voff : kOutOfRange;
@@ -772,8 +775,13 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
             for (int i = 0; i < STEPS + LAG; ++i) {
                 if (i < STEPS) {
                     const int nt = i / TM, mt = i % TM;
+#ifdef DGA_ABL_NOMFMA
+                    part[i % RING] = v4f{0.f, 0.f, 0.f, 0.f};   // diagnostic: the stream without the matrix work
+                    asm volatile("" : "+v"(part[i % RING]) : "v"(bf[nt & 1]), "v"(af[mt]));
+#else
                     part[i % RING] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
                         bf[nt & 1], af[mt], v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
 #ifndef DGA_ABL_NODMA
                     if (i < ISSUE_STEPS) {
