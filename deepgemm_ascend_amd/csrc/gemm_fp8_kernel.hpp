@@ -262,6 +262,10 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
     auto issue_one = [&](int idx, int stage, int kb) {
         const uint32_t sa = lds0 + stage * Cfg::STAGE_BYTES + wave * 1024;
         const int k0 = kb * 128;
+#ifdef DGA_DMA_B_FIRST   // experiment: the pieces that come from HBM (B) go out before the L2-resident ones (A)
+        if (idx < Cfg::B_ITERS) idx += Cfg::A_ITERS;
+        else if (idx < Cfg::A_ITERS + Cfg::B_ITERS) idx -= Cfg::B_ITERS;
+#endif
         if (idx < Cfg::A_ITERS) {
 #ifdef DGA_ABL_NOADMA
             return;   // diagnostic: the A tile is never fetched (whatever lies in the LDS is multiplied)
@@ -297,6 +301,13 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
 
     // ---- epilogue (a lambda so that each wave-group path of the ping-pong loop ends in its own copy: no register
     //      assignment has to agree across the two paths): lane owns row m, columns n0w + 32*j + 8*(lane>>4) + [0,8)
+    // indexed form: the destination rows of this lane's m-tiles, fetched now (needed only in the epilogue)
+    int64_t out_row[TM];
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+        const int m = m0 + wm * (BM / Cfg::kWM) + li + mt * 16;
+        out_row[mt] = (ridx && m < M) ? ridx[m] : (int64_t)m;
+    }
     auto epilogue = [&](v4f (&acc)[TM][TN]) {
         const int m_row = m0 + wm * (BM / Cfg::kWM) + li;
         const int n_base = n0 + wn * (BN / WN) + 8 * kg;
@@ -329,7 +340,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
             const int m = m_row + mt * 16;
             if (m >= M) continue;
             if (p.m_indices && p.m_indices[m] != bg) continue;  // a row of another group / a padding row: untouched
-            uint16_t *crow = C + (ridx ? ridx[m] : (int64_t)m) * p.ldc;
+            uint16_t *crow = C + out_row[mt] * p.ldc;
 #pragma unroll
             for (int j = 0; j < TN / 2; ++j) {
                 const int n = n_base + 32 * j;
@@ -716,10 +727,16 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         // top leaves the newest batch outstanding.
         constexpr int STG = Cfg::STAGES;
         DGA_STAMP_DECL
+        // first fills: the B and scale pieces go out before the A pieces, so that in the indexed form the row-table loads
+        // behind a_voff have the B issue to hide under (per stage the piece count is what the vmcnt waits rely on,
+        // not the order inside a stage)
 #pragma unroll
-        for (int d = 0; d < STG - 1; ++d)
+        for (int d = 0; d < STG - 1; ++d) {
 #pragma unroll
-            for (int idx = 0; idx < Cfg::LOADS_PER_STAGE; ++idx) issue_one(idx, d, kb_begin + d);
+            for (int idx = Cfg::A_ITERS; idx < Cfg::LOADS_PER_STAGE; ++idx) issue_one(idx, d, kb_begin + d);
+#pragma unroll
+            for (int idx = 0; idx < Cfg::A_ITERS; ++idx) issue_one(idx, d, kb_begin + d);
+        }
         DGA_STAMP_START();
         DGA_STAMP_CLOCK(6, 7);   // slots 6/7: shader-clock and 100 MHz real-time ticks across the main loop
         loop_clock.tick();
