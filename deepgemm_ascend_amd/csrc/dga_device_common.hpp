@@ -13,10 +13,14 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
 
-template <int BM, int BN, int WM, int WN, int ST = 2>
+// LC = true ("loader / consumer"): the workgroup carries WM x WN EXTRA waves that do nothing but issue the LDS-DMA, so the
+// computing waves' instruction streams hold no refill at all (plain loop only).  One loader and one computing wave share
+// each SIMD; the refill of a stage goes out in one burst the moment the barrier releases it.
+template <int BM, int BN, int WM, int WN, int ST = 2, bool LC = false>
 struct GemmCfg {
     static constexpr int kBM = BM, kBN = BN, kWM = WM, kWN = WN;
-    static constexpr int NT = WM * WN * 64;
+    static constexpr bool kLC = LC;
+    static constexpr int NT = WM * WN * 64 * (LC ? 2 : 1);
     static constexpr int TM = BM / WM / 16;  // m-tiles (16 rows) per wave
     static constexpr int TN = BN / WN / 16;  // n-tiles per wave (even)
     // Waves that issue the LDS-DMA.  (Giving all of it to the first-dispatched half of an 8-wave workgroup -- the

@@ -51,6 +51,7 @@ struct Variant {
     int (*launch_pp)(const GemmParams &, hipStream_t);  // ping-pong schedule (dispatchPolicyTag 1), or null
     int (*launch_cont)(const GemmParams &, hipStream_t);  // continuous pipeline (dispatchPolicyTag 2), or null
     int stages = 2;
+    int (*launch_lc)(const GemmParams &, hipStream_t) = nullptr;  // loader / consumer wave split (dispatchPolicyTag 4), or null
 };
 
 #define DGA_VARIANT(BM, BN, WM, WN) \
@@ -70,7 +71,8 @@ static const Variant kVariants[] = {
     // (8 waves first: a tiling that names no wave layout -- a swept CSV row, the predictor -- gets this build; the selector
     //  names 2x2 explicitly for the masked grouped stream)
     Variant{128, 256, 2, 4, &launch_cfg<GemmCfg<128, 256, 2, 4, 3>, 0>, GemmCfg<128, 256, 2, 4, 3>::LDS_BYTES, nullptr, nullptr, 3},
-    Variant{128, 256, 2, 2, &launch_cfg<GemmCfg<128, 256, 2, 2, 3>, 0>, GemmCfg<128, 256, 2, 2, 3>::LDS_BYTES, nullptr, nullptr, 3},
+    Variant{128, 256, 2, 2, &launch_cfg<GemmCfg<128, 256, 2, 2, 3>, 0>, GemmCfg<128, 256, 2, 2, 3>::LDS_BYTES, nullptr, nullptr, 3,
+            &launch_cfg<GemmCfg<128, 256, 2, 2, 3, true>, 0>},
     Variant{128, 128, 2, 2, &launch_cfg<GemmCfg<128, 128, 2, 2, 3>, 0>, GemmCfg<128, 128, 2, 2, 3>::LDS_BYTES, nullptr, nullptr, 3},
     Variant{64, 256, 1, 4, &launch_cfg<GemmCfg<64, 256, 1, 4, 3>, 0>, GemmCfg<64, 256, 1, 4, 3>::LDS_BYTES, nullptr, nullptr, 3},
 
@@ -269,6 +271,7 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
             auto clk = find_clock_build(v, policy == 2 && v->launch_cont ? 2 : 0);
             return clk ? clk(q, stream) : DGA_E_TILING;
         }
+        if (policy == DGA_POLICY_LOADER_WAVES && v->launch_lc) return v->launch_lc(q, stream);
         if (policy == 1 && v->launch_pp) return v->launch_pp(q, stream);
         if (policy == 2 && v->launch_cont) return v->launch_cont(q, stream);
         return v->launch(q, stream);

@@ -386,6 +386,9 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
     // (the contiguous layout with one 128-row block per group is the same HBM-bound stream as the masked layout: 4 waves)
     const bool weight_stream = groups > 1 || (contiguous && t.m / std::max(1u, t.groups) <= DGA_CONTIGUOUS_M_ALIGNMENT);
     if (pick.bm == 128 && pick.bn == 256 && t.stages == 3 && !weight_stream) { t.wavesM = 2; t.wavesN = 4; }
+    // ... and on the weight stream the 4-wave build takes four extra loader waves (dispatchPolicyTag 4): the refill leaves
+    // the computing waves' instruction streams, -2 % time on 256 x (128, 7168, 2048) (profiles/r02_grouped_ablation.txt)
+    if (pick.bm == 128 && pick.bn == 256 && t.stages == 3 && weight_stream) t.dispatchPolicyTag = DGA_POLICY_LOADER_WAVES;
     const uint32_t tiles_m = ceil_div(t.m, t.m1), tiles_n = ceil_div(t.n, t.n1);
     const uint64_t blocks = static_cast<uint64_t>(groups) * tiles_m * tiles_n;
     t.blockDim = static_cast<uint32_t>(blocks) * ((contiguous && t.m1 > DGA_CONTIGUOUS_M_ALIGNMENT) ? 2 : 1);

@@ -137,6 +137,11 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    // loader / consumer builds: waves [0, WM*WN) compute, waves [WM*WN, 2*WM*WN) only issue the LDS-DMA
+    constexpr bool LC = Cfg::kLC;
+    const bool loader = LC && wave >= Cfg::kWM * WN;
+    const int dwave = loader ? wave - Cfg::kWM * WN : wave;   // this wave's 1 KiB slot in every DMA piece
+    static_assert(!LC || PP == 0, "the loader / consumer split rides on the plain loop");
 
     // ---- tile id: XCD-aware remap (blocks b, b+8, ... share an XCD and its L2), then
     //      a grouped raster so that an XCD's consecutive tiles share A and B panels.
@@ -260,7 +265,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
     // reads the following bytes of the tile -- valid memory inside the descriptor's range -- into a stage nobody
     // consumes.
     auto issue_one = [&](int idx, int stage, int kb) {
-        const uint32_t sa = lds0 + stage * Cfg::STAGE_BYTES + wave * 1024;
+        const uint32_t sa = lds0 + stage * Cfg::STAGE_BYTES + dwave * 1024;
         const int k0 = kb * 128;
 #ifdef DGA_DMA_B_FIRST   // experiment: the pieces that come from HBM (B) go out before the L2-resident ones (A)
         if (idx < Cfg::B_ITERS) idx += Cfg::A_ITERS;
@@ -282,7 +287,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         } else {
             const int it = idx - Cfg::A_ITERS - Cfg::B_ITERS;
             dma4(sc_src[it] + min(kb, p.kb_n - 1), lds0 + stage * Cfg::STAGE_BYTES + Cfg::A_BYTES + Cfg::B_BYTES +
-                                                       (it * DNT + wave * 64) * 4);
+                                                       (it * DNT + dwave * 64) * 4);
         }
     };
 
@@ -730,20 +735,40 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         // first fills: the B and scale pieces go out before the A pieces, so that in the indexed form the row-table loads
         // behind a_voff have the B issue to hide under (per stage the piece count is what the vmcnt waits rely on,
         // not the order inside a stage)
+        if (!LC || loader) {
 #pragma unroll
-        for (int d = 0; d < STG - 1; ++d) {
+            for (int d = 0; d < STG - 1; ++d) {
 #pragma unroll
-            for (int idx = Cfg::A_ITERS; idx < Cfg::LOADS_PER_STAGE; ++idx) issue_one(idx, d, kb_begin + d);
+                for (int idx = Cfg::A_ITERS; idx < Cfg::LOADS_PER_STAGE; ++idx) issue_one(idx, d, kb_begin + d);
 #pragma unroll
-            for (int idx = 0; idx < Cfg::A_ITERS; ++idx) issue_one(idx, d, kb_begin + d);
+                for (int idx = 0; idx < Cfg::A_ITERS; ++idx) issue_one(idx, d, kb_begin + d);
+            }
         }
         DGA_STAMP_START();
         DGA_STAMP_CLOCK(6, 7);   // slots 6/7: shader-clock and 100 MHz real-time ticks across the main loop
         loop_clock.tick();
         int stage = 0, fill = STG - 1;   // stage being consumed / stage being refilled (with k block kb + STG - 1)
         const bool wave_has_rows = m0 + wm * (BM / Cfg::kWM) < M;  // wave-uniform (wm comes from readfirstlane)
+        if constexpr (LC) {
+            if (loader) {
+                // loader wave: per k block, wait until the oldest batch in flight has landed, meet the computing waves at
+                // the barrier (they have left the stage that is refilled next), send the whole refill in one burst
+                for (int kb = kb_begin; kb < kb_end; ++kb) {
+                    wait_vmcnt<(STG - 2) * Cfg::LOADS_PER_STAGE>();
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int idx = Cfg::A_ITERS; idx < Cfg::LOADS_PER_STAGE; ++idx) issue_one(idx, fill, kb + STG - 1);
+#pragma unroll
+                    for (int idx = 0; idx < Cfg::A_ITERS; ++idx) issue_one(idx, fill, kb + STG - 1);
+                    fill = fill + 1 == STG ? 0 : fill + 1;
+                }
+                wait_vmcnt<0>();   // the refills past the last k block land in LDS nobody reads: drain them before exit
+                return;
+            }
+        }
         for (int kb = kb_begin; kb < kb_end; ++kb) {
-            wait_vmcnt<(STG - 2) * Cfg::LOADS_PER_STAGE>();
+            if constexpr (!LC) wait_vmcnt<(STG - 2) * Cfg::LOADS_PER_STAGE>();
             DGA_STAMP(1);                            // segment 1: vmcnt wait
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");           // no LDS read may be hoisted above the barrier
@@ -753,8 +778,10 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
             if (!wave_has_rows) {
                 // masked-M: every row of this wave's m range is >= masked_m[g].  It still carries its share of the
                 // refill (and the barrier), but computes nothing.
+                if constexpr (!LC) {
 #pragma unroll
-                for (int idx = 0; idx < Cfg::LOADS_PER_STAGE; ++idx) issue_one(idx, fill, kb + STG - 1);
+                    for (int idx = 0; idx < Cfg::LOADS_PER_STAGE; ++idx) issue_one(idx, fill, kb + STG - 1);
+                }
                 stage = stage + 1 == STG ? 0 : stage + 1;
                 fill = fill + 1 == STG ? 0 : fill + 1;
                 continue;
@@ -801,7 +828,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
 #endif
                     __builtin_amdgcn_sched_barrier(0);
 #ifndef DGA_ABL_NODMA
-                    if (i < ISSUE_STEPS) {
+                    if (!LC && i < ISSUE_STEPS) {
 #pragma unroll
                         for (int idx = (i * Cfg::LOADS_PER_STAGE) / ISSUE_STEPS;
                              idx < ((i + 1) * Cfg::LOADS_PER_STAGE) / ISSUE_STEPS; ++idx)

@@ -15,10 +15,13 @@ using namespace dga;
 #define CFG_WN 2
 #define CFG_ST 3
 #endif
+#ifndef CFG_LC
+#define CFG_LC false
+#endif
 int main(int argc, char **argv)
 {
     const int G = argc > 1 ? atoi(argv[1]) : 256, m = 128, n = 2048, k = 7168, reps = argc > 2 ? atoi(argv[2]) : 20;
-    typedef GemmCfg<CFG_BM, CFG_BN, CFG_WM, CFG_WN, CFG_ST> Cfg;
+    typedef GemmCfg<CFG_BM, CFG_BN, CFG_WM, CFG_WN, CFG_ST, CFG_LC> Cfg;
     const int kb = k / 128, nb = n / 128;
     const size_t abytes = (size_t)G * m * k, bbytes = (size_t)G * n * k;
     std::vector<uint8_t> h(1 << 24);
@@ -51,8 +54,8 @@ int main(int argc, char **argv)
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1000 / reps;
     const double bytes = (double)bbytes + (double)abytes + (double)G * m * (4.0 * kb + 2.0 * n) + (double)G * nb * kb * 4;
-    printf("%-28s tile %dx%d waves %dx%d stages %d: %8.1f us  %7.1f GB/s algorithmic (weights alone %7.1f GB/s)  err=%d\n",
-           argc > 3 ? argv[3] : "", Cfg::kBM, Cfg::kBN, Cfg::kWM, Cfg::kWN, Cfg::STAGES, us, bytes / us / 1e3, bbytes / us / 1e3,
+    printf("%-28s tile %dx%d waves %dx%d%s stages %d: %8.1f us  %7.1f GB/s algorithmic (weights alone %7.1f GB/s)  err=%d\n",
+           argc > 3 ? argv[3] : "", Cfg::kBM, Cfg::kBN, Cfg::kWM, Cfg::kWN, Cfg::kLC ? "+loaders" : "", Cfg::STAGES, us, bytes / us / 1e3, bbytes / us / 1e3,
            (int)hipGetLastError());
     return 0;
 }

@@ -180,3 +180,23 @@ def test_copy_rows2(dga):
     dga.copy_rows2(a, payload, k, s2.view(torch.uint8), payload, 4 * kb, src_index=idx, src1_off=k)
     torch.cuda.synchronize()
     assert torch.equal(a[7:], q[7:]) and torch.equal(s2[7:], sf[7:]) and (a[:7] == 0).all() and (s2[:7] == 0).all()
+
+
+def test_loader_wave_build_writes_the_same_bits(dga, oracle):
+    """dispatchPolicyTag 4 (extra waves that only issue the LDS-DMA; the tiling's choice for the masked weight stream)
+    against the plain loop of the same tile: identical output bytes, ragged masks included."""
+    g, mmax, n, k = 12, 128, 2048, 1024
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randint(0, 120, (g, mmax, k), dtype=torch.uint8, device="cuda", generator=gen)
+    b = torch.randint(0, 120, (g, n, k), dtype=torch.uint8, device="cuda", generator=gen)
+    sfa = torch.rand((g, mmax, k // 128), device="cuda", generator=gen) + 0.5
+    sfb = torch.rand((g, n // 128, k // 128), device="cuda", generator=gen) + 0.5
+    masked = torch.tensor([128, 0, 1, 64, 65, 127, 128, 33, 96, 128, 7, 128], dtype=torch.int32, device="cuda")
+    t = dga.tiling(mmax, n, k, groups=g, expected_m=128)
+    assert (t.m1, t.n1, t.stages, t.dispatchPolicyTag) == (128, 256, 3, 4)
+    o4 = torch.full((g, mmax, n), -1.0, dtype=torch.bfloat16, device="cuda")
+    dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), o4, masked, 128, tiling_=t)
+    t.dispatchPolicyTag = 0
+    o0 = torch.full((g, mmax, n), -1.0, dtype=torch.bfloat16, device="cuda")
+    dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), o0, masked, 128, tiling_=t, sync=True)
+    assert torch.equal(o4.view(torch.int16), o0.view(torch.int16))
