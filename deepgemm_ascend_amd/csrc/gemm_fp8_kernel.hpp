@@ -228,8 +228,10 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
 #pragma unroll
     for (int it = 0; it < Cfg::A_ITERS; ++it) {
         const int row = (it * DNT + dtid) >> 3;
+        // rows at or beyond masked_m[g] (M): nothing is fetched for them -- the lane is sent out of the descriptor's range
+        // and the hardware zero-fills its LDS bytes (their outputs are never stored); a dense tile's rows beyond M likewise
         const int rr = min(row, M - 1 - m0);
-        a_voff[it] = (ridx ? (uint32_t)ridx[m0 + rr] : (uint32_t)rr) * (uint32_t)p.lda + a_col;
+        a_voff[it] = row < M - m0 ? (ridx ? (uint32_t)ridx[m0 + rr] : (uint32_t)rr) * (uint32_t)p.lda + a_col : kOutOfRange;
     }
 #pragma unroll
     for (int it = 0; it < Cfg::B_ITERS; ++it) {

@@ -193,7 +193,9 @@ def test_loader_wave_build_writes_the_same_bits(dga, oracle):
     sfb = torch.rand((g, n // 128, k // 128), device="cuda", generator=gen) + 0.5
     masked = torch.tensor([128, 0, 1, 64, 65, 127, 128, 33, 96, 128, 7, 128], dtype=torch.int32, device="cuda")
     t = dga.tiling(mmax, n, k, groups=g, expected_m=128)
-    assert (t.m1, t.n1, t.stages, t.dispatchPolicyTag) == (128, 256, 3, 4)
+    t.m1, t.n1, t.wavesM, t.wavesN, t.stages, t.dispatchPolicyTag = 128, 256, 2, 2, 3, 4
+    big = dga.tiling(128, 2048, 7168, groups=256, expected_m=128)          # BASELINE configs[3]: the tiling's own choice
+    assert (big.m1, big.n1, big.stages, big.dispatchPolicyTag) == (128, 256, 3, 4)
     o4 = torch.full((g, mmax, n), -1.0, dtype=torch.bfloat16, device="cuda")
     dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), o4, masked, 128, tiling_=t)
     t.dispatchPolicyTag = 0
