@@ -439,6 +439,9 @@ constexpr int kCsvCols = 11;
 // to in its own format.
 static const char *kCsvExt[] = {"splitkFactor", "stages", "swizzleOffset", "wavesM", "wavesN", "dispatchPolicyTag"};
 constexpr int kCsvExtCols = 6;
+// ... and two more that key grouped problems (absent = a dense row): groups (> 1: masked grouped with m = m_max; with
+// contiguous = 1: the number of B matrices of the contiguous-grouped layout)
+static const char *kCsvGrp[] = {"groups", "contiguous"};
 
 class Cache {
 public:
@@ -452,7 +455,7 @@ public:
         std::lock_guard<std::mutex> lk(mu_);
         data_.clear();
         path_.clear();
-        ext_ = false;
+        ext_ = grp_ = false;
         if (!path || !*path) return DGA_OK;
         std::ifstream in(path);
         std::string line;
@@ -467,6 +470,7 @@ public:
                 if (!col.count(h)) return DGA_E_IO;
             ext_ = true;
             for (const char *h : kCsvExt) ext_ = ext_ && col.count(h);
+            grp_ = ext_ && col.count(kCsvGrp[0]) && col.count(kCsvGrp[1]);
             while (std::getline(in, line)) {
                 if (line.empty()) continue;
                 const auto cells = split(line);
@@ -485,7 +489,8 @@ public:
                 auto opt = [&](const char *name) -> uint32_t { return col.count(name) ? get(name) : 0; };
                 e.splitk = opt("splitkFactor"); e.stages = opt("stages"); e.raster = opt("swizzleOffset");
                 e.waves_m = opt("wavesM"); e.waves_n = opt("wavesN"); e.policy = opt("dispatchPolicyTag");
-                data_[std::make_tuple(get("m"), get("n"), get("k"), 1u)] = e;
+                const uint32_t groups = std::max(1u, opt("groups")), contiguous = opt("contiguous") ? 1u : 0u;
+                data_[std::make_tuple(get("m"), get("n"), get("k"), groups, contiguous)] = e;
             }
         }
         in.close();
@@ -494,8 +499,8 @@ public:
             if (!out.is_open()) return DGA_E_IO;
             for (int i = 0; i < kCsvCols; ++i) out << (i ? "," : "") << kCsvHead[i];
             for (int i = 0; i < kCsvExtCols; ++i) out << "," << kCsvExt[i];
-            out << "\n";
-            ext_ = true;
+            out << "," << kCsvGrp[0] << "," << kCsvGrp[1] << "\n";
+            ext_ = grp_ = true;
         }
         path_ = path;
         return DGA_OK;
@@ -514,7 +519,7 @@ public:
     bool get(dga_tiling_t &t, bool *swept)
     {
         std::lock_guard<std::mutex> lk(mu_);
-        auto it = data_.find(std::make_tuple(t.m, t.n, t.k, t.groups));
+        auto it = data_.find(std::make_tuple(t.m, t.n, t.k, t.groups, t.contiguous ? 1u : 0u));
         if (it == data_.end()) return false;
         const Entry &e = it->second;
         t.m1 = e.m1; t.n1 = e.n1; t.k1 = e.k1; t.kernelSerial = e.serial;
@@ -529,13 +534,13 @@ public:
     void put(const dga_tiling_t &t)
     {
         std::lock_guard<std::mutex> lk(mu_);
-        const auto key = std::make_tuple(t.m, t.n, t.k, t.groups);
+        const auto key = std::make_tuple(t.m, t.n, t.k, t.groups, t.contiguous ? 1u : 0u);
         if (data_.count(key)) return;
         Entry e{t.m1, t.n1, t.k1, t.kernelSerial, t.paddingTagA, t.paddingTagB, t.paddingTagC, t.blockDim};
         e.splitk = t.splitkFactor; e.stages = t.stages; e.raster = t.swizzleOffset; e.waves_m = t.wavesM;
         e.waves_n = t.wavesN; e.policy = t.dispatchPolicyTag;
         data_[key] = e;
-        if (!path_.empty() && t.groups <= 1) {  // the CSV schema has no group column: dense rows only
+        if (!path_.empty() && (grp_ || (t.groups <= 1 && !t.contiguous))) {  // a file without the group columns: dense rows only
             std::ofstream out(path_, std::ios::app);
             if (out.is_open()) {
                 out << t.m << ',' << t.n << ',' << t.k << ',' << t.m1 << ',' << t.n1 << ',' << t.k1 << ','
@@ -545,6 +550,7 @@ public:
                     out << ',' << unsigned(t.splitkFactor) << ',' << unsigned(t.stages ? t.stages : 2) << ','
                         << unsigned(t.swizzleOffset) << ',' << unsigned(t.wavesM) << ',' << unsigned(t.wavesN) << ','
                         << unsigned(t.dispatchPolicyTag);
+                if (grp_) out << ',' << t.groups << ',' << unsigned(t.contiguous ? 1 : 0);
                 out << "\n";
             }
         }
@@ -589,9 +595,10 @@ private:
         return out;
     }
     std::mutex mu_;
-    std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, Entry> data_;
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, Entry> data_;
     std::string path_;
     bool ext_ = false;   // the open file's header has the CDNA4 columns
+    bool grp_ = false;   // ... and the groups / contiguous columns
 };
 
 // TilingParams ctor (tiling_params.h:45-65): strides from the layouts, swizzle defaults.
@@ -712,7 +719,6 @@ int dga_tiling(const dga_problem_t *problem, dga_tiling_t *out)
 {
     if (!problem || !out) return DGA_E_NULL;
     init_params(*problem, *out);
-    if (out->contiguous) return dga_select_kernel(problem, nullptr, out);  // the (m,n,k) cache holds dense tilings
     bool swept = false;
     if (Cache::instance().get(*out, &swept)) {
         if (swept) {  // a swept entry is complete: use it as it stands

@@ -97,6 +97,71 @@ def candidates(m, n, k, rasters=None):
     return out
 
 
+# ---- the compiled menu (csrc/dga_launch.hip kVariants) and its constraints -------------------------------------------
+# (bm, bn, wavesM, wavesN, stages, dispatch policies the build exists in)
+MENU = [(256, 256, 4, 2, 2, (0, 1, 2)), (128, 256, 2, 2, 2, (0, 2)), (256, 128, 4, 1, 2, (0, 2)), (128, 128, 2, 2, 2, (0, 2)),
+        (64, 256, 1, 4, 2, (0, 2)), (64, 128, 1, 4, 2, (0,)), (128, 256, 2, 4, 2, (0, 2)), (128, 256, 2, 4, 3, (0,)),
+        (128, 256, 2, 2, 3, (0, 4)), (128, 128, 2, 2, 3, (0,)), (64, 256, 1, 4, 3, (0,)), (32, 256, 1, 4, 2, (0,)),
+        (32, 128, 1, 4, 2, (0,)), (16, 256, 1, 4, 2, (0,)), (16, 128, 1, 4, 2, (0,))]
+LDS_BYTES, ACC_REGS, CUS = 160 * 1024, 128, 256
+
+
+def stage_bytes(bm, bn, waves):
+    """GemmCfg::STAGE_BYTES (csrc/dga_device_common.hpp): A rows padded to whole DMA instructions, scale slots."""
+    dnt = waves * 64
+    a_rows = bm if bm * 8 >= dnt else dnt // 8
+    return a_rows * 128 + bn * 128 + (-(-(bm + 8) // dnt) * dnt) * 4
+
+
+def check_candidate(prob, c):
+    """Per-variant constraint checker -- the counterpart of the reference's filter_parameters / per-kernel checkers
+    (/root/reference/get_best_config/catlass_parameter.py:308-368: L1 / L0C capacity, smallmatmul needs one K step and one
+    tile per core, split-K needs a long K ...).  prob: dict(m, n, k, groups, layout in {"dense","masked","contiguous"},
+    rows_per_group).  Returns (ok, reason)."""
+    bm, bn, wm, wn, st, pol, sk = c["m1"], c["n1"], c["wavesM"], c["wavesN"], c["stages"], c["policy"], c["splitk"]
+    build = [v for v in MENU if v[:5] == (bm, bn, wm, wn, st)]
+    if not build:
+        return False, "no such build in the menu"
+    if pol not in build[0][5]:
+        return False, f"dispatch policy {pol} not compiled for this build"
+    if stage_bytes(bm, bn, wm * wn) * st > LDS_BYTES:                       # JudgeSpace: L1 (here LDS) capacity
+        return False, "LDS"
+    if bm * bn // (wm * wn * 64) > ACC_REGS:                               # JudgeSpace: L0C (here accumulator VGPRs)
+        return False, "accumulator registers"
+    kb = -(-prob["k"] // 128)
+    if prob["layout"] == "masked":
+        need = 16 if prob["m"] <= 16 else 32 if prob["m"] <= 32 else 64 if prob["m"] <= 64 else 128
+        if prob["m"] <= 128 and bm != need:
+            return False, "masked layout: one tile row per expert (B is read once)"
+        if sk != 1:
+            return False, "split-K is dense only"
+    elif prob["layout"] == "contiguous":
+        tall = bm == 256 and bn == 256 and prob["rows_per_group"] >= 512
+        if not tall and (bm > 128 or 128 % bm):
+            return False, "contiguous layout: a tile must not straddle two group segments"
+        if sk != 1:
+            return False, "split-K is dense only"
+    else:
+        blocks = -(-prob["m"] // bm) * -(-prob["n"] // bn)
+        if bm >= 2 * max(prob["m"], 16) and bm > 16:
+            return False, "tile twice the problem"
+        if sk > 1 and not (blocks * sk <= 1024 and kb // sk >= 4 and blocks < 192 and pol == 0):
+            return False, "split-K needs few tiles, >= 4 k blocks per split and the plain loop"
+    return True, ""
+
+
+def grouped_candidates(prob):
+    out = []
+    for (bm, bn, wm, wn, st, pols) in MENU:
+        for pol in pols:
+            if pol == 1:
+                continue
+            c = {"m1": bm, "n1": bn, "wavesM": wm, "wavesN": wn, "stages": st, "policy": pol, "splitk": 1, "raster": 0}
+            if check_candidate(prob, c)[0]:
+                out.append(c)
+    return out
+
+
 def gen_data(m, n, k, seed=0):
     """benchmark.py:343-367 analogue, fp8: N(0,1) data, amax block scaling, e4m3fn codes; golden = fp32 matmul of the
     dequantised operands on the device (TF32 is not a thing on gfx950: this is exact-fp32 MFMA / VALU)."""
@@ -186,6 +251,70 @@ def benchmark_shape(shape, out_dir: Path, rank=0, num_processes=1, iters=10, ras
     return best
 
 
+GROUPED_SHAPES = (   # (layout, groups, rows per group (m_max), n, k): DeepSeek-V3-like MoE layers and their decode-time masks
+    [("masked", g, mm, n, k) for (n, k) in ((2048, 7168), (7168, 2048), (4096, 7168)) for g in (32, 256) for mm in (16, 64, 128)] +
+    [("contiguous", g, r, n, k) for (n, k) in ((4096, 7168), (7168, 2048)) for (g, r) in ((32, 128), (8, 1024), (4, 4096))])
+
+
+def benchmark_grouped(shape, out_dir: Path, iters=10, prewarm_s=0.15):
+    """One masked / contiguous grouped problem: every legal build timed (full mask), gate = bit pattern of two groups
+    against the strict kernel under the fast path's bar; records go to the same jsonl format as the dense sweep."""
+    import time as _time
+    import deepgemm_ascend_amd as dga
+    layout, groups, rows, n, k = shape
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    rf = lambda sh: (lambda x: torch.where((x & 0x7F) == 0x7F, x & 0x80, x))(torch.randint(0, 256, sh, dtype=torch.uint8, device="cuda", generator=gen))
+    kb, nb = k // 128, n // 128
+    b = rf((groups, n, k)); sfb = torch.rand((groups, nb, kb), device="cuda", generator=gen) + 0.5
+    if layout == "masked":
+        prob = {"m": rows, "n": n, "k": k, "groups": groups, "layout": layout, "rows_per_group": rows}
+        a = rf((groups, rows, k)); sfa = torch.rand((groups, rows, kb), device="cuda", generator=gen) + 0.5
+        out = torch.empty((groups, rows, n), dtype=torch.bfloat16, device="cuda")
+        masked = torch.full((groups,), rows, dtype=torch.int32, device="cuda")
+        base = lambda: dga.tiling(rows, n, k, groups=groups, expected_m=rows)
+        run = lambda t, strict=False: dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), out, masked, rows, tiling_=t, strict=strict)
+    else:
+        msum = groups * rows
+        prob = {"m": msum, "n": n, "k": k, "groups": groups, "layout": layout, "rows_per_group": rows}
+        a = rf((msum, k)); sfa = torch.rand((msum, kb), device="cuda", generator=gen) + 0.5
+        out = torch.empty((msum, n), dtype=torch.bfloat16, device="cuda")
+        idx = torch.arange(groups, device="cuda", dtype=torch.int32).repeat_interleave(rows).contiguous()
+        base = lambda: dga.tiling(msum, n, k, groups=groups, contiguous=True)
+        run = lambda t, strict=False: dga.m_grouped_gemm_fp8_fp8_bf16_nt_contiguous((a, sfa), (b, sfb), out, idx, tiling_=t, strict=strict)
+    run(base(), strict=True); torch.cuda.synchronize()
+    golden = out.float().clone()
+    tol = golden.abs() * 2.0 ** -7 + golden.abs().max() * 2.0 ** -12
+    t0 = _time.perf_counter()
+    while _time.perf_counter() - t0 < prewarm_s:
+        run(base()); torch.cuda.synchronize()
+    tag = f"{layout}_{groups}x{rows}_{n}_{k}"
+    res_path = out_dir / f"shape_{tag}_rank_0.jsonl"
+    best = None
+    for i, c in enumerate(grouped_candidates(prob)):
+        t = base()
+        t.m1, t.n1, t.wavesM, t.wavesN, t.stages, t.dispatchPolicyTag = c["m1"], c["n1"], c["wavesM"], c["wavesN"], c["stages"], c["policy"]
+        t.splitkFactor, t.kernelSerial = 1, 0
+        tiles = -(-prob["m"] // c["m1"]) * -(-n // c["n1"])
+        t.blockDim = tiles * (groups if layout == "masked" else (2 if c["m1"] == 256 else 1))
+        c = dict(c, raster=int(t.swizzleOffset), groups=groups, layout=layout, rows_per_group=rows)
+        try:
+            run(t); torch.cuda.synchronize()
+            ratio = float(((out.float() - golden).abs() > tol).float().mean())
+            ok = ratio <= ERROR_TOL
+            us = time_us(lambda: run(t), iters=iters) if ok else 999999999
+        except Exception:   # a tiling the launcher refuses (recorded, not fatal)
+            ok, ratio, us = False, -1.0, 999999999
+        with open(res_path, "a") as f:
+            f.write(json.dumps(asdict(Result(i, prob["m"], n, k, us, ratio, not ok, c))) + "\n")
+        if ok and (best is None or us < best[0]):
+            best = (us, c)
+    return prob, best
+
+
+GROUPED_CSV_HEAD = ("m,n,k,m1,n1,k1,kernelSerial,paddingTagA,paddingTagB,paddingTagC,blockDim,"
+                    "splitkFactor,stages,swizzleOffset,wavesM,wavesN,dispatchPolicyTag,groups,contiguous\n")
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="sweep_out")
@@ -199,9 +328,30 @@ def main(argv=None):
     ap.add_argument("--prewarm-ms", type=float, default=150.0, help="clock pre-warm in front of every shape's candidates")
     ap.add_argument("--heuristic-raster", action="store_true",
                     help="one raster per candidate (the heuristic's) instead of the raster sweep")
+    ap.add_argument("--grouped", action="store_true",
+                    help="sweep the masked / contiguous grouped shapes (GROUPED_SHAPES) instead of the dense list")
     a = ap.parse_args(argv)
     torch.cuda.set_device(a.rank % max(1, torch.cuda.device_count()))
     out_dir = Path(a.out); out_dir.mkdir(parents=True, exist_ok=True)
+    if a.grouped:
+        rows_out = []
+        for shape in GROUPED_SHAPES[a.rank::a.num_processes]:
+            prob, best = benchmark_grouped(shape, out_dir, a.iters, a.prewarm_ms / 1e3)
+            if best:
+                us, c = best
+                print(json.dumps({"shape": list(shape), "best_us": round(us, 2), **c}), flush=True)
+                tiles = -(-prob["m"] // c["m1"]) * -(-prob["n"] // c["n1"])
+                contiguous = 1 if prob["layout"] == "contiguous" else 0
+                block_dim = tiles * (1 if contiguous else prob["groups"]) * (2 if contiguous and c["m1"] == 256 else 1)
+                rows_out.append(f"{prob['m']},{prob['n']},{prob['k']},{c['m1']},{c['n1']},128,0,0,0,0,{block_dim},1,{c['stages']},"
+                                f"{c['raster']},{c['wavesM']},{c['wavesN']},{c['policy']},{prob['groups']},{contiguous}\n")
+        if a.cache_csv and rows_out:
+            new = not Path(a.cache_csv).exists()
+            with open(a.cache_csv, "a") as f:
+                if new:
+                    f.write(GROUPED_CSV_HEAD)
+                f.writelines(rows_out)
+        return
     shapes = [[int(x) for x in s.split(",")] for s in a.shapes] if a.shapes else SHAPE_GROUP
     if a.grid:
         shapes = grid_shapes(a.grid, a.grid_seed)

@@ -123,7 +123,7 @@ def test_tiling_cache_creates_header_for_new_file(dga, tmp_path):
         dga.tiling_cache_open(str(path))
         # the reference's eleven columns (csv.cpp:23-26) first, the CDNA4 columns behind them
         assert path.read_text() == ("m,n,k,m1,n1,k1,kernelSerial,paddingTagA,paddingTagB,paddingTagC,blockDim,"
-                                    "splitkFactor,stages,swizzleOffset,wavesM,wavesN,dispatchPolicyTag\n")
+                                    "splitkFactor,stages,swizzleOffset,wavesM,wavesN,dispatchPolicyTag,groups,contiguous\n")
         dga.tiling(256, 256, 256)
         assert len(path.read_text().strip().splitlines()) == 2
     finally:
@@ -144,6 +144,28 @@ def test_tiling_round_trips_through_a_new_cache_file(dga, tmp_path, m, n, k):
         assert dga.tiling_cache_size() == 1
         again = dga.tiling(m, n, k).as_dict()
         assert again == first
+    finally:
+        dga.tiling_cache_open(None)
+        dga.tiling_cache_clear()
+
+
+@pytest.mark.parametrize("kw", [dict(m=128, n=2048, k=7168, groups=256, expected_m=128),
+                                dict(m=4096, n=4096, k=7168, groups=32, contiguous=True),
+                                dict(m=8192, n=4096, k=7168, groups=8, contiguous=True)])
+def test_grouped_tilings_round_trip_too(dga, tmp_path, kw):
+    """The groups / contiguous columns key masked-grouped and contiguous-grouped problems in the same file: the loader-wave
+    policy, the 4-wave build of the weight stream and the two-pass 256x256 tiling of long groups survive a restart, and a
+    dense problem of the same (m, n, k) stays a different entry."""
+    path = tmp_path / "grp.csv"
+    try:
+        dga.tiling_cache_open(str(path))
+        first = dga.tiling(**kw).as_dict()
+        dense = dga.tiling(kw["m"], kw["n"], kw["k"]).as_dict()
+        dga.tiling_cache_open(str(path))
+        assert dga.tiling_cache_size() == 2
+        assert dga.tiling(**kw).as_dict() == first
+        assert dga.tiling(kw["m"], kw["n"], kw["k"]).as_dict() == dense
+        assert first["groups"] == kw["groups"] and dense["groups"] == 1
     finally:
         dga.tiling_cache_open(None)
         dga.tiling_cache_clear()
