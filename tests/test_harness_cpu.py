@@ -50,3 +50,29 @@ def test_sweep_candidates_and_shapes():
     assert {"m1": 256, "n1": 256, "raster": 8, "stages": 2, "splitk": 1, "policy": 0} in c
     assert any(x["splitk"] > 1 for x in sweep.candidates(8, 7168, 18432))
     assert all(x["m1"] <= 16 for x in sweep.candidates(8, 7168, 18432))
+
+
+def test_sweep_constraint_checkers():
+    """harness/sweep.check_candidate: the counterpart of the reference's per-variant constraint checkers
+    (get_best_config/catlass_parameter.py:308-368; test_catlass_parameter.py:142-180 pins e.g. smallmatmul k > k1 -> False)."""
+    from deepgemm_ascend_amd.harness import sweep
+    c = lambda m1, n1, wm, wn, st, pol=0, sk=1: {"m1": m1, "n1": n1, "wavesM": wm, "wavesN": wn, "stages": st, "policy": pol, "splitk": sk}
+    masked = {"m": 128, "n": 2048, "k": 7168, "groups": 256, "layout": "masked", "rows_per_group": 128}
+    assert sweep.check_candidate(masked, c(128, 256, 2, 2, 3, 4)) == (True, "")
+    assert not sweep.check_candidate(masked, c(64, 256, 1, 4, 3))[0]            # two tile rows would read B twice
+    assert not sweep.check_candidate(masked, c(128, 256, 2, 2, 3, 0, 2))[0]     # split-K is dense only
+    assert not sweep.check_candidate(masked, c(128, 256, 2, 2, 2, 4))[0]        # loader waves exist for the 3-stage build only
+    assert not sweep.check_candidate(masked, c(256, 256, 4, 2, 3))[0]           # no such build (3 x 64 KB > LDS)
+    small = dict(masked, m=16, rows_per_group=16)
+    assert sweep.check_candidate(small, c(16, 128, 1, 4, 2))[0] and not sweep.check_candidate(small, c(32, 128, 1, 4, 2))[0]
+    cont = {"m": 32 * 128, "n": 4096, "k": 7168, "groups": 32, "layout": "contiguous", "rows_per_group": 128}
+    assert not sweep.check_candidate(cont, c(256, 256, 4, 2, 2, 2))[0]          # a 256-row tile would straddle two 128-row groups
+    assert sweep.check_candidate(dict(cont, groups=8, rows_per_group=1024, m=8192), c(256, 256, 4, 2, 2, 2))[0]
+    dense = {"m": 64, "n": 4096, "k": 7168, "groups": 1, "layout": "dense", "rows_per_group": 64}
+    assert not sweep.check_candidate(dense, c(256, 256, 4, 2, 2, 2))[0]         # tile twice the problem
+    assert sweep.check_candidate(dense, c(64, 128, 1, 4, 2, 0, 8))[0]           # split-K: few tiles, long K
+    assert not sweep.check_candidate(dict(dense, k=512), c(64, 128, 1, 4, 2, 0, 8))[0]   # < 4 k blocks per split
+    # every build of the menu fits the LDS and the accumulator budget by construction
+    for (bm, bn, wm, wn, st, pols) in sweep.MENU:
+        assert sweep.stage_bytes(bm, bn, wm * wn) * st <= sweep.LDS_BYTES and bm * bn // (wm * wn * 64) <= sweep.ACC_REGS
+    assert len(sweep.grouped_candidates(masked)) >= 8
