@@ -13,19 +13,19 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
 
-// LC = true ("loader / consumer"): the workgroup carries WM x WN EXTRA waves that do nothing but issue the LDS-DMA, so the
-// computing waves' instruction streams hold no refill at all (plain loop only).  One loader and one computing wave share
-// each SIMD; the refill of a stage goes out in one burst the moment the barrier releases it.
-template <int BM, int BN, int WM, int WN, int ST = 2, bool LC = false>
+// LCW > 0 ("loader / consumer"): the workgroup carries LCW EXTRA waves that do nothing but issue the LDS-DMA, so the
+// computing waves' instruction streams hold no refill at all (plain loop only); the refill of a stage goes out in one burst
+// the moment the barrier releases it.
+template <int BM, int BN, int WM, int WN, int ST = 2, int LCW = 0>
 struct GemmCfg {
     static constexpr int kBM = BM, kBN = BN, kWM = WM, kWN = WN;
-    static constexpr bool kLC = LC;
-    static constexpr int NT = WM * WN * 64 * (LC ? 2 : 1);
+    static constexpr bool kLC = LCW > 0;
+    static constexpr int NT = (WM * WN + LCW) * 64;
     static constexpr int TM = BM / WM / 16;  // m-tiles (16 rows) per wave
     static constexpr int TN = BN / WN / 16;  // n-tiles per wave (even)
     // Waves that issue the LDS-DMA.  (Giving all of it to the first-dispatched half of an 8-wave workgroup -- the
     // half that wins every MFMA arbitration -- evens the two halves out but measured 2-4 % slower overall, r01.)
-    static constexpr int DMA_WAVES = WM * WN;
+    static constexpr int DMA_WAVES = LCW > 0 ? LCW : WM * WN;
     static constexpr int DNT = DMA_WAVES * 64;  // threads that issue DMA
     static constexpr int A_ROWS = BM * 8 >= DNT ? BM : DNT / 8;  // tiny BM: pad the image to whole wave-instructions
     static constexpr int A_BYTES = A_ROWS * 128;

@@ -22,8 +22,9 @@ int launch_cfg(const GemmParams &p, hipStream_t stream);
     X(128, 256, 2, 2, 2, 0) X(256, 128, 4, 1, 2, 0) X(128, 128, 2, 2, 2, 0) X(64, 256, 1, 4, 2, 0) X(64, 128, 1, 4, 2, 0) \
     X(128, 256, 2, 4, 2, 0) X(128, 256, 2, 4, 3, 0) X(128, 256, 2, 2, 3, 0) X(128, 128, 2, 2, 3, 0) X(64, 256, 1, 4, 3, 0) \
     X(32, 256, 1, 4, 2, 0) X(32, 128, 1, 4, 2, 0) X(16, 256, 1, 4, 2, 0) X(16, 128, 1, 4, 2, 0)
-// loader / consumer build (GemmCfg<..., LC = true>, dispatchPolicyTag 4): the masked grouped weight stream
-#define DGA_MENU_LC(X) X(128, 256, 2, 2, 3, 0)
+// loader-wave build (GemmCfg<..., LCW = 4>, dispatchPolicyTag 4): the masked grouped weight stream and dense problems
+// that give every CU one 128x256 tile
+#define DGA_MENU_LC(X) X(128, 256, 2, 2, 3, 0) X(128, 128, 2, 2, 3, 0) X(64, 256, 1, 4, 3, 0)
 // loop-clock builds: the kernels of BASELINE configs[1] and configs[2]
 #define DGA_MENU_CLK(X) X(256, 256, 4, 2, 2, 2) X(128, 256, 2, 4, 3, 0)
 
@@ -36,7 +37,7 @@ DGA_MENU_B(DGA_MENU_EXTERN)
 DGA_MENU_C(DGA_MENU_EXTERN)
 DGA_MENU_CLK(DGA_MENU_EXTERN_CLK)
 #define DGA_MENU_EXTERN_LC(BM, BN, WM, WN, ST, PP) \
-    extern template int launch_cfg<GemmCfg<BM, BN, WM, WN, ST, true>, PP, false>(const GemmParams &, hipStream_t);
+    extern template int launch_cfg<GemmCfg<BM, BN, WM, WN, ST, 4>, PP, false>(const GemmParams &, hipStream_t);
 DGA_MENU_LC(DGA_MENU_EXTERN_LC)
 
 }  // namespace dga

@@ -51,7 +51,7 @@ struct Variant {
     int (*launch_pp)(const GemmParams &, hipStream_t);  // ping-pong schedule (dispatchPolicyTag 1), or null
     int (*launch_cont)(const GemmParams &, hipStream_t);  // continuous pipeline (dispatchPolicyTag 2), or null
     int stages = 2;
-    int (*launch_lc)(const GemmParams &, hipStream_t) = nullptr;  // loader / consumer wave split (dispatchPolicyTag 4), or null
+    int (*launch_lc)(const GemmParams &, hipStream_t) = nullptr;  // loader waves + plain loop (dispatchPolicyTag 4), or null
 };
 
 #define DGA_VARIANT(BM, BN, WM, WN) \
@@ -72,9 +72,11 @@ static const Variant kVariants[] = {
     //  names 2x2 explicitly for the masked grouped stream)
     Variant{128, 256, 2, 4, &launch_cfg<GemmCfg<128, 256, 2, 4, 3>, 0>, GemmCfg<128, 256, 2, 4, 3>::LDS_BYTES, nullptr, nullptr, 3},
     Variant{128, 256, 2, 2, &launch_cfg<GemmCfg<128, 256, 2, 2, 3>, 0>, GemmCfg<128, 256, 2, 2, 3>::LDS_BYTES, nullptr, nullptr, 3,
-            &launch_cfg<GemmCfg<128, 256, 2, 2, 3, true>, 0>},
-    Variant{128, 128, 2, 2, &launch_cfg<GemmCfg<128, 128, 2, 2, 3>, 0>, GemmCfg<128, 128, 2, 2, 3>::LDS_BYTES, nullptr, nullptr, 3},
-    Variant{64, 256, 1, 4, &launch_cfg<GemmCfg<64, 256, 1, 4, 3>, 0>, GemmCfg<64, 256, 1, 4, 3>::LDS_BYTES, nullptr, nullptr, 3},
+            &launch_cfg<GemmCfg<128, 256, 2, 2, 3, 4>, 0>},
+    Variant{128, 128, 2, 2, &launch_cfg<GemmCfg<128, 128, 2, 2, 3>, 0>, GemmCfg<128, 128, 2, 2, 3>::LDS_BYTES, nullptr, nullptr, 3,
+            &launch_cfg<GemmCfg<128, 128, 2, 2, 3, 4>, 0>},
+    Variant{64, 256, 1, 4, &launch_cfg<GemmCfg<64, 256, 1, 4, 3>, 0>, GemmCfg<64, 256, 1, 4, 3>::LDS_BYTES, nullptr, nullptr, 3,
+            &launch_cfg<GemmCfg<64, 256, 1, 4, 3, 4>, 0>},
 
     DGA_VARIANT(32, 256, 1, 4),  DGA_VARIANT(32, 128, 1, 4),  DGA_VARIANT(16, 256, 1, 4),
     DGA_VARIANT(16, 128, 1, 4),
@@ -83,6 +85,7 @@ static constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int variant_count() { return kNumVariants; }
 int variant_stages(int i) { return kVariants[i].stages; }
+bool variant_has_loader_waves(int i) { return kVariants[i].launch_lc != nullptr; }
 void variant_info(int i, int *bm, int *bn, int *wm, int *wn, int *lds)
 {
     *bm = kVariants[i].bm; *bn = kVariants[i].bn; *wm = kVariants[i].wm; *wn = kVariants[i].wn;
@@ -235,6 +238,12 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     }
     const Variant *v = find_variant(tiling->m1, tiling->n1, tiling->wavesM, tiling->wavesN, tiling->stages);
     if (!v) return DGA_E_TILING;
+    if (tiling->dispatchPolicyTag == DGA_POLICY_LOADER_WAVES && !v->launch_lc)   // the tile's build that has loader waves
+        for (int i = 0; i < kNumVariants; ++i)
+            if (kVariants[i].bm == v->bm && kVariants[i].bn == v->bn && kVariants[i].stages == v->stages && kVariants[i].launch_lc) {
+                v = &kVariants[i];
+                break;
+            }
     p.tiles_m = (m + v->bm - 1) / v->bm;
     p.tiles_n = (n + v->bn - 1) / v->bn;
     p.raster_group = tiling->swizzleOffset ? tiling->swizzleOffset : 1;

@@ -298,6 +298,7 @@ int dga_select_kernel_with_predictor(const dga_problem_t *problem, dga_tiling_t 
             out->ldsBytes = static_cast<uint32_t>(lds);
             break;
         }
+    dga::prefer_loader_waves(*out);
     if (predicted_us) *predicted_us = best;
     dga::apply_tail_split(*out, dga::device_cus());  // the model picks the tile; a small last wave of 256x256 tiles is still cut along K
     return DGA_OK;

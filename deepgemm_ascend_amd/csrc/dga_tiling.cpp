@@ -304,6 +304,25 @@ static uint32_t menu_lds_bytes(const dga_tiling_t &t)
     return t.ldsBytes;
 }
 
+// Loader waves (dispatchPolicyTag 4): every 4-wave, 3-stage tile has a build with four extra waves that carry the whole
+// LDS-DMA.  Measured on one box (scripts/lc_ab.py): 128x256 60.7 -> 55.7 us at 4096x2048x7168 (against the 8-wave 2x4
+// build), 128x128 40.4 -> 36.0 us at 2048x2048x7168 and 37.4 -> 31.0 us at 1024x2048x7168, 64x256 37.9 -> 32.2 us; the
+// masked grouped stream -2 %.  The output bytes are those of the plain loop, so whatever chose the tile (heuristic,
+// predictor, a swept row from before these builds existed) is upgraded here.
+void prefer_loader_waves(dga_tiling_t &t)
+{
+    if (t.dispatchPolicyTag != DGA_POLICY_PLAIN || t.stages != 3) return;
+    for (int i = 0; i < variant_count(); ++i) {
+        int bm, bn, wm, wn, lds;
+        variant_info(i, &bm, &bn, &wm, &wn, &lds);
+        if (bm != t.m1 || bn != t.n1 || variant_stages(i) != 3 || !variant_has_loader_waves(i)) continue;
+        t.wavesM = static_cast<uint8_t>(wm); t.wavesN = static_cast<uint8_t>(wn);
+        t.ldsBytes = static_cast<uint32_t>(lds);
+        t.dispatchPolicyTag = DGA_POLICY_LOADER_WAVES;
+        return;
+    }
+}
+
 void apply_tail_split(dga_tiling_t &t, uint32_t cus)
 {
     if (t.splitkFactor > 1 || t.m1 != 256 || t.n1 != 256 || t.groups > 1 || t.contiguous || !cus) return;
@@ -388,7 +407,7 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
     if (pick.bm == 128 && pick.bn == 256 && t.stages == 3 && !weight_stream) { t.wavesM = 2; t.wavesN = 4; }
     // ... and on the weight stream the 4-wave build takes four extra loader waves (dispatchPolicyTag 4): the refill leaves
     // the computing waves' instruction streams, -2 % time on 256 x (128, 7168, 2048) (profiles/r02_grouped_ablation.txt)
-    if (pick.bm == 128 && pick.bn == 256 && t.stages == 3 && weight_stream) t.dispatchPolicyTag = DGA_POLICY_LOADER_WAVES;
+    // (the weight stream keeps 2x2 computing waves; prefer_loader_waves() below adds the loader waves to every 3-stage pick)
     const uint32_t tiles_m = ceil_div(t.m, t.m1), tiles_n = ceil_div(t.n, t.n1);
     const uint64_t blocks = static_cast<uint64_t>(groups) * tiles_m * tiles_n;
     t.blockDim = static_cast<uint32_t>(blocks) * ((contiguous && t.m1 > DGA_CONTIGUOUS_M_ALIGNMENT) ? 2 : 1);
@@ -428,6 +447,7 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
     }
     t.swizzleOffset = static_cast<uint8_t>(std::min<uint32_t>(gm, 255));
     t.ldsBytes = menu_lds_bytes(t);   // of the build that will run (stage count and wave grid are settled by now)
+    prefer_loader_waves(t);
 }
 
 // ---- CSV-backed (m,n,k)-keyed cache ---------------------------------------------------------
@@ -622,6 +642,18 @@ int init_params(const dga_problem_t &p, dga_tiling_t &t)
 void complete_from_menu(dga_tiling_t &t)
 {
     if (!t.stages) t.stages = 2;
+    // a row that asks for loader waves (dispatchPolicyTag 4) names the build that has them, whatever wave grid it carries
+    if (t.dispatchPolicyTag == DGA_POLICY_LOADER_WAVES) {
+        for (int i = 0; i < variant_count(); ++i) {
+            int bm, bn, wm, wn, lds;
+            variant_info(i, &bm, &bn, &wm, &wn, &lds);
+            if (bm != t.m1 || bn != t.n1 || variant_stages(i) != (t.stages == 3 ? 3 : 2) || !variant_has_loader_waves(i)) continue;
+            t.wavesM = static_cast<uint8_t>(wm); t.wavesN = static_cast<uint8_t>(wn);
+            t.ldsBytes = static_cast<uint32_t>(lds);
+            return;
+        }
+        t.dispatchPolicyTag = DGA_POLICY_PLAIN;   // no such build for this tile: the plain loop
+    }
     // first build of that tile size with that stage count (the launcher's own preference order), else any build of it
     for (int pass = 0; pass < 2; ++pass)
         for (int i = 0; i < variant_count(); ++i) {
@@ -721,8 +753,9 @@ int dga_tiling(const dga_problem_t *problem, dga_tiling_t *out)
     init_params(*problem, *out);
     bool swept = false;
     if (Cache::instance().get(*out, &swept)) {
-        if (swept) {  // a swept entry is complete: use it as it stands
+        if (swept) {  // a swept entry is complete: use it as it stands (plus the loader waves where a build exists)
             complete_from_menu(*out);
+            dga::prefer_loader_waves(*out);
             return DGA_OK;
         }
         // A reference-format CSV stores the reference's columns only; the CDNA4-only fields (waves, stages, LDS bytes,
@@ -736,6 +769,7 @@ int dga_tiling(const dga_problem_t *problem, dga_tiling_t *out)
             complete_from_menu(*out);
             out->swizzleOffset = 4;
         }
+        dga::prefer_loader_waves(*out);
         return DGA_OK;
     }
     // cache miss: the learned predictor where it applies (it starts from, and falls back to, the heuristic)

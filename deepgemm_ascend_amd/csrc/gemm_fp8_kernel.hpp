@@ -141,7 +141,8 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
     constexpr bool LC = Cfg::kLC;
     const bool loader = LC && wave >= Cfg::kWM * WN;
     const int dwave = loader ? wave - Cfg::kWM * WN : wave;   // this wave's 1 KiB slot in every DMA piece
-    static_assert(!LC || PP == 0, "the loader / consumer split rides on the plain loop");
+    static_assert(!LC || PP == 0, "the loader waves ride on the plain loop");
+    static_assert(!LC || Cfg::DNT * 1 == Cfg::DMA_WAVES * 64, "loader waves carry the whole DMA");
 
     // ---- tile id: XCD-aware remap (blocks b, b+8, ... share an XCD and its L2), then
     //      a grouped raster so that an XCD's consecutive tiles share A and B panels.
@@ -759,10 +760,12 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
                     wait_vmcnt<(STG - 2) * Cfg::LOADS_PER_STAGE>();
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
+#ifndef DGA_ABL_NODMA
 #pragma unroll
                     for (int idx = Cfg::A_ITERS; idx < Cfg::LOADS_PER_STAGE; ++idx) issue_one(idx, fill, kb + STG - 1);
 #pragma unroll
                     for (int idx = 0; idx < Cfg::A_ITERS; ++idx) issue_one(idx, fill, kb + STG - 1);
+#endif
                     fill = fill + 1 == STG ? 0 : fill + 1;
                 }
                 wait_vmcnt<0>();   // the refills past the last k block land in LDS nobody reads: drain them before exit

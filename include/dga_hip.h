@@ -55,8 +55,9 @@ enum { DGA_KERNEL_COMMON = 0, DGA_KERNEL_SMALL = 1, DGA_KERNEL_PADDING_COMMON = 
  *   3 strict: fp32-input MFMA chain in the reference CPU path's own order (fp32 products, fp32 running sum, k ascending:
  *     framework/tests/test.py:37) -- bit-identical to the oracle, any shape, at the fp32 matrix rate (1/32 of the fp8
  *     rate).  $DGA_STRICT=1 forces it for every fp8 call of the process.
- *   4 loader waves: the plain loop with as many extra waves that only issue the LDS-DMA (the masked grouped weight stream:
- *     128x256 tile, 3 stages; -2 % time, same bits as policy 0); a tile without such a build runs policy 0. */
+ *   4 loader waves: the plain loop with four extra waves that only issue the LDS-DMA (128x256 tile, 3 stages): the masked
+ *     grouped weight stream (-2 % time) and dense problems of about one such tile per CU (BASELINE configs[2]: -9 %);
+ *     same bits as policy 0; a tile without such a build runs policy 0. */
 enum { DGA_POLICY_PLAIN = 0, DGA_POLICY_PINGPONG = 1, DGA_POLICY_CONTINUOUS = 2, DGA_POLICY_STRICT = 3,
        DGA_POLICY_LOADER_WAVES = 4 };
 

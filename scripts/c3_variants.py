@@ -14,7 +14,8 @@ for name, (bm, bn, wm, wn, st, pol) in {"auto": (0,) * 6, "128x256 (2,2) st3": (
                                          "256x256 cont": (256, 256, 4, 2, 2, 2), "128x128 st3": (128, 128, 2, 2, 3, 0),
                                          "128x256 (2,4) st3 8 waves": (128, 256, 2, 4, 3, 0), "128x256 (2,4) cont": (128, 256, 2, 4, 2, 2),
                                          "128x256 (2,2) cont": (128, 256, 2, 2, 2, 2), "256x128 (4,1) cont": (256, 128, 4, 1, 2, 2),
-                                         "128x128 cont": (128, 128, 2, 2, 2, 2)}.items():
+                                         "128x128 cont": (128, 128, 2, 2, 2, 2),
+                                         "128x256 (2,2) st3 + loader waves": (128, 256, 2, 2, 3, 4)}.items():
     t = dga.tiling(m, n, k)
     if bm:
         t.m1, t.n1, t.wavesM, t.wavesN, t.stages, t.dispatchPolicyTag, t.kernelSerial, t.splitkFactor = bm, bn, wm, wn, st, pol, 0, 1

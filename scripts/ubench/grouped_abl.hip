@@ -16,11 +16,13 @@ using namespace dga;
 #define CFG_ST 3
 #endif
 #ifndef CFG_LC
-#define CFG_LC false
+#define CFG_LC 0
 #endif
 int main(int argc, char **argv)
 {
-    const int G = argc > 1 ? atoi(argv[1]) : 256, m = 128, n = 2048, k = 7168, reps = argc > 2 ? atoi(argv[2]) : 20;
+    const int G = argc > 1 ? atoi(argv[1]) : 256, reps = argc > 2 ? atoi(argv[2]) : 20;
+    // optional: m n k of ONE group's problem (default the masked grouped configs[3]; "1 40 name 4096 2048 7168" = dense configs[2])
+    const int m = argc > 4 ? atoi(argv[4]) : 128, n = argc > 5 ? atoi(argv[5]) : 2048, k = argc > 6 ? atoi(argv[6]) : 7168;
     typedef GemmCfg<CFG_BM, CFG_BN, CFG_WM, CFG_WN, CFG_ST, CFG_LC> Cfg;
     const int kb = k / 128, nb = n / 128;
     const size_t abytes = (size_t)G * m * k, bbytes = (size_t)G * n * k;
@@ -42,7 +44,7 @@ int main(int argc, char **argv)
     p.lda = k; p.ldb = k; p.ldc = n; p.groups = G; p.b_groups = G; p.sfa_ld = kb;
     p.a_gs = (int64_t)m * k; p.b_gs = (int64_t)n * k; p.c_gs = (int64_t)m * n; p.sfa_gs = (int64_t)m * kb; p.sfb_gs = (int64_t)nb * kb;
     p.tiles_m = (m + Cfg::kBM - 1) / Cfg::kBM; p.tiles_n = (n + Cfg::kBN - 1) / Cfg::kBN;
-    p.raster_group = 1; p.xcd_remap = 1; p.splitk = 1;
+    p.raster_group = p.tiles_m >= 4 ? 4 : 1; p.xcd_remap = 1; p.splitk = 1;
     const int grid = G * p.tiles_m * p.tiles_n;
     auto kfn = gemm_fp8_blockscaled_nt_kernel<Cfg, 0, false>;
     hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
