@@ -12,6 +12,7 @@
 
 namespace dga {
 DGA_MENU_CLK(DGA_MENU_INSTANTIATE_CLK)
+DGA_MENU_CLK_LC(DGA_MENU_INSTANTIATE_CLK_LC)
 }
 
 extern "C" int dga_gemm_fp8_loop_clock(const void *a, const float *sfa, const void *b, const float *sfb, void *out, int m,

@@ -26,7 +26,8 @@ int launch_cfg(const GemmParams &p, hipStream_t stream);
 // that give every CU one 128x256 tile
 #define DGA_MENU_LC(X) X(128, 256, 2, 2, 3, 0) X(128, 128, 2, 2, 3, 0) X(64, 256, 1, 4, 3, 0)
 // loop-clock builds: the kernels of BASELINE configs[1] and configs[2]
-#define DGA_MENU_CLK(X) X(256, 256, 4, 2, 2, 2) X(128, 256, 2, 4, 3, 0)
+#define DGA_MENU_CLK(X) X(256, 256, 4, 2, 2, 2)
+#define DGA_MENU_CLK_LC(X) X(128, 256, 2, 2, 3, 0)   // configs[2] runs the loader-wave build
 
 #define DGA_MENU_EXTERN(BM, BN, WM, WN, ST, PP) \
     extern template int launch_cfg<GemmCfg<BM, BN, WM, WN, ST>, PP, false>(const GemmParams &, hipStream_t);
@@ -36,6 +37,9 @@ DGA_MENU_A(DGA_MENU_EXTERN)
 DGA_MENU_B(DGA_MENU_EXTERN)
 DGA_MENU_C(DGA_MENU_EXTERN)
 DGA_MENU_CLK(DGA_MENU_EXTERN_CLK)
+#define DGA_MENU_EXTERN_CLK_LC(BM, BN, WM, WN, ST, PP) \
+    extern template int launch_cfg<GemmCfg<BM, BN, WM, WN, ST, 4>, PP, true>(const GemmParams &, hipStream_t);
+DGA_MENU_CLK_LC(DGA_MENU_EXTERN_CLK_LC)
 #define DGA_MENU_EXTERN_LC(BM, BN, WM, WN, ST, PP) \
     extern template int launch_cfg<GemmCfg<BM, BN, WM, WN, ST, 4>, PP, false>(const GemmParams &, hipStream_t);
 DGA_MENU_LC(DGA_MENU_EXTERN_LC)

@@ -43,6 +43,8 @@ int launch_cfg(const GemmParams &p, hipStream_t stream)
     template int launch_cfg<GemmCfg<BM, BN, WM, WN, ST>, PP, false>(const GemmParams &, hipStream_t);
 #define DGA_MENU_INSTANTIATE_LC(BM, BN, WM, WN, ST, PP) \
     template int launch_cfg<GemmCfg<BM, BN, WM, WN, ST, 4>, PP, false>(const GemmParams &, hipStream_t);
+#define DGA_MENU_INSTANTIATE_CLK_LC(BM, BN, WM, WN, ST, PP) \
+    template int launch_cfg<GemmCfg<BM, BN, WM, WN, ST, 4>, PP, true>(const GemmParams &, hipStream_t);
 #define DGA_MENU_INSTANTIATE_CLK(BM, BN, WM, WN, ST, PP) \
     template int launch_cfg<GemmCfg<BM, BN, WM, WN, ST>, PP, true>(const GemmParams &, hipStream_t);
 

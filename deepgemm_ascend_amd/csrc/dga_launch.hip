@@ -107,7 +107,7 @@ static const Variant *find_variant(int bm, int bn, int wm, int wn, int stages)
 static int (*find_clock_build(const Variant *v, int policy))(const GemmParams &, hipStream_t)
 {
     if (v->bm == 256 && v->bn == 256 && policy == DGA_POLICY_CONTINUOUS) return &launch_cfg<GemmCfg<256, 256, 4, 2, 2>, 2, true>;
-    if (v->bm == 128 && v->bn == 256 && v->wm == 2 && v->wn == 4 && v->stages == 3) return &launch_cfg<GemmCfg<128, 256, 2, 4, 3>, 0, true>;
+    if (v->bm == 128 && v->bn == 256 && v->stages == 3 && policy == DGA_POLICY_LOADER_WAVES) return &launch_cfg<GemmCfg<128, 256, 2, 2, 3, 4>, 0, true>;
     return nullptr;
 }
 
@@ -277,7 +277,7 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     const int policy = pp_env >= 0 ? pp_env : tiling->dispatchPolicyTag;
     auto launch_main = [&](const GemmParams &q) -> int {
         if (q.stamps) {
-            auto clk = find_clock_build(v, policy == 2 && v->launch_cont ? 2 : 0);
+            auto clk = find_clock_build(v, policy == 2 && v->launch_cont ? 2 : (policy == DGA_POLICY_LOADER_WAVES && v->launch_lc ? policy : 0));
             return clk ? clk(q, stream) : DGA_E_TILING;
         }
         if (policy == DGA_POLICY_LOADER_WAVES && v->launch_lc) return v->launch_lc(q, stream);

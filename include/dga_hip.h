@@ -302,7 +302,7 @@ int dga_copy_rows2(void *dst0, int64_t dst0_row_stride, const void *src0, int64_
  * vendor peak).  Runs `launches` back-to-back launches of the loop-clock build of the kernel `tiling` selects -- the
  * product kernel plus one s_memtime / s_memrealtime pair either side of the k loop -- synchronises `stream`, and returns
  * the median over waves of shader ticks / 100 MHz ticks (clock_mhz) and of the loop's duration (loop_us, nullable).
- * Compiled for the kernels of BASELINE configs[1] / [2] (256x256 continuous, 128x256 8-wave 3-stage); other tilings,
+ * Compiled for the kernels of BASELINE configs[1] / [2] (256x256 continuous, 128x256 3-stage with loader waves); other tilings,
  * split-K, K % 128 != 0: DGA_E_TILING.  scratch: device memory, 16 bytes per wave (128 per tile).  The reference times
  * with msprof from outside (framework/benchmark/benchmark.py:400-418) and has no counterpart. */
 int dga_gemm_fp8_loop_clock(const void *a, const float *sfa, const void *b, const float *sfb, void *out, int m, int n,

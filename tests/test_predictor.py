@@ -129,7 +129,9 @@ def test_fallbacks_and_unload(predictor, tmp_path):
     predictor.predictor_load(str(flat))
     t, a, b = predictor.select_kernel_with_predictor(m, n, k)
     assert (t.m1, t.n1, t.stages, t.splitkFactor) == (native.m1, native.n1, native.stages, native.splitkFactor)
-    assert a == pytest.approx(math.exp(3.0)) and b == pytest.approx(math.exp(3.0))
+    # (a 3-stage tile with a loader-wave build carries the 0.88 calibration of dga_predictor.cpp on both figures)
+    scale = 0.88 if native.dispatchPolicyTag == 4 else 1.0
+    assert a == pytest.approx(scale * math.exp(3.0)) and b == pytest.approx(scale * math.exp(3.0))
     # grouped / contiguous / odd-K problems are outside the model: native
     for bad in (dict(m=64, n=4096, k=1921),):
         t2, a2, _ = predictor.select_kernel_with_predictor(**bad)
