@@ -25,7 +25,7 @@
 namespace dga {
 namespace predictor {
 
-constexpr int kFeatures = 14;
+constexpr int kFeatures = 15;
 constexpr int kMinCandidates = 4;        // get_best_config.py:587 (min_tiling = 60 on the reference's 16-aligned grid)
 constexpr float kGainThreshold = 0.03f;  // get_best_config.py:606-616 (time_diff_threshold)
 
@@ -110,7 +110,7 @@ static inline uint32_t stage_bytes(uint32_t m1, uint32_t n1)
     return std::max(m1, 32u) * 128 + n1 * 128 + ((m1 + 8 + 255) / 256) * 256 * 4;
 }
 
-// One candidate -> the 14 inputs.  Must match harness/train_predictor.py feature_row() exactly.
+// One candidate -> the 15 inputs.  Must match harness/train_predictor.py feature_row() exactly.
 static void feature_row(uint32_t m, uint32_t n, uint32_t k, const Cand &c, float *f)
 {
     const uint32_t tm = cdiv(m, c.m1), tn = cdiv(n, c.n1);
@@ -129,6 +129,7 @@ static void feature_row(uint32_t m, uint32_t n, uint32_t k, const Cand &c, float
     f[11] = std::log2(static_cast<float>(kbps));
     f[12] = static_cast<float>(m) / (static_cast<float>(tm) * c.m1);
     f[13] = static_cast<float>(n) / (static_cast<float>(tn) * c.n1);
+    f[14] = c.policy == DGA_POLICY_LOADER_WAVES ? 1.f : 0.f;
 }
 
 static float forward(const Model &mo, const float *f)
@@ -176,6 +177,8 @@ static std::vector<Cand> candidates(uint32_t m, uint32_t n, uint32_t k)
         for (int st = 2; st <= (three ? 3 : 2); ++st)
             for (int sk : {1, 2, 4, 8, 16}) {
                 if (sk > 1 && !(blocks * sk <= 1024 && kb / sk >= 4 && blocks < 192)) continue;
+                // a 3-stage build runs with loader waves (prefer_loader_waves upgrades the plain loop to them anyway)
+                if (st == 3) { out.push_back(Cand{(int)bm, (int)bn, st, sk, DGA_POLICY_LOADER_WAVES}); continue; }
                 for (int pol = 0; pol <= ((sched && sk == 1) ? 2 : 0); ++pol) out.push_back(Cand{(int)bm, (int)bn, st, sk, pol});
             }
     }
@@ -243,21 +246,6 @@ int dga_predict_time_us(const dga_problem_t *problem, const dga_tiling_t *tiling
     return DGA_OK;
 }
 
-// The shipped weights were trained before the loader-wave builds existed (round 1); every 3-stage candidate whose tile has
-// such a build now runs it (prefer_loader_waves).  Measured ratio to the plain build the model learnt: 0.83-0.92
-// (scripts/lc_ab.py); until the model is retrained on a sweep that times them, its prediction for those candidates is
-// scaled by the middle of that band.
-static float loader_wave_scale(int m1, int n1, int stages)
-{
-    if (stages != 3) return 1.f;
-    for (int i = 0; i < dga::variant_count(); ++i) {
-        int bm, bn, wm, wn, lds;
-        dga::variant_info(i, &bm, &bn, &wm, &wn, &lds);
-        if (bm == m1 && bn == n1 && dga::variant_stages(i) == 3 && dga::variant_has_loader_waves(i)) return 0.88f;
-    }
-    return 1.f;
-}
-
 // SelectKernelWithPredictor (select_kernel.cpp:380-388, commented out in the reference): native tiling first, then
 // the model's greedy pick over the candidate list unless a fallback applies.
 int dga_select_kernel_with_predictor(const dga_problem_t *problem, dga_tiling_t *out, float *predicted_us, float *native_us)
@@ -273,7 +261,7 @@ int dga_select_kernel_with_predictor(const dga_problem_t *problem, dga_tiling_t 
     float f[kFeatures];
     const Cand native{out->m1, out->n1, out->stages == 3 ? 3 : 2, std::max<int>(1, out->splitkFactor), out->dispatchPolicyTag};
     feature_row(problem->m, problem->n, problem->k, native, f);
-    const float t_native = forward(*mo, f) * loader_wave_scale(native.m1, native.n1, native.stages);
+    const float t_native = forward(*mo, f);
     if (native_us) *native_us = t_native;
     if (predicted_us) *predicted_us = t_native;
     const std::vector<Cand> cands = candidates(problem->m, problem->n, problem->k);
@@ -282,7 +270,7 @@ int dga_select_kernel_with_predictor(const dga_problem_t *problem, dga_tiling_t 
     const Cand *pick = nullptr;
     for (const Cand &c : cands) {
         feature_row(problem->m, problem->n, problem->k, c, f);
-        const float t = forward(*mo, f) * loader_wave_scale(c.m1, c.n1, c.stages);
+        const float t = forward(*mo, f);
         if (!pick || t < best) { best = t; pick = &c; }
     }
     if (!pick || !(best <= (1.f - kGainThreshold) * t_native)) return DGA_OK;  // fallback 2: gain below the threshold
@@ -290,7 +278,9 @@ int dga_select_kernel_with_predictor(const dga_problem_t *problem, dga_tiling_t 
     out->stages = static_cast<uint8_t>(pick->stages);
     // schedule of the 256x256 tile: the continuous pipeline wins every A/B at sustained clocks by 1-6 % (scripts/
     // steady_ab.py); the differences the sweep records show between the three schedules are mostly timing noise
-    out->dispatchPolicyTag = static_cast<uint8_t>((pick->m1 == 256 && pick->n1 == 256 && pick->splitk == 1) ? 2 : pick->policy);
+    // (a loader-wave pick is written as the plain loop here: prefer_loader_waves() below names the build and its wave grid)
+    out->dispatchPolicyTag = static_cast<uint8_t>((pick->m1 == 256 && pick->n1 == 256 && pick->splitk == 1) ? 2
+                                                  : pick->policy == DGA_POLICY_LOADER_WAVES ? DGA_POLICY_PLAIN : pick->policy);
     out->splitkFactor = static_cast<uint16_t>(pick->splitk);
     if (pick->splitk > 1) {  // no empty split (the launcher applies the same rule)
         const uint32_t kb = cdiv(problem->k, 128), per = cdiv(kb, pick->splitk);
