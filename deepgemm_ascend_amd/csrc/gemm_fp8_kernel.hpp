@@ -270,10 +270,6 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
     auto issue_one = [&](int idx, int stage, int kb) {
         const uint32_t sa = lds0 + stage * Cfg::STAGE_BYTES + dwave * 1024;
         const int k0 = kb * 128;
-#ifdef DGA_DMA_B_FIRST   // experiment: the pieces that come from HBM (B) go out before the L2-resident ones (A)
-        if (idx < Cfg::B_ITERS) idx += Cfg::A_ITERS;
-        else if (idx < Cfg::A_ITERS + Cfg::B_ITERS) idx -= Cfg::B_ITERS;
-#endif
         if (idx < Cfg::A_ITERS) {
 #ifdef DGA_ABL_NOADMA
             return;   // diagnostic: the A tile is never fetched (whatever lies in the LDS is multiplied)
