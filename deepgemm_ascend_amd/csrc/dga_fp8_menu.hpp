@@ -21,7 +21,8 @@ int launch_cfg(const GemmParams &p, hipStream_t stream);
 #define DGA_MENU_C(X)                                                                                              \
     X(128, 256, 2, 2, 2, 0) X(256, 128, 4, 1, 2, 0) X(128, 128, 2, 2, 2, 0) X(64, 256, 1, 4, 2, 0) X(64, 128, 1, 4, 2, 0) \
     X(128, 256, 2, 4, 2, 0) X(128, 256, 2, 4, 3, 0) X(128, 256, 2, 2, 3, 0) X(128, 128, 2, 2, 3, 0) X(64, 256, 1, 4, 3, 0) \
-    X(32, 256, 1, 4, 2, 0) X(32, 128, 1, 4, 2, 0) X(16, 256, 1, 4, 2, 0) X(16, 128, 1, 4, 2, 0)
+    X(32, 256, 1, 4, 2, 0) X(32, 128, 1, 4, 2, 0) X(16, 256, 1, 4, 2, 0) X(16, 128, 1, 4, 2, 0)                        \
+    X(64, 128, 1, 4, 3, 0) X(32, 256, 1, 4, 3, 0) X(32, 128, 1, 4, 3, 0) X(16, 256, 1, 4, 3, 0) X(16, 128, 1, 4, 3, 0)
 // loader-wave build (GemmCfg<..., LCW = 4>, dispatchPolicyTag 4): the masked grouped weight stream and dense problems
 // that give every CU one 128x256 tile
 #define DGA_MENU_LC(X) X(128, 256, 2, 2, 3, 0) X(128, 128, 2, 2, 3, 0) X(64, 256, 1, 4, 3, 0)

@@ -172,13 +172,17 @@ static std::vector<Cand> candidates(uint32_t m, uint32_t n, uint32_t k)
         if (!has_variant(bm, bn)) continue;
         if (bm >= 2 * std::max(m, 16u) && bm > 16) continue;  // a tile twice the problem is pointless
         const uint64_t blocks = static_cast<uint64_t>(cdiv(m, bm)) * cdiv(n, bn);
-        const bool three = (bm == 128 && bn == 256) || (bm == 128 && bn == 128) || (bm == 64 && bn == 256);
+        const bool three = bm <= 128;   // every tile below 256 rows has a 3-stage build
         const bool sched = (bm == 256 && bn == 256);
         for (int st = 2; st <= (three ? 3 : 2); ++st)
             for (int sk : {1, 2, 4, 8, 16}) {
                 if (sk > 1 && !(blocks * sk <= 1024 && kb / sk >= 4 && blocks < 192)) continue;
                 // a 3-stage build runs with loader waves (prefer_loader_waves upgrades the plain loop to them anyway)
-                if (st == 3) { out.push_back(Cand{(int)bm, (int)bn, st, sk, DGA_POLICY_LOADER_WAVES}); continue; }
+                if (st == 3) {
+                    const bool lw = (bm == 128 && bn == 256) || (bm == 128 && bn == 128) || (bm == 64 && bn == 256);
+                    out.push_back(Cand{(int)bm, (int)bn, st, sk, lw ? DGA_POLICY_LOADER_WAVES : DGA_POLICY_PLAIN});
+                    continue;
+                }
                 for (int pol = 0; pol <= ((sched && sk == 1) ? 2 : 0); ++pol) out.push_back(Cand{(int)bm, (int)bn, st, sk, pol});
             }
     }

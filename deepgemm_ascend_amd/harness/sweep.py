@@ -40,7 +40,8 @@ class Result:
     parameters: dict = field(default_factory=dict)
 
 
-THREE_STAGE = {(128, 256), (128, 128), (64, 256)}   # tiles that also have a 3-stage build (each with a loader-wave variant)
+THREE_STAGE = {(128, 256), (128, 128), (64, 256), (64, 128), (32, 256), (32, 128), (16, 256), (16, 128)}   # tiles with a 3-stage build
+LOADER_WAVES = {(128, 256), (128, 128), (64, 256)}   # ... of which these have a loader-wave variant (dispatchPolicyTag 4)
 PINGPONG = {(256, 256)}                               # ... ping-pong / continuous schedules (dispatchPolicyTag 1 / 2)
 
 
@@ -89,7 +90,7 @@ def candidates(m, n, k, rasters=None):
             for st in ([2, 3] if (bm, bn) in THREE_STAGE else [2]):
                 for sk in splits:
                     # 3-stage builds: the plain loop and its loader-wave variant (dispatchPolicyTag 4)
-                    for pol in ([0, 1, 2] if (bm, bn) in PINGPONG and sk == 1 else ([0, 4] if st == 3 else [0])):
+                    for pol in ([0, 1, 2] if (bm, bn) in PINGPONG and sk == 1 else ([0, 4] if st == 3 and (bm, bn) in LOADER_WAVES else [0])):
                         rr = r if rasters is None else heuristic_raster(m, n, bm, bn, sk, stages=st)
                         out.append({"m1": bm, "n1": bn, "raster": rr, "stages": st, "splitk": sk, "policy": pol})
                         # 256x256, more than one wave of tiles with a small remainder: also with the quarter-tile tail
@@ -103,7 +104,8 @@ def candidates(m, n, k, rasters=None):
 MENU = [(256, 256, 4, 2, 2, (0, 1, 2)), (128, 256, 2, 2, 2, (0, 2)), (256, 128, 4, 1, 2, (0, 2)), (128, 128, 2, 2, 2, (0, 2)),
         (64, 256, 1, 4, 2, (0, 2)), (64, 128, 1, 4, 2, (0,)), (128, 256, 2, 4, 2, (0, 2)), (128, 256, 2, 4, 3, (0,)),
         (128, 256, 2, 2, 3, (0, 4)), (128, 128, 2, 2, 3, (0, 4)), (64, 256, 1, 4, 3, (0, 4)), (32, 256, 1, 4, 2, (0,)),
-        (32, 128, 1, 4, 2, (0,)), (16, 256, 1, 4, 2, (0,)), (16, 128, 1, 4, 2, (0,))]
+        (32, 128, 1, 4, 2, (0,)), (16, 256, 1, 4, 2, (0,)), (16, 128, 1, 4, 2, (0,)),
+        (64, 128, 1, 4, 3, (0,)), (32, 256, 1, 4, 3, (0,)), (32, 128, 1, 4, 3, (0,)), (16, 256, 1, 4, 3, (0,)), (16, 128, 1, 4, 3, (0,))]
 LDS_BYTES, ACC_REGS, CUS = 160 * 1024, 128, 256
 
 
