@@ -25,7 +25,7 @@ int launch_cfg(const GemmParams &p, hipStream_t stream);
     X(64, 128, 1, 4, 3, 0) X(32, 256, 1, 4, 3, 0) X(32, 128, 1, 4, 3, 0) X(16, 256, 1, 4, 3, 0) X(16, 128, 1, 4, 3, 0)
 // loader-wave build (GemmCfg<..., LCW = 4>, dispatchPolicyTag 4): the masked grouped weight stream and dense problems
 // that give every CU one 128x256 tile
-#define DGA_MENU_LC(X) X(128, 256, 2, 2, 3, 0) X(128, 128, 2, 2, 3, 0) X(64, 256, 1, 4, 3, 0)
+#define DGA_MENU_LC(X) X(128, 256, 2, 2, 3, 0) X(128, 128, 2, 2, 3, 0) X(64, 256, 1, 4, 3, 0) X(64, 128, 1, 4, 3, 0) X(16, 128, 1, 4, 3, 0)
 // loop-clock builds: the kernels of BASELINE configs[1] and configs[2]
 #define DGA_MENU_CLK(X) X(256, 256, 4, 2, 2, 2)
 #define DGA_MENU_CLK_LC(X) X(128, 256, 2, 2, 3, 0)   // configs[2] runs the loader-wave build

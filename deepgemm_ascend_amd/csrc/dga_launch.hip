@@ -82,11 +82,13 @@ static const Variant kVariants[] = {
     DGA_VARIANT(16, 128, 1, 4),
     // three stages for the short tiles too: decode shapes stream their weights cold, and a second refill in flight per
     // workgroup is what the HBM round trip needs (profiles/r02_steady_table.json: warm 5.5 TB/s, cold 3.8 with two stages)
-    Variant{64, 128, 1, 4, &launch_cfg<GemmCfg<64, 128, 1, 4, 3>, 0>, GemmCfg<64, 128, 1, 4, 3>::LDS_BYTES, nullptr, nullptr, 3},
+    Variant{64, 128, 1, 4, &launch_cfg<GemmCfg<64, 128, 1, 4, 3>, 0>, GemmCfg<64, 128, 1, 4, 3>::LDS_BYTES, nullptr, nullptr, 3,
+            &launch_cfg<GemmCfg<64, 128, 1, 4, 3, 4>, 0>},
     Variant{32, 256, 1, 4, &launch_cfg<GemmCfg<32, 256, 1, 4, 3>, 0>, GemmCfg<32, 256, 1, 4, 3>::LDS_BYTES, nullptr, nullptr, 3},
     Variant{32, 128, 1, 4, &launch_cfg<GemmCfg<32, 128, 1, 4, 3>, 0>, GemmCfg<32, 128, 1, 4, 3>::LDS_BYTES, nullptr, nullptr, 3},
     Variant{16, 256, 1, 4, &launch_cfg<GemmCfg<16, 256, 1, 4, 3>, 0>, GemmCfg<16, 256, 1, 4, 3>::LDS_BYTES, nullptr, nullptr, 3},
-    Variant{16, 128, 1, 4, &launch_cfg<GemmCfg<16, 128, 1, 4, 3>, 0>, GemmCfg<16, 128, 1, 4, 3>::LDS_BYTES, nullptr, nullptr, 3},
+    Variant{16, 128, 1, 4, &launch_cfg<GemmCfg<16, 128, 1, 4, 3>, 0>, GemmCfg<16, 128, 1, 4, 3>::LDS_BYTES, nullptr, nullptr, 3,
+            &launch_cfg<GemmCfg<16, 128, 1, 4, 3, 4>, 0>},
 };
 static constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 

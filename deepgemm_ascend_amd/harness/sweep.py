@@ -41,7 +41,7 @@ class Result:
 
 
 THREE_STAGE = {(128, 256), (128, 128), (64, 256), (64, 128), (32, 256), (32, 128), (16, 256), (16, 128)}   # tiles with a 3-stage build
-LOADER_WAVES = {(128, 256), (128, 128), (64, 256)}   # ... of which these have a loader-wave variant (dispatchPolicyTag 4)
+LOADER_WAVES = {(128, 256), (128, 128), (64, 256), (64, 128), (16, 128)}   # ... of which these have a loader-wave variant (dispatchPolicyTag 4)
 PINGPONG = {(256, 256)}                               # ... ping-pong / continuous schedules (dispatchPolicyTag 1 / 2)
 
 
@@ -105,7 +105,7 @@ MENU = [(256, 256, 4, 2, 2, (0, 1, 2)), (128, 256, 2, 2, 2, (0, 2)), (256, 128, 
         (64, 256, 1, 4, 2, (0, 2)), (64, 128, 1, 4, 2, (0,)), (128, 256, 2, 4, 2, (0, 2)), (128, 256, 2, 4, 3, (0,)),
         (128, 256, 2, 2, 3, (0, 4)), (128, 128, 2, 2, 3, (0, 4)), (64, 256, 1, 4, 3, (0, 4)), (32, 256, 1, 4, 2, (0,)),
         (32, 128, 1, 4, 2, (0,)), (16, 256, 1, 4, 2, (0,)), (16, 128, 1, 4, 2, (0,)),
-        (64, 128, 1, 4, 3, (0,)), (32, 256, 1, 4, 3, (0,)), (32, 128, 1, 4, 3, (0,)), (16, 256, 1, 4, 3, (0,)), (16, 128, 1, 4, 3, (0,))]
+        (64, 128, 1, 4, 3, (0, 4)), (32, 256, 1, 4, 3, (0,)), (32, 128, 1, 4, 3, (0,)), (16, 256, 1, 4, 3, (0,)), (16, 128, 1, 4, 3, (0, 4))]
 LDS_BYTES, ACC_REGS, CUS = 160 * 1024, 128, 256
 
 

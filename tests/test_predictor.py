@@ -154,7 +154,7 @@ def test_tiling_consults_the_predictor_on_a_cache_miss(predictor):
     t = predictor.tiling(m, n, k)
     assert (t.m1, t.n1, t.stages, t.splitkFactor, t.dispatchPolicyTag) == \
            (t_pred.m1, t_pred.n1, t_pred.stages, t_pred.splitkFactor, t_pred.dispatchPolicyTag)
-    if t.stages == 3 and (t.m1, t.n1) in ((128, 256), (128, 128), (64, 256)):   # the tiles that have a loader-wave build
+    if t.stages == 3 and (t.m1, t.n1) in ((128, 256), (128, 128), (64, 256), (64, 128), (16, 128)):   # the tiles that have a loader-wave build
         assert t.dispatchPolicyTag == 4
 
 
