@@ -78,7 +78,7 @@ def _mmad_workspace(batch, m, n, k, x) -> Tuple[Optional[int], int]:
     return _scratch("mmad", x.device, int(_lib.lib().dga_mmad_workspace_bytes(batch, m, n, k, x.data_ptr())))
 
 
-POLICY_PLAIN, POLICY_PINGPONG, POLICY_CONTINUOUS, POLICY_STRICT, POLICY_LOADER_WAVES = 0, 1, 2, 3, 4
+POLICY_PLAIN, POLICY_PINGPONG, POLICY_CONTINUOUS, POLICY_STRICT, POLICY_LOADER_WAVES, POLICY_PERSISTENT = 0, 1, 2, 3, 4, 5
 
 
 def _with_policy(t: Tiling, strict: bool) -> Tiling:

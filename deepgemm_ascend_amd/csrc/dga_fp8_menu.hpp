@@ -45,4 +45,12 @@ DGA_MENU_CLK_LC(DGA_MENU_EXTERN_CLK_LC)
     extern template int launch_cfg<GemmCfg<BM, BN, WM, WN, ST, 4>, PP, false>(const GemmParams &, hipStream_t);
 DGA_MENU_LC(DGA_MENU_EXTERN_LC)
 
+// persistent loader-wave builds (gemm_fp8_persistent_kernel.hpp, dispatchPolicyTag 5; dga_launch_menu_d.hip): one workgroup
+// per CU walks its share of the tiles, the LDS ring runs across tile boundaries.  Every loader-wave tile has one.
+template <class Cfg>
+int launch_persistent(const GemmParams &p, hipStream_t stream);
+#define DGA_MENU_EXTERN_PS(BM, BN, WM, WN, ST, PP) \
+    extern template int launch_persistent<GemmCfg<BM, BN, WM, WN, ST, 4>>(const GemmParams &, hipStream_t);
+DGA_MENU_LC(DGA_MENU_EXTERN_PS)
+
 }  // namespace dga

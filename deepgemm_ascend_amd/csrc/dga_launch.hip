@@ -52,6 +52,7 @@ struct Variant {
     int (*launch_cont)(const GemmParams &, hipStream_t);  // continuous pipeline (dispatchPolicyTag 2), or null
     int stages = 2;
     int (*launch_lc)(const GemmParams &, hipStream_t) = nullptr;  // loader waves + plain loop (dispatchPolicyTag 4), or null
+    int (*launch_ps)(const GemmParams &, hipStream_t) = nullptr;  // persistent loader waves (dispatchPolicyTag 5), or null
 };
 
 #define DGA_VARIANT(BM, BN, WM, WN) \
@@ -72,23 +73,23 @@ static const Variant kVariants[] = {
     //  names 2x2 explicitly for the masked grouped stream)
     Variant{128, 256, 2, 4, &launch_cfg<GemmCfg<128, 256, 2, 4, 3>, 0>, GemmCfg<128, 256, 2, 4, 3>::LDS_BYTES, nullptr, nullptr, 3},
     Variant{128, 256, 2, 2, &launch_cfg<GemmCfg<128, 256, 2, 2, 3>, 0>, GemmCfg<128, 256, 2, 2, 3>::LDS_BYTES, nullptr, nullptr, 3,
-            &launch_cfg<GemmCfg<128, 256, 2, 2, 3, 4>, 0>},
+            &launch_cfg<GemmCfg<128, 256, 2, 2, 3, 4>, 0>, &launch_persistent<GemmCfg<128, 256, 2, 2, 3, 4>>},
     Variant{128, 128, 2, 2, &launch_cfg<GemmCfg<128, 128, 2, 2, 3>, 0>, GemmCfg<128, 128, 2, 2, 3>::LDS_BYTES, nullptr, nullptr, 3,
-            &launch_cfg<GemmCfg<128, 128, 2, 2, 3, 4>, 0>},
+            &launch_cfg<GemmCfg<128, 128, 2, 2, 3, 4>, 0>, &launch_persistent<GemmCfg<128, 128, 2, 2, 3, 4>>},
     Variant{64, 256, 1, 4, &launch_cfg<GemmCfg<64, 256, 1, 4, 3>, 0>, GemmCfg<64, 256, 1, 4, 3>::LDS_BYTES, nullptr, nullptr, 3,
-            &launch_cfg<GemmCfg<64, 256, 1, 4, 3, 4>, 0>},
+            &launch_cfg<GemmCfg<64, 256, 1, 4, 3, 4>, 0>, &launch_persistent<GemmCfg<64, 256, 1, 4, 3, 4>>},
 
     DGA_VARIANT(32, 256, 1, 4),  DGA_VARIANT(32, 128, 1, 4),  DGA_VARIANT(16, 256, 1, 4),
     DGA_VARIANT(16, 128, 1, 4),
     // three stages for the short tiles too: decode shapes stream their weights cold, and a second refill in flight per
     // workgroup is what the HBM round trip needs (profiles/r02_steady_table.json: warm 5.5 TB/s, cold 3.8 with two stages)
     Variant{64, 128, 1, 4, &launch_cfg<GemmCfg<64, 128, 1, 4, 3>, 0>, GemmCfg<64, 128, 1, 4, 3>::LDS_BYTES, nullptr, nullptr, 3,
-            &launch_cfg<GemmCfg<64, 128, 1, 4, 3, 4>, 0>},
+            &launch_cfg<GemmCfg<64, 128, 1, 4, 3, 4>, 0>, &launch_persistent<GemmCfg<64, 128, 1, 4, 3, 4>>},
     Variant{32, 256, 1, 4, &launch_cfg<GemmCfg<32, 256, 1, 4, 3>, 0>, GemmCfg<32, 256, 1, 4, 3>::LDS_BYTES, nullptr, nullptr, 3},
     Variant{32, 128, 1, 4, &launch_cfg<GemmCfg<32, 128, 1, 4, 3>, 0>, GemmCfg<32, 128, 1, 4, 3>::LDS_BYTES, nullptr, nullptr, 3},
     Variant{16, 256, 1, 4, &launch_cfg<GemmCfg<16, 256, 1, 4, 3>, 0>, GemmCfg<16, 256, 1, 4, 3>::LDS_BYTES, nullptr, nullptr, 3},
     Variant{16, 128, 1, 4, &launch_cfg<GemmCfg<16, 128, 1, 4, 3>, 0>, GemmCfg<16, 128, 1, 4, 3>::LDS_BYTES, nullptr, nullptr, 3,
-            &launch_cfg<GemmCfg<16, 128, 1, 4, 3, 4>, 0>},
+            &launch_cfg<GemmCfg<16, 128, 1, 4, 3, 4>, 0>, &launch_persistent<GemmCfg<16, 128, 1, 4, 3, 4>>},
 };
 static constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -247,7 +248,8 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     }
     const Variant *v = find_variant(tiling->m1, tiling->n1, tiling->wavesM, tiling->wavesN, tiling->stages);
     if (!v) return DGA_E_TILING;
-    if (tiling->dispatchPolicyTag == DGA_POLICY_LOADER_WAVES && !v->launch_lc)   // the tile's build that has loader waves
+    const bool wants_loaders = tiling->dispatchPolicyTag == DGA_POLICY_LOADER_WAVES || tiling->dispatchPolicyTag == DGA_POLICY_PERSISTENT;
+    if (wants_loaders && !v->launch_lc)   // the tile's build that has loader waves
         for (int i = 0; i < kNumVariants; ++i)
             if (kVariants[i].bm == v->bm && kVariants[i].bn == v->bn && kVariants[i].stages == v->stages && kVariants[i].launch_lc) {
                 v = &kVariants[i];
@@ -289,7 +291,9 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
             auto clk = find_clock_build(v, policy == 2 && v->launch_cont ? 2 : (policy == DGA_POLICY_LOADER_WAVES && v->launch_lc ? policy : 0));
             return clk ? clk(q, stream) : DGA_E_TILING;
         }
-        if (policy == DGA_POLICY_LOADER_WAVES && v->launch_lc) return v->launch_lc(q, stream);
+        if (policy == DGA_POLICY_PERSISTENT && v->launch_ps && q.splitk <= 1 && !q.tail_sub && q.launch_tiles == 0)
+            return v->launch_ps(q, stream);
+        if ((policy == DGA_POLICY_LOADER_WAVES || policy == DGA_POLICY_PERSISTENT) && v->launch_lc) return v->launch_lc(q, stream);
         if (policy == 1 && v->launch_pp) return v->launch_pp(q, stream);
         if (policy == 2 && v->launch_cont) return v->launch_cont(q, stream);
         return v->launch(q, stream);

@@ -1,0 +1,42 @@
+// fp8 tile-kernel menu, part D: the persistent loader-wave builds (dga_fp8_menu.hpp, gemm_fp8_persistent_kernel.hpp).
+#include "dga_fp8_menu_impl.hpp"
+#include "gemm_fp8_persistent_kernel.hpp"
+namespace dga {
+
+template <class Cfg, bool KTAIL>
+static int launch_persistent_one(const GemmParams &p, hipStream_t stream)
+{
+    auto kfn = gemm_fp8_blockscaled_nt_persistent_kernel<Cfg, KTAIL>;
+    static std::once_flag once[64];
+    static hipError_t attr_err[64];
+    int dev = 0;
+    if (int rc = record_hip(hipGetDevice(&dev))) return rc;
+    if (dev < 0 || dev >= 64) return DGA_E_HIP;
+    std::call_once(once[dev], [&] {
+        attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    });
+    if (int rc = record_hip(attr_err[dev])) return rc;
+    // one workgroup per CU (a stage ring of this size leaves room for one), fewer when the raster is smaller
+    const int64_t tiles = static_cast<int64_t>(p.groups) * p.tiles_m * p.tiles_n;
+    const int64_t cus = device_cus();
+    const unsigned grid = static_cast<unsigned>(tiles < cus ? tiles : cus);
+    if (grid == 0) return DGA_OK;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p);
+    return record_hip(hipGetLastError());
+}
+
+template <class Cfg>
+int launch_persistent(const GemmParams &p, hipStream_t stream)
+{
+    // the persistent builds take whole rasters only: no split-K slabs, no quarter-tile tail, tiles no taller than the
+    // contiguous layout's segment alignment
+    if (p.splitk > 1 || p.tail_sub || p.launch_tiles > 0) return DGA_E_TILING;
+    if (p.m_indices && Cfg::kBM > DGA_CONTIGUOUS_M_ALIGNMENT) return DGA_E_TILING;
+    return (p.k % 128) ? launch_persistent_one<Cfg, true>(p, stream) : launch_persistent_one<Cfg, false>(p, stream);
+}
+
+#define DGA_MENU_INSTANTIATE_PS(BM, BN, WM, WN, ST, PP) \
+    template int launch_persistent<GemmCfg<BM, BN, WM, WN, ST, 4>>(const GemmParams &, hipStream_t);
+DGA_MENU_LC(DGA_MENU_INSTANTIATE_PS)
+}

@@ -309,17 +309,29 @@ static uint32_t menu_lds_bytes(const dga_tiling_t &t)
 // build), 128x128 40.4 -> 36.0 us at 2048x2048x7168 and 37.4 -> 31.0 us at 1024x2048x7168, 64x256 37.9 -> 32.2 us; the
 // masked grouped stream -2 %.  The output bytes are those of the plain loop, so whatever chose the tile (heuristic,
 // predictor, a swept row from before these builds existed) is upgraded here.
+//
+// Persistent form (dispatchPolicyTag 5, gemm_fp8_persistent_kernel.hpp): where the raster holds more tiles than the chip
+// has CUs, one workgroup per CU walks its share and the ring runs across tile boundaries.  Same bits again.  Measured
+// (scripts/ps_check.py): 256 x (128, 7168, 2048) full mask 770 -> 746 us, random mask 672 -> 657, decode masks 592 -> 577;
+// dense 128x256 rasters of 2-4 tiles per CU -3..-10 %.  Split-K and the quarter-tile tail keep the one-tile builds.
 void prefer_loader_waves(dga_tiling_t &t)
 {
-    if (t.dispatchPolicyTag != DGA_POLICY_PLAIN || t.stages != 3) return;
-    for (int i = 0; i < variant_count(); ++i) {
-        int bm, bn, wm, wn, lds;
-        variant_info(i, &bm, &bn, &wm, &wn, &lds);
-        if (bm != t.m1 || bn != t.n1 || variant_stages(i) != 3 || !variant_has_loader_waves(i)) continue;
-        t.wavesM = static_cast<uint8_t>(wm); t.wavesN = static_cast<uint8_t>(wn);
-        t.ldsBytes = static_cast<uint32_t>(lds);
-        t.dispatchPolicyTag = DGA_POLICY_LOADER_WAVES;
-        return;
+    if (t.dispatchPolicyTag == DGA_POLICY_PLAIN && t.stages == 3) {
+        for (int i = 0; i < variant_count(); ++i) {
+            int bm, bn, wm, wn, lds;
+            variant_info(i, &bm, &bn, &wm, &wn, &lds);
+            if (bm != t.m1 || bn != t.n1 || variant_stages(i) != 3 || !variant_has_loader_waves(i)) continue;
+            t.wavesM = static_cast<uint8_t>(wm); t.wavesN = static_cast<uint8_t>(wn);
+            t.ldsBytes = static_cast<uint32_t>(lds);
+            t.dispatchPolicyTag = DGA_POLICY_LOADER_WAVES;
+            break;
+        }
+    }
+    if (t.dispatchPolicyTag == DGA_POLICY_LOADER_WAVES && t.splitkFactor <= 1 && t.kernelSerial != DGA_KERNEL_STREAMK_TAIL &&
+        t.m1 && t.n1 && !(t.contiguous && t.m1 > DGA_CONTIGUOUS_M_ALIGNMENT)) {
+        const uint64_t groups = t.contiguous ? 1 : std::max<uint32_t>(1, t.groups);
+        const uint64_t tiles = groups * ((t.m + t.m1 - 1) / t.m1) * ((t.n + t.n1 - 1) / t.n1);
+        if (tiles > device_cus()) t.dispatchPolicyTag = DGA_POLICY_PERSISTENT;
     }
 }
 
@@ -643,7 +655,7 @@ void complete_from_menu(dga_tiling_t &t)
 {
     if (!t.stages) t.stages = 2;
     // a row that asks for loader waves (dispatchPolicyTag 4) names the build that has them, whatever wave grid it carries
-    if (t.dispatchPolicyTag == DGA_POLICY_LOADER_WAVES) {
+    if (t.dispatchPolicyTag == DGA_POLICY_LOADER_WAVES || t.dispatchPolicyTag == DGA_POLICY_PERSISTENT) {
         for (int i = 0; i < variant_count(); ++i) {
             int bm, bn, wm, wn, lds;
             variant_info(i, &bm, &bn, &wm, &wn, &lds);

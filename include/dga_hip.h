@@ -57,9 +57,13 @@ enum { DGA_KERNEL_COMMON = 0, DGA_KERNEL_SMALL = 1, DGA_KERNEL_PADDING_COMMON = 
  *     rate).  $DGA_STRICT=1 forces it for every fp8 call of the process.
  *   4 loader waves: the plain loop with four extra waves that only issue the LDS-DMA (128x256 tile, 3 stages): the masked
  *     grouped weight stream (-2 % time) and dense problems of about one such tile per CU (BASELINE configs[2]: -9 %);
- *     same bits as policy 0; a tile without such a build runs policy 0. */
+ *     same bits as policy 0; a tile without such a build runs policy 0.
+ *   5 persistent loader waves: policy 4 with one workgroup per CU that walks its share of the tiles, the LDS ring running
+ *     across tile boundaries (the next tile's first k blocks are in flight while this one is stored) -- what the
+ *     reference's one-block-per-AI-core kernel is by construction (framework/csrc/jit/generate_code.hpp:160-198); same
+ *     bits as policy 0; whole rasters only (split-K and the quarter-tile tail run policy 4). */
 enum { DGA_POLICY_PLAIN = 0, DGA_POLICY_PINGPONG = 1, DGA_POLICY_CONTINUOUS = 2, DGA_POLICY_STRICT = 3,
-       DGA_POLICY_LOADER_WAVES = 4 };
+       DGA_POLICY_LOADER_WAVES = 4, DGA_POLICY_PERSISTENT = 5 };
 
 /* Platform description: the CDNA4 retarget of PlatformInfo
  * (op_tiling/platform_info.h:16-41; Python mirror get_best_config/tiling_calculator.py:25-30).

@@ -195,10 +195,84 @@ def test_loader_wave_build_writes_the_same_bits(dga, oracle):
     t = dga.tiling(mmax, n, k, groups=g, expected_m=128)
     t.m1, t.n1, t.wavesM, t.wavesN, t.stages, t.dispatchPolicyTag = 128, 256, 2, 2, 3, 4
     big = dga.tiling(128, 2048, 7168, groups=256, expected_m=128)          # BASELINE configs[3]: the tiling's own choice
-    assert (big.m1, big.n1, big.stages, big.dispatchPolicyTag) == (128, 256, 3, 4)
+    assert (big.m1, big.n1, big.stages, big.dispatchPolicyTag) == (128, 256, 3, 5)   # 2048 tiles > CUs: the persistent form
     o4 = torch.full((g, mmax, n), -1.0, dtype=torch.bfloat16, device="cuda")
     dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), o4, masked, 128, tiling_=t)
     t.dispatchPolicyTag = 0
     o0 = torch.full((g, mmax, n), -1.0, dtype=torch.bfloat16, device="cuda")
     dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), o0, masked, 128, tiling_=t, sync=True)
     assert torch.equal(o4.view(torch.int16), o0.view(torch.int16))
+
+
+@pytest.mark.parametrize("tile", [(128, 256, 2, 2), (128, 128, 2, 2), (64, 256, 1, 4), (64, 128, 1, 4), (16, 128, 1, 4)])
+def test_persistent_build_writes_the_same_bits(dga, oracle, tile):
+    """dispatchPolicyTag 5 (one workgroup per CU walks its tiles, the LDS ring runs across tile boundaries) against the
+    one-tile plain loop of the same tile shape: identical output bytes.  The raster holds several tiles per workgroup
+    (every workgroup crosses tile boundaries), empty experts in the middle of a workgroup's list, ragged masks, an N edge
+    and a K tail; one expert is also checked against the oracle."""
+    g, mmax, n, k = 300, 64, 392, 400
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    a = torch.randint(0, 120, (g, mmax, k), dtype=torch.uint8, device="cuda", generator=gen)
+    b = torch.randint(0, 120, (g, n, k), dtype=torch.uint8, device="cuda", generator=gen)
+    kb, nb = -(-k // 128), -(-n // 128)
+    sfa = torch.rand((g, mmax, kb), device="cuda", generator=gen) + 0.5
+    sfb = torch.rand((g, nb, kb), device="cuda", generator=gen) + 0.5
+    masked = torch.randint(0, mmax + 1, (g,), dtype=torch.int32, device="cuda", generator=gen)
+    masked[torch.rand((g,), device="cuda", generator=gen) < 0.3] = 0
+    masked[5] = mmax
+    outs = {}
+    for pol in (0, 5):
+        t = dga.tiling(mmax, n, k, groups=g, expected_m=mmax)
+        t.m1, t.n1, t.wavesM, t.wavesN = tile
+        t.stages, t.dispatchPolicyTag, t.kernelSerial, t.splitkFactor = 3, pol, 0, 1
+        o = torch.full((g, mmax, n), -1.0, dtype=torch.bfloat16, device="cuda")
+        for _ in range(2):   # a second launch on the same stream: nothing of the first one's ring state survives
+            dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), o, masked, mmax, tiling_=t, sync=True)
+        outs[pol] = o
+    assert torch.equal(outs[0].view(torch.int16), outs[5].view(torch.int16))
+    an, sfan, bn, sfbn = a[5].cpu().numpy(), sfa[5].cpu().numpy(), b[5].cpu().numpy(), sfb[5].cpu().numpy()
+    want = oracle.gemm_fp8_fp8_bf16_nt(an, sfan, bn, sfbn, threads=8)
+    oracle.assert_parity(_bits(outs[5][5]), want, an, sfan, bn, sfbn, eps=2.0 ** -12, frac=1e-2)
+
+
+def test_persistent_build_dense_and_contiguous(dga, oracle):
+    """The persistent form on a dense raster (groups = 1, M and N edges) and on the contiguous layout (padding rows,
+    padding tiles): the bytes of the plain loop."""
+    gen = torch.Generator(device="cuda").manual_seed(12)
+    m, n, k = 3000, 2100, 640
+    a = torch.randint(0, 120, (m, k), dtype=torch.uint8, device="cuda", generator=gen)
+    b = torch.randint(0, 120, (n, k), dtype=torch.uint8, device="cuda", generator=gen)
+    sfa = torch.rand((m, 5), device="cuda", generator=gen) + 0.5
+    sfb = torch.rand((-(-n // 128), 5), device="cuda", generator=gen) + 0.5
+    outs = {}
+    for pol in (0, 5):
+        t = dga.tiling(m, n, k)
+        t.m1, t.n1, t.wavesM, t.wavesN, t.stages, t.dispatchPolicyTag, t.kernelSerial, t.splitkFactor = 128, 128, 2, 2, 3, pol, 0, 1
+        o = torch.full((m, n), -1.0, dtype=torch.bfloat16, device="cuda")
+        dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), o, tiling_=t, sync=True)
+        outs[pol] = o
+    assert torch.equal(outs[0].view(torch.int16), outs[5].view(torch.int16))
+    groups, n, k = 6, 1024, 512
+    seg = [256, 0, 128, 384, 128, 0]
+    m = sum(seg) + 256                       # two padding tiles at the end
+    idx = torch.full((m,), -1, dtype=torch.int32)
+    pos = 0
+    for gi, sg in enumerate(seg):
+        idx[pos:pos + sg] = gi
+        if sg:
+            idx[pos + sg - 9:pos + sg] = -1   # padding rows behind a segment's valid rows
+        pos += sg
+    idx = idx.cuda()
+    a = torch.randint(0, 120, (m, k), dtype=torch.uint8, device="cuda", generator=gen)
+    b = torch.randint(0, 120, (groups, n, k), dtype=torch.uint8, device="cuda", generator=gen)
+    sfa = torch.rand((m, 4), device="cuda", generator=gen) + 0.5
+    sfb = torch.rand((groups, 8, 4), device="cuda", generator=gen) + 0.5
+    outs = {}
+    for pol in (0, 5):
+        t = dga.tiling(m, n, k, groups=groups, contiguous=True)
+        t.m1, t.n1, t.wavesM, t.wavesN, t.stages, t.dispatchPolicyTag, t.kernelSerial, t.splitkFactor = 64, 128, 1, 4, 3, pol, 0, 1
+        o = torch.full((m, n), -1.0, dtype=torch.bfloat16, device="cuda")
+        dga.m_grouped_gemm_fp8_fp8_bf16_nt_contiguous((a, sfa), (b, sfb), o, idx, tiling_=t, sync=True)
+        outs[pol] = o
+    assert torch.equal(outs[0].view(torch.int16), outs[5].view(torch.int16))
+    assert (outs[5][idx < 0] == -1.0).all()

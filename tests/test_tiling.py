@@ -171,6 +171,20 @@ def test_grouped_tilings_round_trip_too(dga, tmp_path, kw):
         dga.tiling_cache_clear()
 
 
+def test_persistent_form_where_the_raster_exceeds_the_cus(dga):
+    """A loader-wave tiling whose raster holds more tiles than the chip has CUs takes the persistent build
+    (dispatchPolicyTag 5); one tile per CU or fewer, split-K and the quarter-tile tail keep the one-tile builds."""
+    big = dga.tiling(128, 2048, 7168, groups=256, expected_m=128)          # 2048 tiles of 128x256
+    assert (big.m1, big.n1, big.stages, big.dispatchPolicyTag) == (128, 256, 3, dga.api.POLICY_PERSISTENT)
+    one = dga.select_kernel(4096, 2048, 7168)                               # BASELINE configs[2]: 256 tiles, one per CU
+    assert (one.m1, one.n1, one.dispatchPolicyTag) == (128, 256, dga.api.POLICY_LOADER_WAVES)
+    few = dga.select_kernel(128, 2048, 7168, groups=16, expected_m=128)    # 128 tiles
+    assert few.dispatchPolicyTag == dga.api.POLICY_LOADER_WAVES
+    for (m, n, k) in [(64, 7168, 18432), (128, 4096, 7168), (8, 18432, 7168)]:
+        t = dga.select_kernel(m, n, k)
+        assert t.dispatchPolicyTag != dga.api.POLICY_PERSISTENT or t.splitkFactor == 1
+
+
 def test_reference_format_file_keeps_its_format(dga, tmp_path):
     """A file that carries only the reference's eleven columns is appended to in that format."""
     path = tmp_path / "ref.csv"
