@@ -7,6 +7,9 @@ template <class Cfg, bool KTAIL>
 static int launch_persistent_one(const GemmParams &p, hipStream_t stream)
 {
     auto kfn = gemm_fp8_blockscaled_nt_persistent_kernel<Cfg, KTAIL>;
+    // the stage ring, then the loader waves' row-table slots (indexed form): one dword per lane and DMA piece
+    constexpr int kLds = Cfg::LDS_BYTES + Cfg::DMA_WAVES * (Cfg::A_ITERS + Cfg::SC_ITERS) * 256;
+    static_assert(kLds <= 160 * 1024, "LDS of one CU");
     static std::once_flag once[64];
     static hipError_t attr_err[64];
     int dev = 0;
@@ -14,7 +17,7 @@ static int launch_persistent_one(const GemmParams &p, hipStream_t stream)
     if (dev < 0 || dev >= 64) return DGA_E_HIP;
     std::call_once(once[dev], [&] {
         attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     });
     if (int rc = record_hip(attr_err[dev])) return rc;
     // one workgroup per CU (a stage ring of this size leaves room for one), fewer when the raster is smaller
@@ -22,7 +25,7 @@ static int launch_persistent_one(const GemmParams &p, hipStream_t stream)
     const int64_t cus = device_cus();
     const unsigned grid = static_cast<unsigned>(tiles < cus ? tiles : cus);
     if (grid == 0) return DGA_OK;
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), kLds, stream, p);
     return record_hip(hipGetLastError());
 }
 

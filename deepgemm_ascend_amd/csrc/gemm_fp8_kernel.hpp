@@ -232,7 +232,11 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         // rows at or beyond masked_m[g] (M): nothing is fetched for them -- the lane is sent out of the descriptor's range
         // and the hardware zero-fills its LDS bytes (their outputs are never stored); a dense tile's rows beyond M likewise
         const int rr = min(row, M - 1 - m0);
+#ifdef DGA_ABL_IDX_NOA   // diagnostic (identity row table only): the A rows are addressed as in the packed layout
+        a_voff[it] = row < M - m0 ? (uint32_t)(g * p.m + m0 + rr) * (uint32_t)p.lda + a_col : kOutOfRange;
+#else
         a_voff[it] = row < M - m0 ? (ridx ? (uint32_t)ridx[m0 + rr] : (uint32_t)rr) * (uint32_t)p.lda + a_col : kOutOfRange;
+#endif
     }
 #pragma unroll
     for (int it = 0; it < Cfg::B_ITERS; ++it) {
@@ -248,7 +252,11 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         const int s = it * DNT + dtid;
         if (s < BM) {
             const int mr = min(m0 + s, M - 1);
+#ifdef DGA_ABL_IDX_NOSC
+            sc_src[it] = SFA + (int64_t)(ridx ? g * p.m + mr : mr) * p.sfa_ld;
+#else
             sc_src[it] = SFA + (ridx ? ridx[mr] : (int64_t)mr) * p.sfa_ld;
+#endif
         } else {
             const int nb = min(n0 / 128 + min(s - BM, 7), p.nb_n - 1);
             sc_src[it] = SFB + (int64_t)nb * p.kb_n;
@@ -310,7 +318,11 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
         const int m = m0 + wm * (BM / Cfg::kWM) + li + mt * 16;
+#ifdef DGA_ABL_IDX_NOOUT
+        out_row[mt] = ridx ? (int64_t)g * p.m + m : (int64_t)m;
+#else
         out_row[mt] = (ridx && m < M) ? ridx[m] : (int64_t)m;
+#endif
     }
     auto epilogue = [&](v4f (&acc)[TM][TN]) {
         const int m_row = m0 + wm * (BM / Cfg::kWM) + li;

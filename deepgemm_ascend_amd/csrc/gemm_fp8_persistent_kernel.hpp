@@ -48,6 +48,13 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_persistent_ke
         slot = blockIdx.x >> 3;
     }
     struct Tile { int g, bg, M, m0, n0; };
+    // masked_m / m_indices are read through the constant address space: they are inputs nobody writes during the launch,
+    // and only so does the compiler use scalar loads (s_load, lgkmcnt) for them.  Behind the "memory" clobbers of the DMA
+    // and wait statements it would otherwise fall back to a vector load + vmcnt(0) for a uniform address -- which in a
+    // loader wave drains every refill in flight, and in a computing wave waits for the previous tile's stores.
+    typedef const __attribute__((address_space(4))) int32_t *const_i32_ptr;
+    const const_i32_ptr masked_m_c = (const_i32_ptr)p.masked_m;
+    const const_i32_ptr m_indices_c = (const_i32_ptr)p.m_indices;
     // next tile at or behind position `local` of the chunk that has anything to do (wave-uniform: scalar loads only)
     auto seek = [&](int &local, Tile &t) -> bool {
         for (; local < count; local += step) {
@@ -61,12 +68,12 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_persistent_ke
             const int rows = min(p.tiles_m - row0, gm);
             const int loc = t_in - band * per;
             const int tm = row0 + loc % rows, tn = loc / rows;
-            const int M = p.masked_m ? min(p.masked_m[g], p.m) : p.m;
+            const int M = p.masked_m ? min(masked_m_c[g], p.m) : p.m;
             const int m0 = tm * BM;
             if (m0 >= M) continue;              // empty expert / fully masked tile
             int bg = g;
             if (p.m_indices) {                  // contiguous-grouped layout (tile height <= the segment alignment)
-                bg = p.m_indices[m0];
+                bg = m_indices_c[m0];
                 if (bg < 0 || bg >= p.b_groups) continue;
             }
             t.g = g; t.bg = bg; t.M = M; t.m0 = m0; t.n0 = tn * BN;
@@ -86,8 +93,27 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_persistent_ke
         uint32_t a_voff[Cfg::A_ITERS], b_voff[Cfg::B_ITERS];
         const float *sc_src[Cfg::SC_ITERS];
         v4i a_rsrc, b_rsrc;
+        // Indexed form: the row-table entries a lane needs for a tile (one per A piece, one per scale piece) are fetched a
+        // whole tile ahead, by LDS-DMA into this wave's own slots behind the stage ring -- a plain vector load here would
+        // make the compiler wait vmcnt(0) in front of its first use, i.e. drain both refills in flight at every tile
+        // boundary (measured: the indexed stream 6 % behind the packed one).  Only the low dword of an entry is read
+        // (the launcher bounds rows * lda below 2^31).
+        constexpr int IDX_PER_LANE = Cfg::A_ITERS + Cfg::SC_ITERS;
+        const uint32_t idx_lds = lds0 + STG * Cfg::STAGE_BYTES + dwave * IDX_PER_LANE * 256;
+        const uint32_t *idx_mine = (const uint32_t *)(smem + STG * Cfg::STAGE_BYTES + dwave * IDX_PER_LANE * 256) + lane;
+        auto prefetch_idx = [&](const Tile &t) {
+            const int64_t *ridx = p.row_index + (int64_t)t.g * p.m;
+#pragma unroll
+            for (int it = 0; it < Cfg::A_ITERS; ++it) {
+                const int row = (it * DNT + dtid) >> 3;
+                dma4(ridx + min(t.m0 + row, t.M - 1), idx_lds + it * 256);
+            }
+#pragma unroll
+            for (int it = 0; it < Cfg::SC_ITERS; ++it)
+                dma4(ridx + min(t.m0 + it * DNT + dtid, t.M - 1), idx_lds + (Cfg::A_ITERS + it) * 256);
+        };
         auto setup = [&](const Tile &t) {
-            const int64_t *ridx = p.row_index ? p.row_index + (int64_t)t.g * p.m : nullptr;
+            const bool ridx = p.row_index != nullptr;
             const uint8_t *A = p.a + (int64_t)t.g * p.a_gs;
             const uint8_t *B = p.b + (int64_t)t.bg * p.b_gs;
             const float *SFA = p.sfa + (int64_t)t.g * p.sfa_gs;
@@ -97,7 +123,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_persistent_ke
                 const int row = (it * DNT + dtid) >> 3;
                 const int rr = min(row, t.M - 1 - t.m0);
                 a_voff[it] = row < t.M - t.m0
-                                 ? (ridx ? (uint32_t)ridx[t.m0 + rr] : (uint32_t)rr) * (uint32_t)p.lda + a_col
+                                 ? (ridx ? idx_mine[it * 64] : (uint32_t)rr) * (uint32_t)p.lda + a_col
                                  : kOutOfRange;   // rows at or beyond masked_m: nothing fetched, the LDS bytes are zero-filled
             }
 #pragma unroll
@@ -112,7 +138,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_persistent_ke
                 const int s = it * DNT + dtid;
                 if (s < BM) {
                     const int mr = min(t.m0 + s, t.M - 1);
-                    sc_src[it] = SFA + (ridx ? ridx[mr] : (int64_t)mr) * p.sfa_ld;
+                    sc_src[it] = SFA + (ridx ? (int64_t)idx_mine[(Cfg::A_ITERS + it) * 64] : (int64_t)mr) * p.sfa_ld;
                 } else {
                     const int nb = min(t.n0 / 128 + min(s - BM, 7), p.nb_n - 1);
                     sc_src[it] = SFB + (int64_t)nb * p.kb_n;
@@ -140,10 +166,23 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_persistent_ke
             }
         };
         int local = slot;
-        Tile t;
+        Tile t, tn;
         bool have = seek(local, t);
         if (!have) return;                       // the computing waves find the same empty list: no barrier is ever posted
+        int local_n = local + step;
+        bool have_n = seek(local_n, tn);         // the tile after: its row-table entries are fetched while this one streams
+        if (p.row_index) {
+            prefetch_idx(t);
+            wait_vmcnt<0>();                     // first tile: nothing in flight yet, nothing to drain
+        }
         setup(t);
+        auto prefetch_next = [&]() {
+            if (p.row_index && have_n) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // set-up has read its slots before they are overwritten
+                prefetch_idx(tn);
+            }
+        };
+        prefetch_next();
         int kb = 0, fill = 0, ahead = 0;         // ahead = blocks issued - barriers passed
         auto issue_next = [&]() {
             issue_block(fill, kb);
@@ -151,9 +190,20 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_persistent_ke
             ++ahead;
             if (++kb == KB) {                    // on to the next tile: its set-up is off the computing waves' path
                 kb = 0;
-                local += step;
-                have = seek(local, t);
-                if (have) setup(t);
+                have = have_n;
+                if (have) {
+                    t = tn;
+                    local_n += step;
+                    have_n = seek(local_n, tn);
+                    if (p.row_index) {
+                        // this tile's entries were requested a tile ago, KB refills back: with KB >= STG-1 they are older
+                        // than everything that may still fly (a wait that is already met in the steady state)
+                        if (KB >= STG - 1) wait_vmcnt<(STG - 1) * LOADS>();
+                        else wait_vmcnt<0>();
+                    }
+                    setup(t);
+                    prefetch_next();
+                }
             }
         };
         for (int d = 0; d < STG - 1 && have; ++d) issue_next();
@@ -188,11 +238,13 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_persistent_ke
         const int64_t *ridx = p.row_index ? p.row_index + (int64_t)t.g * p.m : nullptr;
         uint16_t *C = p.out + (int64_t)t.g * p.c_gs;
         const int m_row = t.m0 + wm * (BM / Cfg::kWM) + li;
+        // indexed form: the destination rows are requested now and first looked at in the epilogue -- anything that
+        // touched the loaded values here would put a vmcnt(0) (this load AND the previous tile's stores) in front of the
+        // tile's first barrier, which the loader waves and every other computing wave would then wait for
         int64_t out_row[TM];
+        if (ridx) {
 #pragma unroll
-        for (int mt = 0; mt < TM; ++mt) {
-            const int m = m_row + mt * 16;
-            out_row[mt] = (ridx && m < t.M) ? ridx[m] : (int64_t)m;
+            for (int mt = 0; mt < TM; ++mt) out_row[mt] = ridx[min(m_row + mt * 16, t.M - 1)];
         }
         const bool wave_has_rows = t.m0 + wm * (BM / Cfg::kWM) < t.M;   // wave-uniform
         v4f acc[TM][TN];
@@ -265,12 +317,19 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_persistent_ke
         if (wave_has_rows) {
             const int n_base = t.n0 + wn * (BN / WN) + 8 * kg;
             const bool vec_ok = ((p.ldc & 7) == 0) && ((((uintptr_t)C) & 15) == 0);
+            // contiguous layout: the group index of this lane's rows, all requested before the first store goes out (a
+            // load between the stores would wait for every store in front of it)
+            int row_group[TM];
+            if (p.m_indices) {
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) row_group[mt] = p.m_indices[min(m_row + mt * 16, t.M - 1)];
+            }
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
                 const int m = m_row + mt * 16;
                 if (m >= t.M) continue;
-                if (p.m_indices && p.m_indices[m] != t.bg) continue;  // a padding row: untouched
-                uint16_t *crow = C + out_row[mt] * p.ldc;
+                if (p.m_indices && row_group[mt] != t.bg) continue;  // a padding row: untouched
+                uint16_t *crow = C + (ridx ? out_row[mt] : (int64_t)m) * p.ldc;
 #pragma unroll
                 for (int j = 0; j < TN / 2; ++j) {
                     const int n = n_base + 32 * j;

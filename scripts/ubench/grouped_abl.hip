@@ -43,6 +43,15 @@ int main(int argc, char **argv)
     p.a = a; p.sfa = sfa; p.b = b; p.sfb = sfb; p.out = out; p.masked_m = mm; p.m = m; p.n = n; p.k = k; p.kb_n = kb; p.nb_n = nb;
     p.lda = k; p.ldb = k; p.ldc = n; p.groups = G; p.b_groups = G; p.sfa_ld = kb;
     p.a_gs = (int64_t)m * k; p.b_gs = (int64_t)n * k; p.c_gs = (int64_t)m * n; p.sfa_gs = (int64_t)m * kb; p.sfb_gs = (int64_t)nb * kb;
+#ifdef INDEXED   // the indexed form on an identity row table: the same bytes at the same addresses as the packed layout
+    {
+        std::vector<int64_t> hi((size_t)G * m);
+        for (size_t i = 0; i < hi.size(); ++i) hi[i] = (int64_t)i;
+        int64_t *ri; hipMalloc(&ri, hi.size() * 8);
+        hipMemcpy(ri, hi.data(), hi.size() * 8, hipMemcpyHostToDevice);
+        p.row_index = ri; p.a_gs = p.c_gs = p.sfa_gs = 0; p.a_bytes = (int64_t)G * m * k;
+    }
+#endif
     p.tiles_m = (m + Cfg::kBM - 1) / Cfg::kBM; p.tiles_n = (n + Cfg::kBN - 1) / Cfg::kBN;
     p.raster_group = p.tiles_m >= 4 ? 4 : 1; p.xcd_remap = 1; p.splitk = 1;
     const int grid = G * p.tiles_m * p.tiles_n;

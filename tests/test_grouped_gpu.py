@@ -276,3 +276,42 @@ def test_persistent_build_dense_and_contiguous(dga, oracle):
         outs[pol] = o
     assert torch.equal(outs[0].view(torch.int16), outs[5].view(torch.int16))
     assert (outs[5][idx < 0] == -1.0).all()
+
+
+def test_persistent_build_indexed_rows(dga):
+    """The indexed form on the persistent build: every workgroup crosses tile boundaries, so the loader waves' row-table
+    prefetch (one tile ahead, by LDS-DMA) is exercised; against the one-tile plain loop, bit for bit, and rows nobody owns
+    stay untouched."""
+    g, m_max, n, k = 96, 64, 1024, 640
+    kb = k // 128
+    row_bytes = k + 4 * kb + 16
+    rng = np.random.default_rng(21)
+    masked = rng.integers(0, m_max + 1, size=g).astype(np.int32)
+    masked[rng.random(g) < 0.25] = 0
+    masked[0] = m_max
+    rows = int(masked.sum()) + 13
+    payload = rng.integers(0, 120, size=(rows, row_bytes), dtype=np.uint8)
+    payload[:, k:k + 4 * kb] = rng.uniform(0.5, 1.5, size=(rows, kb)).astype(np.float32).view(np.uint8)
+    perm = rng.permutation(rows)
+    row_index = np.full((g, m_max), -1, np.int64)
+    at = 0
+    for i in range(g):
+        row_index[i, :masked[i]] = perm[at:at + masked[i]]
+        at += masked[i]
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    tb = dev(rng.integers(0, 120, size=(g, n, k), dtype=np.uint8))
+    tsfb = dev(rng.uniform(0.5, 1.5, size=(g, n // 128, kb)).astype(np.float32))
+    tp, tidx, tm = dev(payload), dev(row_index.reshape(-1)), dev(masked)
+    outs = {}
+    for pol in (0, 5):
+        t = dga.tiling(m_max, n, k, groups=g, expected_m=m_max)
+        t.m1, t.n1, t.wavesM, t.wavesN, t.stages, t.dispatchPolicyTag, t.kernelSerial, t.splitkFactor = 64, 128, 1, 4, 3, pol, 0, 1
+        o = torch.full((rows, n), -5.0, dtype=torch.bfloat16, device="cuda")
+        dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(tp, tp, k, row_bytes // 4, (tb, tsfb), o, tidx, tm, m_max, m_max,
+                                                          tiling_=t, sync=True)
+        outs[pol] = o
+    assert torch.equal(outs[0].view(torch.int16), outs[5].view(torch.int16))
+    owned = np.zeros(rows, bool)
+    owned[perm[:int(masked.sum())]] = True
+    assert (outs[5][torch.from_numpy(~owned).cuda()] == -5.0).all()
+    assert not (outs[5][torch.from_numpy(owned).cuda()] == -5.0).all()
