@@ -90,7 +90,9 @@ def candidates(m, n, k, rasters=None):
             for st in ([2, 3] if (bm, bn) in THREE_STAGE else [2]):
                 for sk in splits:
                     # 3-stage builds: the plain loop and its loader-wave variant (dispatchPolicyTag 4)
-                    for pol in ([0, 1, 2] if (bm, bn) in PINGPONG and sk == 1 else ([0, 4] if st == 3 and (bm, bn) in LOADER_WAVES else [0])):
+                    # ... and, where the raster holds more tiles than the chip has CUs, the persistent form (5)
+                    lw = ([0, 4, 5] if sk == 1 and blocks > CUS else [0, 4]) if st == 3 and (bm, bn) in LOADER_WAVES else [0]
+                    for pol in ([0, 1, 2] if (bm, bn) in PINGPONG and sk == 1 else lw):
                         rr = r if rasters is None else heuristic_raster(m, n, bm, bn, sk, stages=st)
                         out.append({"m1": bm, "n1": bn, "raster": rr, "stages": st, "splitk": sk, "policy": pol})
                         # 256x256, more than one wave of tiles with a small remainder: also with the quarter-tile tail
@@ -103,9 +105,9 @@ def candidates(m, n, k, rasters=None):
 # (bm, bn, wavesM, wavesN, stages, dispatch policies the build exists in)
 MENU = [(256, 256, 4, 2, 2, (0, 1, 2)), (128, 256, 2, 2, 2, (0, 2)), (256, 128, 4, 1, 2, (0, 2)), (128, 128, 2, 2, 2, (0, 2)),
         (64, 256, 1, 4, 2, (0, 2)), (64, 128, 1, 4, 2, (0,)), (128, 256, 2, 4, 2, (0, 2)), (128, 256, 2, 4, 3, (0,)),
-        (128, 256, 2, 2, 3, (0, 4)), (128, 128, 2, 2, 3, (0, 4)), (64, 256, 1, 4, 3, (0, 4)), (32, 256, 1, 4, 2, (0,)),
+        (128, 256, 2, 2, 3, (0, 4, 5)), (128, 128, 2, 2, 3, (0, 4, 5)), (64, 256, 1, 4, 3, (0, 4, 5)), (32, 256, 1, 4, 2, (0,)),
         (32, 128, 1, 4, 2, (0,)), (16, 256, 1, 4, 2, (0,)), (16, 128, 1, 4, 2, (0,)),
-        (64, 128, 1, 4, 3, (0, 4)), (32, 256, 1, 4, 3, (0,)), (32, 128, 1, 4, 3, (0,)), (16, 256, 1, 4, 3, (0,)), (16, 128, 1, 4, 3, (0, 4))]
+        (64, 128, 1, 4, 3, (0, 4, 5)), (32, 256, 1, 4, 3, (0,)), (32, 128, 1, 4, 3, (0,)), (16, 256, 1, 4, 3, (0,)), (16, 128, 1, 4, 3, (0, 4, 5))]
 LDS_BYTES, ACC_REGS, CUS = 160 * 1024, 128, 256
 
 
@@ -132,6 +134,10 @@ def check_candidate(prob, c):
     if bm * bn // (wm * wn * 64) > ACC_REGS:                               # JudgeSpace: L0C (here accumulator VGPRs)
         return False, "accumulator registers"
     kb = -(-prob["k"] // 128)
+    if pol == 5:   # persistent loader waves: whole rasters with more tiles than CUs (otherwise it IS policy 4)
+        groups = prob["groups"] if prob["layout"] == "masked" else 1
+        if sk != 1 or groups * -(-prob["m"] // bm) * -(-prob["n"] // bn) <= CUS:
+            return False, "persistent form: more tiles than CUs, no split-K"
     if prob["layout"] == "masked":
         need = 16 if prob["m"] <= 16 else 32 if prob["m"] <= 32 else 64 if prob["m"] <= 64 else 128
         if prob["m"] <= 128 and bm != need:
