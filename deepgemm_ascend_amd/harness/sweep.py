@@ -209,10 +209,14 @@ def time_us(fn, warm=3, iters=10):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
-def benchmark_shape(shape, out_dir: Path, rank=0, num_processes=1, iters=10, rasters=None, prewarm_s=0.15):
+def benchmark_shape(shape, out_dir: Path, rank=0, num_processes=1, iters=10, rasters=None, prewarm_s=0.15, only_policy=None):
     import deepgemm_ascend_amd as dga
     m, n, k = shape
     cands = candidates(m, n, k, rasters)
+    if only_policy is not None:   # a supplementary sweep of one dispatch policy (merged into an earlier run's records)
+        cands = [c for c in cands if c["policy"] == only_policy]
+        if not cands:
+            return None
     per = -(-len(cands) // num_processes)
     lo, hi = rank * per, min(len(cands), (rank + 1) * per)
     res_path = out_dir / f"shape_{m}_{n}_{k}_rank_{rank}.jsonl"
@@ -337,6 +341,7 @@ def main(argv=None):
     ap.add_argument("--prewarm-ms", type=float, default=150.0, help="clock pre-warm in front of every shape's candidates")
     ap.add_argument("--heuristic-raster", action="store_true",
                     help="one raster per candidate (the heuristic's) instead of the raster sweep")
+    ap.add_argument("--only-policy", type=int, default=None, help="time only the candidates of this dispatchPolicyTag")
     ap.add_argument("--grouped", action="store_true",
                     help="sweep the masked / contiguous grouped shapes (GROUPED_SHAPES) instead of the dense list")
     a = ap.parse_args(argv)
@@ -367,7 +372,7 @@ def main(argv=None):
     winners = []
     for shape in shapes:
         best = benchmark_shape(shape, out_dir, a.rank, a.num_processes, a.iters, [0] if a.heuristic_raster else None,
-                               a.prewarm_ms / 1e3)
+                               a.prewarm_ms / 1e3, a.only_policy)
         if best:
             us, p = best
             m, n, k = shape
