@@ -204,13 +204,14 @@ def test_loader_wave_build_writes_the_same_bits(dga, oracle):
     assert torch.equal(o4.view(torch.int16), o0.view(torch.int16))
 
 
+@pytest.mark.parametrize("k", [400, 100])   # four k blocks with a K tail; a single (partial) k block per tile
 @pytest.mark.parametrize("tile", [(128, 256, 2, 2), (128, 128, 2, 2), (64, 256, 1, 4), (64, 128, 1, 4), (16, 128, 1, 4)])
-def test_persistent_build_writes_the_same_bits(dga, oracle, tile):
+def test_persistent_build_writes_the_same_bits(dga, oracle, tile, k):
     """dispatchPolicyTag 5 (one workgroup per CU walks its tiles, the LDS ring runs across tile boundaries) against the
     one-tile plain loop of the same tile shape: identical output bytes.  The raster holds several tiles per workgroup
     (every workgroup crosses tile boundaries), empty experts in the middle of a workgroup's list, ragged masks, an N edge
     and a K tail; one expert is also checked against the oracle."""
-    g, mmax, n, k = 300, 64, 392, 400
+    g, mmax, n = 300, 64, 392
     gen = torch.Generator(device="cuda").manual_seed(11)
     a = torch.randint(0, 120, (g, mmax, k), dtype=torch.uint8, device="cuda", generator=gen)
     b = torch.randint(0, 120, (g, n, k), dtype=torch.uint8, device="cuda", generator=gen)
@@ -278,11 +279,13 @@ def test_persistent_build_dense_and_contiguous(dga, oracle):
     assert (outs[5][idx < 0] == -1.0).all()
 
 
-def test_persistent_build_indexed_rows(dga):
+@pytest.mark.parametrize("k", [128, 256, 640])   # one k block per tile, two (= refills in flight), many
+def test_persistent_build_indexed_rows(dga, k):
     """The indexed form on the persistent build: every workgroup crosses tile boundaries, so the loader waves' row-table
-    prefetch (one tile ahead, by LDS-DMA) is exercised; against the one-tile plain loop, bit for bit, and rows nobody owns
+    prefetch (one tile ahead, by LDS-DMA) is exercised -- including tiles shorter than the refill depth, where the wait in
+    front of the prefetched entries is a full one; against the one-tile plain loop, bit for bit, and rows nobody owns
     stay untouched."""
-    g, m_max, n, k = 96, 64, 1024, 640
+    g, m_max, n = 96, 64, 1024
     kb = k // 128
     row_bytes = k + 4 * kb + 16
     rng = np.random.default_rng(21)
