@@ -250,7 +250,10 @@ def roofline_mfma(dga, a, sfa, b, sfb, out, t, m, n, k, kernel_us, cus):
          "kernel": "gemm_fp8_blockscaled_nt_kernel", "tile": f"{t.m1}x{t.n1}x{t.k1}", "clock_mhz": None,
          "frac_at_measured_clock": None}
     try:
-        mhz, loop_us = dga.gemm_fp8_loop_clock((a, sfa), (b, sfb), out, tiling_=t, launches=100)
+        # 1000 launches: the stamps of the last one are read, and after the gap behind the timed region the chip needs a few
+        # hundred launches to be back at the clocks of a busy stream (with 100 the probe read 1.42 GHz where the stream
+        # holds 1.67; scripts/clock_probe_check.py shows the probe's launch interval equal to the product kernel's)
+        mhz, loop_us = dga.gemm_fp8_loop_clock((a, sfa), (b, sfb), out, tiling_=t, launches=1000)
         peak_clk = cus * mhz * 1e6 * FP8_FLOP_PER_CLK_PER_CU / 1e12
         r.update({"clock_mhz": round(mhz, 1), "main_loop_us": round(loop_us, 2),
                   "peak_at_measured_clock": round(peak_clk, 1), "frac_at_measured_clock": round(achieved / peak_clk, 4)})
