@@ -54,13 +54,23 @@ int main(int argc, char **argv)
 #endif
     p.tiles_m = (m + Cfg::kBM - 1) / Cfg::kBM; p.tiles_n = (n + Cfg::kBN - 1) / Cfg::kBN;
     p.raster_group = p.tiles_m >= 4 ? 4 : 1; p.xcd_remap = 1; p.splitk = 1;
+    // optional 7th argument: operand sets rotated launch by launch (cold-cache protocol for shapes that fit the Infinity Cache)
+    const int sets = argc > 7 ? atoi(argv[7]) : 1;
+    std::vector<GemmParams> ps(1, p);
+    for (int sidx = 1; sidx < sets; ++sidx) {
+        GemmParams q = p;
+        uint8_t *b2; hipMalloc(&b2, bbytes);
+        hipMemcpy(b2, b, bbytes, hipMemcpyDeviceToDevice);
+        q.b = b2;
+        ps.push_back(q);
+    }
     const int grid = G * p.tiles_m * p.tiles_n;
     auto kfn = gemm_fp8_blockscaled_nt_kernel<Cfg, 0, false>;
     hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, 0, p);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, 0, ps[i % sets]);
     hipEventRecord(e0);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, 0, p);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, 0, ps[i % sets]);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1000 / reps;
