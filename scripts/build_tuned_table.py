@@ -1,6 +1,7 @@
-"""Merge the winners of a dense sweep (17 columns) and a grouped sweep (19 columns) into the preloaded tiling table
-deepgemm_ascend_amd/tuned/mi355x.csv (19 columns; dense rows get groups = 1, contiguous = 0).
-Usage: python scripts/build_tuned_table.py <dense_winners.csv> <grouped_winners.csv> [out.csv]"""
+"""Merge sweep winners into the preloaded tiling table deepgemm_ascend_amd/tuned/mi355x.csv (19 columns; rows of a 17-column
+dense winners file get groups = 1, contiguous = 0).  Files are read in the order given and the FIRST row of a problem
+(m, n, k, groups, contiguous) wins -- put the --cold sweep of the short-M shapes in front of the warm dense sweep.
+Usage: python scripts/build_tuned_table.py [--out out.csv] winners.csv [winners.csv ...]"""
 import sys
 from pathlib import Path
 
@@ -8,25 +9,28 @@ HEAD = ("m,n,k,m1,n1,k1,kernelSerial,paddingTagA,paddingTagB,paddingTagC,blockDi
         "splitkFactor,stages,swizzleOffset,wavesM,wavesN,dispatchPolicyTag,groups,contiguous")
 
 
-def rows(path, pad):
+def rows(path):
     out = []
     for line in Path(path).read_text().strip().splitlines()[1:]:
         cols = line.split(",")
-        out.append(",".join(cols + pad[len(cols) - 17:] if len(cols) < 19 else cols))
+        out.append(",".join(cols + ["1", "0"] if len(cols) == 17 else cols))
     return out
 
 
 def main():
-    dense, grouped = sys.argv[1], sys.argv[2]
-    out = Path(sys.argv[3]) if len(sys.argv) > 3 else Path(__file__).resolve().parent.parent / "deepgemm_ascend_amd/tuned/mi355x.csv"
+    args = sys.argv[1:]
+    out = Path(__file__).resolve().parent.parent / "deepgemm_ascend_amd/tuned/mi355x.csv"
+    if args and args[0] == "--out":
+        out, args = Path(args[1]), args[2:]
     seen, body = set(), []
-    for r in rows(dense, ["1", "0"]) + rows(grouped, []):
-        c = r.split(",")
-        key = (c[0], c[1], c[2], c[17], c[18])
-        if key in seen:
-            continue
-        seen.add(key)
-        body.append(r)
+    for f in args:
+        for r in rows(f):
+            c = r.split(",")
+            key = (c[0], c[1], c[2], c[17], c[18])
+            if key in seen:
+                continue
+            seen.add(key)
+            body.append(r)
     out.write_text(HEAD + "\n" + "\n".join(body) + "\n")
     print(f"{len(body)} rows -> {out}")
 
