@@ -129,7 +129,7 @@ static void feature_row(uint32_t m, uint32_t n, uint32_t k, const Cand &c, float
     f[11] = std::log2(static_cast<float>(kbps));
     f[12] = static_cast<float>(m) / (static_cast<float>(tm) * c.m1);
     f[13] = static_cast<float>(n) / (static_cast<float>(tn) * c.n1);
-    f[14] = c.policy == DGA_POLICY_LOADER_WAVES ? 1.f : 0.f;
+    f[14] = (c.policy == DGA_POLICY_LOADER_WAVES || c.policy == DGA_POLICY_PERSISTENT) ? 1.f : 0.f;   // (5 is folded into 4 in the records)
 }
 
 static float forward(const Model &mo, const float *f)
