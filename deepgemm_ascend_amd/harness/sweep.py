@@ -83,7 +83,7 @@ def candidates(m, n, k, rasters=None):
         if bm >= 2 * max(m, 16) and bm > 16:      # filter_parameters analogue: tiles twice the problem are pointless
             continue
         blocks = -(-m // bm) * -(-n // bn)
-        splits = [1] + [s for s in (2, 4, 8, 16) if blocks * s <= 1024 and kb // s >= 4 and blocks < 192]
+        splits = [1] + [s for s in (2, 3, 4, 5, 6, 8, 16) if blocks * s <= 1024 and kb // s >= 4 and blocks < 192]
         for r in (RASTERS if rasters is None else [0]):
             if r > max(1, -(-m // bm)):
                 continue
