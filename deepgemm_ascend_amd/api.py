@@ -79,6 +79,7 @@ def _mmad_workspace(batch, m, n, k, x) -> Tuple[Optional[int], int]:
 
 
 POLICY_PLAIN, POLICY_PINGPONG, POLICY_CONTINUOUS, POLICY_STRICT, POLICY_LOADER_WAVES, POLICY_PERSISTENT = 0, 1, 2, 3, 4, 5
+POLICY_CONTINUOUS_PERSISTENT = 6
 
 
 def _with_policy(t: Tiling, strict: bool) -> Tiling:

@@ -53,4 +53,8 @@ int launch_persistent(const GemmParams &p, hipStream_t stream);
     extern template int launch_persistent<GemmCfg<BM, BN, WM, WN, ST, 4>>(const GemmParams &, hipStream_t);
 DGA_MENU_LC(DGA_MENU_EXTERN_PS)
 
+// persistent continuous-pipeline build of the 256x256 tile (gemm_fp8_cont_persistent_kernel.hpp, dispatchPolicyTag 6): dense
+// rasters of full tiles only -- launch_cont_persistent returns DGA_E_TILING for anything else
+int launch_cont_persistent(const GemmParams &p, hipStream_t stream);
+
 }  // namespace dga

@@ -288,14 +288,18 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     const int policy = pp_env >= 0 ? pp_env : tiling->dispatchPolicyTag;
     auto launch_main = [&](const GemmParams &q) -> int {
         if (q.stamps) {
-            auto clk = find_clock_build(v, policy == 2 && v->launch_cont ? 2 : (policy == DGA_POLICY_LOADER_WAVES && v->launch_lc ? policy : 0));
+            auto clk = find_clock_build(v, (policy == 2 || policy == DGA_POLICY_CONTINUOUS_PERSISTENT) && v->launch_cont ? 2 : (policy == DGA_POLICY_LOADER_WAVES && v->launch_lc ? policy : 0));
             return clk ? clk(q, stream) : DGA_E_TILING;
         }
         if (policy == DGA_POLICY_PERSISTENT && v->launch_ps && q.splitk <= 1 && !q.tail_sub && q.launch_tiles == 0)
             return v->launch_ps(q, stream);
         if ((policy == DGA_POLICY_LOADER_WAVES || policy == DGA_POLICY_PERSISTENT) && v->launch_lc) return v->launch_lc(q, stream);
         if (policy == 1 && v->launch_pp) return v->launch_pp(q, stream);
-        if (policy == 2 && v->launch_cont) return v->launch_cont(q, stream);
+        if (policy == DGA_POLICY_CONTINUOUS_PERSISTENT && v->bm == 256 && v->bn == 256 && v->launch_cont) {
+            const int rc = launch_cont_persistent(q, stream);    // DGA_E_TILING = not a raster it takes: the one-tile build
+            return rc == DGA_E_TILING ? v->launch_cont(q, stream) : rc;
+        }
+        if ((policy == 2 || policy == DGA_POLICY_CONTINUOUS_PERSISTENT) && v->launch_cont) return v->launch_cont(q, stream);
         return v->launch(q, stream);
     };
 

@@ -1,6 +1,7 @@
 // fp8 tile-kernel menu, part D: the persistent loader-wave builds (dga_fp8_menu.hpp, gemm_fp8_persistent_kernel.hpp).
 #include "dga_fp8_menu_impl.hpp"
 #include "gemm_fp8_persistent_kernel.hpp"
+#include "gemm_fp8_cont_persistent_kernel.hpp"
 namespace dga {
 
 template <class Cfg, bool KTAIL>
@@ -37,6 +38,31 @@ int launch_persistent(const GemmParams &p, hipStream_t stream)
     if (p.splitk > 1 || p.tail_sub || p.launch_tiles > 0) return DGA_E_TILING;
     if (p.m_indices && Cfg::kBM > DGA_CONTIGUOUS_M_ALIGNMENT) return DGA_E_TILING;
     return (p.k % 128) ? launch_persistent_one<Cfg, true>(p, stream) : launch_persistent_one<Cfg, false>(p, stream);
+}
+
+int launch_cont_persistent(const GemmParams &p, hipStream_t stream)
+{
+    typedef GemmCfg<256, 256, 4, 2, 2> Cfg;
+    // dense rasters of full tiles, at least two k blocks (the refill slots look one tile ahead)
+    if (p.groups != 1 || p.masked_m || p.m_indices || p.row_index || p.splitk > 1 || p.tail_sub || p.stamps) return DGA_E_TILING;
+    if ((p.m % 256) || (p.n % 256) || (p.k % 128) || p.kb_n < 2) return DGA_E_TILING;
+    auto kfn = gemm_fp8_blockscaled_nt_cont_persistent_kernel<Cfg>;
+    static std::once_flag once[64];
+    static hipError_t attr_err[64];
+    int dev = 0;
+    if (int rc = record_hip(hipGetDevice(&dev))) return rc;
+    if (dev < 0 || dev >= 64) return DGA_E_HIP;
+    std::call_once(once[dev], [&] {
+        attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    });
+    if (int rc = record_hip(attr_err[dev])) return rc;
+    const int64_t tiles = p.launch_tiles > 0 ? p.launch_tiles : static_cast<int64_t>(p.tiles_m) * p.tiles_n;
+    const int64_t cus = device_cus();
+    const unsigned grid = static_cast<unsigned>(tiles < cus ? tiles : cus);
+    if (grid == 0) return DGA_OK;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p);
+    return record_hip(hipGetLastError());
 }
 
 #define DGA_MENU_INSTANTIATE_PS(BM, BN, WM, WN, ST, PP) \

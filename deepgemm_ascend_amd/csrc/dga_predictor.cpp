@@ -124,7 +124,7 @@ static void feature_row(uint32_t m, uint32_t n, uint32_t k, const Cand &c, float
     f[3] = std::log2(static_cast<float>(c.m1)); f[4] = std::log2(static_cast<float>(c.n1));
     f[5] = c.stages == 3 ? 1.f : 0.f;
     f[6] = std::log2(static_cast<float>(c.splitk));
-    f[7] = c.policy == 1 ? 1.f : 0.f; f[8] = c.policy == 2 ? 1.f : 0.f;
+    f[7] = c.policy == 1 ? 1.f : 0.f; f[8] = (c.policy == 2 || c.policy == DGA_POLICY_CONTINUOUS_PERSISTENT) ? 1.f : 0.f;
     f[9] = std::log2(static_cast<float>(tiles)); f[10] = std::log2(static_cast<float>(rounds));
     f[11] = std::log2(static_cast<float>(kbps));
     f[12] = static_cast<float>(m) / (static_cast<float>(tm) * c.m1);

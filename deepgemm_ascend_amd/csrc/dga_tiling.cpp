@@ -333,6 +333,16 @@ void prefer_loader_waves(dga_tiling_t &t)
         const uint64_t tiles = groups * ((t.m + t.m1 - 1) / t.m1) * ((t.n + t.n1 - 1) / t.n1);
         if (tiles > device_cus()) t.dispatchPolicyTag = DGA_POLICY_PERSISTENT;
     }
+    // ... and the continuous 256x256 kernel has its own persistent form (dispatchPolicyTag 6,
+    // gemm_fp8_cont_persistent_kernel.hpp) for dense rasters of full tiles: the next tile's first stages are fetched from
+    // inside the last k blocks.  Worth 3-6 % where a tile is short (K <= 4096) and a CU runs more than one
+    // (scripts/cps_check.py: 4096x7168x2048 61.7 -> 58.1 us, 4096x8192x2048 67.6 -> 63.7, 8192x4096x4096 117.2 -> 114.5;
+    // 8192^3 unchanged: the dispatcher already starts a CU's next workgroup while the last one's stores drain).
+    if (t.dispatchPolicyTag == DGA_POLICY_CONTINUOUS && t.m1 == 256 && t.n1 == 256 && t.splitkFactor <= 1 && !t.contiguous &&
+        std::max<uint32_t>(1, t.groups) == 1 && t.m % 256 == 0 && t.n % 256 == 0 && t.k % 128 == 0 && t.k >= 256) {
+        const uint64_t tiles = static_cast<uint64_t>(t.m / 256) * (t.n / 256);
+        if (tiles > device_cus()) t.dispatchPolicyTag = DGA_POLICY_CONTINUOUS_PERSISTENT;
+    }
 }
 
 void apply_tail_split(dga_tiling_t &t, uint32_t cus)

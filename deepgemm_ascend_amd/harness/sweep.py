@@ -92,7 +92,10 @@ def candidates(m, n, k, rasters=None):
                     # 3-stage builds: the plain loop and its loader-wave variant (dispatchPolicyTag 4)
                     # ... and, where the raster holds more tiles than the chip has CUs, the persistent form (5)
                     lw = ([0, 4, 5] if sk == 1 and blocks > CUS else [0, 4]) if st == 3 and (bm, bn) in LOADER_WAVES else [0]
-                    for pol in ([0, 1, 2] if (bm, bn) in PINGPONG and sk == 1 else lw):
+                    # 256x256: the three schedules and, on rasters of full tiles with more tiles than CUs, the persistent
+                    # continuous pipeline (6)
+                    full = m % 256 == 0 and n % 256 == 0 and k % 128 == 0 and k >= 256 and blocks > CUS
+                    for pol in (([0, 1, 2, 6] if full else [0, 1, 2]) if (bm, bn) in PINGPONG and sk == 1 else lw):
                         rr = r if rasters is None else heuristic_raster(m, n, bm, bn, sk, stages=st)
                         out.append({"m1": bm, "n1": bn, "raster": rr, "stages": st, "splitk": sk, "policy": pol})
                         # 256x256, more than one wave of tiles with a small remainder: also with the quarter-tile tail
@@ -103,7 +106,7 @@ def candidates(m, n, k, rasters=None):
 
 # ---- the compiled menu (csrc/dga_launch.hip kVariants) and its constraints -------------------------------------------
 # (bm, bn, wavesM, wavesN, stages, dispatch policies the build exists in)
-MENU = [(256, 256, 4, 2, 2, (0, 1, 2)), (128, 256, 2, 2, 2, (0, 2)), (256, 128, 4, 1, 2, (0, 2)), (128, 128, 2, 2, 2, (0, 2)),
+MENU = [(256, 256, 4, 2, 2, (0, 1, 2, 6)), (128, 256, 2, 2, 2, (0, 2)), (256, 128, 4, 1, 2, (0, 2)), (128, 128, 2, 2, 2, (0, 2)),
         (64, 256, 1, 4, 2, (0, 2)), (64, 128, 1, 4, 2, (0,)), (128, 256, 2, 4, 2, (0, 2)), (128, 256, 2, 4, 3, (0,)),
         (128, 256, 2, 2, 3, (0, 4, 5)), (128, 128, 2, 2, 3, (0, 4, 5)), (64, 256, 1, 4, 3, (0, 4, 5)), (32, 256, 1, 4, 2, (0,)),
         (32, 128, 1, 4, 2, (0,)), (16, 256, 1, 4, 2, (0,)), (16, 128, 1, 4, 2, (0,)),
@@ -138,6 +141,9 @@ def check_candidate(prob, c):
         groups = prob["groups"] if prob["layout"] == "masked" else 1
         if sk != 1 or groups * -(-prob["m"] // bm) * -(-prob["n"] // bn) <= CUS:
             return False, "persistent form: more tiles than CUs, no split-K"
+    if pol == 6 and (prob["layout"] != "dense" or prob["m"] % 256 or prob["n"] % 256 or prob["k"] % 128 or prob["k"] < 256 or
+                     sk != 1 or (prob["m"] // 256) * (prob["n"] // 256) <= CUS):
+        return False, "persistent continuous pipeline: dense rasters of full 256x256 tiles, more tiles than CUs"
     if prob["layout"] == "masked":
         need = 16 if prob["m"] <= 16 else 32 if prob["m"] <= 32 else 64 if prob["m"] <= 64 else 128
         if prob["m"] <= 128 and bm != need:

@@ -44,7 +44,7 @@ def feature_row(m, n, k, p):
     kb = -(-k // 128)
     kb_per_split = -(-kb // sk)
     return [math.log2(m), math.log2(n), math.log2(k), math.log2(m1), math.log2(n1), 1.0 if st == 3 else 0.0,
-            math.log2(sk), 1.0 if pol == 1 else 0.0, 1.0 if pol == 2 else 0.0, math.log2(tiles), math.log2(rounds),
+            math.log2(sk), 1.0 if pol == 1 else 0.0, 1.0 if pol in (2, 6) else 0.0, math.log2(tiles), math.log2(rounds),
             math.log2(kb_per_split), m / (tm * m1), n / (tn * n1), 1.0 if pol in (4, 5) else 0.0]
 
 
@@ -171,7 +171,7 @@ def heuristic_pick(m, n, k, rs):
     t = dga.select_kernel(m, n, k)
     for r in rs:
         p = r["parameters"]
-        pol = 4 if t.dispatchPolicyTag == 5 else t.dispatchPolicyTag   # the persistent form is folded into its sibling's record
+        pol = {5: 4, 6: 2}.get(t.dispatchPolicyTag, t.dispatchPolicyTag)   # a persistent form is folded into its sibling's record
         if (p["m1"], p["n1"], p["stages"], p["splitk"], p["policy"]) == (t.m1, t.n1, t.stages, t.splitkFactor, pol):
             return r
     return None

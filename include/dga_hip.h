@@ -61,9 +61,12 @@ enum { DGA_KERNEL_COMMON = 0, DGA_KERNEL_SMALL = 1, DGA_KERNEL_PADDING_COMMON = 
  *   5 persistent loader waves: policy 4 with one workgroup per CU that walks its share of the tiles, the LDS ring running
  *     across tile boundaries (the next tile's first k blocks are in flight while this one is stored) -- what the
  *     reference's one-block-per-AI-core kernel is by construction (framework/csrc/jit/generate_code.hpp:160-198); same
- *     bits as policy 0; whole rasters only (split-K and the quarter-tile tail run policy 4). */
+ *     bits as policy 0; whole rasters only (split-K and the quarter-tile tail run policy 4).
+ *   6 persistent continuous pipeline: policy 2 (256x256 tile) with one workgroup per CU walking its tiles, the refill slots
+ *     of a tile's last two k blocks fetching the next tile's first two; dense rasters of full tiles (M, N multiples of 256,
+ *     K of 128, at least two k blocks) -- anything else runs policy 2; same bits. */
 enum { DGA_POLICY_PLAIN = 0, DGA_POLICY_PINGPONG = 1, DGA_POLICY_CONTINUOUS = 2, DGA_POLICY_STRICT = 3,
-       DGA_POLICY_LOADER_WAVES = 4, DGA_POLICY_PERSISTENT = 5 };
+       DGA_POLICY_LOADER_WAVES = 4, DGA_POLICY_PERSISTENT = 5, DGA_POLICY_CONTINUOUS_PERSISTENT = 6 };
 
 /* Platform description: the CDNA4 retarget of PlatformInfo
  * (op_tiling/platform_info.h:16-41; Python mirror get_best_config/tiling_calculator.py:25-30).

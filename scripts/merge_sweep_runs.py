@@ -19,9 +19,9 @@ def main():
                 r = json.loads(line)
                 p = dict(r["parameters"])
                 cold = bool(p.pop("cold_sets", 0))   # timed on operand sets rotated past the Infinity Cache (sweep --cold)
-                folded = p.get("policy") == 5
+                folded = p.get("policy") in (5, 6)   # persistent forms: loader waves (5 -> 4), continuous pipeline (6 -> 2)
                 if folded:
-                    p["policy"] = 4
+                    p["policy"] = 4 if p["policy"] == 5 else 2
                 key = (f.name, json.dumps(p, sort_keys=True))
                 if folded and key not in best:   # no loader-wave record of that candidate in the earlier runs: not a candidate
                     continue                     # of the predictor's menu (dga_predictor.cpp), leave it out

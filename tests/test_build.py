@@ -16,7 +16,7 @@ CSRC = ROOT / "deepgemm_ascend_amd" / "csrc"
     ("dga_launch_menu_a.hip", 6, "gemm_fp8_blockscaled_nt_kernel"),
     ("dga_launch_menu_b.hip", 10, "gemm_fp8_blockscaled_nt_kernel"),
     ("dga_launch_menu_c.hip", 28, "gemm_fp8_blockscaled_nt_kernel"),
-    ("dga_launch_menu_d.hip", 10, "gemm_fp8_blockscaled_nt_persistent_kernel"),
+    ("dga_launch_menu_d.hip", 11, "gemm_fp8_blockscaled_nt_"),   # 10 persistent loader-wave builds + the persistent continuous one
     ("dga_diag.hip", 2, "gemm_fp8_blockscaled_nt_kernel"),
     ("dga_b16.hip", 20, "gemm_b16_nt_f32_kernel")])
 def test_no_kernel_spills_or_scratch(unit, min_kernels, tile_kernel):

@@ -288,3 +288,30 @@ def test_quarter_tile_tail(dga, oracle, m, n, k):
     want = oracle.gemm_fp8_fp8_bf16_nt(a[rows], sfa[rows], b, sfb, threads=8)
     oracle.assert_parity(out[torch.from_numpy(rows).cuda()].view(torch.int16).cpu().numpy().view(np.uint16), want,
                          a[rows], sfa[rows], b, sfb)
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 512, 256), (2048, 2048, 640), (5120, 4864, 896), (1024, 18432, 384), (300, 512, 256)])
+def test_persistent_continuous_build_writes_the_same_bits(dga, m, n, k):
+    """dispatchPolicyTag 6 (the 256x256 continuous pipeline, one workgroup per CU walking its tiles, the next tile's first
+    k blocks fetched from inside the last ones) against the one-tile continuous build: identical output bytes -- one tile
+    per workgroup, several (odd and even k-block counts, so the stage parity flips between tiles), and a shape with an M
+    edge, which the launcher hands to the one-tile build."""
+    gen = torch.Generator(device="cuda").manual_seed(m + n + k)
+    a = torch.randint(0, 120, (m, k), dtype=torch.uint8, device="cuda", generator=gen) | (
+        torch.randint(0, 2, (m, k), dtype=torch.uint8, device="cuda", generator=gen) << 7)
+    b = torch.randint(0, 120, (n, k), dtype=torch.uint8, device="cuda", generator=gen)
+    a[1, 3] = 0x7F                       # a NaN byte: its row must not leak into the next tile of the same workgroup
+    kb, nb = -(-k // 128), -(-n // 128)
+    sfa = torch.rand((m, kb), device="cuda", generator=gen) + 0.5
+    sfb = torch.rand((nb, kb), device="cuda", generator=gen) + 0.5
+    outs = {}
+    for pol in (2, 6):
+        t = dga.tiling(m, n, k)
+        t.m1, t.n1, t.wavesM, t.wavesN, t.stages, t.dispatchPolicyTag, t.kernelSerial, t.splitkFactor = 256, 256, 4, 2, 2, pol, 0, 1
+        o = torch.full((m, n), -1.0, dtype=torch.bfloat16, device="cuda")
+        for _ in range(2):
+            dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), o, tiling_=t, sync=True)
+        outs[pol] = o
+    assert torch.equal(outs[2].view(torch.int16), outs[6].view(torch.int16))
+    nan_rows = torch.isnan(outs[6].float()).any(dim=1).nonzero().flatten().tolist()
+    assert nan_rows == [1]

@@ -185,6 +185,17 @@ def test_persistent_form_where_the_raster_exceeds_the_cus(dga):
         assert t.dispatchPolicyTag != dga.api.POLICY_PERSISTENT or t.splitkFactor == 1
 
 
+def test_persistent_continuous_form_on_full_tile_rasters(dga):
+    """256x256 continuous tilings of dense problems made of full tiles take the persistent form (dispatchPolicyTag 6) where
+    the raster holds more tiles than CUs; one tile per CU, edges, or the quarter-tile-free small cases keep policy 2."""
+    big = dga.select_kernel(8192, 8192, 8192)
+    assert (big.m1, big.n1, big.dispatchPolicyTag) == (256, 256, dga.api.POLICY_CONTINUOUS_PERSISTENT)
+    one = dga.select_kernel(4096, 4096, 4096)                              # BASELINE configs[1]: one tile per CU
+    assert (one.m1, one.n1, one.dispatchPolicyTag) == (256, 256, dga.api.POLICY_CONTINUOUS)
+    edge = dga.select_kernel(8192 + 8, 8192, 4096)                          # an M edge: not a raster of full tiles
+    assert edge.dispatchPolicyTag != dga.api.POLICY_CONTINUOUS_PERSISTENT
+
+
 def test_reference_format_file_keeps_its_format(dga, tmp_path):
     """A file that carries only the reference's eleven columns is appended to in that format."""
     path = tmp_path / "ref.csv"
