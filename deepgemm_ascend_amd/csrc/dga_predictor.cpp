@@ -25,7 +25,7 @@
 namespace dga {
 namespace predictor {
 
-constexpr int kFeatures = 15;
+constexpr int kFeatures = 16;
 constexpr int kMinCandidates = 4;        // get_best_config.py:587 (min_tiling = 60 on the reference's 16-aligned grid)
 constexpr float kGainThreshold = 0.03f;  // get_best_config.py:606-616 (time_diff_threshold)
 
@@ -110,7 +110,7 @@ static inline uint32_t stage_bytes(uint32_t m1, uint32_t n1)
     return std::max(m1, 32u) * 128 + n1 * 128 + ((m1 + 8 + 255) / 256) * 256 * 4;
 }
 
-// One candidate -> the 15 inputs.  Must match harness/train_predictor.py feature_row() exactly.
+// One candidate -> the 16 inputs.  Must match harness/train_predictor.py feature_row() exactly.
 static void feature_row(uint32_t m, uint32_t n, uint32_t k, const Cand &c, float *f)
 {
     const uint32_t tm = cdiv(m, c.m1), tn = cdiv(n, c.n1);
@@ -130,6 +130,10 @@ static void feature_row(uint32_t m, uint32_t n, uint32_t k, const Cand &c, float
     f[12] = static_cast<float>(m) / (static_cast<float>(tm) * c.m1);
     f[13] = static_cast<float>(n) / (static_cast<float>(tn) * c.n1);
     f[14] = (c.policy == DGA_POLICY_LOADER_WAVES || c.policy == DGA_POLICY_PERSISTENT) ? 1.f : 0.f;   // (5 is folded into 4 in the records)
+    // the cold regime: a short-M weight stream whose operands fit the Infinity Cache is timed (and tuned) on operand sets
+    // rotated past it (harness/sweep.py --cold) -- a decode step's weights are never cache-resident
+    const uint64_t opbytes = static_cast<uint64_t>(m) * k + static_cast<uint64_t>(n) * k + 2ull * m * n;
+    f[15] = (m <= 256 && opbytes < (256ull << 20)) ? 1.f : 0.f;
 }
 
 static float forward(const Model &mo, const float *f)
@@ -175,11 +179,12 @@ static std::vector<Cand> candidates(uint32_t m, uint32_t n, uint32_t k)
         const bool three = bm <= 128;   // every tile below 256 rows has a 3-stage build
         const bool sched = (bm == 256 && bn == 256);
         for (int st = 2; st <= (three ? 3 : 2); ++st)
-            for (int sk : {1, 2, 4, 8, 16}) {
+            for (int sk : {1, 2, 3, 4, 5, 6, 8, 16}) {
                 if (sk > 1 && !(blocks * sk <= 1024 && kb / sk >= 4 && blocks < 192)) continue;
                 // a 3-stage build runs with loader waves (prefer_loader_waves upgrades the plain loop to them anyway)
                 if (st == 3) {
-                    const bool lw = (bm == 128 && bn == 256) || (bm == 128 && bn == 128) || (bm == 64 && bn == 256);
+                    const bool lw = (bm == 128 && bn == 256) || (bm == 128 && bn == 128) || (bm == 64 && bn == 256) ||
+                                    (bm == 64 && bn == 128) || (bm == 16 && bn == 128);
                     out.push_back(Cand{(int)bm, (int)bn, st, sk, lw ? DGA_POLICY_LOADER_WAVES : DGA_POLICY_PLAIN});
                     continue;
                 }

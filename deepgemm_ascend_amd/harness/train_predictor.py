@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 FEATURES = ["log2_m", "log2_n", "log2_k", "log2_m1", "log2_n1", "stages3", "log2_splitk", "policy1", "policy2",
-            "log2_tiles", "log2_rounds", "log2_kb_per_split", "fill_m", "fill_n", "loader_waves"]
+            "log2_tiles", "log2_rounds", "log2_kb_per_split", "fill_m", "fill_n", "loader_waves", "cold"]
 CUS = 256
 LDS_PER_CU = 160 * 1024
 
@@ -33,7 +33,10 @@ def stage_bytes(m1, n1):
 
 
 def feature_row(m, n, k, p):
-    """One candidate -> the 15 inputs.  Must match csrc/dga_predictor.cpp feature_row() exactly."""
+    """One candidate -> the 16 inputs.  Must match csrc/dga_predictor.cpp feature_row() exactly.
+    cold: the shape is a short-M weight stream (M <= 256, operands smaller than the Infinity Cache) whose records are timed
+    on rotated operand sets (harness/sweep.py --cold) -- another regime than a re-launched shape (HBM round trips, idle CUs
+    cost more), which the model is told about rather than left to infer from log2_m."""
     m1, n1, st, sk, pol = p["m1"], p["n1"], p["stages"], p["splitk"], p["policy"]
     tm, tn = -(-m // m1), -(-n // n1)
     tiles = tm * tn * sk
@@ -45,7 +48,8 @@ def feature_row(m, n, k, p):
     kb_per_split = -(-kb // sk)
     return [math.log2(m), math.log2(n), math.log2(k), math.log2(m1), math.log2(n1), 1.0 if st == 3 else 0.0,
             math.log2(sk), 1.0 if pol == 1 else 0.0, 1.0 if pol in (2, 6) else 0.0, math.log2(tiles), math.log2(rounds),
-            math.log2(kb_per_split), m / (tm * m1), n / (tn * n1), 1.0 if pol in (4, 5) else 0.0]
+            math.log2(kb_per_split), m / (tm * m1), n / (tn * n1), 1.0 if pol in (4, 5) else 0.0,
+            1.0 if (m <= 256 and m * k + n * k + 2 * m * n < (256 << 20)) else 0.0]
 
 
 def load_records(dirs):

@@ -122,9 +122,11 @@ def test_fallbacks_and_unload(predictor, tmp_path):
     assert (t.m1, t.n1, t.stages, t.splitkFactor) == (native.m1, native.n1, native.stages, native.splitkFactor) and a == b == 0.0
     # a model whose output does not depend on the candidate can never promise 3 %: native tiling
     flat = tmp_path / "flat.txt"
-    lines = ["dga-predictor 1", "features 15 " + " ".join(f"f{i}" for i in range(15)),
-             "mean " + " ".join(["0.0"] * 15), "std " + " ".join(["1.0"] * 15), "layers 1", "layer 1 15",
-             " ".join(["0.0"] * 15), "3.0"]
+    from deepgemm_ascend_amd.harness import train_predictor as tp
+    nf = len(tp.FEATURES)
+    lines = ["dga-predictor 1", f"features {nf} " + " ".join(f"f{i}" for i in range(nf)),
+             "mean " + " ".join(["0.0"] * nf), "std " + " ".join(["1.0"] * nf), "layers 1", f"layer 1 {nf}",
+             " ".join(["0.0"] * nf), "3.0"]
     flat.write_text("\n".join(lines) + "\n")
     predictor.predictor_load(str(flat))
     t, a, b = predictor.select_kernel_with_predictor(m, n, k)
