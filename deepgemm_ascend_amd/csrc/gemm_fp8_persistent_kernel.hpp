@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_persistent_ke
     if (loader) {
         // ================= loader waves: the LDS-DMA of every stage, STG-1 k blocks ahead of the barrier =================
         const int dwave = wave - Cfg::kWM * WN;
-        const int dtid = tid & (DNT - 1);
+        const int dtid = dwave * 64 + lane;   // (not tid & (DNT-1): the loader waves need not start at a multiple of DNT threads)
         const int a_col = ((dtid & 7) ^ swz_a(dtid >> 3)) * 16;
         const int b_col = ((dtid & 7) ^ swz_b(dtid >> 3)) * 16;
         uint32_t a_voff[Cfg::A_ITERS], b_voff[Cfg::B_ITERS];
