@@ -84,7 +84,13 @@ __device__ __forceinline__ void dma16(uint32_t voff, v4i rsrc, uint32_t soff, ui
                  :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr) : "memory");
 #endif
 }
-// (The non-temporal form, `... offen nt lds`, was measured on the grouped weight stream: no difference, r01.)
+// The non-temporal form (r01 measured it on the one-tile grouped kernel at a full mask: no difference; on the persistent
+// kernel it pays where an expert has few rows, see gemm_fp8_persistent_kernel.hpp)
+__device__ __forceinline__ void dma16_nt(uint32_t voff, v4i rsrc, uint32_t soff, uint32_t lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen nt lds"
+                 :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr) : "memory");
+}
 // LDS-DMA, 4 B per lane from a per-lane 64-bit address (the strided scale gather)
 __device__ __forceinline__ void dma4(const void *src, uint32_t lds_addr)
 {

@@ -185,6 +185,10 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
         if (p.a_bytes >= 0x7FFFFFFFll) return DGA_E_RANGE;
     }
     p.groups = groups;
+    // masked grouped stream: every weight byte is read once by one CU -- the persistent kernel fetches B non-temporally for
+    // the experts whose row count leaves the L2 something better to keep ($DGA_B_NT = 0 / 1 / 2 overrides)
+    static const int b_nt_env = [] { const char *e = std::getenv("DGA_B_NT"); return e ? std::atoi(e) : -1; }();
+    p.b_nt = b_nt_env >= 0 ? b_nt_env : ((masked_m && !m_indices && groups > 1) ? 2 : 0);
     p.splitk = 1;
     p.stamps = clock_stamps;
 

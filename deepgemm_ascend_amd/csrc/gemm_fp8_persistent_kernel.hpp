@@ -112,7 +112,14 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_persistent_ke
             for (int it = 0; it < Cfg::SC_ITERS; ++it)
                 dma4(ridx + min(t.m0 + it * DNT + dtid, t.M - 1), idx_lds + (Cfg::A_ITERS + it) * 256);
         };
+        // Weights that one CU reads once -- the masked grouped stream -- go past the L2's retention (non-temporal loads)
+        // where the expert's rows leave the L2 something better to keep: measured on 256 x (<=128, 7168, 2048) with every
+        // expert at 8 / 16 / 32 / 64 / 96 / 112 / 128 rows: -9.4 / -7.4 / -3.6 / -1.0 / -1.5 / 0 / +0.5 % (scripts/nt_ab.py);
+        // 532 us = 7.06 TB/s at <= 16 rows.  GemmParams::b_nt: 0 never (dense rasters share their B panels: +10..25 %),
+        // 1 always, 2 per tile by its row count.
+        bool b_nt = p.b_nt == 1;
         auto setup = [&](const Tile &t) {
+            if (p.b_nt == 2) b_nt = t.M <= 48;   // (between 48 and 112 rows the two policies are within a per cent of each other)
             const bool ridx = p.row_index != nullptr;
             const uint8_t *A = p.a + (int64_t)t.g * p.a_gs;
             const uint8_t *B = p.b + (int64_t)t.bg * p.b_gs;
@@ -153,7 +160,8 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_persistent_ke
             for (int it = 0; it < Cfg::B_ITERS; ++it) {
                 uint32_t voff = b_voff[it];
                 if constexpr (KTAIL) voff = (k0 + b_col < p.k) ? voff : kOutOfRange;
-                dma16(voff, b_rsrc, (uint32_t)k0, sa + Cfg::A_BYTES + it * DNT * 16);
+                if (b_nt) dma16_nt(voff, b_rsrc, (uint32_t)k0, sa + Cfg::A_BYTES + it * DNT * 16);
+                else dma16(voff, b_rsrc, (uint32_t)k0, sa + Cfg::A_BYTES + it * DNT * 16);
             }
 #pragma unroll
             for (int it = 0; it < Cfg::SC_ITERS; ++it)

@@ -36,7 +36,7 @@ def test_no_kernel_spills_or_scratch(unit, min_kernels, tile_kernel):
             # the persistent builds park some scalars in VGPR lanes (v_writelane / v_readlane): tile-list state of the
             # loader waves and set-up values of the computing waves, none of it inside the MFMA loop, no scratch.
             # Everything else must not spill at all.
-            allowed = 16 if (m.group(1) == "SGPRs Spill" and "persistent" in (name or "")) else 0
+            allowed = 24 if (m.group(1) == "SGPRs Spill" and "persistent" in (name or "")) else 0
             assert int(m.group(2)) <= allowed, f"{name}: {m.group(1)} = {m.group(2)}"
         m = re.search(r"VGPRs: (\d+)", line)
         if m and tile_kernel in (name or ""):
