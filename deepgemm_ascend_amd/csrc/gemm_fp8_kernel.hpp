@@ -52,6 +52,7 @@ struct GemmParams {
     int splitk, kb_per_split;    // splitk > 1: block -> (split, tile); split s covers k blocks [s*kb_per_split, +kb_per_split)
     int b_nt;                    // persistent builds: B fetched with the non-temporal policy: 0 never, 1 always, 2 per tile
                                  // by its row count (the masked grouped stream: weights read once by one CU)
+    int out_nt;                  // persistent builds: bf16 rows stored with the non-temporal policy (the masked grouped stream)
     int launch_tiles;            // > 0: grid size of this launch (the first launch_tiles tiles of the raster); 0: all tiles
     int tail_begin, tail_sub;    // tail_sub = 2: this launch's tiles are QUARTER tiles (2 x 2 per parent) of the parent
                                  // raster's tiles [tail_begin, ...); tiles_m / tiles_n then hold the PARENT raster

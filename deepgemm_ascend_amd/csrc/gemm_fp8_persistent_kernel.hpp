@@ -112,11 +112,10 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_persistent_ke
             for (int it = 0; it < Cfg::SC_ITERS; ++it)
                 dma4(ridx + min(t.m0 + it * DNT + dtid, t.M - 1), idx_lds + (Cfg::A_ITERS + it) * 256);
         };
-        // Weights that one CU reads once -- the masked grouped stream -- go past the L2's retention (non-temporal loads)
-        // where the expert's rows leave the L2 something better to keep: measured on 256 x (<=128, 7168, 2048) with every
-        // expert at 8 / 16 / 32 / 64 / 96 / 112 / 128 rows: -9.4 / -7.4 / -3.6 / -1.0 / -1.5 / 0 / +0.5 % (scripts/nt_ab.py);
-        // 532 us = 7.06 TB/s at <= 16 rows.  GemmParams::b_nt: 0 never (dense rasters share their B panels: +10..25 %),
-        // 1 always, 2 per tile by its row count.
+        // Weights that one CU reads once -- the weight stream of the grouped layouts -- go past the L2's retention
+        // (non-temporal loads), which together with non-temporal output stores leaves the L2 to the A rows: see the
+        // launcher (dga_launch.hip) for the measurements.  GemmParams::b_nt: 0 never (dense rasters share their B panels:
+        // +10..25 %), 1 always, 2 per tile by its row count (<= 48 rows; what pays with default-policy stores).
         bool b_nt = p.b_nt == 1;
         auto setup = [&](const Tile &t) {
             if (p.b_nt == 2) b_nt = t.M <= 48;   // (between 48 and 112 rows the two policies are within a per cent of each other)
@@ -349,7 +348,12 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_persistent_ke
                     const v4i pk = v4i{__builtin_bit_cast(int, h0), __builtin_bit_cast(int, h1),
                                        __builtin_bit_cast(int, h2), __builtin_bit_cast(int, h3)};
                     if (vec_ok && n + 8 <= p.n) {
-                        *(v4i *)(crow + n) = pk;
+                        // the weight stream's outputs are written once and not read again here: stored non-temporally they do
+                        // not take L2 lines from the A rows the expert's other tiles re-read (-3.5 % on 256 x (128, 7168, 2048))
+                        // (inline asm: written as __builtin_nontemporal_store beside a plain store, the two branches are merged
+                        //  by the compiler and the hint is lost)
+                        if (p.out_nt) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(crow + n), "v"(pk) : "memory");
+                        else *(v4i *)(crow + n) = pk;
                     } else {
                         const uint16_t *e = (const uint16_t *)&pk;
 #pragma unroll
