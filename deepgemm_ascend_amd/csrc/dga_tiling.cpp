@@ -331,7 +331,11 @@ void prefer_loader_waves(dga_tiling_t &t)
         t.m1 && t.n1 && !(t.contiguous && t.m1 > DGA_CONTIGUOUS_M_ALIGNMENT)) {
         const uint64_t groups = t.contiguous ? 1 : std::max<uint32_t>(1, t.groups);
         const uint64_t tiles = groups * ((t.m + t.m1 - 1) / t.m1) * ((t.n + t.n1 - 1) / t.n1);
-        if (tiles > device_cus()) t.dispatchPolicyTag = DGA_POLICY_PERSISTENT;
+        // the weight stream of the grouped layouts runs the persistent build whatever its tile count: that kernel moves the
+        // weights and the outputs with the non-temporal policy (dga_launch.hip), worth more than the tile boundaries
+        const bool weight_stream = t.contiguous ? (t.groups > 1 && static_cast<uint64_t>(t.m) <= static_cast<uint64_t>(t.groups) * DGA_CONTIGUOUS_M_ALIGNMENT)
+                                                : t.groups > 1;
+        if (tiles > device_cus() || weight_stream) t.dispatchPolicyTag = DGA_POLICY_PERSISTENT;
     }
     // ... and the continuous 256x256 kernel has its own persistent form (dispatchPolicyTag 6,
     // gemm_fp8_cont_persistent_kernel.hpp) for dense rasters of full tiles: the next tile's first stages are fetched from

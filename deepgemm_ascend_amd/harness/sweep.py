@@ -139,7 +139,9 @@ def check_candidate(prob, c):
     kb = -(-prob["k"] // 128)
     if pol == 5:   # persistent loader waves: whole rasters with more tiles than CUs (otherwise it IS policy 4)
         groups = prob["groups"] if prob["layout"] == "masked" else 1
-        if sk != 1 or groups * -(-prob["m"] // bm) * -(-prob["n"] // bn) <= CUS:
+        # (a masked grouped problem is a weight stream: the persistent build is also the one that moves weights and outputs
+        #  with the non-temporal policy, whatever the tile count)
+        if sk != 1 or (prob["layout"] != "masked" and groups * -(-prob["m"] // bm) * -(-prob["n"] // bn) <= CUS):
             return False, "persistent form: more tiles than CUs, no split-K"
     if pol == 6 and (prob["layout"] != "dense" or prob["m"] % 256 or prob["n"] % 256 or prob["k"] % 128 or prob["k"] < 256 or
                      sk != 1 or (prob["m"] // 256) * (prob["n"] // 256) <= CUS):

@@ -178,8 +178,10 @@ def test_persistent_form_where_the_raster_exceeds_the_cus(dga):
     assert (big.m1, big.n1, big.stages, big.dispatchPolicyTag) == (128, 256, 3, dga.api.POLICY_PERSISTENT)
     one = dga.select_kernel(4096, 2048, 7168)                               # BASELINE configs[2]: 256 tiles, one per CU
     assert (one.m1, one.n1, one.dispatchPolicyTag) == (128, 256, dga.api.POLICY_LOADER_WAVES)
-    few = dga.select_kernel(128, 2048, 7168, groups=16, expected_m=128)    # 128 tiles
-    assert few.dispatchPolicyTag == dga.api.POLICY_LOADER_WAVES
+    few = dga.select_kernel(128, 2048, 7168, groups=16, expected_m=128)    # 128 tiles, but a weight stream: the persistent
+    assert few.dispatchPolicyTag == dga.api.POLICY_PERSISTENT              # build moves it with the non-temporal policy
+    dense_few = dga.select_kernel(2048, 2048, 7168)                         # a dense raster of 128 loader-wave tiles
+    assert dense_few.dispatchPolicyTag in (dga.api.POLICY_LOADER_WAVES, dga.api.POLICY_PLAIN, dga.api.POLICY_CONTINUOUS)
     for (m, n, k) in [(64, 7168, 18432), (128, 4096, 7168), (8, 18432, 7168)]:
         t = dga.select_kernel(m, n, k)
         assert t.dispatchPolicyTag != dga.api.POLICY_PERSISTENT or t.splitkFactor == 1
