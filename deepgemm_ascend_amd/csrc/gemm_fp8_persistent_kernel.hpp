@@ -8,7 +8,9 @@
 // over the FLATTENED (tile, k block) sequence: while the computing waves convert and store tile i, the loaders already
 // have the first blocks of tile i+1 in flight, and the next tile's set-up (mask, row table, descriptors) is done by waves
 // that have nothing else to do.  Both kinds of wave derive the same tile list from blockIdx and masked_m alone, so the
-// one barrier per k block pairs up without any hand-shake beyond what the one-tile kernel has.
+// one barrier per k block pairs up without any hand-shake beyond what the one-tile kernel has.  (Like every input,
+// masked_m / m_indices must not be written while the launch runs: the two kinds of wave read them separately, and lists that
+// disagree would leave a barrier unmatched.)
 //
 // Same arithmetic, same order, same bits as the one-tile builds (tests/test_grouped_gpu.py compares them byte for byte).
 // Counterpart in the reference: its kernel is persistent by construction -- one block per AI core, which walks the

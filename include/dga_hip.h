@@ -182,7 +182,8 @@ int dga_gemm_fp8_fp8_bf16_nt(const void *a, const float *sfa, const void *b, con
 
 /* m_grouped_gemm_fp8_fp8_bf16_nt_masked: G independent problems
  *   a [G,m_max,K], sfa [G,m_max,KB], b [G,N,K], sfb [G,NB,KB], out [G,m_max,N];
- *   only rows < masked_m[g] (device int32[G]) of out[g] are written.
+ *   only rows < masked_m[g] (device int32[G]) of out[g] are written.  masked_m is read on the device while the call
+ *   executes (like every operand it must not be written concurrently).
  * No reference counterpart beyond the uniform batch loop (generate_code.hpp:149-153); SURVEY.md 8(b). */
 int dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked(const void *a, const float *sfa, const void *b, const float *sfb,
                                               void *out, const int32_t *masked_m, int groups, int m_max, int n,
