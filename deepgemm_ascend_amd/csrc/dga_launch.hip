@@ -204,14 +204,17 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     static const int strict_env = [] { const char *e = std::getenv("DGA_STRICT"); return e ? std::atoi(e) : 0; }();
     if (clock_stamps && (tiling->dispatchPolicyTag == DGA_POLICY_STRICT || strict_env || (k % 16) != 0)) return DGA_E_TILING;
     if (tiling->dispatchPolicyTag == DGA_POLICY_STRICT || strict_env) {
-        const int bm = m > 64 ? 128 : (m > 32 ? 64 : 32);
+        // tile height: 64 rows (two 16-row chains per wave: 105-109 TFLOP/s at 4096^3 where 128 rows -- one wave per SIMD,
+        // its two barriers per k block exposed -- reached 91), 32 rows where 64-row tiles would leave CUs idle
+        // (128x4096x7168: 647 -> 224 us)
+        const int64_t tiles64 = static_cast<int64_t>(groups) * ((m + 63) / 64) * ((n + 127) / 128);
+        const int bm = (m > 32 && tiles64 >= static_cast<int64_t>(device_cus())) ? 64 : 32;
         p.tiles_m = (m + bm - 1) / bm;
         p.tiles_n = (n + 127) / 128;
         const int64_t blocks = static_cast<int64_t>(groups) * p.tiles_m * p.tiles_n;
         if (blocks > 0x7FFFFFFFll) return DGA_E_SHAPE;
         const dim3 grid(static_cast<unsigned>(blocks)), block(256);
-        if (bm == 128) hipLaunchKernelGGL(gemm_fp8_strict_nt_kernel<4>, grid, block, 0, stream, p);
-        else if (bm == 64) hipLaunchKernelGGL(gemm_fp8_strict_nt_kernel<2>, grid, block, 0, stream, p);
+        if (bm == 64) hipLaunchKernelGGL(gemm_fp8_strict_nt_kernel<2>, grid, block, 0, stream, p);
         else hipLaunchKernelGGL(gemm_fp8_strict_nt_kernel<1>, grid, block, 0, stream, p);
         DGA_HIP_TRY(hipGetLastError());
         return DGA_OK;
