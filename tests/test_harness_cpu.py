@@ -76,3 +76,41 @@ def test_sweep_constraint_checkers():
     for (bm, bn, wm, wn, st, pols) in sweep.MENU:
         assert sweep.stage_bytes(bm, bn, wm * wn) * st <= sweep.LDS_BYTES and bm * bn // (wm * wn * 64) <= sweep.ACC_REGS
     assert len(sweep.grouped_candidates(masked)) >= 8
+
+
+def test_merge_sweep_runs_and_table_builder(tmp_path):
+    """scripts/merge_sweep_runs.py: the faster timing per candidate wins, a cold record replaces a warm one whatever the two
+    say, the persistent forms fold into their one-tile siblings; scripts/build_tuned_table.py: first file wins, 17-column
+    dense rows are padded with groups = 1, contiguous = 0."""
+    import json, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    rec = lambda idx, t, p, neg=False: json.dumps({"idx": idx, "M": 64, "N": 512, "K": 512, "time": t, "diff": 0.0, "negative": neg, "parameters": p}) + "\n"
+    base = {"m1": 64, "n1": 128, "raster": 1, "stages": 3, "splitk": 1}
+    a, b, c = tmp_path / "a", tmp_path / "b", tmp_path / "c"
+    for d in (a, b, c):
+        d.mkdir()
+    name = "shape_64_512_512_rank_0.jsonl"
+    (a / name).write_text(rec(0, 20.0, dict(base, policy=4)) + rec(1, 30.0, dict(base, policy=0)) + rec(2, 25.0, dict(base, m1=256, n1=256, stages=2, policy=2)))
+    (b / name).write_text(rec(0, 18.0, dict(base, policy=5)) + rec(1, 35.0, dict(base, policy=0)) + rec(2, 22.0, dict(base, m1=256, n1=256, stages=2, policy=6))
+                          + rec(3, 5.0, dict(base, m1=16, policy=5)))          # no sibling record: dropped
+    (c / name).write_text(rec(1, 40.0, dict(base, policy=0, cold_sets=3)))     # cold: replaces the warm 30.0
+    out = tmp_path / "merged"
+    subprocess.run([sys.executable, str(root / "scripts" / "merge_sweep_runs.py"), str(out), str(a), str(b), str(c)], check=True, capture_output=True)
+    rows = [json.loads(l) for l in (out / name).read_text().splitlines()]
+    by = {(r["parameters"]["m1"], r["parameters"]["policy"]): r for r in rows}
+    assert by[(64, 4)]["time"] == 18.0 and by[(256, 2)]["time"] == 22.0          # folded persistent forms, faster wins
+    assert by[(64, 0)]["time"] == 40.0 and by[(64, 0)]["parameters"].get("cold") == 1
+    assert (16, 4) not in by and len(rows) == 3
+    dense = tmp_path / "dense.csv"; dense2 = tmp_path / "dense2.csv"; grouped = tmp_path / "grouped.csv"
+    head17 = "m,n,k,m1,n1,k1,kernelSerial,paddingTagA,paddingTagB,paddingTagC,blockDim,splitkFactor,stages,swizzleOffset,wavesM,wavesN,dispatchPolicyTag\n"
+    dense.write_text(head17 + "64,512,512,64,128,128,4,0,0,0,16,4,3,1,0,0,0\n")
+    dense2.write_text(head17 + "64,512,512,16,128,128,0,0,0,0,4,1,3,1,0,0,4\n" + "8,512,512,16,128,128,0,0,0,0,4,1,3,1,0,0,4\n")
+    grouped.write_text(head17.strip() + ",groups,contiguous\n" + "64,512,512,64,256,128,0,0,0,0,32,1,3,1,1,4,5,16,0\n")
+    table = tmp_path / "table.csv"
+    subprocess.run([sys.executable, str(root / "scripts" / "build_tuned_table.py"), "--out", str(table), str(dense), str(dense2), str(grouped)],
+                   check=True, capture_output=True)
+    lines = table.read_text().strip().splitlines()
+    assert len(lines) == 4 and all(len(l.split(",")) == 19 for l in lines)
+    assert lines[1].split(",")[3:5] == ["64", "128"] and lines[1].endswith(",1,0")   # the first file's row of (64, 512, 512) won
+    assert lines[3].endswith(",16,0")
