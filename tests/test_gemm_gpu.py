@@ -315,3 +315,24 @@ def test_persistent_continuous_build_writes_the_same_bits(dga, m, n, k):
     assert torch.equal(outs[2].view(torch.int16), outs[6].view(torch.int16))
     nan_rows = torch.isnan(outs[6].float()).any(dim=1).nonzero().flatten().tolist()
     assert nan_rows == [1]
+
+
+def test_persistent_continuous_with_the_quarter_tile_tail(dga):
+    """A raster of 288 full tiles: the tiling asks for whole waves in the persistent continuous kernel (dispatchPolicyTag 6 on
+    the first 256 tiles) plus the last partial wave in quarter tiles (kernelSerial 5); the bytes are those of one plain
+    launch of the one-tile kernel."""
+    m, n, k = 1024, 18432, 640
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    a = torch.randint(0, 120, (m, k), dtype=torch.uint8, device="cuda", generator=gen)
+    b = torch.randint(0, 120, (n, k), dtype=torch.uint8, device="cuda", generator=gen)
+    sfa = torch.rand((m, 5), device="cuda", generator=gen) + 0.5
+    sfb = torch.rand((n // 128, 5), device="cuda", generator=gen) + 0.5
+    t = dga.select_kernel(m, n, k)
+    assert (t.m1, t.n1, t.kernelSerial, t.dispatchPolicyTag) == (256, 256, 5, dga.api.POLICY_CONTINUOUS_PERSISTENT)
+    o6 = torch.full((m, n), -1.0, dtype=torch.bfloat16, device="cuda")
+    dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), o6, tiling_=t, sync=True)
+    t2 = dga.select_kernel(m, n, k)
+    t2.kernelSerial, t2.dispatchPolicyTag = 0, dga.api.POLICY_CONTINUOUS
+    o2 = torch.full((m, n), -1.0, dtype=torch.bfloat16, device="cuda")
+    dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), o2, tiling_=t2, sync=True)
+    assert torch.equal(o6.view(torch.int16), o2.view(torch.int16))
