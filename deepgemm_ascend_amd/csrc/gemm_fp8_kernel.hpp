@@ -85,6 +85,14 @@ struct GemmParams {
         st_seg[slot_t] = c0 - st_seg[slot_t];                                                   \
         st_seg[slot_rt] = c1 - st_seg[slot_rt];                                                 \
     } while (0)
+#define DGA_STAMP_ABS(i)   /* absolute 100 MHz real-time stamp into slot i (wave entry / loop start / loop end / wave exit) */ \
+    do {                                                                                        \
+        unsigned long long st_abs;                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_abs)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        st_seg[i] = st_abs;                                                                     \
+    } while (0)
 #define DGA_STAMP_FLUSH()                                                                       \
     do {                                                                                        \
         if (p.stamps && lane == 0)                                                              \
@@ -94,6 +102,7 @@ struct GemmParams {
 #define DGA_STAMP_DECL
 #define DGA_STAMP_CLOCK(a, b) do { } while (0)
 #define DGA_STAMP_START() do { } while (0)
+#define DGA_STAMP_ABS(i) do { } while (0)
 #define DGA_STAMP(i) do { } while (0)
 #define DGA_STAMP_FLUSH() do { } while (0)
 #endif
@@ -601,6 +610,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         float s[TM], s_prev[TM], s_next[TM], sfb_next = 0.f;
         const int KB = p.kb_n;
         DGA_STAMP_DECL
+        DGA_STAMP_ABS(0);        // (diagnostic builds: wave entry, a few set-up instructions late)
         DGA_STAMP_CLOCK(6, 7);
         loop_clock.tick();
         auto barrier = [&]() {
@@ -639,6 +649,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
                 s_next[mt] = 0.f;
             }
         }
+        DGA_STAMP_ABS(1);        // first fragments in registers: the k loop starts
         for (int kb = 0; kb < KB; ++kb) {
             const uint8_t *st = smem + (kb & 1) * Cfg::STAGE_BYTES;
             const uint8_t *sn = smem + ((kb & 1) ^ 1) * Cfg::STAGE_BYTES;
@@ -727,10 +738,12 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         }
         wait_vmcnt<0>();
         DGA_STAMP_CLOCK(6, 7);
-        DGA_STAMP_FLUSH();
+        DGA_STAMP_ABS(2);
         loop_clock.tick();
         loop_clock.flush(p.stamps, blockIdx.x * (NT / 64) + wave, lane);
         epilogue(acc);
+        DGA_STAMP_ABS(3);        // stores issued (not yet complete)
+        DGA_STAMP_FLUSH();
     } else {
         v4f acc[TM][TN];
 #pragma unroll

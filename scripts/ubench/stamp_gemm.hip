@@ -1,6 +1,7 @@
 // Diagnostic build of the fp8 GEMM kernel with s_memtime stamps (shares, not run time, are meaningful).
 #define DGA_STAMPS 1
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -59,5 +60,20 @@ int main(int argc, char **argv)
     for (int w = 0; w < grid * 8; ++w) { ct += (double)h[(size_t)w * 8 + 6]; crt += (double)h[(size_t)w * 8 + 7]; }
     printf("main loop: %.0f shader ticks, %.0f realtime ticks (100 MHz) per wave -> clock %.3f GHz, loop %.1f us\n",
            ct / (grid * 8), crt / (grid * 8), ct / crt * 0.1, crt / (grid * 8) / 100.0);
+    if (pp == 2) {   // absolute real-time stamps of the last launch: entry / loop start / loop end / stores issued
+        double pro = 0, loop = 0, epi = 0;
+        unsigned long long first = ~0ull, last = 0, first_loop_end = ~0ull, last_loop_start = 0;
+        for (int w = 0; w < grid * 8; ++w) {
+            const unsigned long long *q = &h[(size_t)w * 8];
+            pro += (double)(q[1] - q[0]); loop += (double)(q[2] - q[1]); epi += (double)(q[3] - q[2]);
+            first = std::min(first, q[0]); last = std::max(last, q[3]);
+            first_loop_end = std::min(first_loop_end, q[2]); last_loop_start = std::max(last_loop_start, q[1]);
+        }
+        const double nw = grid * 8.0;
+        printf("per wave: entry -> loop %.2f us, loop %.2f us, loop end -> stores issued %.2f us; first entry -> last exit %.2f us "
+               "(last loop start at +%.2f, first loop end at +%.2f); launch interval %.2f us\n",
+               pro / nw / 100, loop / nw / 100, epi / nw / 100, (double)(last - first) / 100, (double)(last_loop_start - first) / 100,
+               (double)(first_loop_end - first) / 100, ms * 1000 / 20);
+    }
     return 0;
 }
