@@ -116,7 +116,9 @@ class ExpertShardedGroupedGemm:
         self.kb = (k + 127) // 128
         self.nb = (n + 127) // 128
         self.hdr = k + 4 * self.kb                      # byte offset of the 4-byte header in a payload row
-        self.row_bytes = (self.hdr + 4 + 15) // 16 * 16
+        # rows of the exchange buffers start on 128-byte lines: the indexed GEMM reads a row's k blocks (128 B each) where they
+        # lie, and a row stride that is not a line multiple would make every such read straddle two lines
+        self.row_bytes = (self.hdr + 4 + 127) // 128 * 128
         self.device = torch.device(device)
         self.strict = strict
         # indexed (device default): the grouped GEMM gathers token rows where they lie (the caller's tensors at world 1,
