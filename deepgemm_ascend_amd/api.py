@@ -80,15 +80,25 @@ def _mmad_workspace(batch, m, n, k, x) -> Tuple[Optional[int], int]:
 
 POLICY_PLAIN, POLICY_PINGPONG, POLICY_CONTINUOUS, POLICY_STRICT, POLICY_LOADER_WAVES, POLICY_PERSISTENT = 0, 1, 2, 3, 4, 5
 POLICY_CONTINUOUS_PERSISTENT = 6
+POLICY_BF16_EXACT = 7
+
+# The three arithmetic policies of the fp8 GEMMs (README.md "Numerics"; include/dga_hip.h, dispatchPolicyTag):
+#   "fast"        the fp8 matrix instruction (whatever schedule the tiling names) -- the throughput form
+#   "bf16_exact"  e4m3 -> bf16 in registers (exact), bf16 matrix instruction: exact products, fp32-class block sums
+#   "strict"      fp32-input matrix instruction in the oracle's own order: bit-identical to the reference CPU path
+ARITHMETIC_POLICIES = {"fast": None, "bf16_exact": POLICY_BF16_EXACT, "strict": POLICY_STRICT}
 
 
-def _with_policy(t: Tiling, strict: bool) -> Tiling:
-    """strict=True: a copy of the tiling with dispatchPolicyTag = DGA_POLICY_STRICT (the exact-arithmetic kernel)."""
-    if not strict or t.dispatchPolicyTag == POLICY_STRICT:
+def _with_policy(t: Tiling, strict: bool, policy: Optional[str] = None) -> Tiling:
+    """A copy of the tiling with the arithmetic policy's dispatchPolicyTag (strict=True is policy="strict")."""
+    _require(policy is None or policy in ARITHMETIC_POLICIES, f"policy must be one of {sorted(ARITHMETIC_POLICIES)}")
+    _require(not (strict and policy not in (None, "strict")), "strict=True contradicts policy=%r" % (policy,))
+    tag = POLICY_STRICT if strict else ARITHMETIC_POLICIES.get(policy)
+    if tag is None or t.dispatchPolicyTag == tag:
         return t
     c = Tiling()
     ctypes.memmove(ctypes.byref(c), ctypes.byref(t), ctypes.sizeof(Tiling))
-    c.dispatchPolicyTag = POLICY_STRICT
+    c.dispatchPolicyTag = tag
     return c
 
 
@@ -240,12 +250,14 @@ def bench_params_fill(m: int, n: int, k: int, params6: Sequence[int]) -> list:
 
 def gemm_fp8_fp8_bf16_nt(lhs: Tuple[torch.Tensor, torch.Tensor], rhs: Tuple[torch.Tensor, torch.Tensor],
                          out: torch.Tensor, tiling_: Optional[Tiling] = None, sync: bool = False,
-                         strict: bool = False) -> None:
+                         strict: bool = False, policy: Optional[str] = None) -> None:
     """out[M,N] (bf16, written in place) = (A[M,K] fp8, sfa[M,ceil(K/128)]) x (B[N,K] fp8, sfb[ceil(N/128),ceil(K/128)])^T.
 
-    strict=True runs the exact-arithmetic kernel (dispatchPolicyTag 3): fp32 products and sums in the reference CPU
-    path's own order, bit-identical to the oracle, at the fp32 matrix rate.  The default fp8-MFMA path is ~30x faster
-    and differs from it on cancellation-dominated outputs (README.md, "Numerics").
+    strict=True (= policy="strict") runs the exact-arithmetic kernel (dispatchPolicyTag 3): fp32 products and sums in the
+    reference CPU path's own order, bit-identical to the oracle, at the fp32 matrix rate.  policy="bf16_exact"
+    (dispatchPolicyTag 7) up-converts the bytes to bf16 in registers and sums on the bf16 matrix instruction: exact products,
+    fp32-class sums, about half the fast path's rate.  The default fp8-MFMA path ("fast") differs from both on
+    cancellation-dominated outputs (README.md, "Numerics").
 
     Asynchronous on the current stream (the reference syncs on every call, gemm.hpp:110;
     pass sync=True for that behaviour)."""
@@ -267,7 +279,7 @@ def gemm_fp8_fp8_bf16_nt(lhs: Tuple[torch.Tensor, torch.Tensor], rhs: Tuple[torc
     with _device_guard(a, b, sfa, sfb, out):
         if tiling_ is None:
             tiling_ = tiling(m, n, k)
-        tiling_ = _with_policy(tiling_, strict)
+        tiling_ = _with_policy(tiling_, strict, policy)
         ws_ptr, ws_bytes = _workspace(tiling_, out.device)
         rc = _lib.lib().dga_gemm_fp8_fp8_bf16_nt(a.data_ptr(), sfa.data_ptr(), b.data_ptr(), sfb.data_ptr(),
                                                  out.data_ptr(), m, n, k, ctypes.byref(tiling_), ws_ptr, ws_bytes,
@@ -300,7 +312,7 @@ def gemm_fp8_loop_clock(lhs, rhs, out: torch.Tensor, tiling_: Optional[Tiling] =
 
 def m_grouped_gemm_fp8_fp8_bf16_nt_masked(lhs, rhs, out: torch.Tensor, masked_m: torch.Tensor, expected_m: int,
                                           tiling_: Optional[Tiling] = None, sync: bool = False,
-                                          strict: bool = False) -> None:
+                                          strict: bool = False, policy: Optional[str] = None) -> None:
     """Grouped masked-M GEMM: a [G,Mmax,K], sfa [G,Mmax,KB], b [G,N,K], sfb [G,NB,KB], out [G,Mmax,N] bf16;
     only rows < masked_m[g] of out[g] are written (upstream DeepGEMM's convention)."""
     a, sfa = lhs
@@ -320,7 +332,7 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_masked(lhs, rhs, out: torch.Tensor, masked_m:
     with _device_guard(a, b, sfa, sfb, out, masked_m):
         if tiling_ is None:
             tiling_ = tiling(mmax, n, k, groups=g, expected_m=int(expected_m))
-        tiling_ = _with_policy(tiling_, strict)
+        tiling_ = _with_policy(tiling_, strict, policy)
         ws_ptr, ws_bytes = _workspace(tiling_, out.device)
         rc = _lib.lib().dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked(
             a.data_ptr(), sfa.data_ptr(), b.data_ptr(), sfb.data_ptr(), out.data_ptr(), masked_m.data_ptr(),
@@ -334,7 +346,7 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(a_rows: torch.Tensor, sfa_src:
                                                   sfa_ld: int, rhs, out_rows: torch.Tensor, row_index: torch.Tensor,
                                                   masked_m: torch.Tensor, m_max: int, expected_m: int = 0,
                                                   tiling_: Optional[Tiling] = None, sync: bool = False,
-                                                  strict: bool = False) -> None:
+                                                  strict: bool = False, policy: Optional[str] = None) -> None:
     """Masked grouped GEMM on rows that stay where they are (dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed):
     row r of group g is row row_index[g * m_max + r] of the flat byte rows `a_rows` [rows, lda] (first K bytes = fp8),
     its 1x128 scales start at byte sfa_byte_offset of row row_index[...] of `sfa_src` viewed with sfa_ld floats per row
@@ -355,7 +367,7 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(a_rows: torch.Tensor, sfa_src:
     with _device_guard(a_rows, b, sfb, out_rows, row_index, masked_m, sfa_src):
         if tiling_ is None:
             tiling_ = tiling(m_max, n, k, groups=g, expected_m=int(expected_m))
-        tiling_ = _with_policy(tiling_, strict)
+        tiling_ = _with_policy(tiling_, strict, policy)
         rc = _lib.lib().dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(
             a_rows.data_ptr(), lda, sfa_src.data_ptr() + sfa_byte_offset, sfa_ld, b.data_ptr(), sfb.data_ptr(),
             out_rows.data_ptr(), out_rows.stride(0), row_index.data_ptr(), rows, masked_m.data_ptr(), g, m_max, n, k,
@@ -396,7 +408,7 @@ def get_m_alignment_for_contiguous_layout() -> int:
 
 def m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(lhs, rhs, out: torch.Tensor, m_indices: torch.Tensor,
                                               tiling_: Optional[Tiling] = None, sync: bool = False,
-                                              strict: bool = False) -> None:
+                                              strict: bool = False, policy: Optional[str] = None) -> None:
     """Contiguous-grouped GEMM (the prefill-side MoE layout): a [Msum,K], sfa [Msum,KB], b [G,N,K], sfb [G,NB,KB],
     out [Msum,N] bf16, m_indices int32 [Msum].  Row r is multiplied with b[m_indices[r]]; rows with a negative index
     are padding and stay untouched.  Group segments start at multiples of get_m_alignment_for_contiguous_layout()
@@ -418,7 +430,7 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(lhs, rhs, out: torch.Tensor, m_ind
     with _device_guard(a, b, sfa, sfb, out, m_indices):
         if tiling_ is None:
             tiling_ = tiling(msum, n, k, groups=g, contiguous=True)
-        tiling_ = _with_policy(tiling_, strict)
+        tiling_ = _with_policy(tiling_, strict, policy)
         ws_ptr, ws_bytes = _workspace(tiling_, out.device)
         rc = _lib.lib().dga_m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(
             a.data_ptr(), sfa.data_ptr(), b.data_ptr(), sfb.data_ptr(), out.data_ptr(), m_indices.data_ptr(),

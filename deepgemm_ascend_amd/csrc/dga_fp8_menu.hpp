@@ -53,6 +53,16 @@ int launch_persistent(const GemmParams &p, hipStream_t stream);
     extern template int launch_persistent<GemmCfg<BM, BN, WM, WN, ST, 4>>(const GemmParams &, hipStream_t);
 DGA_MENU_LC(DGA_MENU_EXTERN_PS)
 
+// bf16-exact builds (gemm_fp8_kernel.hpp MATH = 1, dispatchPolicyTag 7; dga_launch_menu_e.hip): the e4m3 bytes up-converted to
+// bf16 in registers, a scale block = four chained v_mfma_f32_16x16x32_bf16.  Wave tiles of at most 64 x 64 (the bf16 A
+// fragments and a double-buffered bf16 B fragment live beside the accumulators), three LDS stages.
+template <class Cfg>
+int launch_bf16x(const GemmParams &p, hipStream_t stream);
+#define DGA_MENU_BX(X) X(128, 256, 2, 4, 3, 0) X(128, 128, 2, 2, 3, 0) X(64, 256, 1, 4, 3, 0) X(64, 128, 1, 4, 3, 0) X(32, 128, 1, 4, 3, 0)
+#define DGA_MENU_EXTERN_BX(BM, BN, WM, WN, ST, PP) \
+    extern template int launch_bf16x<GemmCfg<BM, BN, WM, WN, ST>>(const GemmParams &, hipStream_t);
+DGA_MENU_BX(DGA_MENU_EXTERN_BX)
+
 // persistent continuous-pipeline build of the 256x256 tile (gemm_fp8_cont_persistent_kernel.hpp, dispatchPolicyTag 6): dense
 // rasters of full tiles only -- launch_cont_persistent returns DGA_E_TILING for anything else
 int launch_cont_persistent(const GemmParams &p, hipStream_t stream);

@@ -93,6 +93,29 @@ static const Variant kVariants[] = {
 };
 static constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
+// the bf16-exact policy's own menu (dispatchPolicyTag 7; dga_launch_menu_e.hip), tallest and widest first
+struct Bf16xVariant {
+    int bm, bn;
+    int (*launch)(const GemmParams &, hipStream_t);
+};
+static const Bf16xVariant kBf16xVariants[] = {
+    {128, 256, &launch_bf16x<GemmCfg<128, 256, 2, 4, 3>>}, {128, 128, &launch_bf16x<GemmCfg<128, 128, 2, 2, 3>>},
+    {64, 256, &launch_bf16x<GemmCfg<64, 256, 1, 4, 3>>},   {64, 128, &launch_bf16x<GemmCfg<64, 128, 1, 4, 3>>},
+    {32, 128, &launch_bf16x<GemmCfg<32, 128, 1, 4, 3>>},
+};
+// the tiling's (m1, n1) mapped onto that menu: the tile height rounded into {32, 64, 128}, the width kept where the height
+// has a build of that width
+static const Bf16xVariant *find_bf16x_variant(int m1, int n1)
+{
+    const int bm = m1 >= 128 ? 128 : (m1 >= 64 ? 64 : 32);
+    const int bn = n1 >= 256 ? 256 : 128;
+    for (const auto &v : kBf16xVariants)
+        if (v.bm == bm && v.bn == bn) return &v;
+    for (const auto &v : kBf16xVariants)
+        if (v.bm == bm) return &v;
+    return nullptr;
+}
+
 int variant_count() { return kNumVariants; }
 int variant_stages(int i) { return kVariants[i].stages; }
 bool variant_has_loader_waves(int i) { return kVariants[i].launch_lc != nullptr; }
@@ -261,17 +284,22 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
         DGA_HIP_TRY(hipGetLastError());
         return DGA_OK;
     }
+    static const int bf16x_env = [] { const char *e = std::getenv("DGA_BF16_EXACT"); return e ? std::atoi(e) : 0; }();
+    const bool bf16x = tiling->dispatchPolicyTag == DGA_POLICY_BF16_EXACT || bf16x_env;
+    const Bf16xVariant *vx = bf16x ? find_bf16x_variant(tiling->m1, tiling->n1) : nullptr;
+    if (bf16x && (!vx || clock_stamps)) return DGA_E_TILING;
     const Variant *v = find_variant(tiling->m1, tiling->n1, tiling->wavesM, tiling->wavesN, tiling->stages);
-    if (!v) return DGA_E_TILING;
+    if (!v && !vx) return DGA_E_TILING;
+    const int tile_m = vx ? vx->bm : v->bm, tile_n = vx ? vx->bn : v->bn;
     const bool wants_loaders = tiling->dispatchPolicyTag == DGA_POLICY_LOADER_WAVES || tiling->dispatchPolicyTag == DGA_POLICY_PERSISTENT;
-    if (wants_loaders && !v->launch_lc)   // the tile's build that has loader waves
+    if (!vx && wants_loaders && !v->launch_lc)   // the tile's build that has loader waves
         for (int i = 0; i < kNumVariants; ++i)
             if (kVariants[i].bm == v->bm && kVariants[i].bn == v->bn && kVariants[i].stages == v->stages && kVariants[i].launch_lc) {
                 v = &kVariants[i];
                 break;
             }
-    p.tiles_m = (m + v->bm - 1) / v->bm;
-    p.tiles_n = (n + v->bn - 1) / v->bn;
+    p.tiles_m = (m + tile_m - 1) / tile_m;
+    p.tiles_n = (n + tile_n - 1) / tile_n;
     p.raster_group = tiling->swizzleOffset ? tiling->swizzleOffset : 1;
     static const int xcd_remap = [] { const char *e = std::getenv("DGA_XCD_REMAP"); return e ? std::atoi(e) : 1; }();
     p.xcd_remap = xcd_remap;
@@ -289,7 +317,7 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
             p.partial = slabs;
             GemmParams pk = p;
             pk.groups = s;  // grid = splitk x tiles
-            int rc = v->launch(pk, stream);
+            int rc = vx ? vx->launch(pk, stream) : v->launch(pk, stream);
             if (rc != DGA_OK) return rc;
             const int64_t mn = static_cast<int64_t>(m) * n;
             hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3(static_cast<unsigned>((mn / 8 + 255) / 256 + 1)), dim3(256),
@@ -301,6 +329,7 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     }
     static const int pp_env = [] { const char *e = std::getenv("DGA_PINGPONG"); return e ? std::atoi(e) : -1; }();
     const int policy = pp_env >= 0 ? pp_env : tiling->dispatchPolicyTag;
+    if (vx) return vx->launch(p, stream);   // bf16-exact: one launch over the whole raster
     auto launch_main = [&](const GemmParams &q) -> int {
         if (q.stamps) {
             auto clk = find_clock_build(v, (policy == 2 || policy == DGA_POLICY_CONTINUOUS_PERSISTENT) && v->launch_cont ? 2 : (policy == DGA_POLICY_LOADER_WAVES && v->launch_lc ? policy : 0));

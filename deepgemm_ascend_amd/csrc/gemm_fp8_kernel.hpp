@@ -137,7 +137,10 @@ struct LoopClock {
 // PP = 0: every wave runs the same k-block loop (one barrier per k block).
 // PP = 1 ("ping-pong", 256x256 tile with 8 waves only): the second-dispatched half of the workgroup runs half a k
 //         block behind the first, so one half's LDS fragment burst always overlaps the other half's MFMAs.
-template <class Cfg, int PP, bool KTAIL, bool CLK = false>
+// MATH = 0: the fp8 matrix instruction (one v_mfma_scale_f32_16x16x128_f8f6f4 per 128-wide scale block).
+// MATH = 1 (PP = 0, three LDS stages): the bf16-exact policy -- the e4m3 bytes are up-converted to bf16 in registers (exact)
+//         and a scale block is four chained v_mfma_f32_16x16x32_bf16, whose sums are fp32-class (see the loop below).
+template <class Cfg, int PP, bool KTAIL, bool CLK = false, int MATH = 0>
 __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const GemmParams p)
 {
     LoopClock<CLK> loop_clock;
@@ -744,6 +747,163 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         epilogue(acc);
         DGA_STAMP_ABS(3);        // stores issued (not yet complete)
         DGA_STAMP_FLUSH();
+    } else if constexpr (MATH == 1) {
+        // ---- bf16-exact main loop (dispatchPolicyTag 7) ---------------------------------------------------------------
+        // Numerics: every e4m3 value is a bf16 value, so v_cvt_scalef32_pk_bf16_fp8 (scale 1) converts exactly; the products
+        // are exact in fp32 and v_mfma_f32_16x16x32_bf16 sums them with fp32-class error (profiles/r02_mfma_forms.txt: 2^-25 S
+        // on amax-quantised data, 99.75 % of the 128-wide block sums bit-equal to the oracle's), against the 2^-16 S of the fp8
+        // forms.  One scale block = four chained MFMAs (C = 0, then C = the chain), then the same fp32 promotion as the fast
+        // path.  The LDS image, the DMA and the fragment reads are the fast path's: lane (li, kg) holds bytes [16 kg, +16) and
+        // [64 + 16 kg, +16) of its row; MFMA q of the chain takes dwords 2q, 2q + 1 of those 32 bytes from BOTH operands.
+        // Cost model (scripts/ubench/bf16x_ubench.hip): the loop is bound by vector issue, not by the matrix pipe -- per
+        // MFMA one promotion FMA plus the conversions (A fragments are re-converted by the WN waves that share them, B by
+        // the WM waves).  The accumulators, the bf16 A fragments (16 registers per m-tile) and a double-buffered bf16 B
+        // fragment have to fit 256 registers at two waves per SIMD: wave tiles of at most 64 x 64.
+        // Schedule: three LDS stages = {being consumed, landed and readable, being filled}.  ONE barrier per k block, at its
+        // top, behind vmcnt(0): block kb + 1 has landed everywhere, and the stage block kb + 2 goes to is free.  Inside a
+        // block the tiles run (n-tile outer, m-tile inner); a "gap" is the issue slot behind one MFMA:
+        //   * B(nt + 1) is converted during n-tile nt into the other bf16 set (the last n-tile converts the NEXT block's
+        //     B(0) from the readable stage); its raw bytes sit in one 8-register buffer whose halves are reloaded as the
+        //     conversions release them;
+        //   * A fragments are re-converted IN PLACE for the next block as they die: A[mt] sees its last MFMA in tile
+        //     (mt, TN - 1) and is converted during the following tile's four gaps (A[TM - 1] during the next block's first
+        //     tile), raw bytes read one tile ahead into two alternating buffers;
+        //   * the promotion of tile t rides on tile t + LAGT (the first tiles of a block promote the previous block's last
+        //     ones with that block's scales); the refill DMA rides on the second tile onward.
+        static_assert(PP == 0 && Cfg::STAGES == 3 && !LC, "bf16-exact: plain loop, three stages, no loader waves");
+        static_assert((TM == 2 || TM == 4) && (TN == 2 || TN == 4), "bf16-exact: wave tiles of 32..64 x 32..64");
+        constexpr int STG = 3, NL = Cfg::LOADS_PER_STAGE, TILES = TM * TN, G = 4 * TM, LAGT = 2, RING = 4;
+        static_assert(TILES % RING == 0 && TILES > LAGT && 4 * TILES >= 4 + NL && 16 % G == 0, "ring positions / DMA slots line up");
+        typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+        v4f acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+        v4f part[RING];
+#pragma unroll
+        for (int i = 0; i < RING; ++i) part[i] = v4f{0.f, 0.f, 0.f, 0.f};
+        v4i afx[TM][4], bfx[2][4];      // bf16 fragments: [q] = the 8 bf16 of MFMA q of the chain
+        v4i braw[2], araw[2][2];         // raw e4m3 bytes: [0] = bytes [16 kg, +16), [1] = bytes [64 + 16 kg, +16)
+        float s_cur[TM], s_old[TM], s_nxt[TM];
+        // conversion c (0..15) of a fragment: dword c >> 1 of the 32 raw bytes, half c & 1 -> dword c & 3 of MFMA (c >> 2).
+        // (c is a constant after unrolling; the builtin's half selector must be an immediate)
+        auto convert = [](const v4i (&raw)[2], v4i (&dst)[4], int c) {
+            const int w = raw[(c >> 1) >> 2][(c >> 1) & 3];
+            dst[c >> 2][c & 3] = (c & 1) ? __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true))
+                                         : __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false));
+        };
+        auto b_frag_off = [](int nt) { return (nt >> 1) * 4096 + (nt & 1) * 512; };
+        // prologue: blocks 0 and 1 on their way, block 0 landed; its fragments converted in one burst (once per tile)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int idx = 0; idx < NL; ++idx) issue_one(idx, d, kb_begin + d);
+        wait_vmcnt<NL>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        {
+            const float sfb0 = *(const float *)(smem + sb_off);
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                // (buffer mt & 1: block 0's first tile converts A[TM - 1] once more from the buffer it was read into)
+                araw[mt & 1][0] = *(const v4i *)(smem + a_off0 + mt * 2048);
+                araw[mt & 1][1] = *(const v4i *)(smem + a_off1 + mt * 2048);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) convert(araw[mt & 1], afx[mt], c);
+                s_cur[mt] = *(const float *)(smem + sa_off + mt * 64) * sfb0;
+                s_old[mt] = 0.f;    // the first LAGT tiles "promote the previous block": part (= 0) * 0
+                s_nxt[mt] = 0.f;
+            }
+            braw[0] = *(const v4i *)(smem + b_off0);
+            braw[1] = *(const v4i *)(smem + b_off1);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) convert(braw, bfx[0], c);
+            braw[0] = *(const v4i *)(smem + b_off0 + b_frag_off(1));   // B(1) of block 0, raw
+            braw[1] = *(const v4i *)(smem + b_off1 + b_frag_off(1));
+        }
+        DGA_STAMP_DECL
+        DGA_STAMP_START();
+        loop_clock.tick();
+        int cur = 0, nxt = 1, fill = 2;
+        for (int kb = kb_begin; kb < kb_end; ++kb) {
+            wait_vmcnt<0>();                         // this wave's pieces of block kb + 1 (issued a block ago) have landed
+            DGA_STAMP(1);
+            __builtin_amdgcn_s_barrier();            // ... everyone's have; and everyone has left block kb - 1, whose stage
+            asm volatile("" ::: "memory");           //     block kb + 2 is about to overwrite
+            DGA_STAMP(2);
+            const uint8_t *sc = smem + cur * Cfg::STAGE_BYTES;   // being consumed (B raw reloads of this block)
+            const uint8_t *sn = smem + nxt * Cfg::STAGE_BYTES;   // landed: the next block's fragments are read ahead from it
+#pragma unroll
+            for (int u = 0; u < 4 * TILES; ++u) {
+                const int t = u >> 2, q = u & 3, nt = t / TM, mt = t % TM, g = u % G;
+                part[t % RING] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(v8bf, bfx[nt & 1][q]), __builtin_bit_cast(v8bf, afx[mt][q]),
+                    q == 0 ? v4f{0.f, 0.f, 0.f, 0.f} : part[t % RING], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // refill DMA of block kb + 2: one piece per gap from the second tile on
+                if (u >= 4 && u < 4 + NL) issue_one(u - 4, fill, kb + 2);
+                // B(nt + 1) -> bfx[(nt + 1) & 1]: 16 conversions over the n-tile's G gaps; the raw halves are reloaded with
+                // B(nt + 2) as they are released (from the readable stage once nt + 2 runs past this block)
+#pragma unroll
+                for (int c = 0; c < 16 / G; ++c) convert(braw, bfx[(nt + 1) & 1], (16 / G) * g + c);
+                {
+                    const int nn = nt + 2;
+                    const uint8_t *src = nn < TN ? sc : sn;
+                    const int off = b_frag_off(nn < TN ? nn : nn - TN);
+                    if (g == G / 2 - 1) braw[0] = *(const v4i *)(src + b_off0 + off);
+                    if (g == G - 1) braw[1] = *(const v4i *)(src + b_off1 + off);
+                }
+                // A fragments of the NEXT block, in place: raw bytes of A[mt] one tile ahead (at the first gap of its last
+                // tile), conversion during the tile after its last one
+                if (nt == TN - 1 && q == 0) {
+                    araw[mt & 1][0] = *(const v4i *)(sn + a_off0 + mt * 2048);
+                    araw[mt & 1][1] = *(const v4i *)(sn + a_off1 + mt * 2048);
+                }
+                if (nt == TN - 1 && mt >= 1) {     // the tile behind (mt - 1, TN - 1): A[mt - 1] of the next block
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) convert(araw[(mt - 1) & 1], afx[mt - 1], 4 * q + c);
+                }
+                if (t == 0) {                      // the tile behind the previous block's (TM - 1, TN - 1): A[TM - 1] of THIS block
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) convert(araw[(TM - 1) & 1], afx[TM - 1], 4 * q + c);
+                }
+                // the next block's scales (needed from its first promotions, LAGT tiles into it)
+                if (u == 4 * TILES - 8) {
+                    const float sfbn = *(const float *)(sn + sb_off);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) s_nxt[i] = *(const float *)(sn + sa_off + i * 64) * sfbn;
+                }
+                // promotion of tile t - LAGT, one accumulator element per gap
+                {
+                    const int j = t >= LAGT ? t - LAGT : TILES + t - LAGT, jn = j / TM, jm = j % TM;
+                    const float sv = t >= LAGT ? s_cur[jm] : s_old[jm];
+                    acc[jm][jn][q] = __builtin_fmaf(part[j % RING][q], sv, acc[jm][jn][q]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            DGA_STAMP(4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                s_old[i] = s_cur[i];
+                s_cur[i] = s_nxt[i];
+            }
+            const int f = cur;
+            cur = nxt; nxt = fill; fill = f;
+        }
+        // drain: the last LAGT tiles of the last block
+#pragma unroll
+        for (int t = 0; t < LAGT; ++t) {
+            const int j = TILES + t - LAGT, jn = j / TM, jm = j % TM;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[jm][jn][q] = __builtin_fmaf(part[j % RING][q], s_old[jm], acc[jm][jn][q]);
+        }
+        wait_vmcnt<0>();   // the refills past the last k block land in LDS nobody reads: drain them before the stores / exit
+        DGA_STAMP_CLOCK(6, 7);
+        DGA_STAMP_FLUSH();
+        loop_clock.tick();
+        loop_clock.flush(p.stamps, blockIdx.x * (NT / 64) + wave, lane);
+        epilogue(acc);
     } else {
         v4f acc[TM][TN];
 #pragma unroll

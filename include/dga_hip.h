@@ -64,9 +64,18 @@ enum { DGA_KERNEL_COMMON = 0, DGA_KERNEL_SMALL = 1, DGA_KERNEL_PADDING_COMMON = 
  *     bits as policy 0; whole rasters only (split-K and the quarter-tile tail run policy 4).
  *   6 persistent continuous pipeline: policy 2 (256x256 tile) with one workgroup per CU walking its tiles, the refill slots
  *     of a tile's last two k blocks fetching the next tile's first two; dense rasters of full tiles (M, N multiples of 256,
- *     K of 128, at least two k blocks) -- anything else runs policy 2; same bits. */
+ *     K of 128, at least two k blocks) -- anything else runs policy 2; same bits.
+ *   7 bf16-exact: the e4m3 bytes are up-converted to bf16 in registers (exact) and every 128-wide scale block is summed by four
+ *     chained v_mfma_f32_16x16x32_bf16 -- exact products, fp32-class sums (2^-25 of the block's sum of magnitudes, against
+ *     2^-16 on the fp8 matrix instruction), the same fp32 promotion.  The policy between the fast path (policies 0-2, 4-6) and
+ *     the strict one: within 2 bf16 ULP of the reference CPU path (framework/tests/test.py:19-64) on all but ~1e-6 of the
+ *     outputs of BASELINE configs[1] (those are sums that cancel to < 2^-17 of their terms), at the bf16 matrix rate.  Takes
+ *     every layout the tile kernels take (dense, masked, contiguous, indexed, split-K); the tile comes from the tiling's
+ *     (m1, n1) mapped onto the policy's own menu (wave tiles of at most 64 x 64).  $DGA_BF16_EXACT=1 forces it for every fp8
+ *     call of the process. */
 enum { DGA_POLICY_PLAIN = 0, DGA_POLICY_PINGPONG = 1, DGA_POLICY_CONTINUOUS = 2, DGA_POLICY_STRICT = 3,
-       DGA_POLICY_LOADER_WAVES = 4, DGA_POLICY_PERSISTENT = 5, DGA_POLICY_CONTINUOUS_PERSISTENT = 6 };
+       DGA_POLICY_LOADER_WAVES = 4, DGA_POLICY_PERSISTENT = 5, DGA_POLICY_CONTINUOUS_PERSISTENT = 6,
+       DGA_POLICY_BF16_EXACT = 7 };
 
 /* Platform description: the CDNA4 retarget of PlatformInfo
  * (op_tiling/platform_info.h:16-41; Python mirror get_best_config/tiling_calculator.py:25-30).
