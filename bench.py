@@ -18,8 +18,10 @@ the grouped masked-M GEMM with experts partitioned over ranks and an RCCL all-to
 in the extra "grouped" object of the same JSON line (tok/s with and without the exchange).
 
 Extra objects: "roofline" (dominant kernel vs the dense fp8 MFMA peak, with the clock measured inside the kernel's
-main loop), "parity" (every output of the timed kernel against the strict kernel, which tests pin bit for bit to the
-CPU oracle), "dsv3_prefill" (BASELINE configs[2], own roofline), "cpu_baseline" (the CPU oracle and the reference's
+main loop, and vs `ceiling_tflops` = what this box's matrix pipe sustains on the kernel's inner step with the operands
+already in registers), "parity" (every output of the timed kernel against the strict kernel, which tests pin bit for bit
+to the CPU oracle), "policies" (the three arithmetic policies side by side -- fast / bf16_exact / strict: value, roofline
+and parity of each; the headline `value` is the "fast" column), "dsv3_prefill" (BASELINE configs[2], own roofline), "cpu_baseline" (the CPU oracle and the reference's
 numpy formula timed on this box's host cores on a bounded row sample; rank 0, N = 1 only).
 """
 from __future__ import annotations
@@ -37,6 +39,10 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 PEAK_FP8_TFLOPS = 5000.0   # MI355X dense fp8 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md, chip table)
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak: the instruction the bf16-exact policy computes on
+PEAK_FP32_MATRIX_TFLOPS = 157.3   # fp32-input MFMA peak: the instruction the strict policy computes on
+# the parity bar of each arithmetic policy: |d| <= 2 ulp_bf16 + eps * S on every element (README.md, Numerics)
+POLICY_EPS = {"fast": 2.0 ** -15, "bf16_exact": 2.0 ** -22, "strict": 0.0}
 PEAK_HBM_GBPS = 8000.0
 FP8_FLOP_PER_CLK_PER_CU = 8192.0   # peak_fp8 = CUs x clk x 8192
 
@@ -57,6 +63,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-grouped", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-prefill", action="store_true")
+    ap.add_argument("--no-policies", action="store_true",
+                    help="skip the side-by-side legs of the bf16-exact and strict arithmetic policies")
     ap.add_argument("--widen", action="store_true",
                     help="also time the rows either side of the hot path (contiguous-grouped layout, quantiser); off by "
                          "default so that the default command's kernel statistics hold the headline kernels only")
@@ -64,6 +72,9 @@ def parse_args(argv=None):
     ap.add_argument("--grouped-mask", default="full", choices=["full", "random"])
     ap.add_argument("--capacity-factor", type=float, default=1.25,
                     help="sharded grouped path: rows reserved per (chunk, peer) = this x the even share (parallel.py)")
+    ap.add_argument("--sharded-indexed", action="store_true",
+                    help="world > 1: let the grouped GEMM read the receive buffer in place (opt-in until it has run under "
+                         "RCCL; the packed path is the default, parallel.py)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed clock pre-warm in front of the W warmup steps: after idle the GPU needs a few hundred "
@@ -127,8 +138,8 @@ def pmc_traffic(workload: str):
 
 # --------------------------------------------------------------------------------------------------- legs
 
-def parity_vs_strict(dga, a, sfa, b, sfb, fast_out):
-    """Every output of the timed (fast, fp8-MFMA) kernel against the strict kernel on the same inputs.  The strict
+def parity_vs_strict(dga, a, sfa, b, sfb, fast_out, policy="fast"):
+    """Every output of a timed kernel (`policy` names which: its bar is reported beside the figures) against the strict kernel on the same inputs.  The strict
     kernel is the product's exact-arithmetic policy; tests/test_strict_gpu.py pins it bit for bit to the CPU oracle, so
     these figures are the fast path's distance from the oracle over ALL elements.  S = sum |scaled products| comes from
     the strict kernel run on |a|, |b|, |scales| (bf16-rounded, 2^-9 relative)."""
@@ -150,8 +161,10 @@ def parity_vs_strict(dga, a, sfa, b, sfb, fast_out):
     return {
         "against": "strict policy (fp32-MFMA chain in the oracle's order; bit-identical to the CPU oracle in tests/test_strict_gpu.py)",
         "elements": int(m * n), "max_ulp": int(ulps.max()), "frac_gt_2ulp": float((ulps > 2).double().mean()),
-        "worst_excess_over_S": float(excess.max()), "bar": "|d| <= 2 ulp_bf16 + 2^-15 * S (README.md, Numerics)",
-        "within_bar": bool(float(excess.max()) <= 2.0 ** -15 * 1.01),
+        "elements_gt_2ulp": int((ulps > 2).sum()),
+        "worst_excess_over_S": float(excess.max()),
+        "bar": f"|d| <= 2 ulp_bf16 + 2^{int(__import__('math').log2(POLICY_EPS[policy])) if POLICY_EPS[policy] else '-inf'} * S (README.md, Numerics)",
+        "within_bar": bool(float(excess.max()) <= POLICY_EPS[policy] * 1.01),
     }
 
 
@@ -160,7 +173,7 @@ def _median(xs):
     return xs[len(xs) // 2]
 
 
-def cpu_baseline(m, n, k, a, sfa, b, sfb, gpu_out=None, budget_s=15.0):
+def cpu_baseline(m, n, k, a, sfa, b, sfb, gpu_out=None, budget_s=15.0, strict_out=None):
     """The CPU oracle (oracle/dga_oracle.c, kind "port") on a bounded row sample of the same workload: one warm-up,
     median of >= 3 passes.  Beside it the reference's own CPU path restated -- np.matmul(f32, f32) on the dequantised
     operands (/root/reference/deep_gemm_ascend/framework/benchmark/benchmark.py:362) -- as the BLAS-quality bound:
@@ -213,6 +226,10 @@ def cpu_baseline(m, n, k, a, sfa, b, sfb, gpu_out=None, budget_s=15.0):
         rep = O.parity_report(got, want, an[:rows], san[:rows], bn, sbn)
         res["gpu_rows_vs_oracle"] = {"rows": rows, "max_ulp": rep["max_ulp"], "frac_gt_2ulp": rep["frac_gt_max_ulp"],
                                      "worst_excess_over_S": rep["worst_excess_over_S"]}
+    if strict_out is not None:   # policy_legs leaves the strict policy's output in this buffer (it runs last)
+        got = strict_out[:rows].view(__import__("torch").int16).cpu().numpy().view(np.uint16)
+        res["strict_rows_vs_oracle"] = {"rows": rows, "max_ulp": int(O.bf16_ulp_diff(got, want).max(initial=0)),
+                                        "bit_identical": bool(np.array_equal(got, want))}
     return res
 
 
@@ -221,7 +238,8 @@ def grouped_leg(args, rank, world, dist):
     from deepgemm_ascend_amd import parallel
     return parallel.bench_grouped(rank, world, dist, steps=max(3, min(args.steps, 20)), warmup=3,
                                   groups_total=args.groups, m_max=128, n=2048, k=7168,
-                                  mask=args.grouped_mask, capacity_factor=args.capacity_factor)
+                                  mask=args.grouped_mask, capacity_factor=args.capacity_factor,
+                                  indexed=True if args.sharded_indexed else None, parity=not args.no_parity)
 
 
 def _time_us(fn, iters, warm):
@@ -260,6 +278,61 @@ def roofline_mfma(dga, a, sfa, b, sfb, out, t, m, n, k, kernel_us, cus):
     except Exception as e:   # a tiling without a loop-clock build: the vendor-peak fraction stands alone
         r["clock_note"] = repr(e)
     return r
+
+
+def _prewarmed_us(fn, iters, prewarm_ms):
+    """Average launch interval of `iters` back-to-back calls behind an untimed clock pre-warm (HIP events on the current stream)."""
+    import torch
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < prewarm_ms:
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+    return _time_us(fn, iters, 0)
+
+
+def policy_legs(dga, a, sfa, b, sfb, m, n, k, args, fast, ceilings):
+    """The three arithmetic policies side by side on one workload: value, roofline and parity of each.
+      fast        the headline kernel (fp8 matrix instruction; `fast` = its already measured {"kernel_us", "roofline", "parity"})
+      bf16_exact  e4m3 -> bf16 in registers, bf16 matrix instruction (dispatchPolicyTag 7), priced against the bf16 peak
+      strict      fp32-input matrix instruction in the oracle's order (dispatchPolicyTag 3), priced against the fp32 matrix peak
+    Each roofline also carries `ceiling_tflops`: what this box's matrix pipe sustains on the policy's inner step with the
+    operands already in registers (dga_mfma_ceiling), and the kernel's fraction of it."""
+    import torch
+    flops = 2.0 * m * n * k
+    out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    legs = {}
+    spec = {"bf16_exact": (PEAK_BF16_TFLOPS, "v_mfma_f32_16x16x32_bf16 x4 per scale block on e4m3 bytes up-converted in registers",
+                           max(20, min(args.steps, 200)), args.prewarm_ms),
+            "strict": (PEAK_FP32_MATRIX_TFLOPS, "v_mfma_f32_16x16x4_f32 x32 per scale block, the oracle's own order",
+                       max(5, min(args.steps, 20)), min(args.prewarm_ms, 50.0))}
+    fr = dict(fast["roofline"])
+    if ceilings.get("fast"):
+        fr["ceiling_tflops"] = round(ceilings["fast"], 1)
+        fr["frac_of_ceiling"] = round(fr["achieved"] / ceilings["fast"], 4)
+    legs["fast"] = {"dispatchPolicyTag": "0-2, 4-6 (the tiling's schedule)", "value": fr["achieved"], "unit": "TFLOP/s",
+                    "kernel_us": fast["kernel_us"], "roofline": fr, "parity": fast.get("parity")}
+    for pol, (peak, instr, iters, prewarm) in spec.items():
+        try:
+            fn = lambda: dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, policy=pol)
+            us = _prewarmed_us(fn, iters, prewarm)
+            tf = flops / us / 1e6
+            roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                    "kernel_us": round(us, 3), "instruction": instr}
+            if ceilings.get(pol):
+                roof["ceiling_tflops"] = round(ceilings[pol], 1)
+                roof["frac_of_ceiling"] = round(tf / ceilings[pol], 4)
+            leg = {"dispatchPolicyTag": 7 if pol == "bf16_exact" else 3, "value": round(tf, 2), "unit": "TFLOP/s",
+                   "kernel_us": round(us, 3), "roofline": roof}
+            if not args.no_parity:
+                fn(); torch.cuda.synchronize()
+                leg["parity"] = parity_vs_strict(dga, a, sfa, b, sfb, out, policy=pol)
+                if pol == "strict":
+                    leg["parity"]["against"] = "itself (a second run: determinism); the CPU oracle rows are in cpu_baseline.gpu_rows_vs_oracle"
+            legs[pol] = leg
+        except Exception as e:
+            legs[pol] = {"error": repr(e)}
+    return legs, out
 
 
 def widen_leg():
@@ -387,6 +460,13 @@ def main():
         per_rank_us = [round(float(x), 3) for x in gathered]
         kernel_us = float(tt[1])
 
+    # what the ranks saw: so that the first real multi-GPU run of this line can be read without the logs
+    ranks_seen = None
+    if dist and not args.stub:
+        mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(local_rank),
+                "cus": torch.cuda.get_device_properties(local_rank).multi_processor_count, "host": socket.gethostname()}
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, mine)
     flops = 2.0 * m * n * k
     value = world * flops * args.steps / elapsed / 1e12
     res = {
@@ -400,6 +480,12 @@ def main():
                    "backend": backend, "stub": bool(args.stub)},
         "per_rank_kernel_us": per_rank_us,
     }
+    if ranks_seen is not None:
+        try:
+            ver = torch.cuda.nccl.version()
+        except Exception as e:
+            ver = repr(e)
+        res["distributed"] = {"backend": backend, "rccl_version": ver, "world_size": world, "ranks": ranks_seen}
     if args.stub:
         if rank == 0:
             print(json.dumps(res), flush=True)
@@ -420,8 +506,27 @@ def main():
         except Exception as e:
             res["parity"] = {"error": repr(e)}
 
+    # the three arithmetic policies side by side (rank 0; the headline above is the "fast" column)
+    ceilings = {}
+    strict_out = None
+    if rank == 0 and not args.no_policies:
+        for pol in ("fast", "bf16_exact"):
+            try:
+                ceilings[pol] = dga.mfma_ceiling(pol, launches=300)
+            except Exception as e:
+                ceilings[pol] = None
+                res.setdefault("ceiling_errors", {})[pol] = repr(e)
+        if ceilings.get("fast"):
+            res["roofline"]["ceiling_tflops"] = round(ceilings["fast"], 1)
+            res["roofline"]["frac_of_ceiling"] = round(res["roofline"]["achieved"] / ceilings["fast"], 4)
+        res["policies"], strict_out = policy_legs(dga, a, sfa, b, sfb, m, n, k, args,
+                                                  {"kernel_us": round(kernel_us, 3), "roofline": res["roofline"],
+                                                   "parity": res.get("parity")}, ceilings)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(m, n, k, a, sfa, b, sfb, gpu_out=out, budget_s=args.cpu_budget)
+        res["cpu_baseline"] = cpu_baseline(m, n, k, a, sfa, b, sfb, gpu_out=out, budget_s=args.cpu_budget,
+                                           strict_out=strict_out)
+    del strict_out
 
     # BASELINE configs[2] beside the headline (every rank runs it: replicas, like the headline)
     if not args.no_prefill and args.workload == "dense_4096":
@@ -447,6 +552,15 @@ def main():
             if rank == 0 and not args.no_parity:
                 dga.gemm_fp8_fp8_bf16_nt((pa, psfa), (pb, psfb), pout, sync=True)
                 res["dsv3_prefill"]["parity"] = parity_vs_strict(dga, pa, psfa, pb, psfb, pout)
+            if rank == 0 and not args.no_policies:
+                if ceilings.get("fast"):
+                    pr = res["dsv3_prefill"]["roofline"]
+                    pr["ceiling_tflops"] = round(ceilings["fast"], 1)
+                    pr["frac_of_ceiling"] = round(pr["achieved"] / ceilings["fast"], 4)
+                res["dsv3_prefill"]["policies"], _ = policy_legs(
+                    dga, pa, psfa, pb, psfb, pm, pn, pk, args,
+                    {"kernel_us": round(us, 3), "roofline": res["dsv3_prefill"]["roofline"],
+                     "parity": res["dsv3_prefill"].get("parity")}, ceilings)
             del pa, pb, pout
         except Exception as e:
             res["dsv3_prefill"] = {"error": repr(e)}

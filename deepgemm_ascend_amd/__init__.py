@@ -23,6 +23,7 @@ from .api import (  # noqa: F401
     m_grouped_gemm_fp8_fp8_bf16_nt_contiguous,
     m_grouped_gemm_fp8_fp8_bf16_nt_masked,
     m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed,
+    mfma_ceiling,
     per_block_cast_to_fp8,
     per_token_cast_to_fp8,
     platform_ascend910b,

@@ -118,6 +118,7 @@ SIGNATURES = {
     "dga_copy_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p]),
     "dga_gemm_fp8_loop_clock": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(Tiling),
                                         c_void_p, c_size_t, c_int, c_void_p, POINTER(c_float), POINTER(c_float)]),
+    "dga_mfma_ceiling": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, POINTER(c_float)]),
     "dga_status_string": (c_char_p, [c_int]),
     "dga_last_hip_error": (c_int, []),
     "dga_abi_version": (c_int, []),
@@ -154,7 +155,7 @@ def lib() -> ctypes.CDLL:
                 raise DGALibraryError(f"{LIB_PATH} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
-        if L.dga_abi_version() != 2:
+        if L.dga_abi_version() != 3:
             raise DGALibraryError("ABI version mismatch")
         _lib = L
     return _lib

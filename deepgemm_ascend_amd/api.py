@@ -310,6 +310,22 @@ def gemm_fp8_loop_clock(lhs, rhs, out: torch.Tensor, tiling_: Optional[Tiling] =
     return mhz.value, us.value
 
 
+def mfma_ceiling(policy: str = "fast", launches: int = 300, device=None) -> float:
+    """TFLOP/s the matrix pipe of this device sustains on the policy's inner step with the operands already in registers
+    (dga_mfma_ceiling: matrix instruction + fp32 promotion [+ in-register conversions], two waves per SIMD on every CU,
+    random e4m3 bytes, the last of `launches` back-to-back launches).  A diagnostic: it synchronises."""
+    _require(policy in ("fast", "bf16_exact"), "mfma_ceiling: policy must be 'fast' or 'bf16_exact'")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        ws_ptr, ws_bytes = _scratch("ceiling", dev, 16384 + 2048 * cus)
+        tf = ctypes.c_float(0)
+        rc = _lib.lib().dga_mfma_ceiling(0 if policy == "fast" else 1, int(launches), ws_ptr, ws_bytes,
+                                         torch.cuda.current_stream(dev).cuda_stream, ctypes.byref(tf))
+        _lib.check(rc, "mfma_ceiling")
+    return tf.value
+
+
 def m_grouped_gemm_fp8_fp8_bf16_nt_masked(lhs, rhs, out: torch.Tensor, masked_m: torch.Tensor, expected_m: int,
                                           tiling_: Optional[Tiling] = None, sync: bool = False,
                                           strict: bool = False, policy: Optional[str] = None) -> None:
@@ -364,6 +380,13 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(a_rows: torch.Tensor, sfa_src:
     _require(row_index.dtype == torch.int64 and row_index.numel() >= g * m_max and row_index.is_contiguous(), "row_index int64[G*m_max]")
     _require(masked_m.dtype == torch.int32 and tuple(masked_m.shape) == (g,), "masked_m must be int32 [G]")
     _require(sfa_byte_offset % 4 == 0 and sfa_ld >= kb, "scale rows must be float-aligned")
+    # the kernel reads row r's scales at sfa_src + offset + r * sfa_ld floats: the tensor has to be what that arithmetic assumes
+    _require(sfa_src.dim() == 2 and sfa_src.stride(1) == 1 and sfa_src.dtype in (torch.float32, torch.uint8),
+             "sfa_src must be a 2-D float32 (or uint8 payload) row tensor with unit inner stride")
+    _require(sfa_src.stride(0) * sfa_src.element_size() == 4 * sfa_ld, "sfa_ld must be sfa_src's row stride in floats")
+    _require(sfa_src.data_ptr() % 4 == 0 and sfa_src.shape[0] >= rows and
+             sfa_byte_offset + 4 * kb <= sfa_src.shape[1] * sfa_src.element_size(),
+             "sfa_src must hold ceil(K/128) floats at sfa_byte_offset of each of the source's rows")
     with _device_guard(a_rows, b, sfb, out_rows, row_index, masked_m, sfa_src):
         if tiling_ is None:
             tiling_ = tiling(m_max, n, k, groups=g, expected_m=int(expected_m))

@@ -28,7 +28,7 @@ void variant_info(int i, int *bm, int *bn, int *wm, int *wn, int *lds);
 int variant_stages(int i);
 bool variant_has_loader_waves(int i);   // a dispatchPolicyTag-4 build of that menu entry exists
 // a 3-stage tiling on the plain loop whose tile has a loader-wave build takes it (same bits, 9-17 % less time)
-void prefer_loader_waves(dga_tiling_t &t);
+void prefer_loader_waves(dga_tiling_t &t, bool upgrade_plain = true);
 // dense 256x256 tilings: turn a small last partial wave into a K-split tail (dga_tiling.cpp)
 void apply_tail_split(dga_tiling_t &t, uint32_t cus);
 }  // namespace dga

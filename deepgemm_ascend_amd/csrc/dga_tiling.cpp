@@ -314,9 +314,12 @@ static uint32_t menu_lds_bytes(const dga_tiling_t &t)
 // has CUs, one workgroup per CU walks its share and the ring runs across tile boundaries.  Same bits again.  Measured
 // (scripts/ps_check.py): 256 x (128, 7168, 2048) full mask 770 -> 746 us, random mask 672 -> 657, decode masks 592 -> 577;
 // dense 128x256 rasters of 2-4 tiles per CU -3..-10 %.  Split-K and the quarter-tile tail keep the one-tile builds.
-void prefer_loader_waves(dga_tiling_t &t)
+// upgrade_plain = false: a swept row whose file carries the dispatchPolicyTag column names the build the sweep TIMED (the plain
+// loop and the loader-wave build are separate candidates there), so policy 0 stays policy 0; only the persistent forms --
+// folded into their one-tile siblings' records by the sweep -- are still chosen by rule.
+void prefer_loader_waves(dga_tiling_t &t, bool upgrade_plain)
 {
-    if (t.dispatchPolicyTag == DGA_POLICY_PLAIN && t.stages == 3) {
+    if (upgrade_plain && t.dispatchPolicyTag == DGA_POLICY_PLAIN && t.stages == 3) {
         for (int i = 0; i < variant_count(); ++i) {
             int bm, bn, wm, wn, lds;
             variant_info(i, &bm, &bn, &wm, &wn, &lds);
@@ -535,8 +538,9 @@ public:
                 auto opt = [&](const char *name) -> uint32_t { return col.count(name) ? get(name) : 0; };
                 e.splitk = opt("splitkFactor"); e.stages = opt("stages"); e.raster = opt("swizzleOffset");
                 e.waves_m = opt("wavesM"); e.waves_n = opt("wavesN"); e.policy = opt("dispatchPolicyTag");
+                e.has_policy = col.count("dispatchPolicyTag") != 0;
                 const uint32_t groups = std::max(1u, opt("groups")), contiguous = opt("contiguous") ? 1u : 0u;
-                data_[std::make_tuple(get("m"), get("n"), get("k"), groups, contiguous)] = e;
+                data_[key_of(get("m"), get("n"), get("k"), groups, contiguous)] = e;
             }
         }
         in.close();
@@ -561,11 +565,12 @@ public:
         std::lock_guard<std::mutex> lk(mu_);
         return static_cast<int>(data_.size());
     }
-    // *swept = the entry carries the CDNA4 columns of a sweep (complete as it stands)
-    bool get(dga_tiling_t &t, bool *swept)
+    // *swept = the entry carries the CDNA4 columns of a sweep (complete as it stands); *timed_policy = its file also named the
+    // dispatchPolicyTag, i.e. the schedule is the one the sweep timed
+    bool get(dga_tiling_t &t, bool *swept, bool *timed_policy)
     {
         std::lock_guard<std::mutex> lk(mu_);
-        auto it = data_.find(std::make_tuple(t.m, t.n, t.k, t.groups, t.contiguous ? 1u : 0u));
+        auto it = data_.find(key_of(t.m, t.n, t.k, t.groups, t.contiguous ? 1u : 0u));
         if (it == data_.end()) return false;
         const Entry &e = it->second;
         t.m1 = e.m1; t.n1 = e.n1; t.k1 = e.k1; t.kernelSerial = e.serial;
@@ -575,13 +580,18 @@ public:
         t.wavesN = static_cast<uint8_t>(e.waves_n); t.dispatchPolicyTag = static_cast<uint8_t>(e.policy);
         if (e.raster) t.swizzleOffset = static_cast<uint8_t>(e.raster);
         *swept = e.stages != 0;
+        *timed_policy = e.has_policy;
         return true;
     }
     void put(const dga_tiling_t &t)
     {
         std::lock_guard<std::mutex> lk(mu_);
-        const auto key = std::make_tuple(t.m, t.n, t.k, t.groups, t.contiguous ? 1u : 0u);
+        const auto key = key_of(t.m, t.n, t.k, t.groups, t.contiguous ? 1u : 0u);
         if (data_.count(key)) return;
+        // the contiguous layout's row count changes from call to call in prefill serving: its tilings are keyed -- in memory
+        // and in the file -- by the BUCKETED row count (key_of: a handful of rows per (n, k, groups)), and the map stops
+        // growing at a bound
+        if (t.contiguous && data_.size() >= kMaxEntries) return;
         Entry e{t.m1, t.n1, t.k1, t.kernelSerial, t.paddingTagA, t.paddingTagB, t.paddingTagC, t.blockDim};
         e.splitk = t.splitkFactor; e.stages = t.stages; e.raster = t.swizzleOffset; e.waves_m = t.wavesM;
         e.waves_n = t.wavesN; e.policy = t.dispatchPolicyTag;
@@ -589,7 +599,7 @@ public:
         if (!path_.empty() && (grp_ || (t.groups <= 1 && !t.contiguous))) {  // a file without the group columns: dense rows only
             std::ofstream out(path_, std::ios::app);
             if (out.is_open()) {
-                out << t.m << ',' << t.n << ',' << t.k << ',' << t.m1 << ',' << t.n1 << ',' << t.k1 << ','
+                out << std::get<0>(key) << ',' << t.n << ',' << t.k << ',' << t.m1 << ',' << t.n1 << ',' << t.k1 << ','
                     << unsigned(t.kernelSerial) << ',' << unsigned(t.paddingTagA) << ',' << unsigned(t.paddingTagB)
                     << ',' << unsigned(t.paddingTagC) << ',' << t.blockDim;
                 if (ext_)
@@ -603,7 +613,20 @@ public:
     }
 
 private:
-    struct Entry { uint32_t m1, n1, k1, serial, pa, pb, pc, block_dim, splitk = 0, stages = 0, raster = 0, waves_m = 0, waves_n = 0, policy = 0; };
+    struct Entry { uint32_t m1, n1, k1, serial, pa, pb, pc, block_dim, splitk = 0, stages = 0, raster = 0, waves_m = 0, waves_n = 0, policy = 0; bool has_policy = false; };
+    static constexpr size_t kMaxEntries = 16384;
+    // (m, n, k, groups, contiguous); the contiguous layout's m (total rows) is bucketed to 128 x a power of two: what the
+    // tiling depends on is the rows per group against the tile heights, not the exact count
+    static std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t> key_of(uint32_t m, uint32_t n, uint32_t k, uint32_t groups,
+                                                                               uint32_t contiguous)
+    {
+        if (contiguous) {
+            uint32_t blocks = (m + DGA_CONTIGUOUS_M_ALIGNMENT - 1) / DGA_CONTIGUOUS_M_ALIGNMENT, b = 1;
+            while (b < blocks && b < (1u << 24)) b <<= 1;
+            m = b * DGA_CONTIGUOUS_M_ALIGNMENT;
+        }
+        return std::make_tuple(m, n, k, std::max(1u, groups), contiguous);
+    }
     Cache()
     {
         const char *p = std::getenv("DGA_CACHE_FILE_PATH");
@@ -777,11 +800,16 @@ int dga_tiling(const dga_problem_t *problem, dga_tiling_t *out)
 {
     if (!problem || !out) return DGA_E_NULL;
     init_params(*problem, *out);
-    bool swept = false;
-    if (Cache::instance().get(*out, &swept)) {
-        if (swept) {  // a swept entry is complete: use it as it stands (plus the loader waves where a build exists)
+    bool swept = false, timed_policy = false;
+    if (Cache::instance().get(*out, &swept, &timed_policy)) {
+        if (out->contiguous)   // a bucketed key: the workgroup count follows this call's row count
+            out->blockDim = static_cast<uint32_t>(static_cast<uint64_t>((out->m + out->m1 - 1) / std::max<uint32_t>(1, out->m1)) *
+                                                  ((out->n + out->n1 - 1) / std::max<uint32_t>(1, out->n1)) *
+                                                  (out->m1 > DGA_CONTIGUOUS_M_ALIGNMENT ? 2 : 1));
+        if (swept) {  // a swept entry is complete: the build the sweep timed (a file from before the policy column existed, or a
+                      // reference-format one, is upgraded to the loader waves where the tile has such a build)
             complete_from_menu(*out);
-            dga::prefer_loader_waves(*out);
+            dga::prefer_loader_waves(*out, !timed_policy);
             return DGA_OK;
         }
         // A reference-format CSV stores the reference's columns only; the CDNA4-only fields (waves, stages, LDS bytes,

@@ -8,6 +8,10 @@
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
 
+#include <c10/core/DeviceGuard.h>
+
+#include <initializer_list>
+#include <string>
 #include <tuple>
 
 #include "dga_hip.h"
@@ -35,7 +39,18 @@ at::Tensor scratch(const at::Tensor &like, size_t bytes)   // caller-owned works
 {
     return at::empty({static_cast<int64_t>(bytes ? bytes : 1)}, like.options().dtype(at::kByte));
 }
-dga_tiling_t tiling_for(int m, int n, int k, int groups, int expected_m, unsigned flags, bool strict)
+// the arithmetic policy of an fp8 call: strict = true or policy = "strict" -> dispatchPolicyTag 3; "bf16_exact" -> 7;
+// "" / "fast" -> whatever schedule the tiling names (api.py ARITHMETIC_POLICIES)
+int policy_tag(bool strict, const std::string &policy)
+{
+    TORCH_CHECK(policy.empty() || policy == "fast" || policy == "bf16_exact" || policy == "strict",
+                "policy must be one of 'fast', 'bf16_exact', 'strict'");
+    TORCH_CHECK(!(strict && !policy.empty() && policy != "strict"), "strict=True contradicts policy='", policy, "'");
+    if (strict || policy == "strict") return DGA_POLICY_STRICT;
+    if (policy == "bf16_exact") return DGA_POLICY_BF16_EXACT;
+    return -1;
+}
+dga_tiling_t tiling_for(int m, int n, int k, int groups, int expected_m, unsigned flags, int tag)
 {
     dga_problem_t p{};
     p.m = m; p.n = n; p.k = k; p.groups = groups; p.expected_m = expected_m;
@@ -43,8 +58,37 @@ dga_tiling_t tiling_for(int m, int n, int k, int groups, int expected_m, unsigne
     p.dtype = DGA_DT_FP8_E4M3FN; p.flags = flags;
     dga_tiling_t t{};
     check(dga_tiling(&p, &t), "tiling");
-    if (strict) t.dispatchPolicyTag = DGA_POLICY_STRICT;
+    if (tag >= 0) t.dispatchPolicyTag = static_cast<uint8_t>(tag);
     return t;
+}
+// Operand checks of the fp8 operators -- the same the ctypes mirror makes (api.py _require): full shapes, dtypes, contiguity,
+// one device.  Shapes and dtypes are checked BEFORE the device (so that a host-side test can see them), nothing is launched
+// unless every check passed: an undersized out or scale tensor would otherwise be an out-of-bounds device access.
+void want_shape(const at::Tensor &t, std::initializer_list<int64_t> shape, const char *name)
+{
+    TORCH_CHECK(t.dim() == static_cast<int64_t>(shape.size()), name, " must have rank ", shape.size(), ", got ", t.dim());
+    int64_t i = 0;
+    for (int64_t d : shape) {
+        TORCH_CHECK(t.size(i) == d, name, " must be ", at::IntArrayRef(shape), ", got ", t.sizes());
+        ++i;
+    }
+}
+void want_fp8(const at::Tensor &t, const char *name)
+{
+    TORCH_CHECK(t.scalar_type() == at::kFloat8_e4m3fn || t.scalar_type() == at::kByte, name,
+                " must be float8_e4m3fn or uint8 bytes, got ", t.scalar_type());
+}
+void want_dtype(const at::Tensor &t, at::ScalarType st, const char *name)
+{
+    TORCH_CHECK(t.scalar_type() == st, name, " must be ", st, ", got ", t.scalar_type());
+}
+void same_device(std::initializer_list<const at::Tensor *> ts)
+{
+    const at::Tensor *first = *ts.begin();
+    for (const at::Tensor *t : ts) {
+        on_device(*t, "operand");
+        TORCH_CHECK(t->device() == first->device(), "all operands must live on one device");
+    }
 }
 
 // ---- the reference's three entry points -------------------------------------------------------------------------
@@ -54,6 +98,8 @@ void run_mmad_rtc(const at::Tensor &x, const at::Tensor &y, at::Tensor &z)   // 
     TORCH_CHECK(x.dim() == 3 && y.dim() == 3 && z.dim() == 3 && z.scalar_type() == at::kFloat, "x [B,M,K], y [B,K,N], z [B,M,N] f32");
     const int batch = x.size(0), m = x.size(1), k = y.size(1), n = y.size(2);
     TORCH_CHECK(x.size(2) == k && y.size(0) == batch && z.size(0) == batch && z.size(1) == m && z.size(2) == n, "shape mismatch");
+    TORCH_CHECK(x.device() == y.device() && x.device() == z.device(), "all operands must live on one device");
+    const c10::OptionalDeviceGuard guard(at::device_of(z));
     const size_t wsb = dga_mmad_workspace_bytes(batch, m, n, k, x.data_ptr());
     at::Tensor ws = scratch(x, wsb);
     check(dga_run_mmad_rtc_ws(x.data_ptr(), y.data_ptr(), z.data_ptr<float>(), batch, m, n, k, dt16(x),
@@ -68,6 +114,8 @@ void run_mmad_bench(const at::Tensor &x, const at::Tensor &y, at::Tensor &z, at:
     TORCH_CHECK(params.scalar_type() == at::kInt && params.numel() == 28, "params must be int32[28]");
     const int m = x.size(0), k = y.size(0), n = y.size(1);
     TORCH_CHECK(x.size(1) == k && z.size(0) == m && z.size(1) == n, "shape mismatch");
+    TORCH_CHECK(x.device() == y.device() && x.device() == z.device(), "all operands must live on one device");
+    const c10::OptionalDeviceGuard guard(at::device_of(z));
     at::Tensor host = params.to(at::kCPU).contiguous();                        // the reference does 6 .item() syncs (:52-57)
     check(dga_bench_params_fill(m, n, k, host.data_ptr<int32_t>()), "bench_params_fill");
     params.copy_(host);                                                        // write-back of slots 6..27 (:68-81)
@@ -80,15 +128,19 @@ void run_mmad_bench(const at::Tensor &x, const at::Tensor &y, at::Tensor &z, at:
 
 // ---- the fp8 block-scaled operators (names from upstream DeepGEMM) -----------------------------
 void gemm_fp8_fp8_bf16_nt(const at::Tensor &a, const at::Tensor &sfa, const at::Tensor &b, const at::Tensor &sfb,
-                          at::Tensor &out, bool strict)
+                          at::Tensor &out, bool strict, const std::string &policy)
 {
-    for (const at::Tensor *t : {&a, &sfa, &b, &sfb, (const at::Tensor *)&out}) on_device(*t, "operand");
-    TORCH_CHECK(a.dim() == 2 && b.dim() == 2 && a.size(1) == b.size(1), "a [M,K], b [N,K]");
-    TORCH_CHECK(out.scalar_type() == at::kBFloat16 && out.size(0) == a.size(0) && out.size(1) == b.size(0), "out [M,N] bf16");
-    TORCH_CHECK(sfa.scalar_type() == at::kFloat && sfb.scalar_type() == at::kFloat, "scales must be float32");
-    const int m = a.size(0), n = b.size(0), k = a.size(1), kb = (k + 127) / 128, nb = (n + 127) / 128;
-    TORCH_CHECK(sfa.size(0) == m && sfa.size(1) == kb && sfb.size(0) == nb && sfb.size(1) == kb, "sfa [M,ceil(K/128)], sfb [ceil(N/128),ceil(K/128)]");
-    const dga_tiling_t t = tiling_for(m, n, k, 1, 0, 0, strict);
+    const int tag = policy_tag(strict, policy);
+    TORCH_CHECK(a.dim() == 2 && b.dim() == 2, "a [M,K], b [N,K]");
+    const int64_t m = a.size(0), n = b.size(0), k = a.size(1), kb = (k + 127) / 128, nb = (n + 127) / 128;
+    want_fp8(a, "a"); want_fp8(b, "b");
+    want_shape(b, {n, k}, "b");
+    want_shape(out, {m, n}, "out"); want_dtype(out, at::kBFloat16, "out");
+    want_shape(sfa, {m, kb}, "sfa"); want_dtype(sfa, at::kFloat, "sfa");
+    want_shape(sfb, {nb, kb}, "sfb"); want_dtype(sfb, at::kFloat, "sfb");
+    same_device({&a, &sfa, &b, &sfb, &out});
+    const c10::OptionalDeviceGuard guard(at::device_of(out));   // stream, tiling (CU count) and scratch on the tensors' device
+    const dga_tiling_t t = tiling_for(m, n, k, 1, 0, 0, tag);
     const size_t wsb = dga_workspace_bytes(&t);
     at::Tensor ws = scratch(out, wsb);
     check(dga_gemm_fp8_fp8_bf16_nt(a.data_ptr(), sfa.data_ptr<float>(), b.data_ptr(), sfb.data_ptr<float>(), out.data_ptr(),
@@ -97,14 +149,20 @@ void gemm_fp8_fp8_bf16_nt(const at::Tensor &a, const at::Tensor &sfa, const at::
 
 void m_grouped_gemm_fp8_fp8_bf16_nt_masked(const at::Tensor &a, const at::Tensor &sfa, const at::Tensor &b,
                                            const at::Tensor &sfb, at::Tensor &out, const at::Tensor &masked_m,
-                                           int64_t expected_m, bool strict)
+                                           int64_t expected_m, bool strict, const std::string &policy)
 {
-    for (const at::Tensor *t : {&a, &sfa, &b, &sfb, (const at::Tensor *)&out, &masked_m}) on_device(*t, "operand");
-    TORCH_CHECK(a.dim() == 3 && b.dim() == 3 && out.dim() == 3 && a.size(0) == b.size(0) && a.size(2) == b.size(2), "a [G,Mmax,K], b [G,N,K]");
-    TORCH_CHECK(masked_m.scalar_type() == at::kInt && masked_m.numel() == a.size(0), "masked_m int32 [G]");
-    TORCH_CHECK(out.scalar_type() == at::kBFloat16, "out must be bfloat16");
-    const int g = a.size(0), mmax = a.size(1), n = b.size(1), k = a.size(2);
-    const dga_tiling_t t = tiling_for(mmax, n, k, g, static_cast<int>(expected_m), 0, strict);
+    const int tag = policy_tag(strict, policy);
+    TORCH_CHECK(a.dim() == 3 && b.dim() == 3, "a [G,Mmax,K], b [G,N,K]");
+    const int64_t g = a.size(0), mmax = a.size(1), n = b.size(1), k = a.size(2), kb = (k + 127) / 128, nb = (n + 127) / 128;
+    want_fp8(a, "a"); want_fp8(b, "b");
+    want_shape(b, {g, n, k}, "b");
+    want_shape(out, {g, mmax, n}, "out"); want_dtype(out, at::kBFloat16, "out");
+    want_shape(sfa, {g, mmax, kb}, "sfa"); want_dtype(sfa, at::kFloat, "sfa");
+    want_shape(sfb, {g, nb, kb}, "sfb"); want_dtype(sfb, at::kFloat, "sfb");
+    want_shape(masked_m, {g}, "masked_m"); want_dtype(masked_m, at::kInt, "masked_m");
+    same_device({&a, &sfa, &b, &sfb, &out, &masked_m});
+    const c10::OptionalDeviceGuard guard(at::device_of(out));
+    const dga_tiling_t t = tiling_for(mmax, n, k, g, static_cast<int>(expected_m), 0, tag);
     check(dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked(a.data_ptr(), sfa.data_ptr<float>(), b.data_ptr(), sfb.data_ptr<float>(),
                                                     out.data_ptr(), masked_m.data_ptr<int32_t>(), g, mmax, n, k,
                                                     static_cast<int>(expected_m), &t, nullptr, 0, cur_stream()),
@@ -112,16 +170,26 @@ void m_grouped_gemm_fp8_fp8_bf16_nt_masked(const at::Tensor &a, const at::Tensor
 }
 
 void m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(const at::Tensor &a, const at::Tensor &sfa, const at::Tensor &b,
-                                               const at::Tensor &sfb, at::Tensor &out, const at::Tensor &m_indices, bool strict)
+                                               const at::Tensor &sfb, at::Tensor &out, const at::Tensor &m_indices, bool strict,
+                                               const std::string &policy)
 {
-    for (const at::Tensor *t : {&a, &sfa, &b, &sfb, (const at::Tensor *)&out, &m_indices}) on_device(*t, "operand");
-    TORCH_CHECK(a.dim() == 2 && b.dim() == 3 && a.size(1) == b.size(2), "a [Msum,K], b [G,N,K]");
-    TORCH_CHECK(m_indices.scalar_type() == at::kInt && m_indices.numel() == a.size(0), "m_indices int32 [Msum]");
-    const int msum = a.size(0), g = b.size(0), n = b.size(1), k = a.size(1);
-    const dga_tiling_t t = tiling_for(msum, n, k, g, 0, DGA_PROBLEM_CONTIGUOUS_M, strict);
+    const int tag = policy_tag(strict, policy);
+    TORCH_CHECK(a.dim() == 2 && b.dim() == 3, "a [Msum,K], b [G,N,K]");
+    const int64_t msum = a.size(0), g = b.size(0), n = b.size(1), k = a.size(1), kb = (k + 127) / 128, nb = (n + 127) / 128;
+    want_fp8(a, "a"); want_fp8(b, "b");
+    want_shape(b, {g, n, k}, "b");
+    want_shape(out, {msum, n}, "out"); want_dtype(out, at::kBFloat16, "out");
+    want_shape(sfa, {msum, kb}, "sfa"); want_dtype(sfa, at::kFloat, "sfa");
+    want_shape(sfb, {g, nb, kb}, "sfb"); want_dtype(sfb, at::kFloat, "sfb");
+    want_shape(m_indices, {msum}, "m_indices"); want_dtype(m_indices, at::kInt, "m_indices");
+    same_device({&a, &sfa, &b, &sfb, &out, &m_indices});
+    const c10::OptionalDeviceGuard guard(at::device_of(out));
+    const dga_tiling_t t = tiling_for(msum, n, k, g, 0, DGA_PROBLEM_CONTIGUOUS_M, tag);
+    const size_t wsb = dga_workspace_bytes(&t);
+    at::Tensor ws = scratch(out, wsb);
     check(dga_m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(a.data_ptr(), sfa.data_ptr<float>(), b.data_ptr(),
                                                         sfb.data_ptr<float>(), out.data_ptr(), m_indices.data_ptr<int32_t>(),
-                                                        msum, g, n, k, &t, nullptr, 0, cur_stream()),
+                                                        msum, g, n, k, &t, wsb ? ws.data_ptr() : nullptr, wsb, cur_stream()),
           "m_grouped_gemm_fp8_fp8_bf16_nt_contiguous");
 }
 
@@ -131,6 +199,7 @@ std::tuple<at::Tensor, at::Tensor> cast_to_fp8(const at::Tensor &x, int block_ro
     TORCH_CHECK(x.dim() == 2, "x must be [rows, k]");
     const at::ScalarType st = x.scalar_type();
     TORCH_CHECK(st == at::kFloat || st == at::kBFloat16 || st == at::kHalf, "x must be float32 / bfloat16 / float16");
+    const c10::OptionalDeviceGuard guard(at::device_of(x));
     at::Tensor q = at::empty(x.sizes(), x.options().dtype(at::kFloat8_e4m3fn));
     at::Tensor sf = at::empty({(x.size(0) + block_rows - 1) / block_rows, (x.size(1) + 127) / 128}, x.options().dtype(at::kFloat));
     const int dt = st == at::kFloat ? DGA_DT_FP32 : st == at::kBFloat16 ? DGA_DT_BF16 : DGA_DT_FP16;
@@ -150,11 +219,13 @@ PYBIND11_MODULE(deep_gemm_cpp, m)   // the reference's module name (python_api.c
     m.def("run_mmad_rtc", &run_mmad_rtc, "run_mmad_rtc");
     m.def("run_mmad_bench", &run_mmad_bench, "run_mmad_bench");
     m.def("gemm_fp8_fp8_bf16_nt", &gemm_fp8_fp8_bf16_nt, py::arg("a"), py::arg("sfa"), py::arg("b"), py::arg("sfb"),
-          py::arg("out"), py::arg("strict") = false);
+          py::arg("out"), py::arg("strict") = false, py::arg("policy") = "");
     m.def("m_grouped_gemm_fp8_fp8_bf16_nt_masked", &m_grouped_gemm_fp8_fp8_bf16_nt_masked, py::arg("a"), py::arg("sfa"),
-          py::arg("b"), py::arg("sfb"), py::arg("out"), py::arg("masked_m"), py::arg("expected_m"), py::arg("strict") = false);
+          py::arg("b"), py::arg("sfb"), py::arg("out"), py::arg("masked_m"), py::arg("expected_m"), py::arg("strict") = false,
+          py::arg("policy") = "");
     m.def("m_grouped_gemm_fp8_fp8_bf16_nt_contiguous", &m_grouped_gemm_fp8_fp8_bf16_nt_contiguous, py::arg("a"),
-          py::arg("sfa"), py::arg("b"), py::arg("sfb"), py::arg("out"), py::arg("m_indices"), py::arg("strict") = false);
+          py::arg("sfa"), py::arg("b"), py::arg("sfb"), py::arg("out"), py::arg("m_indices"), py::arg("strict") = false,
+          py::arg("policy") = "");
     m.def("get_m_alignment_for_contiguous_layout", [] { return DGA_CONTIGUOUS_M_ALIGNMENT; });
     m.def("per_token_cast_to_fp8", [](const at::Tensor &x) { return cast_to_fp8(x, 1); });
     m.def("per_block_cast_to_fp8", [](const at::Tensor &x) { return cast_to_fp8(x, 128); });

@@ -37,9 +37,9 @@ def _default_compute(a, sfa, b, sfb, out, masked_m, expected_m):
     api.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), out, masked_m, expected_m)
 
 
-def _default_compute_strict(a, sfa, b, sfb, out, masked_m, expected_m, strict):
+def _default_compute_policy(a, sfa, b, sfb, out, masked_m, expected_m, policy):
     from . import api
-    api.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), out, masked_m, expected_m, strict=strict)
+    api.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), out, masked_m, expected_m, policy=policy)
 
 
 def _rows(dst, src, dst_index=None, src_index=None, row_bytes=None, dst_off=0, src_off=0):
@@ -108,7 +108,7 @@ class ExpertShardedGroupedGemm:
     def __init__(self, rank: int, world: int, groups_total: int, m_max: int, n: int, k: int, device,
                  dist=None, compute: Optional[Callable] = None, chunks: Optional[int] = None,
                  capacity_factor: Optional[float] = None, max_tokens: Optional[int] = None, strict: bool = False,
-                 indexed: Optional[bool] = None):
+                 indexed: Optional[bool] = None, policy: Optional[str] = None):
         assert groups_total % world == 0, "experts must divide evenly over ranks"
         self.rank, self.world, self.dist = rank, world, dist
         self.G, self.Gl = groups_total, groups_total // world
@@ -120,13 +120,23 @@ class ExpertShardedGroupedGemm:
         # lie, and a row stride that is not a line multiple would make every such read straddle two lines
         self.row_bytes = (self.hdr + 4 + 127) // 128 * 128
         self.device = torch.device(device)
-        self.strict = strict
-        # indexed (device default): the grouped GEMM gathers token rows where they lie (the caller's tensors at world 1,
-        # the receive buffer otherwise) and scatters result rows straight into the buffer that travels back -- no
-        # pack / unpack copy either side of it.  An injected `compute` (the CPU tests) works on the packed masked layout.
-        self.indexed = (compute is None and self.device.type == "cuda") if indexed is None else bool(indexed)
+        assert not (strict and policy not in (None, "strict")), "strict=True contradicts policy"
+        self.policy = "strict" if strict else policy          # arithmetic policy of the GEMM (api.ARITHMETIC_POLICIES)
+        # indexed: the grouped GEMM gathers token rows where they lie (the caller's tensors at world 1, the receive buffer
+        # otherwise) and scatters result rows straight into the buffer that travels back -- no pack / unpack copy either side
+        # of it.  The device default at world 1.  At world > 1 it is OPT-IN (indexed=True): there the kernel reads the receive
+        # buffer of a collective through a slot table built on another stream, and that ordering has only run against an
+        # in-process emulation of the exchange (tests/test_parallel_gpu.py), never against RCCL with more than one rank; the
+        # packed path (one unpack copy, one gather copy) is the default until tests/test_parallel_rccl.py has run on a
+        # multi-GPU box.  An injected `compute` (the CPU tests) works on the packed masked layout.
+        if indexed is None:
+            indexed = compute is None and self.device.type == "cuda" and world == 1
+        self.indexed = bool(indexed)
+        # the tile loads address a row's scales as floats inside the payload row: K must keep them 4-byte aligned
+        if self.indexed and world > 1 and k % 4:
+            self.indexed = False
         assert not (self.indexed and compute is not None), "an injected compute takes the packed layout"
-        self.compute = compute or (lambda a, sfa, b, sfb, out, mm, em: _default_compute_strict(a, sfa, b, sfb, out, mm, em, strict))
+        self.compute = compute or (lambda a, sfa, b, sfb, out, mm, em: _default_compute_policy(a, sfa, b, sfb, out, mm, em, self.policy))
         if chunks is None:
             chunks = 2 if (world > 1 and self.Gl % 2 == 0 and self.Gl >= 8) else 1
         assert self.Gl % chunks == 0, "chunks must divide the experts per rank"
@@ -135,16 +145,27 @@ class ExpertShardedGroupedGemm:
         # the largest number of tokens one rank brings to a forward: it sizes the exchange slices, so every rank must
         # pass the same value (default: what a rank's own experts can hold)
         self.max_tokens = int(max_tokens) if max_tokens is not None else self.Gl * m_max
-        # resident buffers sized once (288 GB HBM: weights + masked activations stay put)
-        self.a = torch.zeros((self.Gl, m_max, k), dtype=torch.uint8, device=device)
-        self.sfa = torch.ones((self.Gl, m_max, self.kb), dtype=torch.float32, device=device)
-        self.out = torch.zeros((self.Gl, m_max, n), dtype=torch.bfloat16, device=device)
+        # resident buffers sized once (288 GB HBM: weights stay put); the packed masked layout [Gl, m_max, K] (+ scales, + the
+        # output) exists only where the packed path runs -- the indexed forward never touches it
+        self._packed = None
         self.masked_m = torch.zeros((self.Gl,), dtype=torch.int32, device=device)
         self.overflow = torch.zeros((1,), dtype=torch.int32, device=device)
         self.b = None
         self.sfb = None
         self._T = -1
         self._side = None
+
+    def _packed_layout(self):
+        if self._packed is None:
+            dev = self.device
+            self._packed = (torch.zeros((self.Gl, self.m_max, self.k), dtype=torch.uint8, device=dev),
+                            torch.ones((self.Gl, self.m_max, self.kb), dtype=torch.float32, device=dev),
+                            torch.zeros((self.Gl, self.m_max, self.n), dtype=torch.bfloat16, device=dev))
+        return self._packed
+
+    a = property(lambda self: self._packed_layout()[0])
+    sfa = property(lambda self: self._packed_layout()[1])
+    out = property(lambda self: self._packed_layout()[2])
 
     def set_weights(self, b: torch.Tensor, sfb: torch.Tensor):
         assert tuple(b.shape) == (self.Gl, self.n, self.k) and tuple(sfb.shape) == (self.Gl, self.nb, self.kb)
@@ -197,15 +218,19 @@ class ExpertShardedGroupedGemm:
     # ------------------------------------------------------------------ world 1: route straight into the masked layout
     def _forward_local(self, tok_q, tok_sf, expert_ids, expected_m, marks):
         T = tok_q.shape[0]
-        if self.indexed:
+        # the indexed GEMM reads the caller's rows where they lie: it needs plain [T, K] bytes and [T, KB] float rows
+        indexed = (self.indexed and tok_q.is_contiguous() and tok_sf.is_contiguous() and tok_sf.dtype == torch.float32
+                   and tuple(tok_sf.shape) == (T, self.kb))
+        if indexed:
             from . import api
             _route_slots(expert_ids, 8, 0, T, self.Gl, self.m_max, self.masked_m, self.slot, self.overflow,
                          inverse=self.row_of_slot)
             marks("route")
-            res = torch.empty((T, self.n), dtype=self.out.dtype, device=self.out.device)
+            # zeros: the row of a token that found no slot (a full expert: check() reports it) is never written
+            res = torch.zeros((T, self.n), dtype=torch.bfloat16, device=self.device)
             api.m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(tok_q, tok_sf, 0, self.kb, (self.b, self.sfb), res,
                                                               self.row_of_slot, self.masked_m, self.m_max,
-                                                              expected_m or self.m_max, strict=self.strict)
+                                                              expected_m or self.m_max, policy=self.policy)
             marks("gemm")
             return res
         flat_a = self.a.view(self.Gl * self.m_max, self.k)
@@ -216,7 +241,7 @@ class ExpertShardedGroupedGemm:
         marks("pack")
         self.compute(self.a, self.sfa, self.b, self.sfb, self.out, self.masked_m, expected_m or self.m_max)
         marks("gemm")
-        res = torch.empty((T, self.n), dtype=self.out.dtype, device=self.out.device)
+        res = torch.zeros((T, self.n), dtype=torch.bfloat16, device=self.device)   # dropped tokens' rows stay zero
         _rows(res.view(torch.uint8), self.out.view(self.Gl * self.m_max, self.n).view(torch.uint8), src_index=self.slot[:T],
               row_bytes=2 * self.n)
         marks("unpack")
@@ -226,9 +251,10 @@ class ExpertShardedGroupedGemm:
     def _forward_sharded(self, tok_q, tok_sf, expert_ids, expected_m, marks, overlap):
         T, w, ch, C = tok_q.shape[0], self.world, self.chunks, self.C
         per = w * C                                             # rows of one chunk's exchange
-        flat_a = self.a.view(self.Gl * self.m_max, self.k)
-        flat_sfa = self.sfa.view(self.Gl * self.m_max, self.kb).view(torch.uint8)
-        flat_out = self.out.view(self.Gl * self.m_max, self.n).view(torch.uint8)
+        if not self.indexed:
+            flat_a = self.a.view(self.Gl * self.m_max, self.k)
+            flat_sfa = self.sfa.view(self.Gl * self.m_max, self.kb).view(torch.uint8)
+            flat_out = self.out.view(self.Gl * self.m_max, self.n).view(torch.uint8)
         cuda = tok_q.is_cuda
         # ---- source side: slot of every token in its (chunk, destination) slice, header = expert index on its owner
         self.send[:, self.hdr:self.hdr + 4] = 255              # every header -1: rows nobody fills are skipped by the receiver
@@ -252,8 +278,8 @@ class ExpertShardedGroupedGemm:
                 sl = slice(c * per, (c + 1) * per)
                 self.dist.all_to_all_single(self.recv[sl], self.send[sl])
                 _route_slots(self.recv[sl], self.row_bytes, self.hdr, per, self.Gl, self.m_max, self.masked_m,
-                             self.rdest[sl], self.overflow, zero_counts=False, inverse=self.row_of_slot,
-                             inverse_base=c * per)
+                             self.rdest[sl], self.overflow, zero_counts=False,
+                             inverse=self.row_of_slot if self.indexed else None, inverse_base=c * per)
                 if not self.indexed:
                     _rows2(flat_a, self.recv[sl], self.k, flat_sfa, self.recv[sl], 4 * self.kb, self.rdest[sl],
                            src1_off=self.k)
@@ -269,7 +295,7 @@ class ExpertShardedGroupedGemm:
                 api.m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(
                     self.recv, self.recv, self.k, self.row_bytes // 4, (self.b[g0:g1], self.sfb[g0:g1]), self.osend,
                     self.row_of_slot[g0 * self.m_max:g1 * self.m_max], self.masked_m[g0:g1], self.m_max,
-                    expected_m or self.m_max, strict=self.strict)
+                    expected_m or self.m_max, policy=self.policy)
             else:
                 self.compute(self.a[g0:g1], self.sfa[g0:g1], self.b[g0:g1], self.sfb[g0:g1], self.out[g0:g1],
                              self.masked_m[g0:g1], expected_m or self.m_max)
@@ -290,7 +316,7 @@ class ExpertShardedGroupedGemm:
             for e in ev_c:
                 main.wait_event(e)
         marks("combine")
-        res = torch.empty((T, self.n), dtype=self.out.dtype, device=self.out.device)
+        res = torch.zeros((T, self.n), dtype=torch.bfloat16, device=self.device)   # dropped tokens' rows stay zero
         _rows(res.view(torch.uint8), self.oback.view(torch.uint8), src_index=self.slot[:T], row_bytes=2 * self.n)
         marks("unpack")
         return res
@@ -350,33 +376,127 @@ def _kernel_of(eng) -> dict:
 
 
 def _rand_fp8(shape, gen, device):
+    """Uniformly random e4m3fn bytes without NaN codes (development scripts; the bench legs use the 8(d) recipe below)."""
     x = torch.randint(0, 256, shape, dtype=torch.uint8, device=device, generator=gen)
     return torch.where((x & 0x7F) == 0x7F, x & 0x80, x)
 
 
+def _quantised_tokens(rows, k, gen, device):
+    """SURVEY.md 8(d) recipe for the A operand: fp32 ~ N(0,1), amax-scaled per 1x128, cast to e4m3fn -- by the product's own
+    quantiser (dga_cast_to_fp8_1x128, byte-exact against the oracle's in tests/test_cast_gpu.py)."""
+    from . import api
+    q = torch.empty((rows, k), dtype=torch.uint8, device=device)
+    sf = torch.empty((rows, (k + 127) // 128), dtype=torch.float32, device=device)
+    step = 8192
+    for r0 in range(0, rows, step):
+        r1 = min(rows, r0 + step)
+        qq, ss = api.per_token_cast_to_fp8(torch.randn((r1 - r0, k), device=device, generator=gen))
+        q[r0:r1] = qq.view(torch.uint8); sf[r0:r1] = ss
+    return q, sf
+
+
+def _quantised_weights(groups, n, k, gen, device):
+    """... and for the B operand: per-128x128 amax scaling, expert by expert (dga_cast_to_fp8_128x128)."""
+    from . import api
+    assert n % 128 == 0, "the bench shapes keep an expert's rows on 128-row block boundaries"
+    kb, nb = (k + 127) // 128, n // 128
+    b = torch.empty((groups, n, k), dtype=torch.uint8, device=device)
+    sfb = torch.empty((groups, nb, kb), dtype=torch.float32, device=device)
+    step = 8
+    for g0 in range(0, groups, step):
+        g1 = min(groups, g0 + step)
+        qq, ss = api.per_block_cast_to_fp8(torch.randn(((g1 - g0) * n, k), device=device, generator=gen))
+        b[g0:g1] = qq.view(torch.uint8).view(g1 - g0, n, k); sfb[g0:g1] = ss.view(g1 - g0, nb, kb)
+    return b, sfb
+
+
+def masked_parity(a, sfa, b, sfb, masked, policies=("fast", "bf16_exact")) -> dict:
+    """Every valid output row of a masked grouped problem under each policy against the strict kernel (which the tests pin bit
+    for bit to the CPU oracle): max_ulp, frac_gt_2ulp, worst_excess_over_S with S = sum of the magnitudes of the scaled
+    products (the strict kernel on |a|, |b|, |scales|).  Rows at or beyond masked_m must keep the bytes they had."""
+    from . import api
+    g, mmax, _ = a.shape
+    n = b.shape[1]
+    dev = a.device
+    sentinel = -7.0
+    run = lambda aa, sa, bb, sb, out, pol: api.m_grouped_gemm_fp8_fp8_bf16_nt_masked((aa, sa), (bb, sb), out, masked, mmax, policy=pol)
+    exact = torch.full((g, mmax, n), sentinel, dtype=torch.bfloat16, device=dev)
+    s_abs = torch.full((g, mmax, n), sentinel, dtype=torch.bfloat16, device=dev)
+    run(a, sfa, b, sfb, exact, "strict")
+    run(a & 0x7F, sfa.abs(), b & 0x7F, sfb.abs(), s_abs, "strict")
+    valid = (torch.arange(mmax, device=dev)[None, :] < masked[:, None].to(torch.int64))[:, :, None].expand(g, mmax, n)
+
+    def key(t):   # monotone integer map of bf16 bit patterns (+0 / -0 coincide)
+        v = t.view(torch.int16).to(torch.int32)
+        mag = v & 0x7FFF
+        return torch.where(v < 0, -mag, mag)
+    res = {"against": "strict policy on the same experts (bit-identical to the CPU oracle in tests/test_strict_gpu.py)",
+           "experts": int(g), "masked_m": [int(x) for x in masked.cpu()], "elements": int(valid.sum())}
+    for pol in policies:
+        out = torch.full((g, mmax, n), sentinel, dtype=torch.bfloat16, device=dev)
+        run(a, sfa, b, sfb, out, pol)
+        torch.cuda.synchronize()
+        untouched = bool((out[~valid] == sentinel).all()) if bool((~valid).any()) else True
+        ulps = (key(out) - key(exact)).abs()[valid]
+        f, e, ss = out.double()[valid], exact.double()[valid], s_abs.double()[valid]
+        ulp = torch.exp2(torch.floor(torch.log2(e.abs().clamp_min(2.0 ** -126))) - 7)
+        excess = ((f - e).abs() - 2 * ulp).clamp_min(0) / ss.clamp_min(1e-300)
+        res[pol] = {"max_ulp": int(ulps.max()) if ulps.numel() else 0,
+                    "frac_gt_2ulp": float((ulps > 2).double().mean()) if ulps.numel() else 0.0,
+                    "worst_excess_over_S": float(excess.max()) if excess.numel() else 0.0,
+                    "masked_rows_untouched": untouched}
+    return res
+
+
+def _gemm_only_us(eng, steps, warmup):
+    for _ in range(warmup):
+        eng.run_local()
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        eng.run_local()
+    ev1.record()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, ev0.elapsed_time(ev1) * 1e3 / steps
+
+
+def _stream_roofline(eng, kernel_us):
+    """Algorithmic bytes of the local grouped GEMM at the engine's current masked_m (weights of the non-empty
+    experts once, the valid rows' activations, scales and outputs) against 8 TB/s."""
+    rows = int(eng.masked_m.sum().item())
+    active = int((eng.masked_m > 0).sum().item())
+    alg = active * eng.n * eng.k + rows * (eng.k + 4 * eng.kb + 2 * eng.n) + eng.Gl * eng.nb * eng.kb * 4
+    gbps = alg / (kernel_us * 1e-6) / 1e9
+    return rows, {"bound": "hbm", "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4),
+                  "traffic": None, "kernel_us": round(kernel_us, 2), "algorithmic_bytes": alg,
+                  "tflops": round(2.0 * eng.n * eng.k * rows / (kernel_us * 1e-6) / 1e12, 1)}
+
+
 def bench_grouped(rank, world, dist, steps=10, warmup=3, groups_total=256, m_max=128, n=2048, k=7168, mask="full",
-                  capacity_factor=1.25):
-    """BASELINE.json configs[3] (world 1) / configs[4] (world 8): G experts x (M<=128, K=7168, N=2048).
-    Tokens are born uniformly on the ranks; `full` = every expert gets m_max rows, `random` = randint(0, m_max+1)."""
+                  capacity_factor=1.25, indexed=None, parity=True):
+    """BASELINE.json configs[3] (world 1) / configs[4] (world 8): G experts x (M<=128, K=7168, N=2048) on the SURVEY.md 8(d)
+    data recipe (N(0,1), amax-quantised per 1x128 / 128x128).  Tokens are born uniformly on the ranks; `full` = every expert
+    gets m_max rows, `random` = randint(0, m_max+1).  The GEMM-only figures are reported for BOTH masks, and `parity` holds
+    the fast and the bf16-exact kernel against the strict one on 8 sampled experts with ragged masks."""
     dev = torch.device("cuda", torch.cuda.current_device())
-    eng = ExpertShardedGroupedGemm(rank, world, groups_total, m_max, n, k, dev, dist, capacity_factor=capacity_factor)
+    eng = ExpertShardedGroupedGemm(rank, world, groups_total, m_max, n, k, dev, dist, capacity_factor=capacity_factor,
+                                   indexed=indexed)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     kb, nb = eng.kb, eng.nb
-    eng.set_weights(_rand_fp8((eng.Gl, n, k), g, dev), torch.rand((eng.Gl, nb, kb), device=dev, generator=g) + 0.5)
+    eng.set_weights(*_quantised_weights(eng.Gl, n, k, g, dev))
     # tokens per expert contributed by this rank
     gc = torch.Generator().manual_seed(99)  # same on every rank
-    if mask == "full":
-        per_expert = torch.full((groups_total,), m_max, dtype=torch.int64)
-    else:
-        per_expert = torch.randint(0, m_max + 1, (groups_total,), generator=gc)
+    per_expert_random = torch.randint(0, m_max + 1, (groups_total,), generator=gc)
+    per_expert = torch.full((groups_total,), m_max, dtype=torch.int64) if mask == "full" else per_expert_random
     base = per_expert // world
     extra = per_expert % world
     mine = base + (rank < extra).to(torch.int64)
     expert_ids = torch.repeat_interleave(torch.arange(groups_total), mine).to(dev)
     expert_ids = expert_ids[torch.randperm(expert_ids.numel(), device=dev, generator=g)].contiguous()
     T = expert_ids.numel()
-    tok_q = _rand_fp8((T, k), g, dev)
-    tok_sf = torch.rand((T, kb), device=dev, generator=g) + 0.5
+    tok_q, tok_sf = _quantised_tokens(T, k, g, dev)
     total_tokens = int(per_expert.sum())
 
     def sync():
@@ -421,44 +541,57 @@ def bench_grouped(rank, world, dist, steps=10, warmup=3, groups_total=256, m_max
             eng.forward(tok_q, tok_sf, expert_ids)
         eng.forward(tok_q, tok_sf, expert_ids, phase_us=phases)
     phases = {kk: round(v / 3, 1) for kk, v in phases.items()}
-    # GEMM only (activations already in the masked layout on the owning rank; random bytes there -- the indexed forward
-    # never fills that layout, and zeros would run at a higher clock than real data)
-    eng.a.copy_(_rand_fp8(tuple(eng.a.shape), g, dev))
-    eng.sfa.copy_(torch.rand(tuple(eng.sfa.shape), device=dev, generator=g) + 0.5)
-    for _ in range(warmup):
-        eng.run_local()
-    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
-    sync()
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(steps):
-        eng.run_local()
-    ev1.record()
-    sync()
-    gemm = (time.perf_counter() - t0) / steps
-    kernel_us = ev0.elapsed_time(ev1) * 1e3 / steps
+    counts_forward = eng.masked_m.clone()      # rows every local expert received in the forward above
+    # GEMM only (activations already in the masked layout on the owning rank: the same recipe, quantised in place)
+    qa, qs = _quantised_tokens(eng.Gl * m_max, k, g, dev)
+    eng.a.copy_(qa.view(eng.Gl, m_max, k)); eng.sfa.copy_(qs.view(eng.Gl, m_max, kb))
+    del qa, qs
+    gemm, kernel_us = _gemm_only_us(eng, steps, warmup)
     eng.check()
+    rows_local, roof = _stream_roofline(eng, kernel_us)
+    # ... and under the OTHER mask of SURVEY.md 8(d) (full <-> randint(0, m_max + 1)), same buffers
+    other = "random" if mask == "full" else "full"
+    lo = rank * eng.Gl
+    other_counts = (per_expert_random[lo:lo + eng.Gl] if other == "random" else torch.full((eng.Gl,), m_max)).to(torch.int32)
+    eng.masked_m.copy_(other_counts.to(dev))
+    gemm_o, kernel_us_o = _gemm_only_us(eng, steps, warmup)
+    rows_o, roof_o = _stream_roofline(eng, kernel_us_o)
+    eng.masked_m.copy_(counts_forward)
     if dist is not None and world > 1:
-        tt = torch.tensor([e2e, gemm, kernel_us], device=dev, dtype=torch.float64)
+        tt = torch.tensor([e2e, gemm, kernel_us, gemm_o, kernel_us_o], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        e2e, gemm, kernel_us = (float(x) for x in tt)
-    rows_local = int(eng.masked_m.sum().item())
-    active = int((eng.masked_m > 0).sum().item())
-    alg_bytes = active * n * k + rows_local * (k + 4 * kb + 2 * n) + eng.Gl * nb * kb * 4
-    flops_local = 2.0 * n * k * rows_local
+        e2e, gemm, kernel_us, gemm_o, kernel_us_o = (float(x) for x in tt)
+    phases_per_rank = None
+    if dist is not None and world > 1:     # per-phase device time of every rank (the max over ranks hides a slow link)
+        phases_per_rank = [None] * world
+        dist.all_gather_object(phases_per_rank, phases)
+    kern = _kernel_of(eng)
+    roof.update(kern); roof_o.update(kern)
     res = {
         "workload": f"m_grouped_gemm_fp8_fp8_bf16_nt_masked G={groups_total} x (M<={m_max}, K={k}, N={n}), "
                     f"mask={mask}, {groups_total // world} experts/GPU",
+        "data": "fp32 ~ N(0,1), amax-quantised per 1x128 (tokens) / per 128x128 (weights) to e4m3fn by the product's quantisers "
+                "(SURVEY.md 8(d))",
         "n_gpus": world, "tokens": total_tokens,
         "tok_per_s_gemm_only": round(total_tokens / gemm, 1),
         "tok_per_s_with_alltoall": round(total_tokens / e2e, 1),
         "ms_gemm": round(gemm * 1e3, 4), "ms_end_to_end": round(e2e * 1e3, 4),
         "ms_end_to_end_graph": round(e2e_graph * 1e3, 4) if e2e_graph else None,
-        "phase_us": phases, "chunks": eng.chunks, "indexed_rows": bool(eng.indexed),
+        "phase_us": phases, "phase_us_per_rank": phases_per_rank, "chunks": eng.chunks, "indexed_rows": bool(eng.indexed),
         "pair_capacity_rows": getattr(eng, "C", None), "capacity_factor": capacity_factor if world > 1 else None,
-        "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (kernel_us * 1e-6) / 1e9, 1), "peak": 8000.0,
-                     "unit": "GB/s", "frac": round(alg_bytes / (kernel_us * 1e-6) / 1e9 / 8000.0, 4),
-                     "traffic": None, "kernel_us": round(kernel_us, 2), "algorithmic_bytes": alg_bytes,
-                     "tflops": round(flops_local / (kernel_us * 1e-6) / 1e12, 1), **_kernel_of(eng)},
+        "roofline": roof,
+        f"{other}_mask": {"rows_per_gpu": rows_o, "ms_gemm": round(gemm_o * 1e3, 4),
+                          "tok_per_s_gemm_only": round(rows_o * world / gemm_o, 1), "roofline": roof_o},
     }
+    if parity and rank == 0:
+        try:
+            idx = sorted({0, 1, eng.Gl // 5, eng.Gl // 3, eng.Gl // 2, (2 * eng.Gl) // 3, eng.Gl - 2, eng.Gl - 1} & set(range(eng.Gl)))
+            masks = [m_max, 1, 77, m_max - 1, 64, 16, m_max, 33][:len(idx)]
+            it = torch.tensor(idx, device=dev)
+            res["parity"] = masked_parity(eng.a[it].contiguous(), eng.sfa[it].contiguous(), eng.b[it].contiguous(),
+                                          eng.sfb[it].contiguous(),
+                                          torch.tensor([min(x, m_max) for x in masks], dtype=torch.int32, device=dev))
+            res["parity"]["local_experts_sampled"] = idx
+        except Exception as e:
+            res["parity"] = {"error": repr(e)}
     return res

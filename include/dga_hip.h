@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define DGA_ABI_VERSION 2
+#define DGA_ABI_VERSION 3
 
 /* ---- status codes (reference: DGA_HOST_ASSERT throws DGAException,
  *      deep_gemm_ascend/framework/csrc/utils/exception.hpp:9-33; op hooks return
@@ -325,6 +325,14 @@ int dga_copy_rows2(void *dst0, int64_t dst0_row_stride, const void *src0, int64_
 int dga_gemm_fp8_loop_clock(const void *a, const float *sfa, const void *b, const float *sfb, void *out, int m, int n,
                             int k, const dga_tiling_t *tiling, void *scratch, size_t scratch_bytes, int launches,
                             void *stream, float *clock_mhz, float *loop_us);
+
+/* What the matrix pipe of this device sustains with the operands already in registers: `launches` back-to-back launches of
+ * a loop of the policy's matrix instruction with the fp32 promotion beside it (mode 0: v_mfma_scale_f32_16x16x128_f8f6f4 + 4
+ * FMAs -- the fast path; mode 1: 4 chained v_mfma_f32_16x16x32_bf16 + 4 FMAs + 8 e4m3 -> bf16 conversions -- the bf16-exact
+ * policy's 64 x 64 wave tile), two waves per SIMD on every CU, random e4m3 bytes; *tflops = the last launch's rate.  The
+ * ceiling bench.py prices the product kernels against beside the vendor peak (`roofline.ceiling_tflops`).
+ * scratch: device memory, >= 16 KiB + 2 KiB per CU.  A diagnostic (it synchronises); no reference counterpart. */
+int dga_mfma_ceiling(int mode, int launches, void *scratch, size_t scratch_bytes, void *stream, float *tflops);
 
 /* ---- misc -------------------------------------------------------------------------------- */
 const char *dga_status_string(int status);

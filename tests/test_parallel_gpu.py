@@ -50,7 +50,8 @@ def _engine(rank, world, dist, indexed, **kw):
     """indexed: the GEMM gathers / scatters rows itself (strict policy); packed: copies into the masked layout first."""
     from deepgemm_ascend_amd.parallel import ExpertShardedGroupedGemm
     if indexed:
-        return ExpertShardedGroupedGemm(rank, world, G_TOTAL, M_MAX, N, K, "cuda", dist, strict=True, max_tokens=128, **kw)
+        return ExpertShardedGroupedGemm(rank, world, G_TOTAL, M_MAX, N, K, "cuda", dist, strict=True, max_tokens=128,
+                                        indexed=True, **kw)
     return ExpertShardedGroupedGemm(rank, world, G_TOTAL, M_MAX, N, K, "cuda", dist, compute=_strict_compute,
                                     max_tokens=128, **kw)
 

@@ -254,3 +254,39 @@ def test_contiguous_layout_long_groups_take_two_pass_tiles(dga, m, n, k, g):
     t = dga.tiling(m, n, k, groups=g, contiguous=True)
     assert (t.m1, t.n1, t.contiguous) == (256, 256, 1)
     assert t.blockDim == 2 * -(-m // 256) * -(-n // 256)
+
+
+def test_swept_row_keeps_the_build_the_sweep_timed(dga, tmp_path):
+    """A swept row whose file carries the dispatchPolicyTag column names the build that was timed: a 3-stage tile on the
+    plain loop (policy 0) stays there.  The same row in a file from before that column existed is upgraded to the tile's
+    loader-wave build, as every heuristic pick is."""
+    head = "m,n,k,m1,n1,k1,kernelSerial,paddingTagA,paddingTagB,paddingTagC,blockDim,splitkFactor,stages,swizzleOffset,wavesM,wavesN"
+    row = "2048,2048,7168,128,256,128,0,0,0,0,128,1,3,4,2,4"
+    try:
+        new = tmp_path / "with_policy.csv"
+        new.write_text(head + ",dispatchPolicyTag\n" + row + ",0\n")
+        dga.tiling_cache_open(str(new))
+        t = dga.tiling(2048, 2048, 7168)
+        assert (t.m1, t.n1, t.stages, t.wavesM, t.wavesN, t.dispatchPolicyTag) == (128, 256, 3, 2, 4, dga.api.POLICY_PLAIN)
+    finally:
+        dga.tiling_cache_open(None)
+        dga.tiling_cache_clear()
+
+
+def test_contiguous_rows_share_a_bucketed_key(dga, tmp_path):
+    """Prefill serving changes the contiguous layout's row count on almost every call: the cache keys it by 128 x a power
+    of two, so the map and the file hold a handful of rows per (n, k, groups) instead of one per call."""
+    path = tmp_path / "contig.csv"
+    try:
+        dga.tiling_cache_open(str(path))
+        for msum in (4096 + 128, 4096 + 256, 6144, 8192 - 128, 8192):
+            t = dga.tiling(msum, 4096, 7168, groups=8, contiguous=True)
+            assert t.m == msum and t.m1 in (128, 256)
+            assert t.blockDim == (-(-msum // t.m1)) * (4096 // t.n1) * (2 if t.m1 > 128 else 1)
+        assert dga.tiling_cache_size() == 1
+        assert len(path.read_text().strip().splitlines()) == 2      # header + one row
+        dga.tiling(8192 + 128, 4096, 7168, groups=8, contiguous=True)
+        assert dga.tiling_cache_size() == 2
+    finally:
+        dga.tiling_cache_open(None)
+        dga.tiling_cache_clear()
