@@ -1,0 +1,89 @@
+"""The parity bar of the fp8 block-scaled GEMMs, stated once for the product harness.
+
+BASELINE.json's north_star asks for "within 2 ULP bf16" of the reference CPU path (fp32 accumulate,
+/root/reference/deep_gemm_ascend/framework/tests/test.py:19-64; the reference's own verifiers use a mismatch budget:
+scripts/verify.py:10-35, framework/benchmark/benchmark.py:384-398).  Per arithmetic policy (README.md "Numerics"):
+
+    |got - want| <= 2 * ulp_bf16(want) + eps * S          on EVERY element, NaN positions identical,
+    and at most `frac` of the elements may need the eps term at all,
+
+    S[m, n] = sum_kb |sfa * sfb| * sum_k |a| |b|          (the magnitude the matrix instruction's internal error scales with)
+
+    policy        eps      frac      why
+    fast          2^-15    2e-3      the fp8 matrix instruction drops bits ~13 below each octet's largest product
+    (K < 128 or arbitrary bytes: 2^-12, 1e-2 -- S then spans a couple of octets; pass short_k=True)
+    bf16_exact    2^-22    1e-5      exact products, fp32-class sums in the instruction's own order
+    strict        0        0         the oracle's own order: bit-identical
+
+The bbit file verifier (harness/files.py) and the sweep's correctness gate (harness/sweep.py) both call `check`; the
+test-side statement of the same bar is oracle.assert_parity (tests never import this module's caller paths)."""
+from __future__ import annotations
+
+import numpy as np
+
+MAX_ULP = 2
+EPS = {"fast": 2.0 ** -15, "bf16_exact": 2.0 ** -22, "strict": 0.0}
+FRAC = {"fast": 2e-3, "bf16_exact": 1e-5, "strict": 0.0}
+EPS_SHORT_K = 2.0 ** -12      # fast path, K < 128 or arbitrary bit patterns: the hardware's own envelope
+FRAC_SHORT_K = 1e-2
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+def check(got, want, s, policy: str = "fast", short_k: bool = False, small: int = 8):
+    """(ok, report).  got / want / s: float arrays of one shape -- numpy arrays, or torch tensors (then everything runs where
+    the tensors live).  `want` is the reference value ALREADY rounded to bf16 (or exactly representable in it); s >= 0.
+    `small`: on small samples a handful of elements may exceed 2 ulp whatever the fraction (a population statement)."""
+    if policy not in EPS:
+        raise ValueError(f"policy must be one of {sorted(EPS)}")
+    eps = EPS_SHORT_K if (short_k and policy == "fast") else EPS[policy]
+    frac = FRAC_SHORT_K if (short_k and policy == "fast") else FRAC[policy]
+    if _is_torch(got):
+        import torch
+        g, w, ss = got.double(), want.double(), s.double()
+        gn, wn = torch.isnan(g), torch.isnan(w)
+        nan_ok = bool(torch.equal(gn, wn))
+        fin = ~wn & ~gn
+        diff = torch.where(fin, (g - w).abs(), torch.zeros_like(g))
+        ulp = torch.exp2(torch.floor(torch.log2(w.abs().clamp_min(2.0 ** -126))) - 7)
+        ulp = torch.where(fin, ulp, torch.ones_like(ulp))
+        exc = (diff - MAX_ULP * ulp).clamp_min(0)
+        ratio = torch.where(ss > 0, exc / ss.clamp_min(1e-300), torch.where(exc > 0, torch.full_like(exc, float("inf")), torch.zeros_like(exc)))
+        worst = float(ratio.max()) if ratio.numel() else 0.0
+        beyond = int((exc > 0).sum())
+        size = int(g.numel())
+        max_ulp = float((diff / ulp).max()) if size else 0.0
+    else:
+        g = np.asarray(got, np.float64); w = np.asarray(want, np.float64); ss = np.asarray(s, np.float64)
+        gn, wn = np.isnan(g), np.isnan(w)
+        nan_ok = bool(np.array_equal(gn, wn))
+        fin = ~wn & ~gn
+        diff = np.where(fin, np.abs(np.where(fin, g - w, 0.0)), 0.0)
+        ulp = np.where(fin, 2.0 ** (np.floor(np.log2(np.maximum(np.abs(np.where(fin, w, 1.0)), 2.0 ** -126))) - 7), 1.0)
+        exc = np.maximum(diff - MAX_ULP * ulp, 0.0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ratio = np.where(ss > 0, exc / np.maximum(ss, 1e-300), np.where(exc > 0, np.inf, 0.0))
+        worst = float(ratio.max(initial=0.0))
+        beyond = int((exc > 0).sum())
+        size = int(g.size)
+        max_ulp = float((diff / ulp).max(initial=0.0))
+    rep = {"policy": policy, "eps": eps, "frac_allowed": frac, "elements": size, "max_ulp": max_ulp,
+           "elements_gt_2ulp": beyond, "frac_gt_2ulp": beyond / max(1, size), "worst_excess_over_S": worst,
+           "nan_positions_equal": nan_ok}
+    ok = nan_ok and worst <= eps * (1 + 1e-6) and beyond <= max(frac * size, small if frac > 0 else 0)
+    rep["ok"] = bool(ok)
+    return bool(ok), rep
+
+
+def bf16_round(x):
+    """fp32 -> the nearest bf16 value (RNE), as fp32: numpy arrays (torch tensors: x.to(torch.bfloat16).float())."""
+    if _is_torch(x):
+        import torch
+        return x.to(torch.bfloat16).float()
+    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    nan = np.isnan(np.asarray(x, np.float32))
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    out = r.astype(np.uint32).view(np.float32)
+    return np.where(nan, np.float32(np.nan), out)

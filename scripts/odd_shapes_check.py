@@ -9,12 +9,12 @@ from deepgemm_ascend_amd.harness import sweep
 shapes = [(8192, 128, 7168), (128, 128, 16384), (4096, 256, 256), (256, 256, 256), (16, 16, 128), (7, 24, 48), (16384, 256, 128),
           (64, 128, 128), (2048, 384, 4096), (333, 200, 1000), (8192, 8192, 128), (1, 7168, 7168), (4, 256, 16384)]
 for (m, n, k) in shapes:
-    a, sfa, b, sfb, golden = sweep.gen_data(m, n, k)
+    a, sfa, b, sfb, golden, s_abs = sweep.gen_data(m, n, k)
     out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
     def run(t):
         fn = lambda: dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, tiling_=t)
         fn(); torch.cuda.synchronize()
-        ok, _ = sweep.is_correct(golden, out)
+        ok, _ = sweep.is_correct(golden, out, s_abs, short_k=k < 128)
         return min(sweep.time_us(fn, warm=5, iters=30) for _ in range(3)), ok
     td, okd = run(dga.tiling(m, n, k))
     th, okh = run(dga.select_kernel(m, n, k))

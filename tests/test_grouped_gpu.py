@@ -145,6 +145,51 @@ def test_config4_full_size(dga, oracle):
         assert torch.equal(dense, out[e, :r])
 
 
+def test_config4_full_size_on_the_survey_recipe(dga, oracle):
+    """BASELINE configs[3] at full size on SURVEY.md 8(d)'s data recipe (fp32 ~ N(0,1), amax-quantised per 1x128 / 128x128
+    by the product's quantisers), random masks.  Sampled experts against the CPU oracle: the fast path at its amax-quantised
+    bar (2 ulp + 2^-15 S, at most 2e-3 of the elements beyond 2 ulp), the bf16-exact policy at 2^-22 S with at most 1e-5
+    beyond 2 ulp, the strict policy bit for bit; rows >= masked_m keep their sentinel under every policy; and
+    parallel.masked_parity (what bench.py prints as grouped.parity) agrees with the oracle's figures."""
+    from deepgemm_ascend_amd import parallel
+    G, MMAX, N, K = 256, 128, 2048, 7168
+    g = torch.Generator(device="cuda").manual_seed(21)
+    b, sfb = parallel._quantised_weights(G, N, K, g, "cuda")
+    qa, qs = parallel._quantised_tokens(G * MMAX, K, g, "cuda")
+    a, sfa = qa.view(G, MMAX, K), qs.view(G, MMAX, K // 128)
+    masked = torch.randint(0, MMAX + 1, (G,), dtype=torch.int32, device="cuda", generator=g)
+    masked[7] = 0; masked[8] = 128; masked[9] = 1
+    mm = masked.cpu().numpy()
+    row_ix = torch.arange(MMAX, device="cuda")[None, :, None]
+    untouched = (row_ix >= masked[:, None, None])
+    sample = (7, 8, 9, 100, 200, 255)
+    wants = {}
+    for e in sample:
+        r = int(mm[e])
+        if r:
+            wants[e] = oracle.gemm_fp8_fp8_bf16_nt(a[e, :r].cpu().numpy(), sfa[e, :r].cpu().numpy(), b[e].cpu().numpy(),
+                                                   sfb[e].cpu().numpy(), threads=16)
+    for policy, eps, frac in (("fast", 2.0 ** -15, 2e-3), ("bf16_exact", 2.0 ** -22, 1e-5), ("strict", 0.0, 0.0)):
+        out = torch.full((G, MMAX, N), -7.0, dtype=torch.bfloat16, device="cuda")
+        dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), out, masked, expected_m=64, policy=policy, sync=True)
+        assert ((out == -7.0) | ~untouched).all(), policy
+        for e, want in wants.items():
+            r = int(mm[e])
+            got = _bits(out[e, :r])
+            if policy == "strict":
+                assert np.array_equal(got, want), f"expert {e}"
+                continue
+            rep = oracle.parity_report(got, want, a[e, :r].cpu().numpy(), sfa[e, :r].cpu().numpy(), b[e].cpu().numpy(),
+                                       sfb[e].cpu().numpy())
+            assert rep["nan_positions_equal"] and rep["worst_excess_over_S"] <= eps, (policy, e, rep)
+            assert rep["frac_gt_max_ulp"] * got.size <= max(frac * got.size, 2), (policy, e, rep)
+    it = torch.tensor(sample, device="cuda")
+    rep = parallel.masked_parity(a[it].contiguous(), sfa[it].contiguous(), b[it].contiguous(), sfb[it].contiguous(), masked[it])
+    assert rep["fast"]["masked_rows_untouched"] and rep["bf16_exact"]["masked_rows_untouched"]
+    assert rep["fast"]["worst_excess_over_S"] <= 2.0 ** -15 * 1.01 and rep["fast"]["frac_gt_2ulp"] <= 2e-3, rep
+    assert rep["bf16_exact"]["worst_excess_over_S"] <= 2.0 ** -22 * 1.01 and rep["bf16_exact"]["frac_gt_2ulp"] <= 1e-5, rep
+
+
 def test_route_tokens(dga):
     """dga_route_tokens: counts = histogram, pos = a permutation that sorts the tokens by expert; out-of-range ids -> -1."""
     g = torch.Generator(device="cuda").manual_seed(3)
