@@ -13,6 +13,10 @@ Fixtures (SURVEY.md 8c "Golden vectors to commit"):
   config_vectors.json     (v)   28-int Config tuples from the reference header itself
   op_tiling_vectors.json  (vi)  (m1,n1,k1,kernelSerial,blockDim,padding) from the reference's Python mirror
                                 (coreNum 20) and the C++ probes recorded in SURVEY.md 8(a7) (coreNum 24)
+  ref_gen_golden_96x160x320.npz (vii) the files the reference's OWN generator writes: deep_gemm_ascend/scripts/gen_golden.py
+                                is imported, numpy's global generator seeded, gen_golden_data(96, 160, 320) run in a scratch
+                                directory; the bytes of input/x1_gm.bin, input/x2_gm.bin and output/golden.bin are stored.
+                                `python tests/golden/make_golden.py ref_gen_golden` writes this one alone.
 """
 import json
 import sys
@@ -106,7 +110,35 @@ def op_tiling():
         {"layout": "NT (A row-major, B column-major)", "python_mirror": rows, "survey_cpp_probes": survey}, indent=0))
 
 
+def ref_gen_golden(m=96, n=160, k=320, seed=20251004):
+    """The reference's own golden generator, imported and run (data only is kept: three file images)."""
+    import contextlib
+    import io
+    import os
+    import tempfile
+    sys.path.insert(0, str(REF / "deep_gemm_ascend" / "scripts"))
+    import gen_golden as ref   # the reference's module (imported, never copied)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        os.chdir(d)
+        try:
+            np.random.seed(seed)           # gen_golden.py:11-12 draws from numpy's global generator
+            with contextlib.redirect_stdout(io.StringIO()):
+                ref.gen_golden_data(m, n, k)
+            x1 = np.fromfile("input/x1_gm.bin", dtype=np.float16).reshape(m, k)
+            x2 = np.fromfile("input/x2_gm.bin", dtype=np.float16).reshape(k, n)
+            golden = np.fromfile("output/golden.bin", dtype=np.float32).reshape(m, n)
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(HERE / f"ref_gen_golden_{m}x{n}x{k}.npz", x1_gm=x1, x2_gm=x2, golden=golden,
+                        meta=np.array([m, n, k, seed], np.int64),
+                        source=np.array("deep_gemm_ascend/scripts/gen_golden.py:10-23 gen_golden_data, np.random.seed(seed), numpy " + np.__version__))
+
+
 if __name__ == "__main__":
-    O.build()
-    table(); c1(); scaled(); grouped(); configs(); op_tiling()
+    if sys.argv[1:] == ["ref_gen_golden"]:
+        ref_gen_golden()
+    else:
+        O.build()
+        table(); c1(); scaled(); grouped(); configs(); op_tiling(); ref_gen_golden()
     print("fixtures written to", HERE)
