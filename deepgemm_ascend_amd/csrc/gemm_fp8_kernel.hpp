@@ -660,7 +660,10 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
             for (int i = 0; i < STEPS; ++i) {
                 const int nt = i / TM, mt = i % TM;
                 if (i == SB) {
+#ifndef DGA_ABL_NOWAIT   // diagnostic (results are garbage): the refill is issued and moves its bytes, nobody waits for it --
+                         // the bound of what a deeper ring could save (a ring removes the WAIT, not the traffic)
                     wait_vmcnt<0>();
+#endif
                     barrier();
                 }
                 part[i % RING] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
