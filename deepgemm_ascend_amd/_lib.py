@@ -60,6 +60,41 @@ PROBLEM_CONTIGUOUS_M = 1
 CONTIGUOUS_M_ALIGNMENT = 128
 
 
+class ShardedShape(ctypes.Structure):      # dga_sharded_shape_t
+    _fields_ = [("world", c_int32), ("rank", c_int32), ("groups_total", c_int32), ("m_max", c_int32), ("n", c_int32),
+                ("k", c_int32), ("chunks", c_int32), ("max_tokens", c_int32), ("capacity_factor", c_float),
+                ("indexed", c_int32), ("policy", c_int32)]
+
+
+class ShardedLayout(ctypes.Structure):     # dga_sharded_layout_t
+    _fields_ = [("groups_local", c_int32), ("groups_per_chunk", c_int32), ("chunks", c_int32), ("kb", c_int32), ("nb", c_int32),
+                ("indexed", c_int32), ("hdr_offset", c_int64), ("row_bytes", c_int64), ("pair_capacity", c_int64),
+                ("rows_per_chunk", c_int64), ("rows_total", c_int64), ("max_tokens", c_int64),
+                ("send_bytes", ctypes.c_uint64), ("recv_bytes", ctypes.c_uint64), ("osend_bytes", ctypes.c_uint64),
+                ("oback_bytes", ctypes.c_uint64), ("slot_bytes", ctypes.c_uint64), ("rdest_bytes", ctypes.c_uint64),
+                ("row_of_slot_bytes", ctypes.c_uint64), ("pair_cnt_bytes", ctypes.c_uint64), ("masked_m_bytes", ctypes.c_uint64),
+                ("packed_a_bytes", ctypes.c_uint64), ("packed_sfa_bytes", ctypes.c_uint64), ("packed_out_bytes", ctypes.c_uint64),
+                ("events", c_int32), ("steps", c_int32)]
+
+
+class ShardedBuffers(ctypes.Structure):    # dga_sharded_buffers_t
+    _fields_ = [("send", c_void_p), ("recv", c_void_p), ("osend", c_void_p), ("oback", c_void_p), ("slot", c_void_p),
+                ("rdest", c_void_p), ("row_of_slot", c_void_p), ("pair_cnt", c_void_p), ("masked_m", c_void_p),
+                ("overflow", c_void_p), ("packed_a", c_void_p), ("packed_sfa", c_void_p), ("packed_out", c_void_p),
+                ("b", c_void_p), ("sfb", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+
+
+class ShardedStep(ctypes.Structure):       # dga_sharded_step_t
+    _fields_ = [("op", c_int32), ("stream", c_int32), ("chunk", c_int32), ("event", c_int32), ("row_begin", c_int64),
+                ("rows", c_int64), ("group_begin", c_int32), ("groups", c_int32)]
+
+
+(STEP_WAIT_EVENT, STEP_RECORD_EVENT, STEP_CLEAR_HEADERS, STEP_ROUTE_SOURCE, STEP_PACK, STEP_ZERO_COUNTS, STEP_ZERO_RESULT,
+ STEP_ALL_TO_ALL_DISPATCH, STEP_ROUTE_RECEIVED, STEP_UNPACK, STEP_GEMM, STEP_GATHER_OUT, STEP_ALL_TO_ALL_COMBINE,
+ STEP_RESTORE_ORDER) = range(14)
+ALL_TO_ALL_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p)
+
+
 DT_FP16, DT_BF16, DT_FP8_E4M3FN, DT_FP32 = 1, 2, 3, 4
 LAYOUT_ROW_MAJOR, LAYOUT_COLUMN_MAJOR = 0, 1
 
@@ -118,6 +153,12 @@ SIGNATURES = {
     "dga_copy_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p]),
     "dga_gemm_fp8_loop_clock": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(Tiling),
                                         c_void_p, c_size_t, c_int, c_void_p, POINTER(c_float), POINTER(c_float)]),
+    "dga_sharded_layout": (c_int, [POINTER(ShardedShape), POINTER(ShardedLayout)]),
+    "dga_sharded_plan": (c_int, [POINTER(ShardedShape), POINTER(ShardedStep), c_int, POINTER(c_int)]),
+    "dga_sharded_forward": (c_int, [POINTER(ShardedShape), POINTER(ShardedBuffers), c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                    c_int, POINTER(c_void_p), POINTER(c_void_p), ALL_TO_ALL_FN, c_void_p]),
+    "dga_sharded_events_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "dga_sharded_events_destroy": (c_int, [c_int, POINTER(c_void_p)]),
     "dga_mfma_ceiling": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, POINTER(c_float)]),
     "dga_status_string": (c_char_p, [c_int]),
     "dga_last_hip_error": (c_int, []),

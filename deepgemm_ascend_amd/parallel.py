@@ -25,6 +25,7 @@ as the checker; the default is the HIP operator (no CPU fallback in the product 
 """
 from __future__ import annotations
 
+import ctypes
 import time
 from typing import Callable, Optional
 
@@ -105,20 +106,20 @@ def _route_slots(keys, key_stride, key_off, rows, buckets, cap, counts, dest, ov
 
 
 class ExpertShardedGroupedGemm:
+    """First client of the C ABI's sharded forward (include/dga_hip.h: dga_sharded_layout / _plan / _forward).  The layout of
+    the exchange buffers and the step sequence come from the library; on device tensors with the default compute the library's
+    executor runs the plan (this class hands it torch.distributed.all_to_all_single as the collective callback), otherwise --
+    CPU tensors of the gloo tests, an injected `compute`, per-phase timing -- the SAME plan is interpreted here."""
+
     def __init__(self, rank: int, world: int, groups_total: int, m_max: int, n: int, k: int, device,
                  dist=None, compute: Optional[Callable] = None, chunks: Optional[int] = None,
                  capacity_factor: Optional[float] = None, max_tokens: Optional[int] = None, strict: bool = False,
                  indexed: Optional[bool] = None, policy: Optional[str] = None):
+        from . import _lib, api
         assert groups_total % world == 0, "experts must divide evenly over ranks"
         self.rank, self.world, self.dist = rank, world, dist
-        self.G, self.Gl = groups_total, groups_total // world
+        self.G = groups_total
         self.m_max, self.n, self.k = m_max, n, k
-        self.kb = (k + 127) // 128
-        self.nb = (n + 127) // 128
-        self.hdr = k + 4 * self.kb                      # byte offset of the 4-byte header in a payload row
-        # rows of the exchange buffers start on 128-byte lines: the indexed GEMM reads a row's k blocks (128 B each) where they
-        # lie, and a row stride that is not a line multiple would make every such read straddle two lines
-        self.row_bytes = (self.hdr + 4 + 127) // 128 * 128
         self.device = torch.device(device)
         assert not (strict and policy not in (None, "strict")), "strict=True contradicts policy"
         self.policy = "strict" if strict else policy          # arithmetic policy of the GEMM (api.ARITHMETIC_POLICIES)
@@ -131,22 +132,27 @@ class ExpertShardedGroupedGemm:
         # multi-GPU box.  An injected `compute` (the CPU tests) works on the packed masked layout.
         if indexed is None:
             indexed = compute is None and self.device.type == "cuda" and world == 1
-        self.indexed = bool(indexed)
-        # the tile loads address a row's scales as floats inside the payload row: K must keep them 4-byte aligned
-        if self.indexed and world > 1 and k % 4:
-            self.indexed = False
-        assert not (self.indexed and compute is not None), "an injected compute takes the packed layout"
-        self.compute = compute or (lambda a, sfa, b, sfb, out, mm, em: _default_compute_policy(a, sfa, b, sfb, out, mm, em, self.policy))
-        if chunks is None:
-            chunks = 2 if (world > 1 and self.Gl % 2 == 0 and self.Gl >= 8) else 1
-        assert self.Gl % chunks == 0, "chunks must divide the experts per rank"
-        self.chunks, self.Glc = chunks, self.Gl // chunks
+        assert not (indexed and compute is not None), "an injected compute takes the packed layout"
+        tag = api.ARITHMETIC_POLICIES.get(self.policy) if self.policy else None
+        self.shape = _lib.ShardedShape(world, rank, groups_total, m_max, n, k, int(chunks or 0), int(max_tokens or 0),
+                                       float(capacity_factor) if capacity_factor is not None else 0.0, 1 if indexed else 0,
+                                       -1 if tag is None else int(tag))
+        lay = _lib.ShardedLayout()
+        _lib.check(_lib.lib().dga_sharded_layout(ctypes.byref(self.shape), ctypes.byref(lay)), "sharded_layout")
+        self.layout = lay
+        self.Gl, self.Glc, self.chunks = lay.groups_local, lay.groups_per_chunk, lay.chunks
+        self.kb, self.nb = lay.kb, lay.nb
+        self.hdr, self.row_bytes = int(lay.hdr_offset), int(lay.row_bytes)
+        self.indexed = bool(lay.indexed)
         self.capacity_factor = capacity_factor
-        # the largest number of tokens one rank brings to a forward: it sizes the exchange slices, so every rank must
-        # pass the same value (default: what a rank's own experts can hold)
-        self.max_tokens = int(max_tokens) if max_tokens is not None else self.Gl * m_max
-        # resident buffers sized once (288 GB HBM: weights stay put); the packed masked layout [Gl, m_max, K] (+ scales, + the
-        # output) exists only where the packed path runs -- the indexed forward never touches it
+        self.max_tokens = int(lay.max_tokens)
+        if world > 1:
+            self.C = int(lay.pair_capacity)
+        steps = (_lib.ShardedStep * lay.steps)()
+        cnt = ctypes.c_int(0)
+        _lib.check(_lib.lib().dga_sharded_plan(ctypes.byref(self.shape), steps, lay.steps, ctypes.byref(cnt)), "sharded_plan")
+        self.steps = [steps[i] for i in range(cnt.value)]
+        self.compute = compute
         self._packed = None
         self.masked_m = torch.zeros((self.Gl,), dtype=torch.int32, device=device)
         self.overflow = torch.zeros((1,), dtype=torch.int32, device=device)
@@ -154,8 +160,20 @@ class ExpertShardedGroupedGemm:
         self.sfb = None
         self._T = -1
         self._side = None
+        self._events = None
+        self._cb = None
+        self._cb_error = None
+
+    def __del__(self):
+        try:
+            if self._events is not None:
+                from . import _lib
+                _lib.lib().dga_sharded_events_destroy(len(self._events), self._events)
+        except Exception:
+            pass
 
     def _packed_layout(self):
+        """The masked layout [Gl, m_max, K] (+ scales, + the output): it exists only where the packed path runs."""
         if self._packed is None:
             dev = self.device
             self._packed = (torch.zeros((self.Gl, self.m_max, self.k), dtype=torch.uint8, device=dev),
@@ -169,42 +187,40 @@ class ExpertShardedGroupedGemm:
 
     def set_weights(self, b: torch.Tensor, sfb: torch.Tensor):
         assert tuple(b.shape) == (self.Gl, self.n, self.k) and tuple(sfb.shape) == (self.Gl, self.nb, self.kb)
+        assert b.is_contiguous() and sfb.is_contiguous() and sfb.dtype == torch.float32
         self.b, self.sfb = b, sfb
 
     def owner(self, g):
         return g // self.Gl
 
     def pair_capacity(self, tokens: int) -> int:
-        """Rows reserved per (expert chunk, destination rank).  The bound min(tokens, experts in the chunk x m_max) cannot
-        overflow before an expert does; capacity_factor trades that guarantee for less padding on the wire."""
-        bound = max(1, min(tokens, self.Glc * self.m_max))
-        if self.capacity_factor is None:
-            return bound
-        even = tokens / float(self.world * self.chunks)
-        return int(min(bound, max(16, -(-int(np.ceil(self.capacity_factor * even)) // 16) * 16)))
+        """Rows reserved per (expert chunk, destination rank) for a rank that brings `tokens` tokens (dga_sharded_layout)."""
+        from . import _lib
+        sh = _lib.ShardedShape.from_buffer_copy(self.shape)
+        sh.max_tokens = int(tokens)
+        lay = _lib.ShardedLayout()
+        _lib.check(_lib.lib().dga_sharded_layout(ctypes.byref(sh), ctypes.byref(lay)), "sharded_layout")
+        return int(lay.pair_capacity) if self.world > 1 else max(1, min(int(tokens), self.Glc * self.m_max))
 
     def _ensure(self, tokens: int):
-        """Static exchange buffers, allocated once for max_tokens rows (the same size on every rank)."""
+        """Static exchange buffers, allocated once for max_tokens rows (the same size on every rank), sized by the layout."""
         if tokens > self.max_tokens:
             raise ValueError(f"{tokens} tokens on rank {self.rank} > max_tokens {self.max_tokens} the engine was built for")
         if self._T >= 0:
             return
-        dev, w, ch = self.device, self.world, self.chunks
+        dev, lay = self.device, self.layout
         self._T = self.max_tokens
         self.slot = torch.empty((max(self.max_tokens, 1),), dtype=torch.int64, device=dev)
         self.row_of_slot = torch.zeros((self.Gl * self.m_max,), dtype=torch.int64, device=dev) if self.indexed else None
-        if w == 1:
-            self.indexed = self.indexed and self.max_tokens * self.k < 2 ** 31 - 1    # 32-bit offsets in the tile loads
+        if self.world == 1:
             return
-        C = self.C = self.pair_capacity(self.max_tokens)
-        rows = ch * w * C
-        self.pair_cnt = torch.zeros((ch * w,), dtype=torch.int32, device=dev)
+        rows = int(lay.rows_total)
+        self.pair_cnt = torch.zeros((self.chunks * self.world,), dtype=torch.int32, device=dev)
         self.send = torch.zeros((rows, self.row_bytes), dtype=torch.uint8, device=dev)
         self.recv = torch.zeros((rows, self.row_bytes), dtype=torch.uint8, device=dev)
         self.rdest = torch.empty((rows,), dtype=torch.int64, device=dev)
         self.osend = torch.zeros((rows, self.n), dtype=torch.bfloat16, device=dev)
         self.oback = torch.zeros((rows, self.n), dtype=torch.bfloat16, device=dev)
-        self.indexed = self.indexed and rows * self.row_bytes < 2 ** 31 - 1
         if dev.type == "cuda" and self._side is None:
             self._side = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
 
@@ -215,110 +231,153 @@ class ExpertShardedGroupedGemm:
             raise ValueError(f"capacity exceeded: an expert received more than m_max = {self.m_max} rows, or a "
                              f"(chunk, rank) pair more than its {getattr(self, 'C', self.m_max)} reserved rows")
 
-    # ------------------------------------------------------------------ world 1: route straight into the masked layout
-    def _forward_local(self, tok_q, tok_sf, expert_ids, expected_m, marks):
+    # ------------------------------------------------------------------ the library's executor (device tensors)
+    def _forward_library(self, tok_q, tok_sf, expert_ids, expected_m, overlap: bool):
+        from . import _lib, api
+        L = _lib.lib()
         T = tok_q.shape[0]
-        # the indexed GEMM reads the caller's rows where they lie: it needs plain [T, K] bytes and [T, KB] float rows
-        indexed = (self.indexed and tok_q.is_contiguous() and tok_sf.is_contiguous() and tok_sf.dtype == torch.float32
-                   and tuple(tok_sf.shape) == (T, self.kb))
-        if indexed:
-            from . import api
-            _route_slots(expert_ids, 8, 0, T, self.Gl, self.m_max, self.masked_m, self.slot, self.overflow,
-                         inverse=self.row_of_slot)
-            marks("route")
-            # zeros: the row of a token that found no slot (a full expert: check() reports it) is never written
-            res = torch.zeros((T, self.n), dtype=torch.bfloat16, device=self.device)
-            api.m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(tok_q, tok_sf, 0, self.kb, (self.b, self.sfb), res,
-                                                              self.row_of_slot, self.masked_m, self.m_max,
-                                                              expected_m or self.m_max, policy=self.policy)
-            marks("gemm")
-            return res
-        flat_a = self.a.view(self.Gl * self.m_max, self.k)
-        flat_sfa = self.sfa.view(self.Gl * self.m_max, self.kb).view(torch.uint8)
-        _route_slots(expert_ids, 8, 0, T, self.Gl, self.m_max, self.masked_m, self.slot, self.overflow)
-        marks("route")
-        _rows2(flat_a, tok_q, self.k, flat_sfa, tok_sf.view(torch.uint8), 4 * self.kb, self.slot[:T])
-        marks("pack")
-        self.compute(self.a, self.sfa, self.b, self.sfb, self.out, self.masked_m, expected_m or self.m_max)
-        marks("gemm")
-        res = torch.zeros((T, self.n), dtype=torch.bfloat16, device=self.device)   # dropped tokens' rows stay zero
-        _rows(res.view(torch.uint8), self.out.view(self.Gl * self.m_max, self.n).view(torch.uint8), src_index=self.slot[:T],
-              row_bytes=2 * self.n)
-        marks("unpack")
+        dev = self.device
+        res = torch.empty((T, self.n), dtype=torch.bfloat16, device=dev)     # zeroed by the plan's ZERO_RESULT step
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        bufs = _lib.ShardedBuffers()
+        if self.world > 1:
+            bufs.send, bufs.recv, bufs.osend, bufs.oback = ptr(self.send), ptr(self.recv), ptr(self.osend), ptr(self.oback)
+            bufs.rdest, bufs.pair_cnt = ptr(self.rdest), ptr(self.pair_cnt)
+        bufs.slot, bufs.row_of_slot = ptr(self.slot), ptr(self.row_of_slot)
+        bufs.masked_m, bufs.overflow = ptr(self.masked_m), ptr(self.overflow)
+        if not self.indexed:
+            bufs.packed_a, bufs.packed_sfa, bufs.packed_out = ptr(self.a), ptr(self.sfa), ptr(self.out)
+        bufs.b, bufs.sfb = ptr(self.b), ptr(self.sfb)
+        with torch.cuda.device(dev):
+            main = torch.cuda.current_stream(dev)
+            t = api.tiling(self.m_max, self.n, self.k, groups=self.Glc, expected_m=int(expected_m or self.m_max))
+            ws_ptr, ws_bytes = api._workspace(t, dev)
+            bufs.workspace, bufs.workspace_bytes = ws_ptr, ws_bytes
+            if self.world > 1 and overlap:
+                handles = [main.cuda_stream, self._side[0].cuda_stream, self._side[1].cuda_stream]
+            else:
+                handles = [main.cuda_stream] * 3
+            streams = (ctypes.c_void_p * 3)(*handles)
+            if self.world > 1 and self._events is None:
+                ev = (ctypes.c_void_p * int(self.layout.events))()
+                _lib.check(L.dga_sharded_events_create(len(ev), ev), "sharded_events_create")
+                self._events = ev
+            if self.world > 1 and self._cb is None:
+                per = int(self.layout.rows_per_chunk)
+
+                def a2a(user, direction, chunk, send, recv, bytes_per_peer, stream):
+                    try:   # the executor says which stream the collective belongs on; torch wants it as the current stream
+                        sl = slice(chunk * per, (chunk + 1) * per)
+                        with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
+                            if direction == 0:
+                                self.dist.all_to_all_single(self.recv[sl], self.send[sl])
+                            else:
+                                self.dist.all_to_all_single(self.oback[sl], self.osend[sl])
+                        return 0
+                    except BaseException as e:   # never let an exception cross the C frames
+                        self._cb_error = e
+                        return 1
+                self._cb = _lib.ALL_TO_ALL_FN(a2a)
+            cb = self._cb if self.world > 1 else _lib.ALL_TO_ALL_FN()
+            rc = L.dga_sharded_forward(ctypes.byref(self.shape), ctypes.byref(bufs), tok_q.data_ptr(), tok_sf.data_ptr(),
+                                       expert_ids.data_ptr(), T, res.data_ptr(), int(expected_m or 0), streams,
+                                       self._events if self.world > 1 else None, cb, None)
+            if self._cb_error is not None:
+                e, self._cb_error = self._cb_error, None
+                raise e
+            _lib.check(rc, "sharded_forward")
         return res
 
-    # ------------------------------------------------------------------ world > 1
-    def _forward_sharded(self, tok_q, tok_sf, expert_ids, expected_m, marks, overlap):
-        T, w, ch, C = tok_q.shape[0], self.world, self.chunks, self.C
-        per = w * C                                             # rows of one chunk's exchange
+    # ------------------------------------------------------------------ the same plan, interpreted (CPU tensors, injected compute, phases)
+    def _forward_interpreted(self, tok_q, tok_sf, expert_ids, expected_m, marks, overlap: bool):
+        from . import _lib
+        T, w, ch = tok_q.shape[0], self.world, self.chunks
+        cuda = tok_q.is_cuda
+        em = expected_m or self.m_max
+        res = torch.empty((T, self.n), dtype=torch.bfloat16, device=self.device)
+        main = torch.cuda.current_stream(self.device) if cuda else None
+        side = self._side if (cuda and overlap and w > 1) else (main, main)
+        streams = (main, side[0], side[1])
+        events = {}
+        compute = self.compute or (lambda a, sfa, b, sfb, out, mm, e: _default_compute_policy(a, sfa, b, sfb, out, mm, e, self.policy))
         if not self.indexed:
             flat_a = self.a.view(self.Gl * self.m_max, self.k)
             flat_sfa = self.sfa.view(self.Gl * self.m_max, self.kb).view(torch.uint8)
             flat_out = self.out.view(self.Gl * self.m_max, self.n).view(torch.uint8)
-        cuda = tok_q.is_cuda
-        # ---- source side: slot of every token in its (chunk, destination) slice, header = expert index on its owner
-        self.send[:, self.hdr:self.hdr + 4] = 255              # every header -1: rows nobody fills are skipped by the receiver
-        _route_slots(expert_ids, 8, 0, T, ch * w, C, self.pair_cnt, self.slot, self.overflow, key_div=self.Gl,
-                     key_sub=self.Glc, key_mul=w, tags=self.send, tag_stride=self.row_bytes, tag_off=self.hdr)
-        marks("route")
-        _rows2(self.send, tok_q, self.k, self.send, tok_sf.view(torch.uint8), 4 * self.kb, self.slot[:T], dst1_off=self.k)
-        self.masked_m.zero_()
-        marks("pack")
-        main = torch.cuda.current_stream(self.device) if cuda else None
-        s_disp, s_comb = self._side if (cuda and overlap) else (main, main)
-        ev_d, ev_g, ev_c = [], [], []
-
-        def on(stream):
-            return torch.cuda.stream(stream) if cuda else _Null()
-
-        if cuda and overlap:
-            s_disp.wait_stream(main)
-        for c in range(ch):                                     # dispatch: exchange, then receive-side slots + scatter
-            with on(s_disp):
-                sl = slice(c * per, (c + 1) * per)
-                self.dist.all_to_all_single(self.recv[sl], self.send[sl])
-                _route_slots(self.recv[sl], self.row_bytes, self.hdr, per, self.Gl, self.m_max, self.masked_m,
-                             self.rdest[sl], self.overflow, zero_counts=False,
-                             inverse=self.row_of_slot if self.indexed else None, inverse_base=c * per)
-                if not self.indexed:
-                    _rows2(flat_a, self.recv[sl], self.k, flat_sfa, self.recv[sl], 4 * self.kb, self.rdest[sl],
-                           src1_off=self.k)
-                if cuda and overlap:
-                    ev_d.append(torch.cuda.Event()); ev_d[-1].record(s_disp)
-        marks("dispatch")
-        for c in range(ch):                                     # grouped GEMM of the chunk's experts
-            if cuda and overlap:
-                main.wait_event(ev_d[c])
-            g0, g1 = c * self.Glc, (c + 1) * self.Glc
-            if self.indexed:    # rows read from the receive buffer, results written into the buffer that travels back
-                from . import api
-                api.m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(
-                    self.recv, self.recv, self.k, self.row_bytes // 4, (self.b[g0:g1], self.sfb[g0:g1]), self.osend,
-                    self.row_of_slot[g0 * self.m_max:g1 * self.m_max], self.masked_m[g0:g1], self.m_max,
-                    expected_m or self.m_max, policy=self.policy)
-            else:
-                self.compute(self.a[g0:g1], self.sfa[g0:g1], self.b[g0:g1], self.sfb[g0:g1], self.out[g0:g1],
-                             self.masked_m[g0:g1], expected_m or self.m_max)
-            if cuda and overlap:
-                ev_g.append(torch.cuda.Event()); ev_g[-1].record(main)
-        marks("gemm")
-        for c in range(ch):                                     # combine: rows back in arrival order, exchange
-            with on(s_comb):
-                if cuda and overlap:
-                    s_comb.wait_event(ev_g[c])
-                sl = slice(c * per, (c + 1) * per)
-                if not self.indexed:
+        phase_of = {_lib.STEP_ROUTE_SOURCE: "route", _lib.STEP_PACK: "pack", _lib.STEP_ZERO_COUNTS: "pack",
+                    _lib.STEP_ROUTE_RECEIVED: "dispatch", _lib.STEP_UNPACK: "dispatch", _lib.STEP_ALL_TO_ALL_DISPATCH: "dispatch",
+                    _lib.STEP_GEMM: "gemm", _lib.STEP_GATHER_OUT: "combine", _lib.STEP_ALL_TO_ALL_COMBINE: "combine",
+                    _lib.STEP_RESTORE_ORDER: "unpack"}
+        last_phase = None
+        for st in self.steps:
+            ph = phase_of.get(st.op)
+            if ph is not None and last_phase is not None and ph != last_phase:
+                marks(last_phase)
+            last_phase = ph or last_phase
+            stream = streams[st.stream]
+            ctx = torch.cuda.stream(stream) if (cuda and stream is not None) else _Null()
+            sl = slice(int(st.row_begin), int(st.row_begin + st.rows))
+            g0, g1 = int(st.group_begin), int(st.group_begin + st.groups)
+            with ctx:
+                if st.op == _lib.STEP_WAIT_EVENT:
+                    if cuda and overlap and w > 1:
+                        stream.wait_event(events[st.event])
+                elif st.op == _lib.STEP_RECORD_EVENT:
+                    if cuda and overlap and w > 1:
+                        events[st.event] = torch.cuda.Event(); events[st.event].record(stream)
+                elif st.op == _lib.STEP_CLEAR_HEADERS:
+                    self.send[:, self.hdr:self.hdr + 4] = 255
+                elif st.op == _lib.STEP_ROUTE_SOURCE:
+                    if w == 1:
+                        _route_slots(expert_ids, 8, 0, T, self.Gl, self.m_max, self.masked_m, self.slot, self.overflow,
+                                     inverse=self.row_of_slot if self.indexed else None)
+                    else:
+                        _route_slots(expert_ids, 8, 0, T, ch * w, self.C, self.pair_cnt, self.slot, self.overflow, key_div=self.Gl,
+                                     key_sub=self.Glc, key_mul=w, tags=self.send, tag_stride=self.row_bytes, tag_off=self.hdr)
+                elif st.op == _lib.STEP_PACK:
+                    if w == 1:
+                        _rows2(flat_a, tok_q, self.k, flat_sfa, tok_sf.view(torch.uint8), 4 * self.kb, self.slot[:T])
+                    else:
+                        _rows2(self.send, tok_q, self.k, self.send, tok_sf.view(torch.uint8), 4 * self.kb, self.slot[:T],
+                               dst1_off=self.k)
+                elif st.op == _lib.STEP_ZERO_COUNTS:
+                    self.masked_m.zero_()
+                elif st.op == _lib.STEP_ZERO_RESULT:
+                    res.zero_()                       # dropped tokens' rows stay zero
+                elif st.op == _lib.STEP_ALL_TO_ALL_DISPATCH:
+                    self.dist.all_to_all_single(self.recv[sl], self.send[sl])
+                elif st.op == _lib.STEP_ROUTE_RECEIVED:
+                    _route_slots(self.recv[sl], self.row_bytes, self.hdr, int(st.rows), self.Gl, self.m_max, self.masked_m,
+                                 self.rdest[sl], self.overflow, zero_counts=False,
+                                 inverse=self.row_of_slot if self.indexed else None, inverse_base=int(st.row_begin))
+                elif st.op == _lib.STEP_UNPACK:
+                    _rows2(flat_a, self.recv[sl], self.k, flat_sfa, self.recv[sl], 4 * self.kb, self.rdest[sl], src1_off=self.k)
+                elif st.op == _lib.STEP_GEMM:
+                    if self.indexed:
+                        from . import api
+                        if w == 1:
+                            api.m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(tok_q, tok_sf, 0, self.kb, (self.b, self.sfb), res,
+                                                                              self.row_of_slot, self.masked_m, self.m_max, em,
+                                                                              policy=self.policy)
+                        else:
+                            api.m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(
+                                self.recv, self.recv, self.k, self.row_bytes // 4, (self.b[g0:g1], self.sfb[g0:g1]), self.osend,
+                                self.row_of_slot[g0 * self.m_max:g1 * self.m_max], self.masked_m[g0:g1], self.m_max, em,
+                                policy=self.policy)
+                    else:
+                        compute(self.a[g0:g1], self.sfa[g0:g1], self.b[g0:g1], self.sfb[g0:g1], self.out[g0:g1],
+                                self.masked_m[g0:g1], em)
+                elif st.op == _lib.STEP_GATHER_OUT:
                     _rows(self.osend[sl].view(torch.uint8), flat_out, src_index=self.rdest[sl], row_bytes=2 * self.n)
-                self.dist.all_to_all_single(self.oback[sl], self.osend[sl])
-                if cuda and overlap:
-                    ev_c.append(torch.cuda.Event()); ev_c[-1].record(s_comb)
-        if cuda and overlap:
-            for e in ev_c:
-                main.wait_event(e)
-        marks("combine")
-        res = torch.zeros((T, self.n), dtype=torch.bfloat16, device=self.device)   # dropped tokens' rows stay zero
-        _rows(res.view(torch.uint8), self.oback.view(torch.uint8), src_index=self.slot[:T], row_bytes=2 * self.n)
-        marks("unpack")
+                elif st.op == _lib.STEP_ALL_TO_ALL_COMBINE:
+                    self.dist.all_to_all_single(self.oback[sl], self.osend[sl])
+                elif st.op == _lib.STEP_RESTORE_ORDER:
+                    src = flat_out if w == 1 else self.oback.view(torch.uint8)
+                    _rows(res.view(torch.uint8), src, src_index=self.slot[:T], row_bytes=2 * self.n)
+                else:
+                    raise ValueError(f"unknown plan step {st.op}")
+        if last_phase is not None:
+            marks(last_phase)
         return res
 
     def forward(self, tok_q, tok_sf, expert_ids, expected_m: int = 0, phase_us: Optional[dict] = None) -> torch.Tensor:
@@ -327,6 +386,8 @@ class ExpertShardedGroupedGemm:
         phase_us: a dict that receives the device time of each phase (the phases then run back to back on one stream)."""
         T = tok_q.shape[0]
         assert expert_ids.dtype == torch.int64 and expert_ids.is_contiguous()
+        assert tok_q.is_contiguous() and tok_sf.is_contiguous() and tok_sf.dtype == torch.float32
+        assert tuple(tok_q.shape) == (T, self.k) and tuple(tok_sf.shape) == (T, self.kb)
         self._ensure(T)
         cuda = tok_q.is_cuda
         events = []
@@ -335,11 +396,11 @@ class ExpertShardedGroupedGemm:
             if phase_us is not None and cuda:
                 e = torch.cuda.Event(enable_timing=True); e.record(); events.append((name, e))
 
-        marks("start")
-        if self.world == 1:
-            res = self._forward_local(tok_q, tok_sf, expert_ids, expected_m, marks)
+        if cuda and self.compute is None and phase_us is None:
+            res = self._forward_library(tok_q, tok_sf, expert_ids, expected_m, overlap=True)
         else:
-            res = self._forward_sharded(tok_q, tok_sf, expert_ids, expected_m, marks, overlap=phase_us is None)
+            marks("start")
+            res = self._forward_interpreted(tok_q, tok_sf, expert_ids, expected_m, marks, overlap=phase_us is None)
         if phase_us is not None and cuda:
             torch.cuda.synchronize()
             for (_, e0), (name, e1) in zip(events[:-1], events[1:]):
@@ -349,7 +410,8 @@ class ExpertShardedGroupedGemm:
         return res
 
     def run_local(self, expected_m: int = 0):
-        self.compute(self.a, self.sfa, self.b, self.sfb, self.out, self.masked_m, expected_m or self.m_max)
+        compute = self.compute or (lambda a, sfa, b, sfb, out, mm, e: _default_compute_policy(a, sfa, b, sfb, out, mm, e, self.policy))
+        compute(self.a, self.sfa, self.b, self.sfb, self.out, self.masked_m, expected_m or self.m_max)
 
 
 class _Null:

@@ -313,6 +313,98 @@ int dga_copy_rows2(void *dst0, int64_t dst0_row_stride, const void *src0, int64_
                    void *dst1, int64_t dst1_row_stride, const void *src1, int64_t src1_row_stride, int64_t row_bytes1,
                    const int64_t *dst_index, const int64_t *src_index, int64_t rows, void *stream);
 
+/* ---- the expert-sharded forward behind the C ABI (csrc/dga_sharded.cpp) ----------------------------------
+ * What a C++ host (the reference's host language: framework/csrc/python_api.cpp) calls to run BASELINE configs[4]: expert g
+ * lives on rank g / (groups_total / world), one all-to-all of payload rows each way, every shape static, nothing read back.
+ * The library computes the buffer layout, the fixed step sequence ("plan") and executes it on the caller's streams; the two
+ * collectives are the caller's (a callback), so the library does not link RCCL.  The reference has no counterpart ("multi-card"
+ * = independent processes: benchmark_msprof/main.cpp:24-26, framework/benchmark/benchmark.py:249-253). */
+typedef struct dga_sharded_shape_t {
+    int32_t world, rank;
+    int32_t groups_total;     /* experts over all ranks (a multiple of world) */
+    int32_t m_max, n, k;      /* rows per expert (capacity), output columns, reduction length */
+    int32_t chunks;           /* a rank's experts are processed in this many chunks, whose dispatch / GEMM / combine overlap on
+                                 three streams; <= 0: 2 when world > 1 and the experts per rank allow it, else 1 */
+    int32_t max_tokens;       /* the largest number of tokens one rank brings to a forward (sizes the exchange slices: the same
+                                 on every rank); <= 0: groups_local * m_max */
+    float capacity_factor;    /* rows reserved per (chunk, destination rank) = this x the even share, rounded up to 16;
+                                 <= 0: the provable bound min(max_tokens, experts per chunk x m_max) */
+    int32_t indexed;          /* 1: the GEMM gathers its rows from the receive buffer and scatters results into the buffer that
+                                 travels back (no unpack / gather copy); 0: packed masked layout */
+    int32_t policy;           /* dispatchPolicyTag of the GEMM (DGA_POLICY_STRICT, DGA_POLICY_BF16_EXACT, ...) or -1 = the tiling's */
+} dga_sharded_shape_t;
+
+/* Payload row of the dispatch exchange: [K fp8 bytes][ceil(K/128) fp32 scales][int32 header = expert index on its owner, -1 =
+ * unused row], padded to a multiple of 128 bytes.  Exchange buffers hold chunks x world x pair_capacity rows; a rank sends
+ * peer p the rows [c * rows_per_chunk + p * pair_capacity, + pair_capacity) of chunk c (EQUAL splits: a static shape). */
+typedef struct dga_sharded_layout_t {
+    int32_t groups_local, groups_per_chunk, chunks, kb, nb;
+    int32_t indexed;          /* the shape's flag after the limits are applied (32-bit tile offsets, K % 4) */
+    int64_t hdr_offset, row_bytes, pair_capacity, rows_per_chunk, rows_total, max_tokens;
+    uint64_t send_bytes, recv_bytes;       /* payload rows out / in */
+    uint64_t osend_bytes, oback_bytes;     /* bf16 [rows_total, n] result rows out / back */
+    uint64_t slot_bytes;                   /* int64 [max_tokens]: slot of every token */
+    uint64_t rdest_bytes;                  /* int64 [rows_total]: row of every received row in the masked layout */
+    uint64_t row_of_slot_bytes;            /* int64 [groups_local * m_max]: slot -> source row (indexed only) */
+    uint64_t pair_cnt_bytes;               /* int32 [chunks * world] */
+    uint64_t masked_m_bytes;               /* int32 [groups_local]: rows every local expert received (the GEMM's masked_m) */
+    uint64_t packed_a_bytes, packed_sfa_bytes, packed_out_bytes;   /* the masked layout [Gl, m_max, .] (packed path only) */
+    int32_t events;           /* events the executor needs (dga_sharded_events_create) */
+    int32_t steps;            /* length of the plan */
+} dga_sharded_layout_t;
+
+typedef struct dga_sharded_buffers_t {
+    void *send, *recv, *osend, *oback;
+    int64_t *slot, *rdest, *row_of_slot;
+    int32_t *pair_cnt, *masked_m;
+    int32_t *overflow;        /* sticky device flag: a full expert / pair slice dropped a row (the caller clears and inspects it) */
+    void *packed_a; float *packed_sfa; void *packed_out;
+    const void *b;            /* resident weights of this rank: [groups_local, n, k] e4m3fn */
+    const float *sfb;         /* [groups_local, ceil(n/128), ceil(k/128)] */
+    void *workspace; size_t workspace_bytes;   /* dga_workspace_bytes of the grouped tiling (may be NULL) */
+} dga_sharded_buffers_t;
+
+/* Steps of the plan.  stream: 0 = the caller's, 1 = dispatch side stream, 2 = combine side stream. */
+enum { DGA_STEP_WAIT_EVENT = 0,          /* stream waits for event */
+       DGA_STEP_RECORD_EVENT = 1,        /* event recorded on stream */
+       DGA_STEP_CLEAR_HEADERS = 2,       /* header of every send row = -1 */
+       DGA_STEP_ROUTE_SOURCE = 3,        /* dga_route_slots on the tokens' expert ids (+ header tags) */
+       DGA_STEP_PACK = 4,                /* dga_copy_rows2: token bytes + scales into their slots */
+       DGA_STEP_ZERO_COUNTS = 5,         /* masked_m = 0 */
+       DGA_STEP_ZERO_RESULT = 6,         /* result rows = 0 (a dropped token's row is never written) */
+       DGA_STEP_ALL_TO_ALL_DISPATCH = 7, /* the callback, direction 0: payload rows of one chunk */
+       DGA_STEP_ROUTE_RECEIVED = 8,      /* dga_route_slots keyed by the received headers: masked_m and the row tables */
+       DGA_STEP_UNPACK = 9,              /* packed path: received rows into the masked layout */
+       DGA_STEP_GEMM = 10,               /* the grouped masked-M GEMM of a chunk's experts */
+       DGA_STEP_GATHER_OUT = 11,         /* packed path: result rows into the buffer that travels back */
+       DGA_STEP_ALL_TO_ALL_COMBINE = 12, /* the callback, direction 1: bf16 result rows of one chunk */
+       DGA_STEP_RESTORE_ORDER = 13 };    /* result[t] = returned row slot[t] */
+typedef struct dga_sharded_step_t {
+    int32_t op, stream, chunk, event;
+    int64_t row_begin, rows;             /* slice of the exchange buffers */
+    int32_t group_begin, groups;         /* local experts of the step */
+} dga_sharded_step_t;
+
+/* The collective: send peer p the `bytes_per_peer` bytes at send + p * bytes_per_peer, receive its slice at recv + p *
+ * bytes_per_peer, asynchronously on `stream` (ncclGroupStart; ncclSend/ncclRecv x world; ncclGroupEnd -- or ncclAllToAll).
+ * direction 0 = dispatch, 1 = combine.  Returns 0 on success. */
+typedef int (*dga_all_to_all_fn)(void *user, int direction, int chunk, const void *send, void *recv, size_t bytes_per_peer,
+                                 void *stream);
+
+int dga_sharded_layout(const dga_sharded_shape_t *shape, dga_sharded_layout_t *out);
+/* steps == NULL: *count = the plan's length.  Pure host arithmetic (no device is touched). */
+int dga_sharded_plan(const dga_sharded_shape_t *shape, dga_sharded_step_t *steps, int capacity, int *count);
+/* One forward: tok_q [tokens, k] e4m3fn, tok_sf [tokens, ceil(k/128)] f32, expert_ids int64 [tokens] (global expert of every
+ * token), all device memory -> result bf16 [tokens, n] in token order.  streams[3]: hipStream_t (they may all be the same one);
+ * events: layout.events handles (dga_sharded_events_create).  Asynchronous; nothing is read back; capturable in a HIP graph.
+ * world == 1: no exchange, all_to_all and events may be NULL. */
+int dga_sharded_forward(const dga_sharded_shape_t *shape, const dga_sharded_buffers_t *buffers, const void *tok_q,
+                        const float *tok_sf, const int64_t *expert_ids, int tokens, void *result, int expected_m,
+                        void *const *streams, void *const *events, dga_all_to_all_fn all_to_all, void *user);
+/* hipEvent_t handles (timing disabled) for the executor: host objects, no device memory. */
+int dga_sharded_events_create(int count, void **events);
+int dga_sharded_events_destroy(int count, void **events);
+
 /* ---- diagnostics ------------------------------------------------------------------------- */
 
 /* The shader clock held inside the dense kernel's main loop ("record the measured clock" beside the

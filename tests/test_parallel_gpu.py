@@ -97,25 +97,45 @@ def test_phase_timings_are_reported(dga):
 
 
 class _FakeDist:
-    """all_to_all_single between engines that live in threads of one process (equal splits, device copies)."""
+    """all_to_all_single between engines that live in threads of one process: equal splits, device copies ORDERED BY EVENTS
+    on the stream the engine calls it on -- no device synchronisation anywhere, so the dispatch / GEMM / combine streams of
+    an engine (and the two engines) really run concurrently, as they would around an RCCL collective.  The host barrier only
+    makes sure both ranks have posted their buffers."""
 
     def __init__(self, rank, world, box, barrier):
         self.rank, self.world, self.box, self.barrier = rank, world, box, barrier
 
     def all_to_all_single(self, out, inp):
-        self.box[self.rank] = inp
-        torch.cuda.synchronize()
+        s = torch.cuda.current_stream()
+        ready = torch.cuda.Event(); ready.record(s)                 # my send slice is complete at this point of MY stream
+        self.box[self.rank] = (inp, ready, None)
         self.barrier.wait()
         per = inp.shape[0] // self.world
         for src in range(self.world):
-            out[src * per:(src + 1) * per].copy_(self.box[src][self.rank * per:(self.rank + 1) * per])
-        torch.cuda.synchronize()
+            buf, ev, _ = self.box[src]
+            s.wait_event(ev)                                        # the peer's slice is complete
+            out[src * per:(src + 1) * per].copy_(buf[self.rank * per:(self.rank + 1) * per], non_blocking=True)
+        done = torch.cuda.Event(); done.record(s)                   # I have read every peer's buffer
+        self.box[self.rank] = (inp, ready, done)
+        self.barrier.wait()
+        for src in range(self.world):                               # nobody overwrites a send buffer a peer is still reading
+            s.wait_event(self.box[src][2])
         self.barrier.wait()
 
 
+def _library_packed_engine(rank, world, dist, **kw):
+    """The packed path through the LIBRARY's executor (no injected compute): strict policy, unpack / gather copies."""
+    from deepgemm_ascend_amd.parallel import ExpertShardedGroupedGemm
+    return ExpertShardedGroupedGemm(rank, world, G_TOTAL, M_MAX, N, K, "cuda", dist, strict=True, max_tokens=128,
+                                    indexed=False, **kw)
+
+
 @pytest.mark.parametrize("chunks,capacity_factor,indexed", [(1, None, True), (2, None, True), (2, 2.5, True),
-                                                            (2, None, False)])
+                                                            (2, None, False), (2, None, "library_packed"),
+                                                            (1, 2.5, "library_packed")])
 def test_world2_emulated_on_one_device(dga, oracle, chunks, capacity_factor, indexed):
+    """indexed True / "library_packed": dga_sharded_forward (the C ABI's executor) runs the plan, this test's fake exchange is
+    its collective callback; indexed False: the same plan interpreted in Python around an injected compute."""
     world = 2
     b, sfb, toks = _data(world)
     gl = G_TOTAL // world
@@ -125,8 +145,9 @@ def test_world2_emulated_on_one_device(dga, oracle, chunks, capacity_factor, ind
     def run(rank):
         try:
             torch.cuda.set_device(0)
-            eng = _engine(rank, world, _FakeDist(rank, world, box, barrier), indexed, chunks=chunks,
-                          capacity_factor=capacity_factor)
+            mk = _library_packed_engine if indexed == "library_packed" else (lambda r, w, d, **kw: _engine(r, w, d, indexed, **kw))
+            eng = mk(rank, world, _FakeDist(rank, world, box, barrier), chunks=chunks, capacity_factor=capacity_factor)
+            assert eng.indexed == (indexed is True)
             eng.set_weights(torch.from_numpy(b[rank * gl:(rank + 1) * gl]).cuda(),
                             torch.from_numpy(sfb[rank * gl:(rank + 1) * gl]).cuda())
             q, sf, ids = toks[rank]
