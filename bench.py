@@ -123,11 +123,18 @@ def make_dense_inputs(m, n, k, seed):
     return qa.contiguous(), sa.contiguous().float(), qb.contiguous(), sb.contiguous().float()
 
 
+def pmc_traffic_source():
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        if (ROOT / "profiles" / name).exists():
+            return f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel (a committed measurement, not this run)"
+    return None
+
+
 def pmc_traffic(workload: str):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r0N_traffic.json: FETCH_SIZE and
     WRITE_SIZE collected in separate passes and corrected as MI355X_MICROARCH.md prescribes).  PMC counters cannot be
     read from inside this process, so this is the figure of the profiled run of the same kernel, not of this run."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             d = json.loads((ROOT / "profiles" / name).read_text())
             return int(d[workload]["traffic_bytes"])
@@ -498,6 +505,7 @@ def main():
     res["roofline"] = roofline_mfma(dga, a, sfa, b, sfb, out, t, m, n, k, kernel_us, cus)
     if args.workload == "dense_4096":
         res["roofline"]["traffic"] = pmc_traffic("dense")
+        res["roofline"]["traffic_source"] = pmc_traffic_source()
 
     if rank == 0 and not args.no_parity:
         try:
@@ -522,6 +530,10 @@ def main():
         res["policies"], strict_out = policy_legs(dga, a, sfa, b, sfb, m, n, k, args,
                                                   {"kernel_us": round(kernel_us, 3), "roofline": res["roofline"],
                                                    "parity": res.get("parity")}, ceilings)
+        bx = res["policies"].get("bf16_exact", {}).get("roofline")
+        if isinstance(bx, dict) and args.workload == "dense_4096":
+            bx["traffic"] = pmc_traffic("dense_bf16_exact")
+            bx["algorithmic_bytes"] = res["roofline"]["algorithmic_bytes"]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(m, n, k, a, sfa, b, sfb, gpu_out=out, budget_s=args.cpu_budget,

@@ -773,6 +773,11 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         //     tile), raw bytes read one tile ahead into two alternating buffers;
         //   * the promotion of tile t rides on tile t + LAGT (the first tiles of a block promote the previous block's last
         //     ones with that block's scales); the refill DMA rides on the second tile onward.
+        // Measured (scripts/ubench/stamp_tile_bx128x256, profiles/r03_bf16_exact.txt): 3440 ticks per k block against 2048 of
+        // matrix pipe and ~2870 of the register-resident loop with the same vector work (dga_mfma_ceiling mode 1): the gap is the
+        // barrier (the older wave of each SIMD wins every arbitration, finishes its block in 2036 ticks and waits 1222 for its
+        // partner; a priority that falls as a wave advances -- s_setprio 3..0 per quarter block -- evens the two out, 2699 / 3119,
+        // and changes the total by 0.8 %: the sum of the two waves' issue slots is what counts, not who takes them).
         static_assert(PP == 0 && Cfg::STAGES == 3 && !LC, "bf16-exact: plain loop, three stages, no loader waves");
         static_assert((TM == 2 || TM == 4) && (TN == 2 || TN == 4), "bf16-exact: wave tiles of 32..64 x 32..64");
         constexpr int STG = 3, NL = Cfg::LOADS_PER_STAGE, TILES = TM * TN, G = 4 * TM, LAGT = 2, RING = 4;

@@ -14,6 +14,9 @@
 #include <vector>
 #include "gemm_fp8_kernel.hpp"
 using namespace dga;
+#ifndef CFG_MATH
+#define CFG_MATH 0      // 1: the bf16-exact loop (gemm_fp8_kernel.hpp MATH = 1; three stages, no loader waves)
+#endif
 #ifndef CFG_BM
 #define CFG_BM 128
 #define CFG_BN 256
@@ -46,7 +49,7 @@ int main(int argc, char **argv)
     const int grid = p.tiles_m * p.tiles_n, waves = Cfg::NT / 64, cwaves = Cfg::kWM * Cfg::kWN;
     hipMalloc(&st, (size_t)grid * waves * 8 * 8); hipMemset(st, 0, (size_t)grid * waves * 8 * 8);
     p.stamps = st;
-    auto kfn = gemm_fp8_blockscaled_nt_kernel<Cfg, 0, false>;
+    auto kfn = gemm_fp8_blockscaled_nt_kernel<Cfg, 0, false, false, CFG_MATH>;
     hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < warm; ++i) hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, 0, p);
@@ -67,7 +70,17 @@ int main(int argc, char **argv)
            Cfg::kWM, Cfg::kWN, Cfg::kLC ? "+loaders" : "", Cfg::STAGES, m, n, k, ms * 1000 / 20, warm);
     printf("  per k block: wait %.0f  barrier %.0f  frags %.0f  pipe %.0f  = %.0f ticks (matrix pipe alone: %d)\n", seg[1] / nw / kb,
            seg[2] / nw / kb, seg[3] / nw / kb, seg[4] / nw / kb, (seg[1] + seg[2] + seg[3] + seg[4]) / nw / kb,
-           Cfg::TM * Cfg::TN * 32 * cwaves / 4);
+           Cfg::TM * Cfg::TN * (CFG_MATH ? 64 : 32) * cwaves / 4);
     printf("  main loop: %.0f ticks, clock %.3f GHz, %.1f us\n", ct / nw, ct / crt * 0.1, crt / nw / 100.0);
+    if (cwaves == 8)   // the two waves of a SIMD: first-dispatched half against second-dispatched half
+        for (int half = 0; half < 2; ++half) {
+            double sg[8] = {0};
+            for (int w = 0; w < grid * waves; ++w)
+                if (w % waves < cwaves && ((w % waves) >= 4) == half)
+                    for (int q = 0; q < 6; ++q) sg[q] += (double)h[(size_t)w * 8 + q];
+            const double hw = (double)grid * 4;
+            printf("  waves %s: wait %.0f  barrier %.0f  frags %.0f  pipe %.0f\n", half ? "4-7" : "0-3", sg[1] / hw / kb, sg[2] / hw / kb,
+                   sg[3] / hw / kb, sg[4] / hw / kb);
+        }
     return 0;
 }
