@@ -21,7 +21,8 @@ Extra objects: "roofline" (dominant kernel vs the dense fp8 MFMA peak, with the 
 main loop, and vs `ceiling_tflops` = what this box's matrix pipe sustains on the kernel's inner step with the operands
 already in registers), "parity" (every output of the timed kernel against the strict kernel, which tests pin bit for bit
 to the CPU oracle), "policies" (the three arithmetic policies side by side -- fast / bf16_exact / strict: value, roofline
-and parity of each; the headline `value` is the "fast" column), "dsv3_prefill" (BASELINE configs[2], own roofline), "cpu_baseline" (the CPU oracle and the reference's
+and parity of each; the headline `value` is the "fast" column), "shape_list" (the reference's 18 sweep shapes,
+framework/benchmark/benchmark.py:24-44: time, rate, bound and parity gate of each), "dsv3_prefill" (BASELINE configs[2], own roofline), "cpu_baseline" (the CPU oracle and the reference's
 numpy formula timed on this box's host cores on a bounded row sample; rank 0, N = 1 only).
 """
 from __future__ import annotations
@@ -63,6 +64,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-grouped", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-prefill", action="store_true")
+    ap.add_argument("--no-shape-list", action="store_true", help="skip the reference's 18-shape sweep list leg")
     ap.add_argument("--no-policies", action="store_true",
                     help="skip the side-by-side legs of the bf16-exact and strict arithmetic policies")
     ap.add_argument("--widen", action="store_true",
@@ -342,6 +344,38 @@ def policy_legs(dga, a, sfa, b, sfb, m, n, k, args, fast, ceilings):
     return legs, out
 
 
+def shape_list_leg(dga, iters=20):
+    """The reference's own sweep shape list (framework/benchmark/benchmark.py:24-44: 18 shapes) through the operator as a
+    caller makes it -- tiling from the cache / tuned table / predictor, fast policy -- each gated by the product's parity bar
+    (harness/tolerance.py) against the fp32 matmul of the dequantised operands, then timed warm (one operand set re-launched;
+    the cold-cache figures of the short-M shapes are in profiles/r03_decode_cold.txt).  Per shape: the bound that applies
+    (min of the MFMA and the HBM floor), and the fraction of it reached."""
+    import torch
+    from deepgemm_ascend_amd.harness import sweep
+    rows = []
+    for (m, n, k) in sweep.SHAPE_GROUP:
+        try:
+            a, sfa, b, sfb, golden, s_abs = sweep.gen_data(m, n, k)
+            out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+            t = dga.tiling(m, n, k)
+            fn = lambda: dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, tiling_=t)
+            fn(); torch.cuda.synchronize()
+            ok, frac = sweep.is_correct(golden, out, s_abs, short_k=k < 128)
+            us = _prewarmed_us(fn, 3 if k % 16 else iters, 30.0)
+            flops, byt = 2.0 * m * n * k, m * k + n * k + 2 * m * n + 4 * (sfa.numel() + sfb.numel())
+            t_mfma, t_hbm = flops / (PEAK_FP8_TFLOPS * 1e6), byt / (PEAK_HBM_GBPS * 1e3)     # us at the two peaks
+            bound = "mfma" if t_mfma >= t_hbm else "hbm"
+            rows.append({"m": m, "n": n, "k": k, "tile": f"{t.m1}x{t.n1}", "stages": int(t.stages), "splitk": int(t.splitkFactor),
+                         "policy": int(t.dispatchPolicyTag), "us": round(us, 2), "tflops": round(flops / us / 1e6, 1),
+                         "gbps": round(byt / us / 1e3, 1), "bound": bound, "frac": round(max(t_mfma, t_hbm) / us, 4),
+                         "parity_ok": bool(ok), "frac_gt_2ulp": frac})
+            del a, b, out, golden, s_abs
+        except Exception as e:
+            rows.append({"m": m, "n": n, "k": k, "error": repr(e)})
+    return {"source": "framework/benchmark/benchmark.py:24-44 (the reference's sweep shape list)", "protocol": "warm, auto tiling, fast policy",
+            "shapes": rows}
+
+
 def widen_leg():
     """The rows either side of the hot path, reported beside the headline metric:
     the contiguous-grouped (prefill MoE) layout and the activation quantiser that feeds the GEMM."""
@@ -585,6 +619,11 @@ def main():
             res["grouped"] = grouped
         except Exception as e:  # the primary metric must still be reported
             res["grouped"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_shape_list:
+        try:
+            res["shape_list"] = shape_list_leg(dga)
+        except Exception as e:
+            res["shape_list"] = {"error": repr(e)}
     if rank == 0 and world == 1 and args.widen:
         try:
             res["widen"] = widen_leg()
