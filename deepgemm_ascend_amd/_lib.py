@@ -89,9 +89,9 @@ class ShardedStep(ctypes.Structure):       # dga_sharded_step_t
                 ("rows", c_int64), ("group_begin", c_int32), ("groups", c_int32)]
 
 
-(STEP_WAIT_EVENT, STEP_RECORD_EVENT, STEP_CLEAR_HEADERS, STEP_ROUTE_SOURCE, STEP_PACK, STEP_ZERO_COUNTS, STEP_ZERO_RESULT,
+(STEP_WAIT_EVENT, STEP_RECORD_EVENT, STEP_CLEAR_HEADERS, STEP_ROUTE_SOURCE, STEP_PACK, STEP_ZERO_COUNTS, STEP_ZERO_DROPPED,
  STEP_ALL_TO_ALL_DISPATCH, STEP_ROUTE_RECEIVED, STEP_UNPACK, STEP_GEMM, STEP_GATHER_OUT, STEP_ALL_TO_ALL_COMBINE,
- STEP_RESTORE_ORDER) = range(14)
+ STEP_RESTORE_ORDER, STEP_ZERO_UNROUTED) = range(15)
 ALL_TO_ALL_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p)
 
 

@@ -80,7 +80,7 @@ int build_plan(const dga_sharded_shape_t &s, const Derived &d, std::vector<dga_s
     v.clear();
     if (s.world == 1) {   // no exchange: tokens are routed straight into (or addressed through) the masked layout
         push(v, DGA_STEP_ROUTE_SOURCE, 0, -1, -1, 0, 0, 0, d.gl);
-        push(v, DGA_STEP_ZERO_RESULT, 0, -1, -1, 0, 0, 0, 0);
+        push(v, DGA_STEP_ZERO_DROPPED, 0, -1, -1, 0, 0, 0, 0);
         if (!d.indexed) push(v, DGA_STEP_PACK, 0, -1, -1, 0, 0, 0, 0);
         push(v, DGA_STEP_GEMM, 0, 0, -1, 0, 0, 0, d.gl);
         if (!d.indexed) push(v, DGA_STEP_RESTORE_ORDER, 0, -1, -1, 0, 0, 0, 0);
@@ -91,12 +91,13 @@ int build_plan(const dga_sharded_shape_t &s, const Derived &d, std::vector<dga_s
     push(v, DGA_STEP_ROUTE_SOURCE, 0, -1, -1, 0, d.rows, 0, 0);
     push(v, DGA_STEP_PACK, 0, -1, -1, 0, d.rows, 0, 0);
     push(v, DGA_STEP_ZERO_COUNTS, 0, -1, -1, 0, 0, 0, d.gl);
-    push(v, DGA_STEP_ZERO_RESULT, 0, -1, -1, 0, 0, 0, 0);
+    push(v, DGA_STEP_ZERO_DROPPED, 0, -1, -1, 0, 0, 0, 0);
     push(v, DGA_STEP_RECORD_EVENT, 0, -1, 0, 0, 0, 0, 0);
     push(v, DGA_STEP_WAIT_EVENT, 1, -1, 0, 0, 0, 0, 0);
     for (int c = 0; c < ch; ++c) {   // dispatch: exchange, then receive-side slots (+ the unpack copy of the packed path)
         push(v, DGA_STEP_ALL_TO_ALL_DISPATCH, 1, c, -1, c * d.per, d.per, 0, 0);
         push(v, DGA_STEP_ROUTE_RECEIVED, 1, c, -1, c * d.per, d.per, c * d.glc, d.glc);
+        push(v, DGA_STEP_ZERO_UNROUTED, 1, c, -1, c * d.per, d.per, c * d.glc, d.glc);
         if (!d.indexed) push(v, DGA_STEP_UNPACK, 1, c, -1, c * d.per, d.per, c * d.glc, d.glc);
         push(v, DGA_STEP_RECORD_EVENT, 1, c, 1 + c, 0, 0, 0, 0);
     }
@@ -124,6 +125,30 @@ __global__ void fill_i32_strided_kernel(uint8_t *base, int64_t stride, int64_t r
         uint8_t *p = base + r * stride;
         for (int i = 0; i < 4; ++i) p[i] = static_cast<uint8_t>(static_cast<uint32_t>(value) >> (8 * i));
     }
+}
+
+// rows whose index entry is negative are zeroed (one wave per row; the others are left alone): the result row of a token that
+// found no slot, the returning row of a received row that found no place in its expert -- instead of a memset of everything
+__global__ void __launch_bounds__(256) zero_rows_where_negative_kernel(uint8_t *dst, int64_t row_stride, const int64_t *index,
+                                                                       int64_t rows, int64_t row_bytes)
+{
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (r >= rows || index[r] >= 0) return;
+    uint8_t *p = dst + r * row_stride;
+    const int lane = threadIdx.x & 63;
+    if ((((uintptr_t)p | (uintptr_t)row_bytes) & 15) == 0) {
+        for (int64_t o = lane * 16; o < row_bytes; o += 64 * 16) *reinterpret_cast<int4 *>(p + o) = int4{0, 0, 0, 0};
+    } else {
+        for (int64_t o = lane; o < row_bytes; o += 64) p[o] = 0;
+    }
+}
+
+int zero_rows_where_negative(void *dst, int64_t row_stride, const int64_t *index, int64_t rows, int64_t row_bytes, hipStream_t s)
+{
+    if (rows <= 0) return DGA_OK;
+    hipLaunchKernelGGL(zero_rows_where_negative_kernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s,
+                       static_cast<uint8_t *>(dst), row_stride, index, rows, row_bytes);
+    return dga::record_hip(hipGetLastError());
 }
 
 }  // namespace
@@ -243,8 +268,11 @@ int dga_sharded_forward(const dga_sharded_shape_t *shape, const dga_sharded_buff
         case DGA_STEP_ZERO_COUNTS:
             rc = dga::record_hip(hipMemsetAsync(buf->masked_m, 0, static_cast<size_t>(d.gl) * 4, hs));
             break;
-        case DGA_STEP_ZERO_RESULT:     // the row of a token that found no slot (a full bucket: *overflow says so) is never written
-            if (tokens > 0) rc = dga::record_hip(hipMemsetAsync(result, 0, static_cast<size_t>(tokens) * n * 2, hs));
+        case DGA_STEP_ZERO_DROPPED:    // the row of a token that found no slot (a full bucket: *overflow says so) is never written
+            rc = zero_rows_where_negative(result, 2ll * n, buf->slot, tokens, 2ll * n, hs);
+            break;
+        case DGA_STEP_ZERO_UNROUTED:   // ... and a received row that found no place in its expert travels back as zeros
+            rc = zero_rows_where_negative(osend + st.row_begin * n * 2, 2ll * n, buf->rdest + st.row_begin, st.rows, 2ll * n, hs);
             break;
         case DGA_STEP_ALL_TO_ALL_DISPATCH:
             rc = all_to_all(user, 0, st.chunk, send + st.row_begin * d.row_bytes, recv + st.row_begin * d.row_bytes,

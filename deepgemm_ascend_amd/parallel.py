@@ -237,7 +237,7 @@ class ExpertShardedGroupedGemm:
         L = _lib.lib()
         T = tok_q.shape[0]
         dev = self.device
-        res = torch.empty((T, self.n), dtype=torch.bfloat16, device=dev)     # zeroed by the plan's ZERO_RESULT step
+        res = torch.empty((T, self.n), dtype=torch.bfloat16, device=dev)     # dropped tokens' rows: the plan's ZERO_DROPPED step
         ptr = lambda t: t.data_ptr() if t is not None else None
         bufs = _lib.ShardedBuffers()
         if self.world > 1:
@@ -342,8 +342,10 @@ class ExpertShardedGroupedGemm:
                                dst1_off=self.k)
                 elif st.op == _lib.STEP_ZERO_COUNTS:
                     self.masked_m.zero_()
-                elif st.op == _lib.STEP_ZERO_RESULT:
-                    res.zero_()                       # dropped tokens' rows stay zero
+                elif st.op == _lib.STEP_ZERO_DROPPED:
+                    res.masked_fill_((self.slot[:T] < 0)[:, None], 0)   # (no host sync) a token without a slot: nothing else writes its row
+                elif st.op == _lib.STEP_ZERO_UNROUTED:
+                    self.osend[sl].masked_fill_((self.rdest[sl] < 0)[:, None], 0)
                 elif st.op == _lib.STEP_ALL_TO_ALL_DISPATCH:
                     self.dist.all_to_all_single(self.recv[sl], self.send[sl])
                 elif st.op == _lib.STEP_ROUTE_RECEIVED:

@@ -371,14 +371,15 @@ enum { DGA_STEP_WAIT_EVENT = 0,          /* stream waits for event */
        DGA_STEP_ROUTE_SOURCE = 3,        /* dga_route_slots on the tokens' expert ids (+ header tags) */
        DGA_STEP_PACK = 4,                /* dga_copy_rows2: token bytes + scales into their slots */
        DGA_STEP_ZERO_COUNTS = 5,         /* masked_m = 0 */
-       DGA_STEP_ZERO_RESULT = 6,         /* result rows = 0 (a dropped token's row is never written) */
+       DGA_STEP_ZERO_DROPPED = 6,        /* result rows of the tokens that found no slot = 0 (nothing else ever writes them) */
        DGA_STEP_ALL_TO_ALL_DISPATCH = 7, /* the callback, direction 0: payload rows of one chunk */
        DGA_STEP_ROUTE_RECEIVED = 8,      /* dga_route_slots keyed by the received headers: masked_m and the row tables */
        DGA_STEP_UNPACK = 9,              /* packed path: received rows into the masked layout */
        DGA_STEP_GEMM = 10,               /* the grouped masked-M GEMM of a chunk's experts */
        DGA_STEP_GATHER_OUT = 11,         /* packed path: result rows into the buffer that travels back */
        DGA_STEP_ALL_TO_ALL_COMBINE = 12, /* the callback, direction 1: bf16 result rows of one chunk */
-       DGA_STEP_RESTORE_ORDER = 13 };    /* result[t] = returned row slot[t] */
+       DGA_STEP_RESTORE_ORDER = 13,      /* result[t] = returned row slot[t] */
+       DGA_STEP_ZERO_UNROUTED = 14 };    /* returning rows of the received rows that found no place in their expert = 0 */
 typedef struct dga_sharded_step_t {
     int32_t op, stream, chunk, event;
     int64_t row_begin, rows;             /* slice of the exchange buffers */

@@ -85,6 +85,32 @@ def test_world1_eager_and_graph(dga, oracle, indexed):
     assert np.array_equal(_bits(out), want[perm])
 
 
+@pytest.mark.parametrize("indexed", [True, False])
+def test_tokens_beyond_an_experts_capacity_come_back_as_zero_rows(dga, oracle, indexed):
+    """More tokens for expert 2 than m_max: the surplus is dropped, its result rows are zeros (written by the plan's
+    ZERO_DROPPED step, not left uninitialised), every other row is right, and check() reports the overflow."""
+    from deepgemm_ascend_amd.parallel import ExpertShardedGroupedGemm
+    b, sfb, _ = _data(1)
+    rng = np.random.default_rng(11)
+    T = M_MAX + 40
+    ids = np.full(T, 2, np.int64); ids[::7] = 4
+    q = rng.integers(0, 120, size=(T, K), dtype=np.uint8); sf = rng.uniform(0.5, 1.5, size=(T, K // 128)).astype(np.float32)
+    eng = ExpertShardedGroupedGemm(0, 1, G_TOTAL, M_MAX, N, K, "cuda", None, strict=True, max_tokens=T, indexed=indexed)
+    eng.set_weights(torch.from_numpy(b).cuda(), torch.from_numpy(sfb).cuda())
+    junk = torch.full((T, N), 7.0, dtype=torch.bfloat16, device="cuda"); del junk     # the allocator hands dirty memory back
+    res = eng.forward(torch.from_numpy(q).cuda(), torch.from_numpy(sf).cuda(), torch.from_numpy(ids).cuda())
+    torch.cuda.synchronize()
+    got = _bits(res)
+    slot = eng.slot[:T].cpu().numpy()
+    dropped = slot < 0
+    assert dropped.sum() == (ids == 2).sum() - M_MAX and (ids[dropped] == 2).all()
+    assert (got[dropped] == 0).all()
+    want = _want(oracle, q, sf, ids, b, sfb)
+    assert np.array_equal(got[~dropped], want[~dropped])
+    with pytest.raises(ValueError):
+        eng.check()
+
+
 def test_phase_timings_are_reported(dga):
     from deepgemm_ascend_amd.parallel import ExpertShardedGroupedGemm
     b, sfb, toks = _data(1)

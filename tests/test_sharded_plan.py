@@ -60,7 +60,7 @@ def test_plan_is_well_ordered(kw):
             recorded[st.event] = st.stream
         elif st.op == S.STEP_WAIT_EVENT:
             assert st.event in recorded and recorded[st.event] != st.stream, "an event is waited for before it is recorded"
-        elif st.op in (S.STEP_ALL_TO_ALL_DISPATCH, S.STEP_ROUTE_RECEIVED, S.STEP_GEMM, S.STEP_ALL_TO_ALL_COMBINE):
+        elif st.op in (S.STEP_ALL_TO_ALL_DISPATCH, S.STEP_ROUTE_RECEIVED, S.STEP_GEMM, S.STEP_ALL_TO_ALL_COMBINE):  # (+ the zero / copy steps)
             seen[st.chunk].append(st.op)
             assert st.row_begin == st.chunk * lay.rows_per_chunk and st.rows == lay.rows_per_chunk
         if st.op in (S.STEP_UNPACK, S.STEP_GATHER_OUT):
@@ -78,9 +78,9 @@ def test_world1_has_no_exchange():
     rc, lay, steps = _plan(world=1, rank=0, indexed=1, max_tokens=0)
     ops = [s.op for s in steps]
     assert rc == 0 and lay.events == 0 and lay.rows_total == 0 and lay.max_tokens == 256 * 128
-    assert ops == [_lib.STEP_ROUTE_SOURCE, _lib.STEP_ZERO_RESULT, _lib.STEP_GEMM]
+    assert ops == [_lib.STEP_ROUTE_SOURCE, _lib.STEP_ZERO_DROPPED, _lib.STEP_GEMM]
     rc, lay, steps = _plan(world=1, rank=0, indexed=0)
-    assert [s.op for s in steps] == [_lib.STEP_ROUTE_SOURCE, _lib.STEP_ZERO_RESULT, _lib.STEP_PACK, _lib.STEP_GEMM, _lib.STEP_RESTORE_ORDER]
+    assert [s.op for s in steps] == [_lib.STEP_ROUTE_SOURCE, _lib.STEP_ZERO_DROPPED, _lib.STEP_PACK, _lib.STEP_GEMM, _lib.STEP_RESTORE_ORDER]
 
 
 def test_shape_errors_and_indexed_limits():
