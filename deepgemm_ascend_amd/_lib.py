@@ -103,6 +103,7 @@ SIGNATURES = {
     "dga_infer_shape": (c_int, [POINTER(c_int64), c_int, POINTER(c_int64), c_int, POINTER(c_int64)]),
     "dga_infer_dtype": (c_int, [c_int, c_int, POINTER(c_int)]),
     "dga_tiling": (c_int, [POINTER(Problem), POINTER(Tiling)]),
+    "dga_tiling_bf16_exact": (c_int, [POINTER(Problem), POINTER(Tiling)]),
     "dga_select_kernel": (c_int, [POINTER(Problem), POINTER(Platform), POINTER(Tiling)]),
     "dga_platform_mi355x": (None, [POINTER(Platform)]),
     "dga_platform_ascend910b": (None, [POINTER(Platform), c_uint32]),

@@ -133,13 +133,18 @@ def _problem(m, n, k, groups=1, expected_m=0, dtype=_lib.DT_FP8_E4M3FN, contiguo
                    _lib.LAYOUT_ROW_MAJOR, dtype, _lib.PROBLEM_CONTIGUOUS_M if contiguous else 0)
 
 
-def tiling(m: int, n: int, k: int, groups: int = 1, expected_m: int = 0, contiguous: bool = False) -> Tiling:
+def tiling(m: int, n: int, k: int, groups: int = 1, expected_m: int = 0, contiguous: bool = False,
+           policy: Optional[str] = None) -> Tiling:
     """TilingFunc hook with the (m,n,k) cache (catlass_dynamic_matmul_tiling.cpp:77-122).
-    contiguous=True: the contiguous-grouped layout (m = total rows, groups = number of B matrices)."""
+    contiguous=True: the contiguous-grouped layout (m = total rows, groups = number of B matrices).
+    policy="bf16_exact": that policy's own tile / split-K pick (dga_tiling_bf16_exact); "strict": the tag alone."""
     t = Tiling()
     p = _problem(m, n, k, groups, expected_m, contiguous=contiguous)
+    if policy == "bf16_exact":
+        _lib.check(_lib.lib().dga_tiling_bf16_exact(ctypes.byref(p), ctypes.byref(t)), "tiling_bf16_exact")
+        return t
     _lib.check(_lib.lib().dga_tiling(ctypes.byref(p), ctypes.byref(t)), "tiling")
-    return t
+    return _with_policy(t, False, policy) if policy else t
 
 
 def select_kernel(m: int, n: int, k: int, platform: Optional[Platform] = None, groups: int = 1,
@@ -278,7 +283,7 @@ def gemm_fp8_fp8_bf16_nt(lhs: Tuple[torch.Tensor, torch.Tensor], rhs: Tuple[torc
         _require(t.is_contiguous(), "operands must be contiguous")
     with _device_guard(a, b, sfa, sfb, out):
         if tiling_ is None:
-            tiling_ = tiling(m, n, k)
+            tiling_ = tiling(m, n, k, policy=policy if policy == "bf16_exact" else None)
         tiling_ = _with_policy(tiling_, strict, policy)
         ws_ptr, ws_bytes = _workspace(tiling_, out.device)
         rc = _lib.lib().dga_gemm_fp8_fp8_bf16_nt(a.data_ptr(), sfa.data_ptr(), b.data_ptr(), sfb.data_ptr(),

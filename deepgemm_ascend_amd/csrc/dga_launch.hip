@@ -167,7 +167,8 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
         pr.layoutTagA = DGA_LAYOUT_ROW_MAJOR; pr.layoutTagB = DGA_LAYOUT_COLUMN_MAJOR;
         pr.layoutTagC = DGA_LAYOUT_ROW_MAJOR; pr.dtype = DGA_DT_FP8_E4M3FN;
         pr.flags = m_indices ? DGA_PROBLEM_CONTIGUOUS_M : 0;
-        int rc = dga_tiling(&pr, &local);
+        static const int bf16x_auto = [] { const char *e = std::getenv("DGA_BF16_EXACT"); return e ? std::atoi(e) : 0; }();
+        int rc = bf16x_auto ? dga_tiling_bf16_exact(&pr, &local) : dga_tiling(&pr, &local);
         if (rc != DGA_OK) return rc;
         tiling = &local;
     }

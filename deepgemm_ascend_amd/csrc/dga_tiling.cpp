@@ -833,6 +833,52 @@ int dga_tiling(const dga_problem_t *problem, dga_tiling_t *out)
     return DGA_OK;
 }
 
+// Tiling of the bf16-exact policy (dispatchPolicyTag 7).  Its menu (dga_launch_menu_e.hip) and its costs are not the fast
+// path's: one 8-wave build (128x256) and four 4-wave builds whose single wave per SIMD issues conversions and promotions at
+// about 0.6-0.75 of the rate, and a split-K combine that costs a launch.  The fast path's tuned tile mapped onto that menu
+// was 10-40 % off on mid-M shapes (512..1024 x 4096 x 7168 took the 4-wave 128x128 build; profiles/r03_bx_tile_sweep.txt), so
+// dense problems get their own pick from a small cost model fitted to that sweep: rounds x (per-workgroup time) + combine.
+// Grouped layouts keep the fast tiling's tile (its height is dictated by the layout).
+int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out)
+{
+    int rc = dga_tiling(problem, out);
+    if (rc != DGA_OK) return rc;
+    out->dispatchPolicyTag = DGA_POLICY_BF16_EXACT;
+    if (std::max<uint32_t>(1, out->groups) > 1 || out->contiguous || !out->m || !out->n || out->k < 128 || (out->k % 16)) return DGA_OK;
+    struct Cand { int bm, bn; double rate; };
+    static const Cand kMenu[] = {{128, 256, 1.0}, {128, 128, 0.72}, {64, 256, 0.70}, {64, 128, 0.74}, {32, 128, 0.58}};
+    static const int kSplits[] = {1, 2, 3, 4, 6, 8};
+    const double cus = dga::device_cus(), kb = (out->k + 127) / 128;
+    const double t_block = 1.8;        // us per k block of one 128x256 tile with every CU busy (4096^3: 117 us / (2 rounds x 32))
+    const double t_fixed = 5.0;        // launch, first stage, epilogue
+    const double cu_gbps = 25.0;       // what one CU streams from HBM (MI355X_MICROARCH "Indexed rows")
+    double best = 1e30;
+    int bm = out->m1, bn = out->n1, sk = 1;
+    for (const Cand &c : kMenu)
+        for (int s : kSplits) {
+            if (s > 1 && kb / s < 4) continue;
+            if (out->m <= 32 && c.bm > 32) continue;     // a decode step's few rows: the shortest tile (the rest would multiply zeros)
+            const double tiles = std::ceil(out->m / double(c.bm)) * std::ceil(out->n / double(c.bn));
+            const double wgs = tiles * s;
+            if (s > 1 && wgs > 4 * cus) continue;
+            const double rounds = std::ceil(wgs / cus);
+            const double kbs = std::ceil(kb / s);
+            const double compute = kbs * (c.bm * c.bn) / (128.0 * 256.0) / c.rate * t_block;
+            const double stream = c.bn * kbs * 128.0 / (cu_gbps * 1e3);     // the weight rows (the A rows are shared: L2)
+            double t = rounds * (std::max(compute, stream) + t_fixed);
+            if (s > 1) t += 6.0 + 2.0 * double(out->m) * out->n * 4.0 * s / 12e6;  // combine launch + slabs out and back (cache-resident)
+            if (t < best) { best = t; bm = c.bm; bn = c.bn; sk = s; }
+        }
+    out->m1 = static_cast<uint16_t>(bm); out->n1 = static_cast<uint16_t>(bn);
+    out->splitkFactor = static_cast<uint16_t>(sk);
+    out->kernelSerial = sk > 1 ? DGA_KERNEL_STREAMK : DGA_KERNEL_COMMON;
+    out->stages = 3; out->wavesM = 0; out->wavesN = 0;
+    out->swizzleOffset = 4;
+    const uint64_t tiles = static_cast<uint64_t>((out->m + bm - 1) / bm) * ((out->n + bn - 1) / bn);
+    out->blockDim = static_cast<uint32_t>(tiles * sk);
+    return DGA_OK;
+}
+
 int dga_tiling_cache_open(const char *csv_path) { return Cache::instance().open(csv_path); }
 int dga_tiling_cache_clear(void) { Cache::instance().clear(); return DGA_OK; }
 int dga_tiling_cache_size(void) { return Cache::instance().size(); }

@@ -57,6 +57,10 @@ dga_tiling_t tiling_for(int m, int n, int k, int groups, int expected_m, unsigne
     p.layoutTagA = DGA_LAYOUT_ROW_MAJOR; p.layoutTagB = DGA_LAYOUT_COLUMN_MAJOR; p.layoutTagC = DGA_LAYOUT_ROW_MAJOR;
     p.dtype = DGA_DT_FP8_E4M3FN; p.flags = flags;
     dga_tiling_t t{};
+    if (tag == DGA_POLICY_BF16_EXACT) {   // that policy's own tile / split-K pick
+        check(dga_tiling_bf16_exact(&p, &t), "tiling_bf16_exact");
+        return t;
+    }
     check(dga_tiling(&p, &t), "tiling");
     if (tag >= 0) t.dispatchPolicyTag = static_cast<uint8_t>(tag);
     return t;

@@ -143,6 +143,11 @@ int dga_infer_dtype(int self_dtype, int mat2_dtype, int *out_dtype);
  * optionally CSV-backed through $CACHE_FILE_PATH / $DGA_CACHE_FILE_PATH (cache.cpp:22-101). */
 int dga_tiling(const dga_problem_t *problem, dga_tiling_t *out);
 
+/* TilingFunc of the bf16-exact arithmetic policy (dispatchPolicyTag 7): dga_tiling, then -- for dense problems -- the tile and
+ * split-K factor picked from that policy's own menu by its own cost model (wave tiles <= 64 x 64, one 8-wave build; the fast path's
+ * tuned tile is 10-40 % off there on mid-M shapes).  out->dispatchPolicyTag = DGA_POLICY_BF16_EXACT.  No reference counterpart. */
+int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out);
+
 /* SelectKernel without the cache, on an explicit platform (select_kernel.cpp:333-369).
  * platform == NULL -> MI355X.  With dga_platform_ascend910b() it replays the reference's
  * DoTilingLayout01 + handler chain for parity tests. */
