@@ -90,3 +90,63 @@ def test_contiguous_random_segments(dga, oracle, seed):
         rows = np.nonzero(idx == gi)[0]
         if rows.size * n >= 2048:
             oracle.assert_parity(got[rows], want[rows], a[rows], sfa[rows], b[gi], sfb[gi])
+
+
+# ---------------------------------------------------------------- the bf16-exact policy (dispatchPolicyTag 7) on the same draws
+
+def _bf16x_bar(oracle, got, want, a, sfa, b, sfb, k):
+    """2 ulp on all but 1e-5 of the elements (2 on small samples), the rest within 2 ulp + 2^-22 S (2^-19 below K = 128)."""
+    rep = oracle.parity_report(got, want, a, sfa, b, sfb)
+    size = int(np.asarray(got).size)
+    assert rep["nan_positions_equal"], rep
+    assert rep["frac_gt_max_ulp"] * size <= max(1e-5 * size, 2), rep
+    assert rep["worst_excess_over_S"] <= (2.0 ** -22 if k >= 128 else 2.0 ** -19), rep
+
+
+@pytest.mark.parametrize("m,n,k", _shapes(777, 20 * SCALE))
+def test_bf16_exact_dense_random_shapes(dga, oracle, m, n, k):
+    """Whatever dga_tiling_bf16_exact picks (tile of the policy's menu, split-K, the padding pass for odd K) is what runs."""
+    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=m * 13 + n * 5 + k)
+    out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    dga.gemm_fp8_fp8_bf16_nt((torch.from_numpy(a).cuda(), torch.from_numpy(sfa).cuda()),
+                             (torch.from_numpy(b).cuda(), torch.from_numpy(sfb).cuda()), out, policy="bf16_exact", sync=True)
+    _bf16x_bar(oracle, _bits(out), oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, threads=8), a, sfa, b, sfb, k)
+
+
+@pytest.mark.parametrize("seed", range(4 * SCALE))
+def test_bf16_exact_grouped_random_masks_and_indexed_rows(dga, oracle, seed):
+    """Masked grouped layout under the policy, packed and through a slot -> row table (the indexed form on scrambled rows):
+    the two must agree bit for bit, rows >= masked_m stay untouched, and every expert meets the policy's bar."""
+    rng = np.random.default_rng(300 + seed)
+    g = int(rng.integers(2, 7)); mmax = int(rng.choice([16, 48, 128])); n = int(rng.choice([128, 256, 392])); k = int(rng.choice([128, 384, 1024]))
+    masks = rng.integers(0, mmax + 1, size=g).astype(np.int32)
+    parts = [oracle.make_inputs(mmax, n, k, seed=seed * 70 + i) for i in range(g)]
+    a, sfa, b, sfb = (np.stack([p[j] for p in parts]) for j in range(4))
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    init = np.full((g, mmax, n), 0x7FC1, np.uint16)
+    out = torch.from_numpy(init.view(np.int16)).cuda().view(torch.bfloat16)
+    dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((dev(a), dev(sfa)), (dev(b), dev(sfb)), out, dev(masks), expected_m=int(masks.max()),
+                                              policy="bf16_exact", sync=True)
+    got = _bits(out)
+    want = oracle.m_grouped_gemm_fp8_fp8_bf16_nt_masked(a, sfa, b, sfb, init, masks, threads=8)
+    # the same rows, scrambled into one flat buffer and addressed through the table
+    rows = g * mmax
+    perm = rng.permutation(rows)
+    flat_a = np.zeros((rows, k), np.uint8); flat_sf = np.ones((rows, sfa.shape[2]), np.float32)
+    table = np.full((g, mmax), -1, np.int64)
+    for i in range(g):
+        for r in range(int(masks[i])):
+            dst = int(perm[i * mmax + r])
+            flat_a[dst] = a[i, r]; flat_sf[dst] = sfa[i, r]; table[i, r] = dst
+    out_rows = torch.full((rows, n), -5.0, dtype=torch.bfloat16, device="cuda")
+    dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(dev(flat_a), dev(flat_sf), 0, sfa.shape[2], (dev(b), dev(sfb)), out_rows,
+                                                      dev(table.reshape(-1)), dev(masks), mmax, int(masks.max()),
+                                                      policy="bf16_exact", sync=True)
+    got_rows = _bits(out_rows)
+    for i in range(g):
+        mm = int(masks[i])
+        assert (got[i, mm:] == 0x7FC1).all()
+        if mm:
+            assert np.array_equal(got_rows[table[i, :mm]], got[i, :mm]), f"expert {i}: indexed != packed"
+        if mm * n >= 2048:
+            _bf16x_bar(oracle, got[i, :mm], want[i, :mm], a[i, :mm], sfa[i, :mm], b[i], sfb[i], k)
