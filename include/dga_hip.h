@@ -69,7 +69,7 @@ enum { DGA_KERNEL_COMMON = 0, DGA_KERNEL_SMALL = 1, DGA_KERNEL_PADDING_COMMON = 
  *     chained v_mfma_f32_16x16x32_bf16 -- exact products, fp32-class sums (2^-25 of the block's sum of magnitudes, against
  *     2^-16 on the fp8 matrix instruction), the same fp32 promotion.  The policy between the fast path (policies 0-2, 4-6) and
  *     the strict one: within 2 bf16 ULP of the reference CPU path (framework/tests/test.py:19-64) on all but ~1e-6 of the
- *     outputs of BASELINE configs[1] (those are sums that cancel to < 2^-17 of their terms), at the bf16 matrix rate.  Takes
+ *     outputs of BASELINE configs[1] (every one a sum that cancels to < 2^-21 of its terms), at the bf16 matrix rate.  Takes
  *     every layout the tile kernels take (dense, masked, contiguous, indexed, split-K); the tile comes from the tiling's
  *     (m1, n1) mapped onto the policy's own menu (wave tiles of at most 64 x 64).  $DGA_BF16_EXACT=1 forces it for every fp8
  *     call of the process. */

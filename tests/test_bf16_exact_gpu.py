@@ -6,7 +6,7 @@ registers (exact) and sums every 128-wide scale block on v_mfma_f32_16x16x32_bf1
 the instruction's own order.  Its bar, asserted here:
 
   * PLAIN bound |got - want| <= 2 ulp_bf16(want) on at least 99.999 % of the elements (on small samples: all but 2);
-  * the remainder -- sums that cancel to less than ~2^-17 of their terms, where the oracle's own fp32 rounding is as
+  * the remainder -- sums that cancel to less than ~2^-21 of their terms (measured on configs[1]: scripts/bf16_exact_outliers.py), where the oracle's own fp32 rounding is as
     large as the difference -- within 2 ulp + 2^-22 * S (S = sum of the magnitudes of the scaled products; 2^-19 for
     arbitrary bit patterns), i.e. 128 times tighter than the fast path's 2^-15;
   * NaN positions identical.
