@@ -209,8 +209,8 @@ static int launch_b16(const void *x, const void *y, float *z, int batch, int m, 
             if (!x_in_place) {
                 uint16_t *xp = reinterpret_cast<uint16_t *>(ws + yt_bytes);
                 const int64_t rows = static_cast<int64_t>(batch) * m;
-                hipLaunchKernelGGL(pad_rows_b16_kernel, dim3(static_cast<unsigned>((rows * kp + 255) / 256)), dim3(256), 0, stream,
-                                   xs, xp, rows, k, static_cast<int>(kp));
+                if (pad_rows(xs, xp, rows, nullptr, nullptr, 0, static_cast<int64_t>(k) * 2, static_cast<int64_t>(kp) * 2, stream) != DGA_OK)
+                    return DGA_E_HIP;
                 xs = xp;
             }
             if (record_hip(hipGetLastError()) != DGA_OK) return DGA_E_HIP;
@@ -317,11 +317,7 @@ static int launch_b16_nt(const void *a, const void *b, void *out, int m, int n, 
         at = (static_cast<size_t>(m) * kp * 2 + 255) & ~size_t(255);
         uint16_t *bp = reinterpret_cast<uint16_t *>(ws + at);
         at += (static_cast<size_t>(n) * kp * 2 + 255) & ~size_t(255);
-        hipLaunchKernelGGL(pad_rows_b16_kernel, dim3(static_cast<unsigned>((static_cast<int64_t>(m) * kp + 255) / 256)), dim3(256), 0,
-                           stream, as, ap, static_cast<int64_t>(m), k, static_cast<int>(kp));
-        hipLaunchKernelGGL(pad_rows_b16_kernel, dim3(static_cast<unsigned>((static_cast<int64_t>(n) * kp + 255) / 256)), dim3(256), 0,
-                           stream, bs, bp, static_cast<int64_t>(n), k, static_cast<int>(kp));
-        if (record_hip(hipGetLastError()) != DGA_OK) return DGA_E_HIP;
+        if (pad_rows(as, ap, m, bs, bp, n, static_cast<int64_t>(k) * 2, static_cast<int64_t>(kp) * 2, stream) != DGA_OK) return DGA_E_HIP;
         as = ap; bs = bp;
     }
     B16Params p{};

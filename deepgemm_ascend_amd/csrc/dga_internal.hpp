@@ -29,6 +29,10 @@ int variant_stages(int i);
 bool variant_has_loader_waves(int i);   // a dispatchPolicyTag-4 build of that menu entry exists
 // a 3-stage tiling on the plain loop whose tile has a loader-wave build takes it (same bits, 9-17 % less time)
 void prefer_loader_waves(dga_tiling_t &t, bool upgrade_plain = true);
+// odd-K re-layout pass (dga_rows.hip): rows of src_row_bytes at any byte alignment -> 16-byte aligned rows of dst_row_bytes, zero tail;
+// two operands in one launch (rows1 == 0: one)
+int pad_rows(const void *src0, void *dst0, int64_t rows0, const void *src1, void *dst1, int64_t rows1, int64_t src_row_bytes,
+             int64_t dst_row_bytes, hipStream_t stream);
 // dense 256x256 tilings: turn a small last partial wave into a K-split tail (dga_tiling.cpp)
 void apply_tail_split(dga_tiling_t &t, uint32_t cus);
 }  // namespace dga

@@ -258,13 +258,9 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
         const int64_t rows_a = static_cast<int64_t>(groups) * m, rows_b = static_cast<int64_t>(b_groups) * n;
         uint8_t *pa = carve(static_cast<size_t>(rows_a) * kp);
         uint8_t *pb = pa ? carve(static_cast<size_t>(rows_b) * kp) : nullptr;
-        if (pa && pb) {
-            const int cpr = kp / 16;
-            hipLaunchKernelGGL(pad_rows_kernel, dim3(static_cast<unsigned>((rows_a * cpr + 255) / 256)), dim3(256), 0,
-                               stream, p.a, pa, rows_a, k, kp);
-            hipLaunchKernelGGL(pad_rows_kernel, dim3(static_cast<unsigned>((rows_b * cpr + 255) / 256)), dim3(256), 0,
-                               stream, p.b, pb, rows_b, k, kp);
-            DGA_HIP_TRY(hipGetLastError());
+        if (pa && pb && ((reinterpret_cast<uintptr_t>(pa) | reinterpret_cast<uintptr_t>(pb)) & 15) == 0) {
+            const int st = pad_rows(p.a, pa, rows_a, p.b, pb, rows_b, k, kp, stream);   // both operands, one launch
+            if (st != DGA_OK) return st;
             p.a = pa; p.b = pb;
             p.k = kp; p.lda = kp; p.ldb = kp;
             p.a_gs = static_cast<int64_t>(m) * kp;

@@ -209,6 +209,81 @@ extern "C" int dga_route_tokens(const int64_t *expert_ids, int64_t tokens, int g
     return dga::record_hip(hipGetLastError());
 }
 
+namespace dga {
+
+// Rows of src_row_bytes bytes at arbitrary byte alignment -> rows of dst_row_bytes (a multiple of 16, >= src_row_bytes, 16-byte
+// aligned destination) with a zero-filled tail: the re-layout pass in front of the tile kernels when K does not cut into 16-byte DMA
+// chunks (the CDNA4 reading of the reference's PaddingCommon variant, op_kernel/kernel/padding_common_matmul_kernel.h:33-107).
+// HBM-bound byte work: one thread per 16-byte destination chunk; the source is read as ALIGNED dwords (five of them cover any 16
+// bytes) funnel-shifted into place by v_alignbyte_b32, so a wave reads 1 KB of consecutive bytes per pass whatever the row's
+// alignment.  Two operands (A and B of one GEMM) share a launch.  Only dwords that overlap the operand are touched (an aligned dword
+// that holds one byte of an allocation lies inside it).
+struct PadOperand {
+    const uint8_t *src;
+    uint8_t *dst;
+    int64_t rows;
+};
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef uint32_t v4u_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+__global__ void __launch_bounds__(256) pad_rows_kernel(PadOperand o0, PadOperand o1, int64_t chunks0, int64_t chunks, int src_row_bytes,
+                                                       int dst_row_bytes)
+{
+    int64_t chunk = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (chunk >= chunks) return;
+    const bool second = chunk >= chunks0;
+    const PadOperand o = second ? o1 : o0;
+    if (second) chunk -= chunks0;
+    const int cpr = dst_row_bytes >> 4;
+    const int64_t r = chunk / cpr;
+    const int c0 = (int)(chunk - r * cpr) << 4;
+    const int valid = src_row_bytes - c0;   // bytes of this row at and after c0
+    v4u w = {0u, 0u, 0u, 0u};
+    if (valid > 0) {
+        const uint8_t *s = o.src + r * src_row_bytes + c0;
+        const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(s) & 3);
+        const uint32_t *al = reinterpret_cast<const uint32_t *>(s - sh);
+        const uint8_t *end = o.src + o.rows * src_row_bytes;
+        uint32_t d[5];
+        if (reinterpret_cast<const uint8_t *>(al + 5) <= end) {
+            const v4u q = *reinterpret_cast<const v4u_a4 *>(al);
+            d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w; d[4] = al[4];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) d[j] = (reinterpret_cast<const uint8_t *>(al + j) < end) ? al[j] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t x = __builtin_amdgcn_alignbyte(d[j + 1], d[j], sh);
+            const int nb = valid - 4 * j;   // bytes of word j that belong to the row
+            if (nb < 4) x = nb <= 0 ? 0u : (x & ((1u << (8 * nb)) - 1u));
+            w[j] = x;
+        }
+    }
+    *reinterpret_cast<v4u *>(o.dst + r * dst_row_bytes + c0) = w;
+}
+
+int pad_rows(const void *src0, void *dst0, int64_t rows0, const void *src1, void *dst1, int64_t rows1, int64_t src_row_bytes,
+             int64_t dst_row_bytes, hipStream_t stream)
+{
+    if (rows0 < 0 || rows1 < 0 || src_row_bytes < 0 || dst_row_bytes < src_row_bytes || (dst_row_bytes & 15) ||
+        dst_row_bytes > 0x7FFFFFF0ll)
+        return DGA_E_SHAPE;
+    if (((reinterpret_cast<uintptr_t>(dst0) | reinterpret_cast<uintptr_t>(dst1)) & 15) != 0) return DGA_E_ALIGN;
+    const int64_t cpr = dst_row_bytes >> 4;
+    const int64_t chunks0 = rows0 * cpr, chunks = chunks0 + rows1 * cpr;
+    if (chunks == 0) return DGA_OK;
+    if ((rows0 && (!src0 || !dst0)) || (rows1 && (!src1 || !dst1))) return DGA_E_NULL;
+    if ((chunks + 255) / 256 > 0x7FFFFFFFll) return DGA_E_RANGE;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(static_cast<unsigned>((chunks + 255) / 256)), dim3(256), 0, stream,
+                       PadOperand{static_cast<const uint8_t *>(src0), static_cast<uint8_t *>(dst0), rows0},
+                       PadOperand{static_cast<const uint8_t *>(src1), static_cast<uint8_t *>(dst1), rows1}, chunks0, chunks,
+                       static_cast<int>(src_row_bytes), static_cast<int>(dst_row_bytes));
+    return record_hip(hipGetLastError());
+}
+
+}  // namespace dga
+
 extern "C" int dga_copy_rows2(void *dst0, int64_t dst0_row_stride, const void *src0, int64_t src0_row_stride, int64_t row_bytes0,
                               void *dst1, int64_t dst1_row_stride, const void *src1, int64_t src1_row_stride, int64_t row_bytes1,
                               const int64_t *dst_index, const int64_t *src_index, int64_t rows, void *stream)

@@ -429,14 +429,4 @@ __global__ void __launch_bounds__(256) gemm_b16_nt_generic_kernel(const uint16_t
     }
 }
 
-// x [M][K] -> xp [M][kp] zero filled (only when K is not a multiple of 64 or x is not 16-byte aligned)
-__global__ void __launch_bounds__(256) pad_rows_b16_kernel(const uint16_t *x, uint16_t *xp, int64_t rows, int k, int kp)
-{
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t r = i / kp;
-    if (r >= rows) return;
-    const int c = (int)(i - r * kp);
-    xp[i] = c < k ? x[r * k + c] : (uint16_t)0;
-}
-
 }  // namespace dga

@@ -1,4 +1,4 @@
-// Non-template helper kernels of the fp8 path (element-wise fallback, split-K combine, odd-K padding pass).  Included by
+// Non-template helper kernels of the fp8 path (element-wise fallback, split-K combine; the odd-K padding pass is dga_rows.hip's pad_rows).  Included by
 // dga_launch.hip only: they are ordinary (non-inline) kernels, one definition per library.
 #pragma once
 #include "gemm_fp8_kernel.hpp"
@@ -74,24 +74,6 @@ __global__ void __launch_bounds__(256) splitk_reduce_bf16_kernel(const float *pa
             out[i + q] = (uint16_t)(__builtin_bit_cast(uint32_t, h) & 0xFFFFu);
         }
     }
-}
-
-// K not a multiple of 16: rows cannot be cut into aligned 16-byte DMA chunks.  Re-lay the operand once into the
-// workspace with its rows padded (zero-filled) to a multiple of 128 -- the CDNA4 reading of the reference's
-// PaddingCommon variant (op_kernel/kernel/padding_common_matmul_kernel.h:33-107: a re-layout pass on the vector
-// cores in front of the matmul) -- and run the LDS-DMA kernel on that.
-__global__ void __launch_bounds__(256) pad_rows_kernel(const uint8_t *src, uint8_t *dst, int64_t rows, int k, int kp)
-{
-    const int64_t chunk = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one 16-byte output chunk per thread
-    const int cpr = kp / 16;
-    const int64_t r = chunk / cpr;
-    if (r >= rows) return;
-    const int c0 = (int)(chunk - r * cpr) * 16;
-    const uint8_t *s = src + r * k + c0;
-    uint8_t v[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = (c0 + j < k) ? s[j] : (uint8_t)0;
-    *(v4i *)(dst + r * kp + c0) = *(const v4i *)v;
 }
 
 }  // namespace dga

@@ -196,6 +196,22 @@ def test_odd_k_padding_pass(dga, oracle, m, n, k):
     _check(oracle, got, a, sfa, b, sfb)
 
 
+@pytest.mark.parametrize("off_a,off_b", [(1, 3), (2, 0), (3, 2)])
+def test_odd_k_padding_pass_takes_operands_at_any_byte_offset(dga, oracle, off_a, off_b):
+    """The re-layout pass reads aligned dwords and shifts them into place: operands that start at odd byte addresses, rows of
+    odd length, and a last row that ends on the last byte of its allocation."""
+    m, n, k = 70, 200, 1001
+    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=off_a * 4 + off_b)
+    buf_a = torch.zeros(off_a + m * k, dtype=torch.uint8, device="cuda")
+    buf_b = torch.zeros(off_b + n * k, dtype=torch.uint8, device="cuda")
+    ta = buf_a[off_a:].view(m, k); ta.copy_(_dev(a))
+    tb = buf_b[off_b:].view(n, k); tb.copy_(_dev(b))
+    assert ta.data_ptr() % 4 == off_a % 4
+    out = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dga.gemm_fp8_fp8_bf16_nt((ta, _dev(sfa)), (tb, _dev(sfb)), out, sync=True)
+    _check(oracle, out.view(torch.int16).cpu().numpy().view(np.uint16), a, sfa, b, sfb)
+
+
 def test_config3_full_size_properties(dga, oracle):
     """BASELINE config 3 (M=4096, K=7168, N=2048) at full size: (a) scaling a whole column block of sfb by 2 doubles
     exactly those 128 output columns, (b) row-permuting A permutes the output rows (bitwise), (c) 48 sampled rows
