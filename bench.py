@@ -82,6 +82,10 @@ def parse_args(argv=None):
                     help="untimed clock pre-warm in front of the W warmup steps: after idle the GPU needs a few hundred "
                          "steps to reach its sustained clocks (20 warmup steps alone leave the first 200 timed steps 14 %% "
                          "slow, scripts/warm_effect.py)")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="N > 1 ranks that all use cuda:0, gloo with collectives staged through the host: runs every N > 1 "
+                         "branch of this file and of parallel.py on a one-GPU box.  A rehearsal of the control flow -- the line "
+                         "says so and its numbers mean nothing (the ranks time-slice one GPU)")
     ap.add_argument("--stub", action="store_true",
                     help="no GPU: gloo backend, CPU tensors and a numpy stand-in for the step -- exercises the launcher, the "
                          "rendezvous, the barrier / max-over-ranks timing and the JSON contract (tests/test_bench_launcher.py)")
@@ -408,6 +412,54 @@ def widen_leg():
     return res
 
 
+class _HostStagedCollectives:
+    """--rehearse-shared-gpu only: torch.distributed's interface as this file and parallel.py use it, every device tensor staged
+    through the host around a gloo collective (RCCL refuses two ranks on one device)."""
+
+    def __init__(self, dist):
+        self._d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    @staticmethod
+    def _host(t):
+        import torch
+        torch.cuda.current_stream().synchronize()
+        return t.detach().cpu()
+
+    def barrier(self):
+        self._d.barrier()
+
+    def all_reduce(self, t, op=None):
+        c = self._host(t)
+        self._d.all_reduce(c, op=op if op is not None else self.ReduceOp.SUM)
+        t.copy_(c)
+
+    def all_gather(self, outs, t):
+        c = self._host(t)
+        cs = [c.new_empty(c.shape) for _ in outs]
+        self._d.all_gather(cs, c)
+        for o, x in zip(outs, cs):
+            o.copy_(x)
+
+    def all_to_all_single(self, out, inp):
+        c = self._host(inp).contiguous()
+        o = c.new_empty(tuple(out.shape))
+        self._d.all_to_all_single(o, c)
+        out.copy_(o)
+
+    def all_gather_object(self, objs, obj):
+        self._d.all_gather_object(objs, obj)
+
+    def get_world_size(self):
+        return self._d.get_world_size()
+
+    def get_rank(self):
+        return self._d.get_rank()
+
+    def destroy_process_group(self):
+        self._d.destroy_process_group()
+
+
 # --------------------------------------------------------------------------------------------------- main
 
 def main():
@@ -432,6 +484,12 @@ def main():
         if args.stub:
             backend = "gloo"
             dist.init_process_group(backend)
+        elif args.rehearse_shared_gpu:
+            backend = "gloo, host-staged, every rank on cuda:0 (REHEARSAL of the control flow, not a measurement)"
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+            dist = _HostStagedCollectives(dist)
         else:
             backend = "nccl"   # RCCL on ROCm
             torch.cuda.set_device(local_rank)

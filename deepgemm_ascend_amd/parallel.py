@@ -579,6 +579,26 @@ def bench_grouped(rank, world, dist, steps=10, warmup=3, groups_total=256, m_max
         eng.forward(tok_q, tok_sf, expert_ids)
     sync()
     e2e = (time.perf_counter() - t0) / steps
+    # end-to-end self-check that needs no remote weights: a token's result row does not depend on where the token sits in the
+    # batch (other slot, other chunk, other position in the exchange buffers), bit for bit
+    forward_check = None
+    try:
+        r1 = eng.forward(tok_q, tok_sf, expert_ids).clone()
+        perm = torch.randperm(T, device=dev, generator=g)
+        r2 = eng.forward(tok_q[perm].contiguous(), tok_sf[perm].contiguous(), expert_ids[perm].contiguous())
+        sync()
+        eng.check()
+        forward_check = {"rows": int(T), "permuted_batch_gives_the_same_rows_bitwise":
+                         bool(torch.equal(r1[perm].view(torch.int16), r2.view(torch.int16))),
+                         "nonzero_rows": int((r1.view(torch.int16) != 0).any(dim=1).sum())}
+        del r1, r2, perm
+    except Exception as e:
+        forward_check = {"error": repr(e)}
+    if dist is not None and world > 1:   # every rank reaches this: the line carries the AND over the ranks
+        ok = torch.tensor([1.0 if forward_check.get("permuted_batch_gives_the_same_rows_bitwise") else 0.0], device=dev,
+                          dtype=torch.float64)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        forward_check["on_every_rank"] = bool(float(ok[0]) == 1.0)
     # the same forward replayed from one HIP graph (possible because no phase reads anything back)
     e2e_graph = None
     if world == 1:
@@ -641,7 +661,7 @@ def bench_grouped(rank, world, dist, steps=10, warmup=3, groups_total=256, m_max
         "tok_per_s_with_alltoall": round(total_tokens / e2e, 1),
         "ms_gemm": round(gemm * 1e3, 4), "ms_end_to_end": round(e2e * 1e3, 4),
         "ms_end_to_end_graph": round(e2e_graph * 1e3, 4) if e2e_graph else None,
-        "phase_us": phases, "phase_us_per_rank": phases_per_rank, "chunks": eng.chunks, "indexed_rows": bool(eng.indexed),
+        "forward_check": forward_check, "phase_us": phases, "phase_us_per_rank": phases_per_rank, "chunks": eng.chunks, "indexed_rows": bool(eng.indexed),
         "pair_capacity_rows": getattr(eng, "C", None), "capacity_factor": capacity_factor if world > 1 else None,
         "roofline": roof,
         f"{other}_mask": {"rows_per_gpu": rows_o, "ms_gemm": round(gemm_o * 1e3, 4),
