@@ -12,7 +12,9 @@ CSRC = ROOT / "deepgemm_ascend_amd" / "csrc"
 
 
 @pytest.mark.parametrize("unit,min_kernels,tile_kernel", [
-    ("dga_launch.hip", 5, "gemm_fp8_strict_nt_kernel"),          # strict x 2, element-wise, split-K combine, padding
+    ("dga_launch.hip", 4, "gemm_fp8_strict_nt_kernel"),          # strict x 2, element-wise, split-K combine
+    ("dga_rows.hip", 5, "pad_rows_kernel"),                      # row copies, routing, the odd-K re-layout pass
+    ("dga_launch_menu_e.hip", 10, "gemm_fp8_blockscaled_nt_kernel"),   # bf16-exact builds (5 tiles x k-tail / no k-tail)
     ("dga_launch_menu_a.hip", 6, "gemm_fp8_blockscaled_nt_kernel"),
     ("dga_launch_menu_b.hip", 10, "gemm_fp8_blockscaled_nt_kernel"),
     ("dga_launch_menu_c.hip", 28, "gemm_fp8_blockscaled_nt_kernel"),
