@@ -787,6 +787,7 @@ int dga_select_kernel(const dga_problem_t *problem, const dga_platform_t *platfo
     init_params(*problem, *out);
     if (problem->m == 0 || problem->n == 0) { out->blockDim = 0; return DGA_OK; }
     if (pf.xcdNum <= 1) {
+        if (problem->k == 0) return DGA_E_SHAPE;   // the reference's padding simulator divides by K (select_kernel.cpp:147-180)
         select_reference(*out, pf);
     } else {
         if (out->contiguous) select_mi355x(*out, pf, 1, 0, true);  // one A/out matrix; groups counts the B matrices
