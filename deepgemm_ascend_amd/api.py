@@ -27,22 +27,39 @@ from ._lib import DGAError, Platform, Problem, Tiling
 _FP8 = getattr(torch, "float8_e4m3fn", None)
 
 
+# Host time per call matters for the short shapes of the reference's sweep list (a 64 x 32768 x 512 GEMM is 6 us of device
+# time): the helpers below keep a call at a handful of Python-level operations -- no tensor views, no stream / device objects,
+# no message formatting unless a check fails (scripts/host_overhead.py: 12.5 -> 5 us per call).
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream_of(index: int) -> int:
+    """The current HIP stream of device `index` as the raw handle the C ABI takes."""
+    if _raw_stream is not None:
+        return _raw_stream(index)
+    return torch.cuda.current_stream(index).cuda_stream
+
+
 def _stream_ptr(t: torch.Tensor) -> int:
     if t.is_cuda:
-        return torch.cuda.current_stream(t.device).cuda_stream
+        return _stream_of(t.device.index)
     return 0
 
 
-def _require(cond: bool, msg: str):
+def _fail(msg: str):
     # DGA_HOST_ASSERT analogue (csrc/utils/exception.hpp:26-33)
+    raise DGAError(-2, "host assert", msg)
+
+
+def _require(cond: bool, msg: str):
     if not cond:
-        raise DGAError(-2, "host assert", msg)
+        _fail(msg)
 
 
 def _fp8_bytes(t: torch.Tensor) -> torch.Tensor:
-    if _FP8 is not None and t.dtype == _FP8:
-        return t.view(torch.uint8)
-    _require(t.dtype == torch.uint8, f"fp8 operand must be float8_e4m3fn or uint8 bytes, got {t.dtype}")
+    """Checks that `t` holds e4m3fn bytes; the tensor itself is returned (its data pointer is what the C ABI takes)."""
+    if t.dtype != _FP8 and t.dtype != torch.uint8:
+        _fail(f"fp8 operand must be float8_e4m3fn or uint8 bytes, got {t.dtype}")
     return t
 
 
@@ -50,15 +67,16 @@ _WORKSPACES = {}   # (kind, device index, stream handle) -> uint8 tensor
 _RETIRED = []      # outgrown buffers: a HIP graph captured earlier may still hold their address, so they stay alive
 
 
-def _scratch(kind: str, device, need: int) -> Tuple[Optional[int], int]:
+def _scratch(kind: str, device, need: int, stream: Optional[int] = None) -> Tuple[Optional[int], int]:
     """Device scratch, one grow-only buffer per (kind, device, stream): two GEMMs issued on different streams never
     share split-K slabs or padded operand copies, and the capture stream of a HIP graph has a buffer of its own.  A
     buffer that has to grow is replaced, not freed (a captured graph may replay into the old one); growth is geometric
     so that few are ever retired.  The callee never allocates (the op runtime hands the workspace in)."""
     if need == 0:
         return None, 0
-    dev = torch.device(device)
-    key = (kind, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    dev = device if isinstance(device, torch.device) else torch.device(device)
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (kind, index, _stream_of(index) if stream is None else stream)
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < need:
         if buf is not None:
@@ -69,9 +87,18 @@ def _scratch(kind: str, device, need: int) -> Tuple[Optional[int], int]:
     return buf.data_ptr(), buf.numel()
 
 
-def _workspace(t: Tiling, device) -> Tuple[Optional[int], int]:
+_WS_BYTES = {}     # bytes of a Tiling -> dga_workspace_bytes of it (pure function of the struct)
+
+
+def _workspace(t: Tiling, device, stream: Optional[int] = None) -> Tuple[Optional[int], int]:
     """Split-K slabs / odd-K padding of the fp8 kernels, sized by dga_workspace_bytes."""
-    return _scratch("fp8", device, workspace_bytes(t))
+    key = bytes(t)
+    need = _WS_BYTES.get(key)
+    if need is None:
+        if len(_WS_BYTES) > 4096:
+            _WS_BYTES.clear()
+        need = _WS_BYTES[key] = workspace_bytes(t)
+    return _scratch("fp8", device, need, stream)
 
 
 def _mmad_workspace(batch, m, n, k, x) -> Tuple[Optional[int], int]:
@@ -102,12 +129,47 @@ def _with_policy(t: Tiling, strict: bool, policy: Optional[str] = None) -> Tilin
     return c
 
 
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
 def _device_guard(*ts: torch.Tensor):
+    """All tensors on one HIP device; that device current for the call (nothing to do when it already is)."""
     dev = ts[0].device
     for t in ts:
-        _require(t.device == dev, "all tensors must live on one device")
-    _require(dev.type == "cuda", "tensors must be on a HIP device (there is no CPU path)")
-    return torch.cuda.device(dev)
+        if t.device != dev:
+            _fail("all tensors must live on one device")
+    if dev.type != "cuda":
+        _fail("tensors must be on a HIP device (there is no CPU path)")
+    return _NO_GUARD if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+
+_PLANS = {}        # what a GEMM call without an explicit tiling resolves to: key -> Tiling (with the policy's tag)
+
+
+def _plans_clear():
+    _PLANS.clear()
+
+
+def _planned(index: int, m: int, n: int, k: int, groups: int, expected_m: int, contiguous: bool, strict: bool,
+             policy: Optional[str]) -> Tiling:
+    """tiling(...) + the arithmetic policy's tag, remembered per problem: the C side's (m,n,k) cache answers the same question, but
+    through two ctypes calls and a struct copy per GEMM.  Dropped whenever the cache file, the cache or the predictor changes."""
+    key = (index, m, n, k, groups, expected_m, contiguous, strict, policy)
+    t = _PLANS.get(key)
+    if t is None:
+        if len(_PLANS) > 4096:
+            _PLANS.clear()
+        t = tiling(m, n, k, groups=groups, expected_m=expected_m, contiguous=contiguous, policy=policy if policy == "bf16_exact" else None)
+        t = _PLANS[key] = _with_policy(t, strict, policy)
+    return t
 
 
 # ----------------------------------------------------------------------------- operator hooks
@@ -159,10 +221,12 @@ def select_kernel(m: int, n: int, k: int, platform: Optional[Platform] = None, g
 
 def predictor_load(path: Optional[str] = None) -> None:
     """Load a predictor weights file (None = tuned/predictor_mi355x.txt next to the library)."""
+    _plans_clear()
     _lib.check(_lib.lib().dga_predictor_load(path.encode() if path else None), "predictor_load")
 
 
 def predictor_unload() -> None:
+    _plans_clear()
     _lib.lib().dga_predictor_unload()
 
 
@@ -206,10 +270,12 @@ def workspace_bytes(t: Tiling) -> int:
 
 
 def tiling_cache_open(path: Optional[str]):
+    _plans_clear()
     _lib.check(_lib.lib().dga_tiling_cache_open(path.encode() if path else None), "tiling_cache_open")
 
 
 def tiling_cache_clear():
+    _plans_clear()
     _lib.lib().dga_tiling_cache_clear()
 
 
@@ -268,28 +334,38 @@ def gemm_fp8_fp8_bf16_nt(lhs: Tuple[torch.Tensor, torch.Tensor], rhs: Tuple[torc
     pass sync=True for that behaviour)."""
     a, sfa = lhs
     b, sfb = rhs
-    a = _fp8_bytes(a); b = _fp8_bytes(b)
-    _require(a.dim() == 2 and b.dim() == 2 and out.dim() == 2, "rank must be 2")
+    _fp8_bytes(a); _fp8_bytes(b)
+    if a.dim() != 2 or b.dim() != 2 or out.dim() != 2:
+        _fail("rank must be 2")
     m, k = a.shape
     n, k2 = b.shape
-    _require(k == k2, "self dimk is not equal with mat2 dimk")
-    _require(tuple(out.shape) == (m, n), f"out must be [{m},{n}]")
-    _require(out.dtype == torch.bfloat16, "out must be bfloat16")
+    if k != k2:
+        _fail("self dimk is not equal with mat2 dimk")
+    if out.shape[0] != m or out.shape[1] != n:
+        _fail(f"out must be [{m},{n}]")
+    if out.dtype != torch.bfloat16:
+        _fail("out must be bfloat16")
     kb, nb = (k + 127) // 128, (n + 127) // 128
-    _require(sfa.dtype == torch.float32 and sfb.dtype == torch.float32, "scales must be float32")
-    _require(tuple(sfa.shape) == (m, kb), f"sfa must be [{m},{kb}]")
-    _require(tuple(sfb.shape) == (nb, kb), f"sfb must be [{nb},{kb}]")
-    for t in (a, b, sfa, sfb, out):
-        _require(t.is_contiguous(), "operands must be contiguous")
+    if sfa.dtype != torch.float32 or sfb.dtype != torch.float32:
+        _fail("scales must be float32")
+    if sfa.dim() != 2 or sfa.shape[0] != m or sfa.shape[1] != kb:
+        _fail(f"sfa must be [{m},{kb}]")
+    if sfb.dim() != 2 or sfb.shape[0] != nb or sfb.shape[1] != kb:
+        _fail(f"sfb must be [{nb},{kb}]")
+    if not (a.is_contiguous() and b.is_contiguous() and sfa.is_contiguous() and sfb.is_contiguous() and out.is_contiguous()):
+        _fail("operands must be contiguous")
     with _device_guard(a, b, sfa, sfb, out):
+        index = out.device.index
         if tiling_ is None:
-            tiling_ = tiling(m, n, k, policy=policy if policy == "bf16_exact" else None)
-        tiling_ = _with_policy(tiling_, strict, policy)
-        ws_ptr, ws_bytes = _workspace(tiling_, out.device)
+            tiling_ = _planned(index, m, n, k, 1, 0, False, strict, policy)
+        else:
+            tiling_ = _with_policy(tiling_, strict, policy)
+        stream = _stream_of(index)
+        ws_ptr, ws_bytes = _workspace(tiling_, out.device, stream)
         rc = _lib.lib().dga_gemm_fp8_fp8_bf16_nt(a.data_ptr(), sfa.data_ptr(), b.data_ptr(), sfb.data_ptr(),
-                                                 out.data_ptr(), m, n, k, ctypes.byref(tiling_), ws_ptr, ws_bytes,
-                                                 _stream_ptr(out))
-        _lib.check(rc, "gemm_fp8_fp8_bf16_nt")
+                                                 out.data_ptr(), m, n, k, ctypes.byref(tiling_), ws_ptr, ws_bytes, stream)
+        if rc:
+            _lib.check(rc, "gemm_fp8_fp8_bf16_nt")
         if sync:
             torch.cuda.current_stream(out.device).synchronize()
 
@@ -299,7 +375,7 @@ def gemm_fp8_loop_clock(lhs, rhs, out: torch.Tensor, tiling_: Optional[Tiling] =
     and that loop's duration, from the loop-clock build (dga_gemm_fp8_loop_clock; a diagnostic: it synchronises)."""
     a, sfa = lhs
     b, sfb = rhs
-    a = _fp8_bytes(a); b = _fp8_bytes(b)
+    _fp8_bytes(a); _fp8_bytes(b)
     m, k = a.shape
     n = b.shape[0]
     with _device_guard(a, b, sfa, sfb, out):
@@ -338,27 +414,39 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_masked(lhs, rhs, out: torch.Tensor, masked_m:
     only rows < masked_m[g] of out[g] are written (upstream DeepGEMM's convention)."""
     a, sfa = lhs
     b, sfb = rhs
-    a = _fp8_bytes(a); b = _fp8_bytes(b)
-    _require(a.dim() == 3 and b.dim() == 3 and out.dim() == 3, "rank must be 3")
+    _fp8_bytes(a); _fp8_bytes(b)
+    if a.dim() != 3 or b.dim() != 3 or out.dim() != 3:
+        _fail("rank must be 3")
     g, mmax, k = a.shape
     g2, n, k2 = b.shape
-    _require(g == g2 and k == k2, "group / k mismatch")
-    _require(tuple(out.shape) == (g, mmax, n) and out.dtype == torch.bfloat16, "out must be [G,Mmax,N] bfloat16")
+    if g != g2 or k != k2:
+        _fail("group / k mismatch")
+    if tuple(out.shape) != (g, mmax, n) or out.dtype != torch.bfloat16:
+        _fail("out must be [G,Mmax,N] bfloat16")
     kb, nb = (k + 127) // 128, (n + 127) // 128
-    _require(tuple(sfa.shape) == (g, mmax, kb) and sfa.dtype == torch.float32, f"sfa must be [{g},{mmax},{kb}] f32")
-    _require(tuple(sfb.shape) == (g, nb, kb) and sfb.dtype == torch.float32, f"sfb must be [{g},{nb},{kb}] f32")
-    _require(masked_m.dtype == torch.int32 and tuple(masked_m.shape) == (g,), "masked_m must be int32 [G]")
-    for t in (a, b, sfa, sfb, out, masked_m):
-        _require(t.is_contiguous(), "operands must be contiguous")
+    if tuple(sfa.shape) != (g, mmax, kb) or sfa.dtype != torch.float32:
+        _fail(f"sfa must be [{g},{mmax},{kb}] f32")
+    if tuple(sfb.shape) != (g, nb, kb) or sfb.dtype != torch.float32:
+        _fail(f"sfb must be [{g},{nb},{kb}] f32")
+    if masked_m.dtype != torch.int32 or masked_m.dim() != 1 or masked_m.shape[0] != g:
+        _fail("masked_m must be int32 [G]")
+    if not (a.is_contiguous() and b.is_contiguous() and sfa.is_contiguous() and sfb.is_contiguous() and out.is_contiguous() and
+            masked_m.is_contiguous()):
+        _fail("operands must be contiguous")
+    expected_m = int(expected_m)
     with _device_guard(a, b, sfa, sfb, out, masked_m):
+        index = out.device.index
         if tiling_ is None:
-            tiling_ = tiling(mmax, n, k, groups=g, expected_m=int(expected_m))
-        tiling_ = _with_policy(tiling_, strict, policy)
-        ws_ptr, ws_bytes = _workspace(tiling_, out.device)
+            tiling_ = _planned(index, mmax, n, k, g, expected_m, False, strict, policy)
+        else:
+            tiling_ = _with_policy(tiling_, strict, policy)
+        stream = _stream_of(index)
+        ws_ptr, ws_bytes = _workspace(tiling_, out.device, stream)
         rc = _lib.lib().dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked(
             a.data_ptr(), sfa.data_ptr(), b.data_ptr(), sfb.data_ptr(), out.data_ptr(), masked_m.data_ptr(),
-            g, mmax, n, k, int(expected_m), ctypes.byref(tiling_), ws_ptr, ws_bytes, _stream_ptr(out))
-        _lib.check(rc, "m_grouped_gemm_fp8_fp8_bf16_nt_masked")
+            g, mmax, n, k, expected_m, ctypes.byref(tiling_), ws_ptr, ws_bytes, stream)
+        if rc:
+            _lib.check(rc, "m_grouped_gemm_fp8_fp8_bf16_nt_masked")
         if sync:
             torch.cuda.current_stream(out.device).synchronize()
 
@@ -374,7 +462,7 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(a_rows: torch.Tensor, sfa_src:
     (the same payload rows, or a separate [rows, KB] float tensor with offset 0), and its result is written to that row
     of `out_rows` [rows, ldc] bf16.  b [G,N,K], sfb [G,NB,KB]; only r < masked_m[g] is read or written."""
     b, sfb = rhs
-    b = _fp8_bytes(b); a_rows = _fp8_bytes(a_rows)
+    _fp8_bytes(b); _fp8_bytes(a_rows)
     _require(a_rows.dim() == 2 and a_rows.stride(1) == 1 and out_rows.dim() == 2 and out_rows.stride(1) == 1, "2-D row tensors")
     g, n, k = b.shape
     rows, lda = a_rows.shape[0], a_rows.stride(0)
@@ -394,8 +482,9 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(a_rows: torch.Tensor, sfa_src:
              "sfa_src must hold ceil(K/128) floats at sfa_byte_offset of each of the source's rows")
     with _device_guard(a_rows, b, sfb, out_rows, row_index, masked_m, sfa_src):
         if tiling_ is None:
-            tiling_ = tiling(m_max, n, k, groups=g, expected_m=int(expected_m))
-        tiling_ = _with_policy(tiling_, strict, policy)
+            tiling_ = _planned(out_rows.device.index, m_max, n, k, g, int(expected_m), False, strict, policy)
+        else:
+            tiling_ = _with_policy(tiling_, strict, policy)
         rc = _lib.lib().dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(
             a_rows.data_ptr(), lda, sfa_src.data_ptr() + sfa_byte_offset, sfa_ld, b.data_ptr(), sfb.data_ptr(),
             out_rows.data_ptr(), out_rows.stride(0), row_index.data_ptr(), rows, masked_m.data_ptr(), g, m_max, n, k,
@@ -443,7 +532,7 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(lhs, rhs, out: torch.Tensor, m_ind
     rows, padding rows follow a segment's valid rows."""
     a, sfa = lhs
     b, sfb = rhs
-    a = _fp8_bytes(a); b = _fp8_bytes(b)
+    _fp8_bytes(a); _fp8_bytes(b)
     _require(a.dim() == 2 and b.dim() == 3 and out.dim() == 2, "a/out rank 2, b rank 3")
     msum, k = a.shape
     g, n, k2 = b.shape
@@ -456,7 +545,7 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(lhs, rhs, out: torch.Tensor, m_ind
     for t in (a, b, sfa, sfb, out, m_indices):
         _require(t.is_contiguous(), "operands must be contiguous")
     with _device_guard(a, b, sfa, sfb, out, m_indices):
-        if tiling_ is None:
+        if tiling_ is None:   # (the C side buckets Msum in its cache key and re-derives the workgroup count per call: not memoised here)
             tiling_ = tiling(msum, n, k, groups=g, contiguous=True)
         tiling_ = _with_policy(tiling_, strict, policy)
         ws_ptr, ws_bytes = _workspace(tiling_, out.device)
