@@ -306,30 +306,13 @@ def _prewarmed_us(fn, iters, prewarm_ms):
 
 def _graph_us(fn, iters, replays=5, prewarm_ms=30.0):
     """Device time per call: `iters` calls captured into one HIP graph on a side stream, the graph replayed `replays` times
-    between two events.  The host issues one graph launch per `iters` calls, so a call whose kernel is shorter than the host
-    time of issuing it (5-13 us through Python) is timed by what the device spends on it."""
-    import torch
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        fn()                       # workspace of the capture stream exists before the capture
-    side.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=side):
-        for _ in range(iters):
-            fn()
-    t0 = time.perf_counter()
-    while (time.perf_counter() - t0) * 1e3 < prewarm_ms:   # the capture was an idle gap: back to sustained clocks first
-        g.replay()
-        torch.cuda.synchronize()
-    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(replays):
-        g.replay()
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / (iters * replays)
-    del g
+    between two events, behind a clock pre-warm (harness/sweep.py graph_us).  The host issues one graph launch per `iters` calls,
+    so a call whose kernel is shorter than the host time of issuing it (5-8 us through Python) is timed by what the device
+    spends on it."""
+    from deepgemm_ascend_amd.harness import sweep
+    us = sweep.graph_us(fn, iters, replays, prewarm_ms)
+    if us is None:
+        raise RuntimeError("graph capture failed")
     return us
 
 

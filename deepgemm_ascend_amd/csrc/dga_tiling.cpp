@@ -319,7 +319,11 @@ static uint32_t menu_lds_bytes(const dga_tiling_t &t)
 // folded into their one-tile siblings' records by the sweep -- are still chosen by rule.
 void prefer_loader_waves(dga_tiling_t &t, bool upgrade_plain)
 {
-    if (upgrade_plain && t.dispatchPolicyTag == DGA_POLICY_PLAIN && t.stages == 3) {
+    // (not the 128x256 tile under split-K: its plain 3-stage build has 8 computing waves, and with the short k range of a split
+    //  the 4 + 4 loader-wave build is 6-11 % slower -- device-timed sweep of 641 shapes, profiles/r03_predictor; every other tile
+    //  is the same kernel within 0.1 % under split-K)
+    if (upgrade_plain && t.dispatchPolicyTag == DGA_POLICY_PLAIN && t.stages == 3 &&
+        !(t.splitkFactor > 1 && t.m1 == 128 && t.n1 == 256)) {
         for (int i = 0; i < variant_count(); ++i) {
             int bm, bn, wm, wn, lds;
             variant_info(i, &bm, &bn, &wm, &wn, &lds);
@@ -338,7 +342,12 @@ void prefer_loader_waves(dga_tiling_t &t, bool upgrade_plain)
         // weights and the outputs with the non-temporal policy (dga_launch.hip), worth more than the tile boundaries
         const bool weight_stream = t.contiguous ? (t.groups > 1 && static_cast<uint64_t>(t.m) <= static_cast<uint64_t>(t.groups) * DGA_CONTIGUOUS_M_ALIGNMENT)
                                                 : t.groups > 1;
-        if (tiles > device_cus() || weight_stream) t.dispatchPolicyTag = DGA_POLICY_PERSISTENT;
+        // dense rasters: the persistent builds of the tall tiles win (128x256 -3..-9 %, 128x128 -5..-9 %, 64x256 -1..-6 %), those of
+        // the short ones lose (64x128 +9..+20 %, 16x128 +33 %: the tile list walk and the loaders' look-ahead cost more than a tile
+        // boundary of theirs does) -- the same device-timed sweep; round 2's rule (every tile) came from launch intervals timed
+        // through Python, which could not tell kernels under ~12 us apart
+        const bool tall = (t.m1 == 128 && (t.n1 == 256 || t.n1 == 128)) || (t.m1 == 64 && t.n1 == 256);
+        if ((tiles > device_cus() && tall) || weight_stream) t.dispatchPolicyTag = DGA_POLICY_PERSISTENT;
     }
     // ... and the continuous 256x256 kernel has its own persistent form (dispatchPolicyTag 6,
     // gemm_fp8_cont_persistent_kernel.hpp) for dense rasters of full tiles: the next tile's first stages are fetched from
@@ -364,6 +373,62 @@ void apply_tail_split(dga_tiling_t &t, uint32_t cus)
 }
 
 namespace tiling {
+
+// ---- dense problems: (tile, split-K) by a cost model fitted to a device-timed sweep -----------------------------------------
+// 641 + 120 shapes x every (tile, split-K, stages, policy) candidate, two runs merged by min, each candidate timed by graph replay (harness/sweep.py
+// graph_us; the launch intervals of rounds 1-2 were taken through Python and could not tell kernels under ~12 us apart,
+// profiles/r03_host_overhead.txt), short-M shapes on operand sets rotated past the Infinity Cache.  scripts/fit_heuristic.py fits
+//   T = launch + rounds x (k blocks per item x us_per_kblock[tile] x share^e + prologue)            (the tile pass)
+//       floored by launch + bytes / min(HBM rate, workgroups in flight x per-workgroup stream rate)  (the operand stream;
+//       a short-M weight stream is cold, so every tile row streams B again)
+//       + combine + slab bytes / slab rate                                                            (split-K only)
+// in log time on the 641 training shapes (rmse 0.13); picking by it costs 2.1 % over the best candidate on the 120 HELD-OUT shapes
+// (geomean of pick / best 1.021, p90 1.10, max 1.23; 1.013 / 1.26 in sample) where the tile-first rule it replaces cost 21-24 %
+// (max 3.5x: mid-M, short-N, long-K shapes that want tall tiles and a split, which a rule that fills the chip with tiles first
+// never considers).  profiles/r03_predictor/heuristic_fit.txt.
+struct DenseTileCost { int bm, bn; double us_per_kblock; };
+static const DenseTileCost kDenseTileCost[] = {{256, 256, 1.547}, {128, 256, 0.933}, {256, 128, 1.153}, {128, 128, 0.579},
+                                               {64, 256, 0.650},  {64, 128, 0.367},  {32, 256, 0.449},  {32, 128, 0.256},
+                                               {16, 256, 0.394},  {16, 128, 0.213}};
+static constexpr double kShareExponent = 0.8845, kLaunchUs = 2.66, kPrologueUs = 1.31, kCombineUs = 3.53;
+static constexpr double kSlabBytesPerUs = 5.09e6, kHbmBytesPerUs = 8.0e6, kWorkgroupBytesPerUs = 48.6e3;
+static constexpr uint32_t kDenseSplits[] = {1, 2, 3, 4, 5, 6, 8, 16};   // what the sweep covers
+
+static bool tile_has_three_stages(int bm, int bn)
+{
+    for (int i = 0; i < variant_count(); ++i) {
+        int vm, vn, wm, wn, lds;
+        variant_info(i, &vm, &vn, &wm, &wn, &lds);
+        if (vm == bm && vn == bn && variant_stages(i) == 3) return true;
+    }
+    return false;
+}
+
+// one LDS stage of a tile (dga_device_common.hpp GemmCfg with 256 DMA threads)
+static uint32_t dense_stage_bytes(uint32_t bm, uint32_t bn) { return std::max(bm, 32u) * 128 + bn * 128 + ((bm + 8 + 255) / 256) * 1024; }
+
+static double dense_cost_us(uint32_t m, uint32_t n, uint32_t k, const DenseTileCost &c, uint32_t splitk, uint32_t cus, uint32_t lds_per_cu,
+                            uint32_t *splitk_eff)
+{
+    const uint32_t kb = ceil_div(std::max(k, 1u), 128), per = ceil_div(kb, splitk), s = ceil_div(kb, per);
+    *splitk_eff = s;
+    const uint64_t tiles_m = ceil_div(m, c.bm), tiles = tiles_m * ceil_div(n, c.bn), items = tiles * s;
+    const uint32_t stages = tile_has_three_stages(c.bm, c.bn) ? 3 : 2;
+    const uint64_t wpc = std::max<uint64_t>(1, std::min<uint64_t>(lds_per_cu / (stages * dense_stage_bytes(c.bm, c.bn)), 4));
+    double rounds = std::ceil(static_cast<double>(items) / static_cast<double>(cus * wpc));
+    if (c.bm == 256 && c.bn == 256 && s == 1 && tiles > cus) {   // a small last wave is cut along K (apply_tail_split)
+        const uint64_t tail = tiles % cus;
+        if (tail > 0 && tail * 4 <= cus) rounds = static_cast<double>(tiles / cus) + 0.5;
+    }
+    const double share = static_cast<double>(std::min<uint64_t>(wpc, (items + cus - 1) / cus));
+    double t = kLaunchUs + rounds * (per * c.us_per_kblock * std::pow(share, kShareExponent) + kPrologueUs);
+    const double bytes = static_cast<double>(m) * k + static_cast<double>(n) * k * (m <= 256 ? static_cast<double>(tiles_m) : 1.0) +
+                         2.0 * m * n;
+    const double in_flight = static_cast<double>(std::min<uint64_t>(items, cus * wpc));
+    t = std::max(t, kLaunchUs + bytes / std::min(kHbmBytesPerUs, in_flight * kWorkgroupBytesPerUs));
+    if (s > 1) t += kCombineUs + static_cast<double>(s) * m * n * 8.0 / kSlabBytesPerUs;
+    return t;
+}
 
 void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, uint32_t expected_m,
                    bool contiguous = false)
@@ -415,6 +480,25 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
         cost *= 1.0 + 1e-3 * (e.bm > m_eff ? (e.bm - m_eff) / 16.0 : 0.0);
         if (cost < best) { best = cost; pick = e; found = true; }
     }
+    uint32_t dense_splitk = 0;   // > 0: (tile, split-K) chosen together by the fitted cost model
+    if (groups == 1 && !contiguous) {
+        double best_us = 1e300;
+        for (const MenuEntry &e : seen) {
+            if (static_cast<uint64_t>(e.lds) > pf.l1Size || 4ull * e.bm * e.bn > pf.l0CSize) continue;
+            const DenseTileCost *c = nullptr;
+            for (const DenseTileCost &q : kDenseTileCost)
+                if (q.bm == e.bm && q.bn == e.bn) c = &q;
+            if (!c) continue;
+            if (c->bn == 256 && c->bm <= 32 && t.m > 256) continue;   // never the best of a tall problem (1 shape of 381), and their warm builds differ
+            for (uint32_t sk : kDenseSplits) {
+                if (sk > 1 && (kb < 4 * sk || static_cast<uint64_t>(sk) * t.m * t.n * 4 > (1ull << 30))) continue;  // >= 4 k blocks per split, slabs <= 1 GiB
+                uint32_t s_eff = 1;
+                double us = dense_cost_us(t.m, t.n, t.k, *c, sk, pf.coreNum, static_cast<uint32_t>(pf.l1Size), &s_eff);
+                us *= 1.0 + 1e-3 * (e.bm > static_cast<int>(t.m) ? (e.bm - static_cast<int>(t.m)) / 16.0 : 0.0);   // ties: the tile with fewer idle rows
+                if (us < best_us) { best_us = us; pick = e; dense_splitk = s_eff; found = true; }
+            }
+        }
+    }
     if (!found) { t.m1 = t.n1 = 0; return; }
     t.m1 = static_cast<uint16_t>(pick.bm); t.n1 = static_cast<uint16_t>(pick.bn); t.k1 = 128;
     t.wavesM = static_cast<uint8_t>(pick.wm); t.wavesN = static_cast<uint8_t>(pick.wn);
@@ -428,6 +512,9 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
     if ((pick.bm == 128 && pick.bn == 256 && pick.wm == 2 && pick.wn == 2) || (pick.bm == 128 && pick.bn == 128) ||
         (pick.bm == 64 && pick.bn == 256))
         t.stages = 3;
+    // dense: the same sweep has the three-stage build (with its loader waves where it has them) ahead on every tile, cold by
+    // 13-32 % and warm by 3-26 % (except the 256-wide short tiles on warm operands, which tall problems do not get)
+    if (dense_splitk && tile_has_three_stages(pick.bm, pick.bn)) t.stages = 3;
     // 128x256 with three stages has two builds: 4 waves (2x2) and 8 waves (2x4, two per SIMD).  The masked grouped
     // stream (HBM-bound) is 3 % faster on 4 waves, everything compute-bound 3-14 % faster on 8 (4096x2048x7168: 66.8 ->
     // 61.8 us; scripts/steady_ab.py, scripts/contig_ab.py).
@@ -446,7 +533,11 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
     // is long, K is cut so that every CU streams a share of the operands; the fp32 partial tiles are combined by a
     // second kernel.  Worth it only while the partial slabs stay small next to the operand stream.
     t.kernelSerial = (blocks <= pf.coreNum && t.k <= t.k1) ? DGA_KERNEL_SMALL : DGA_KERNEL_COMMON;
-    if (groups == 1 && !contiguous && blocks * 4 <= pf.coreNum * 3 && kb >= 8) {
+    if (dense_splitk > 1) {
+        t.splitkFactor = static_cast<uint16_t>(dense_splitk);
+        t.kernelSerial = DGA_KERNEL_STREAMK;
+        t.blockDim = static_cast<uint32_t>(blocks) * t.splitkFactor;
+    } else if (!dense_splitk && groups == 1 && !contiguous && blocks * 4 <= pf.coreNum * 3 && kb >= 8) {
         uint32_t s = std::min<uint32_t>({pf.coreNum * 2 / static_cast<uint32_t>(blocks), kb / 4, 32u});
         const uint64_t operand_bytes = static_cast<uint64_t>(t.m + t.n) * t.k;
         while (s > 1 && static_cast<uint64_t>(s) * t.m * t.n * 8 * 2 > operand_bytes) --s;  // slab write + read <= half the operand read

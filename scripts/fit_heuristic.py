@@ -1,0 +1,111 @@
+"""Fit the dense selector's cost model to a device-timed sweep (harness/sweep.py --cold --heuristic-raster records) and report the
+regret of picking by it: per shape, time of the (tile, split-K) the model prefers / time of the best candidate.
+usage: python scripts/fit_heuristic.py TRAIN_DIR [TRAIN_DIR ...] [--eval DIR [DIR ...]]   (regret on the --eval records, held out)"""
+import glob, json, math, sys
+from pathlib import Path
+import numpy as np
+from scipy.optimize import least_squares
+
+TILES = [(256, 256), (128, 256), (256, 128), (128, 128), (64, 256), (64, 128), (32, 256), (32, 128), (16, 256), (16, 128)]
+CUS = 256
+
+
+def load(dirs):
+    shapes = {}
+    for d in dirs:
+        for f in glob.glob(str(Path(d) / "shape_*_rank_*.jsonl")):
+            for line in open(f):
+                r = json.loads(line)
+                if r["negative"] or r["time"] <= 0:
+                    continue
+                p = r["parameters"]
+                if p.get("tail"):
+                    continue
+                key = (r["M"], r["N"], r["K"])
+                c = (p["m1"], p["n1"], p["splitk"])
+                cur = shapes.setdefault(key, {})
+                if c not in cur or r["time"] < cur[c]:
+                    cur[c] = r["time"]           # best build (stages / policy / run) of that tile and split
+    return shapes
+
+
+def stage_bytes(bm, bn):
+    return max(bm, 32) * 128 + bn * 128 + ((bm + 8 + 255) // 256) * 256 * 4
+
+
+def wg_per_cu(bm, bn):
+    st = 2 if (bm, bn) in ((256, 256), (256, 128)) else 3
+    waves = 8 if (bm, bn) in ((256, 256),) else 8     # 4 computing + 4 loader waves, or 8 computing
+    return max(1, min(160 * 1024 // (st * stage_bytes(bm, bn)), 2048 // (waves * 64)))
+
+
+def features(m, n, k, c):
+    bm, bn, sk = c
+    kb = -(-k // 128)
+    per = -(-kb // sk)
+    sk_eff = -(-kb // per)
+    tiles = -(-m // bm) * -(-n // bn)
+    items = tiles * sk_eff
+    w = wg_per_cu(bm, bn)
+    rounds = math.ceil(items / (CUS * w))
+    share = min(w, math.ceil(items / CUS))
+    return bm, bn, sk_eff, per, tiles, items, rounds, share
+
+
+def predict(theta, m, n, k, c):
+    ti = TILES.index((c[0], c[1]))
+    ckb = theta[ti]                         # us per k block of one workgroup alone on its CU
+    sh = theta[10]                          # slowdown exponent when `share` workgroups run on one CU
+    launch, pro, comb, slab_bw, hbm = theta[11], theta[12], theta[13], theta[14], theta[15]
+    bm, bn, sk, per, tiles, items, rounds, share = features(m, n, k, c)
+    t_item = per * ckb * share ** sh + pro
+    t = launch + rounds * t_item
+    tiles_m = -(-m // bm)
+    byt = m * k + n * k * (tiles_m if m <= 256 else 1) + 2 * m * n   # a short-M weight stream is cold: every tile row streams B again
+    # operand stream floor: the chip's rate, or what the workgroups in flight can pull (theta[16] GB/s each)
+    active = min(items, CUS * wg_per_cu(bm, bn))
+    bw = min(hbm * 1e6, active * theta[16] * 1e3)      # bytes per us
+    t = max(t, launch + byt / bw)
+    if sk > 1:
+        t += comb + sk * m * n * 8 / (slab_bw * 1e6)
+    return t
+
+
+def main():
+    args = sys.argv[1:]
+    held = load(args[args.index("--eval") + 1:]) if "--eval" in args else None
+    shapes = load(args[:args.index("--eval")] if "--eval" in args else args)
+    rows = [(m, n, k, c, t) for (m, n, k), cs in shapes.items() for c, t in cs.items() if (c[0], c[1]) in TILES]
+    print(len(shapes), "shapes", len(rows), "records")
+    x0 = np.array([1.6, 0.95, 0.95, 0.62, 0.55, 0.35, 0.45, 0.3, 0.4, 0.27, 0.8, 3.0, 2.0, 4.0, 3.0, 4.5, 40.0])
+
+    def resid(th):
+        return [math.log(predict(th, m, n, k, c) / t) for (m, n, k, c, t) in rows]
+    lo = [0.02] * 10 + [0.0, 0.5, 0.0, 0.5, 0.3, 1.0, 5.0]
+    hi = [5.0] * 10 + [1.5, 12.0, 10.0, 15.0, 12.0, 8.0, 400.0]
+    fit = least_squares(resid, x0, bounds=(lo, hi), loss="soft_l1", f_scale=0.2)
+    th = fit.x
+    r = np.array(resid(th))
+    print("rmse(log)", float(np.sqrt((r ** 2).mean())))
+    for tile, v in zip(TILES, th[:10]):
+        print(f"  us per k block {tile}: {v:.3f}")
+    print("  share exponent %.3f launch %.2f prologue %.2f combine %.2f slab TB/s %.2f hbm TB/s %.2f" % tuple(th[10:16]), "per-workgroup GB/s %.1f" % th[16])
+    reg = []
+    worst = []
+    if held is not None:
+        print("regret on the held-out records (%d shapes):" % len(held))
+    for (m, n, k), cs in (held if held is not None else shapes).items():
+        cand = [c for c in cs if (c[0], c[1]) in TILES]
+        best = min(cs[c] for c in cand)
+        pick = min(cand, key=lambda c: predict(th, m, n, k, c))
+        reg.append(cs[pick] / best)
+        worst.append((cs[pick] / best, (m, n, k), pick, cs[pick], min(cand, key=lambda c: cs[c]), best))
+    reg = np.array(reg)
+    print("pick / best: geomean %.4f mean %.4f p90 %.3f max %.3f" % (math.exp(np.log(reg).mean()), reg.mean(), np.quantile(reg, 0.9), reg.max()))
+    for w in sorted(worst, reverse=True)[:12]:
+        print("  %.2f %s pick %s %.1f best %s %.1f" % w)
+    print("theta =", [round(float(v), 4) for v in th])
+
+
+if __name__ == "__main__":
+    main()

@@ -187,6 +187,30 @@ def test_persistent_form_where_the_raster_exceeds_the_cus(dga):
         assert t.dispatchPolicyTag != dga.api.POLICY_PERSISTENT or t.splitkFactor == 1
 
 
+def test_dense_selector_follows_the_device_timed_sweep(dga):
+    """The dense selector picks (tile, split-K) together by the cost model fitted to the device-timed sweep
+    (scripts/fit_heuristic.py, profiles/r03_predictor): tall tiles with a split where the tile-first rule took 16-row
+    tiles without one; three LDS stages wherever the tile has such a build; no loader waves on 128x256 under split-K; the
+    persistent form only on the tall tiles; a weight stream of M <= 64 rows is not cut along M (every tile row streams B again)."""
+    for (m, n, k) in [(310, 1280, 15744), (992, 512, 11776), (331, 1536, 11904)]:      # 2.5-3.5x off the best before
+        t = dga.select_kernel(m, n, k)
+        assert t.m1 >= 64 and t.splitkFactor >= 3 and t.stages == 3, (m, n, k, t.m1, t.n1, t.splitkFactor)
+    t = dga.select_kernel(630, 8320, 14080)
+    assert (t.m1, t.n1) == (128, 256) and t.splitkFactor > 1 and t.dispatchPolicyTag == dga.api.POLICY_PLAIN and (t.wavesM, t.wavesN) == (2, 4)
+    t = dga.select_kernel(1536, 16384, 7168)                                           # 768 tiles of 128x256: persistent
+    assert (t.m1, t.n1, t.dispatchPolicyTag) == (128, 256, dga.api.POLICY_PERSISTENT)
+    for (m, n, k) in [(4658, 12032, 2304), (300, 30000, 512), (2000, 2000, 256)]:      # whatever is picked: short tiles never persistent
+        t = dga.select_kernel(m, n, k)
+        if (t.m1, t.n1) in ((64, 128), (16, 128), (32, 128)):
+            assert t.dispatchPolicyTag != dga.api.POLICY_PERSISTENT
+    for (m, n, k) in [(8, 18432, 7168), (16, 7296, 15232), (32, 9344, 15744), (64, 4096, 7168)]:
+        t = dga.select_kernel(m, n, k)
+        assert t.m1 >= m and t.m1 < 2 * max(m, 16) and t.stages == 3, (m, t.m1)       # one tile row, the smallest tile that covers M
+    # the BASELINE headline shapes keep their builds
+    assert [(t.m1, t.n1, t.splitkFactor) for t in (dga.select_kernel(4096, 4096, 4096), dga.select_kernel(4096, 2048, 7168))] == \
+        [(256, 256, 1), (128, 256, 1)]
+
+
 def test_persistent_continuous_form_on_full_tile_rasters(dga):
     """256x256 continuous tilings of dense problems made of full tiles take the persistent form (dispatchPolicyTag 6) where
     the raster holds more tiles than CUs; one tile per CU, edges, or the quarter-tile-free small cases keep policy 2."""
