@@ -387,13 +387,20 @@ namespace tiling {
 // (max 3.5x: mid-M, short-N, long-K shapes that want tall tiles and a split, which a rule that fills the chip with tiles first
 // never considers).  profiles/r03_predictor/heuristic_fit.txt.
 struct DenseTileCost { int bm, bn; double us_per_kblock; };
+struct DenseCostModel {
+    const DenseTileCost *tiles; int n_tiles;
+    double share_exponent, launch_us, prologue_us, combine_us, slab_bytes_per_us, hbm_bytes_per_us, workgroup_bytes_per_us;
+};
 static const DenseTileCost kDenseTileCost[] = {{256, 256, 1.547}, {128, 256, 0.933}, {256, 128, 1.153}, {128, 128, 0.579},
                                                {64, 256, 0.650},  {64, 128, 0.367},  {32, 256, 0.449},  {32, 128, 0.256},
                                                {16, 256, 0.394},  {16, 128, 0.213}};
-static constexpr double kShareExponent = 0.8845, kLaunchUs = 2.66, kPrologueUs = 1.31, kCombineUs = 3.53;
-static constexpr double kSlabBytesPerUs = 5.09e6, kHbmBytesPerUs = 8.0e6, kWorkgroupBytesPerUs = 48.6e3;
-static constexpr uint32_t kDenseSplits[] = {1, 2, 3, 4, 5, 6, 8, 16};   // what the sweep covers
-
+static const DenseCostModel kFastModel = {kDenseTileCost, 10, 0.8845, 2.66, 1.31, 3.53, 5.09e6, 8.0e6, 48.6e3};
+// the bf16-exact policy's menu (dga_launch_menu_e.hip: three stages, no loader waves), fitted the same way on its own
+// device-timed sweep (scripts/bx_sweep.py, 214 + 120 shapes): held-out pick / best 1.017 geomean, max 1.32 (the hand-set model
+// of this policy's first version, fitted to 19 shapes timed through Python: 1.069, max 1.47)
+static const DenseTileCost kBf16xTileCost[] = {{128, 256, 1.566}, {128, 128, 1.165}, {64, 256, 1.235}, {64, 128, 0.710}, {32, 128, 0.447}};
+static const DenseCostModel kBf16xModel = {kBf16xTileCost, 5, 0.619, 2.35, 2.81, 3.21, 5.41e6, 5.40e6, 23.8e3};
+static constexpr uint32_t kDenseSplits[] = {1, 2, 3, 4, 5, 6, 8, 16};   // what the sweeps cover
 static bool tile_has_three_stages(int bm, int bn)
 {
     for (int i = 0; i < variant_count(); ++i) {
@@ -407,26 +414,25 @@ static bool tile_has_three_stages(int bm, int bn)
 // one LDS stage of a tile (dga_device_common.hpp GemmCfg with 256 DMA threads)
 static uint32_t dense_stage_bytes(uint32_t bm, uint32_t bn) { return std::max(bm, 32u) * 128 + bn * 128 + ((bm + 8 + 255) / 256) * 1024; }
 
-static double dense_cost_us(uint32_t m, uint32_t n, uint32_t k, const DenseTileCost &c, uint32_t splitk, uint32_t cus, uint32_t lds_per_cu,
-                            uint32_t *splitk_eff)
+static double dense_cost_us(const DenseCostModel &mo, uint32_t m, uint32_t n, uint32_t k, const DenseTileCost &c, uint32_t splitk,
+                            uint32_t stages, uint32_t cus, uint32_t lds_per_cu, uint32_t *splitk_eff)
 {
     const uint32_t kb = ceil_div(std::max(k, 1u), 128), per = ceil_div(kb, splitk), s = ceil_div(kb, per);
     *splitk_eff = s;
     const uint64_t tiles_m = ceil_div(m, c.bm), tiles = tiles_m * ceil_div(n, c.bn), items = tiles * s;
-    const uint32_t stages = tile_has_three_stages(c.bm, c.bn) ? 3 : 2;
     const uint64_t wpc = std::max<uint64_t>(1, std::min<uint64_t>(lds_per_cu / (stages * dense_stage_bytes(c.bm, c.bn)), 4));
     double rounds = std::ceil(static_cast<double>(items) / static_cast<double>(cus * wpc));
-    if (c.bm == 256 && c.bn == 256 && s == 1 && tiles > cus) {   // a small last wave is cut along K (apply_tail_split)
+    if (&mo == &kFastModel && c.bm == 256 && c.bn == 256 && s == 1 && tiles > cus) {   // a small last wave is cut along K (apply_tail_split)
         const uint64_t tail = tiles % cus;
         if (tail > 0 && tail * 4 <= cus) rounds = static_cast<double>(tiles / cus) + 0.5;
     }
     const double share = static_cast<double>(std::min<uint64_t>(wpc, (items + cus - 1) / cus));
-    double t = kLaunchUs + rounds * (per * c.us_per_kblock * std::pow(share, kShareExponent) + kPrologueUs);
+    double t = mo.launch_us + rounds * (per * c.us_per_kblock * std::pow(share, mo.share_exponent) + mo.prologue_us);
     const double bytes = static_cast<double>(m) * k + static_cast<double>(n) * k * (m <= 256 ? static_cast<double>(tiles_m) : 1.0) +
                          2.0 * m * n;
     const double in_flight = static_cast<double>(std::min<uint64_t>(items, cus * wpc));
-    t = std::max(t, kLaunchUs + bytes / std::min(kHbmBytesPerUs, in_flight * kWorkgroupBytesPerUs));
-    if (s > 1) t += kCombineUs + static_cast<double>(s) * m * n * 8.0 / kSlabBytesPerUs;
+    t = std::max(t, mo.launch_us + bytes / std::min(mo.hbm_bytes_per_us, in_flight * mo.workgroup_bytes_per_us));
+    if (s > 1) t += mo.combine_us + static_cast<double>(s) * m * n * 8.0 / mo.slab_bytes_per_us;
     return t;
 }
 
@@ -493,7 +499,8 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
             for (uint32_t sk : kDenseSplits) {
                 if (sk > 1 && (kb < 4 * sk || static_cast<uint64_t>(sk) * t.m * t.n * 4 > (1ull << 30))) continue;  // >= 4 k blocks per split, slabs <= 1 GiB
                 uint32_t s_eff = 1;
-                double us = dense_cost_us(t.m, t.n, t.k, *c, sk, pf.coreNum, static_cast<uint32_t>(pf.l1Size), &s_eff);
+                double us = dense_cost_us(kFastModel, t.m, t.n, t.k, *c, sk, tile_has_three_stages(c->bm, c->bn) ? 3 : 2, pf.coreNum,
+                                          static_cast<uint32_t>(pf.l1Size), &s_eff);
                 us *= 1.0 + 1e-3 * (e.bm > static_cast<int>(t.m) ? (e.bm - static_cast<int>(t.m)) / 16.0 : 0.0);   // ties: the tile with fewer idle rows
                 if (us < best_us) { best_us = us; pick = e; dense_splitk = s_eff; found = true; }
             }
@@ -937,30 +944,21 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out)
     if (rc != DGA_OK) return rc;
     out->dispatchPolicyTag = DGA_POLICY_BF16_EXACT;
     if (std::max<uint32_t>(1, out->groups) > 1 || out->contiguous || !out->m || !out->n || out->k < 128 || (out->k % 16)) return DGA_OK;
-    struct Cand { int bm, bn; double rate; };
-    static const Cand kMenu[] = {{128, 256, 1.0}, {128, 128, 0.72}, {64, 256, 0.70}, {64, 128, 0.74}, {32, 128, 0.58}};
-    static const int kSplits[] = {1, 2, 3, 4, 6, 8};
-    const double cus = dga::device_cus(), kb = (out->k + 127) / 128;
-    const double t_block = 1.8;        // us per k block of one 128x256 tile with every CU busy (4096^3: 117 us / (2 rounds x 32))
-    const double t_fixed = 5.0;        // launch, first stage, epilogue
-    const double cu_gbps = 25.0;       // what one CU streams from HBM (MI355X_MICROARCH "Indexed rows")
-    double best = 1e30;
-    int bm = out->m1, bn = out->n1, sk = 1;
-    for (const Cand &c : kMenu)
-        for (int s : kSplits) {
-            if (s > 1 && kb / s < 4) continue;
-            if (out->m <= 32 && c.bm > 32) continue;     // a decode step's few rows: the shortest tile (the rest would multiply zeros)
-            const double tiles = std::ceil(out->m / double(c.bm)) * std::ceil(out->n / double(c.bn));
-            const double wgs = tiles * s;
-            if (s > 1 && wgs > 4 * cus) continue;
-            const double rounds = std::ceil(wgs / cus);
-            const double kbs = std::ceil(kb / s);
-            const double compute = kbs * (c.bm * c.bn) / (128.0 * 256.0) / c.rate * t_block;
-            const double stream = c.bn * kbs * 128.0 / (cu_gbps * 1e3);     // the weight rows (the A rows are shared: L2)
-            double t = rounds * (std::max(compute, stream) + t_fixed);
-            if (s > 1) t += 6.0 + 2.0 * double(out->m) * out->n * 4.0 * s / 12e6;  // combine launch + slabs out and back (cache-resident)
-            if (t < best) { best = t; bm = c.bm; bn = c.bn; sk = s; }
+    using namespace dga::tiling;
+    const uint32_t cus = dga::device_cus(), kb = (out->k + 127) / 128;
+    double best = 1e300;
+    int bm = out->m1, bn = out->n1;
+    uint32_t sk = 1;
+    for (int i = 0; i < kBf16xModel.n_tiles; ++i) {
+        const DenseTileCost &c = kBf16xModel.tiles[i];
+        for (uint32_t s : kDenseSplits) {
+            if (s > 1 && (kb < 4 * s || static_cast<uint64_t>(s) * out->m * out->n * 4 > (1ull << 30))) continue;
+            uint32_t s_eff = 1;
+            double us = dense_cost_us(kBf16xModel, out->m, out->n, out->k, c, s, 3, cus, 160 * 1024, &s_eff);
+            us *= 1.0 + 1e-3 * (c.bm > static_cast<int>(out->m) ? (c.bm - static_cast<int>(out->m)) / 16.0 : 0.0);
+            if (us < best) { best = us; bm = c.bm; bn = c.bn; sk = s_eff; }
         }
+    }
     out->m1 = static_cast<uint16_t>(bm); out->n1 = static_cast<uint16_t>(bn);
     out->splitkFactor = static_cast<uint16_t>(sk);
     out->kernelSerial = sk > 1 ? DGA_KERNEL_STREAMK : DGA_KERNEL_COMMON;

@@ -15,6 +15,14 @@ scripts/verify.py:10-35, framework/benchmark/benchmark.py:384-398).  Per arithme
     bf16_exact    2^-22    1e-5      exact products, fp32-class sums in the instruction's own order
     strict        0        0         the oracle's own order: bit-identical
 
+Those figures hold against a reference in the ORACLE's summation order (k ascending inside a 128-block, blocks promoted in
+order).  The product harness's goldens are not that: gen_golden / the sweep compute `matmul(f32, f32)` of the dequantised
+operands (the reference's own golden formula, gen_golden.py:17-22), whose summation order is the BLAS's.  Against such a golden
+even the strict kernel -- bit-identical to the oracle -- has 2.3e-5 .. 5.6e-5 of its outputs beyond 2 ULP and a worst excess of
+2^-23.5 * S (K = 1024 .. 16384; profiles/r03_golden_order_noise.txt): that is the golden's own rounding.  `golden_order="any"`
+(what both harness callers pass) therefore floors the bar at eps = 2^-21 and frac = 2e-4 for every policy; the fast policy's
+own figures are wider and stay.
+
 The bbit file verifier (harness/files.py) and the sweep's correctness gate (harness/sweep.py) both call `check`; the
 test-side statement of the same bar is oracle.assert_parity (tests never import this module's caller paths)."""
 from __future__ import annotations
@@ -26,20 +34,28 @@ EPS = {"fast": 2.0 ** -15, "bf16_exact": 2.0 ** -22, "strict": 0.0}
 FRAC = {"fast": 2e-3, "bf16_exact": 1e-5, "strict": 0.0}
 EPS_SHORT_K = 2.0 ** -12      # fast path, K < 128 or arbitrary bit patterns: the hardware's own envelope
 FRAC_SHORT_K = 1e-2
+EPS_ANY_ORDER = 2.0 ** -21    # a golden summed in an unspecified fp32 order: its own distance from the oracle-order result
+FRAC_ANY_ORDER = 2e-4
 
 
 def _is_torch(x) -> bool:
     return type(x).__module__.split(".")[0] == "torch"
 
 
-def check(got, want, s, policy: str = "fast", short_k: bool = False, small: int = 8):
+def check(got, want, s, policy: str = "fast", short_k: bool = False, small: int = 8, golden_order: str = "oracle"):
     """(ok, report).  got / want / s: float arrays of one shape -- numpy arrays, or torch tensors (then everything runs where
     the tensors live).  `want` is the reference value ALREADY rounded to bf16 (or exactly representable in it); s >= 0.
-    `small`: on small samples a handful of elements may exceed 2 ulp whatever the fraction (a population statement)."""
+    `small`: on small samples a handful of elements may exceed 2 ulp whatever the fraction (a population statement).
+    golden_order: "oracle" = `want` was summed in the oracle's order (the tests' references); "any" = an fp32 matmul of
+    unspecified order (gen_golden's np.matmul, the sweep's torch.matmul): the bar is floored at that golden's own noise."""
     if policy not in EPS:
         raise ValueError(f"policy must be one of {sorted(EPS)}")
+    if golden_order not in ("oracle", "any"):
+        raise ValueError("golden_order must be 'oracle' or 'any'")
     eps = EPS_SHORT_K if (short_k and policy == "fast") else EPS[policy]
     frac = FRAC_SHORT_K if (short_k and policy == "fast") else FRAC[policy]
+    if golden_order == "any":
+        eps, frac = max(eps, EPS_ANY_ORDER), max(frac, FRAC_ANY_ORDER)
     if _is_torch(got):
         import torch
         g, w, ss = got.double(), want.double(), s.double()

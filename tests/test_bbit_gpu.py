@@ -52,6 +52,23 @@ def test_bbit_verifier_is_the_one_parity_bar(dga, tmp_path, monkeypatch):
     assert files.verify_result("output/output.bin", "output/golden.bin", mode="fp8", policy="bf16_exact")
 
 
+def test_bbit_verifier_takes_the_exact_policies_at_a_long_k(dga, tmp_path, monkeypatch):
+    """K = 8192: the golden file is np.matmul(f32, f32) in the BLAS's summation order, 2e-5..6e-5 of whose elements are more than
+    2 ULP from the oracle-order result (profiles/r03_golden_order_noise.txt).  The verifier's bar is floored at that noise
+    (tolerance.check golden_order="any"), so the bit-exact strict kernel and the bf16-exact one pass it -- they would not
+    pass their oracle-order bars (0 / 1e-5 of the elements) against this file."""
+    from deepgemm_ascend_amd.harness import files, tolerance
+    monkeypatch.chdir(tmp_path)
+    m, n, k = 384, 1024, 8192
+    (a, sfa), (b, sfb), golden = files.gen_golden_data(m, n, k, mode="fp8", seed=5)
+    for env, policy in (({"DGA_STRICT": "1"}, "strict"), ({"DGA_BF16_EXACT": "1"}, "bf16_exact")):
+        assert _run(tmp_path, [0, m, n, k, 1, 1, 3, 8, 20, 10], **env).returncode == 0
+        assert files.verify_result("output/output.bin", "output/golden.bin", mode="fp8", policy=policy)
+    out = (np.fromfile("output/output.bin", dtype=np.uint16).astype(np.uint32) << 16).view(np.float32).reshape(m, n)
+    ok, rep = tolerance.check(out, tolerance.bf16_round(golden.reshape(m, n)), files.abs_term_sum_fp8(a, sfa, b, sfb), policy="bf16_exact")
+    assert rep["worst_excess_over_S"] <= 2.0 ** -21                          # whatever the oracle-order bar says about this golden
+
+
 def test_bbit_argument_errors(dga, tmp_path):
     assert _run(tmp_path, [0, 16, 16, 16]).returncode == 2                   # argc != 11 (benchmark_util.h:50)
     assert _run(tmp_path, [0, 16, 16, 16, 1, 1, 0, 8, 20, 10]).returncode == 2  # zero knob

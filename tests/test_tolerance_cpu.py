@@ -59,6 +59,32 @@ def test_bar_rejects_too_many_elements_past_two_ulp_and_nan_mismatch(oracle):
     assert not tolerance.check(nan, want, s, policy="fast")[0]
 
 
+def test_bar_against_a_golden_of_unspecified_summation_order(oracle):
+    """The harness's goldens are np.matmul / torch.matmul of the dequantised operands: their own rounding puts 2e-5..6e-5 of the
+    outputs of even the bit-exact strict kernel beyond 2 ULP (profiles/r03_golden_order_noise.txt).  golden_order="any" floors
+    the bar there (eps 2^-21, frac 2e-4) -- and not further."""
+    a, sfa, b, sfb, golden, s = _case(m=128, n=512, k=384)
+    want = tolerance.bf16_round(golden).astype(np.float64)
+    ulp = oracle.bf16_ulp_of(want.astype(np.float32)).astype(np.float64)
+    noisy = want.copy()
+    idx = np.unravel_index(np.arange(0, want.size, want.size // 12)[:12], want.shape)    # 12 of 65536 = 1.8e-4 of the elements
+    noisy[idx] += 2 * ulp[idx] + 2.0 ** -23 * s[idx]
+    for policy in ("strict", "bf16_exact"):
+        assert not tolerance.check(noisy, want, s, policy=policy)[0]                      # against an oracle-order reference: rejected
+        ok, rep = tolerance.check(noisy, want, s, policy=policy, golden_order="any")
+        assert ok and rep["elements_gt_2ulp"] == 12, rep
+    worse = want.copy()
+    worse[idx] += 2 * ulp[idx] + 2.0 ** -19 * s[idx]                                      # past the floor: still rejected
+    assert not tolerance.check(worse, want, s, policy="strict", golden_order="any")[0]
+    many = want.copy()
+    sel = np.unravel_index(np.arange(0, want.size, 1000), want.shape)                     # 1e-3 of the elements
+    many[sel] += 2 * ulp[sel] + 2.0 ** -24 * s[sel]
+    assert not tolerance.check(many, want, s, policy="bf16_exact", golden_order="any")[0]
+    assert tolerance.check(many, want, s, policy="fast", golden_order="any")[0]          # the fast policy's own bar is wider and stays
+    with pytest.raises(ValueError):
+        tolerance.check(want, want, s, golden_order="blas")
+
+
 def test_file_verifier_uses_the_same_bar(tmp_path, monkeypatch, oracle):
     monkeypatch.chdir(tmp_path)
     (a, sfa), (b, sfb), golden = files.gen_golden_data(64, 256, 512, mode="fp8", seed=4)
