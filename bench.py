@@ -67,6 +67,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-shape-list", action="store_true", help="skip the reference's 18-shape sweep list leg")
     ap.add_argument("--no-policies", action="store_true",
                     help="skip the side-by-side legs of the bf16-exact and strict arithmetic policies")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the committed PMC passes instead of two rocprofv3 child runs of this invocation")
     ap.add_argument("--widen", action="store_true",
                     help="also time the rows either side of the hot path (contiguous-grouped layout, quantiser); off by "
                          "default so that the default command's kernel statistics hold the headline kernels only")
@@ -147,6 +149,47 @@ def pmc_traffic(workload: str):
         except Exception:
             continue
     return None
+
+
+def live_pmc_traffic(m, n, k, launches=260, skip=200, timeout_s=150):
+    """HBM-side bytes per launch of the dense tile kernel measured BY THIS RUN: two child processes (scripts/prof_dense.py, the
+    same kernel on the same recipe) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... WRITE_SIZE` -- separate passes,
+    the counters' units and the gfx950 correction as MI355X_MICROARCH.md prescribes (FETCH_SIZE counts 64 B per 128-B request of
+    wide coalesced reads: x 2; KB: x 1024), mean over the launches after the first `skip` (sustained clocks).  The children are
+    started, not exec'ed (this process has initialised the GPU), with rocprofv3's program directly behind `--`.
+    Returns (bytes or None, how / why not)."""
+    import csv as _csv
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    mean = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="dga_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   str(ROOT / "scripts" / "prof_dense.py"), str(m), str(n), str(k), str(launches)]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            files = sorted(Path(d).rglob("*_counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter}: rc {r.returncode}, {(r.stderr or '')[-200:]!r}"
+            per = {}
+            with open(files[0]) as f:
+                for row in _csv.DictReader(f):
+                    if "gemm_fp8_blockscaled" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        per[int(row["Dispatch_Id"])] = per.get(int(row["Dispatch_Id"]), 0.0) + float(row["Counter_Value"])
+            vals = [v for _, v in sorted(per.items())][skip:]
+            if not vals:
+                return None, f"no launches of the tile kernel in the {counter} pass"
+            mean[counter] = sum(vals) / len(vals)
+        except Exception as e:
+            return None, f"{counter} pass: {e!r}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    byt = int(mean["FETCH_SIZE"] * 2 * 1024 + mean["WRITE_SIZE"] * 1024)
+    return byt, (f"this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate child processes of bench.py, scripts/prof_dense.py, "
+                 f"mean of launches {skip + 1}..{launches}; FETCH_SIZE {mean['FETCH_SIZE']:.0f} KB x 2 (gfx950), WRITE_SIZE {mean['WRITE_SIZE']:.0f} KB)")
 
 
 # --------------------------------------------------------------------------------------------------- legs
@@ -617,6 +660,13 @@ def main():
     if args.workload == "dense_4096":
         res["roofline"]["traffic"] = pmc_traffic("dense")
         res["roofline"]["traffic_source"] = pmc_traffic_source()
+        if rank == 0 and world == 1 and not args.no_live_traffic:   # the counters of THIS run where rocprofv3 is there to take them
+            live, how = live_pmc_traffic(m, n, k)
+            if live is not None:
+                res["roofline"]["traffic_committed"] = res["roofline"]["traffic"]
+                res["roofline"]["traffic"], res["roofline"]["traffic_source"] = live, how
+            else:
+                res["roofline"]["traffic_live_error"] = how
 
     if rank == 0 and not args.no_parity:
         try:

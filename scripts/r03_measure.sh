@@ -9,7 +9,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --steps 200 --warmup 20 > $O/bench.json 2> $O/bench.err
 echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o r03 -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof_stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o r03 -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-live-traffic > $O/bench_under_rocprof.json 2> $O/rocprof_stats.err
 echo "stats done"
 # traffic: dense configs[1], configs[2], grouped configs[3]; 400 warm launches first so that the counters are read at
 # sustained clocks
