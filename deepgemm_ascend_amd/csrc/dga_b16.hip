@@ -11,6 +11,8 @@
 //     (8 two-byte loads down a column) -- no LDS, no transposition pass; correct, slow.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include <cstdint>
@@ -131,7 +133,36 @@ static B16Plan b16_plan(int batch, int m, int n, int k)
     const int ks_n = (k + 63) / 64;
     auto tiles_of = [&](int bm, int bn) { return static_cast<int64_t>(batch) * ((m + bm - 1) / bm) * ((n + bn - 1) / bn); };
     B16Plan pl{128, 128, 1, ks_n};
+    if (const char *e = std::getenv("DGA_B16_PLAN")) {   // development: "bm,bn,splitk" (scripts/op16_plan_ab.py)
+        int bm = 0, bn = 0, s = 1;
+        if (std::sscanf(e, "%d,%d,%d", &bm, &bn, &s) >= 2 && bm > 0 && bn > 0) {
+            pl.bm = bm; pl.bn = bn;
+            if (s > 1) { pl.ks_per_split = (ks_n + s - 1) / s; pl.splitk = (ks_n + pl.ks_per_split - 1) / pl.ks_per_split; }
+            return pl;
+        }
+    }
     const int64_t cus = device_cus();            // 256 on a whole MI355X; fewer under a compute-partition mode
+    // More than one short tile row: (tile, split-K) by rounds x k steps x the tile's measured time per 64-wide k step, + the
+    // combine of a split (device-timed A/B of the plans on nine mid-size shapes, scripts/op16_plan_ab.py ->
+    // profiles/r03_op16_plan_ab.txt: 1024x4096x7168 84 -> 64 us, 1536x6144x4096 101 -> 78, 512x7168x4096 49 -> 41,
+    // 1024x18432x7168 326 -> 287 against the fill-the-chip-with-the-biggest-tile rule below, which stays for M <= 64).
+    if (m > 64) {
+        struct Cand { int bm, bn; double us_per_step; int wpc; };
+        static const Cand kCands[] = {{256, 256, 1.45, 1}, {128, 256, 0.87, 1}, {128, 128, 0.73, 2}};
+        double best = 1e300;
+        for (const Cand &c : kCands)
+            for (int s : {1, 2, 3, 4}) {
+                if (s > 1 && ks_n / s < 8) continue;
+                const int per = (ks_n + s - 1) / s, s_eff = (ks_n + per - 1) / per;
+                const int64_t items = tiles_of(c.bm, c.bn) * s_eff;
+                const double rounds = std::ceil(static_cast<double>(items) / static_cast<double>(cus * c.wpc));
+                const double share = static_cast<double>(std::min<int64_t>(c.wpc, (items + cus - 1) / cus));
+                double t = 3.0 + rounds * per * c.us_per_step * std::pow(share, 0.6);
+                if (s_eff > 1) t += 4.0 + static_cast<double>(s_eff) * batch * m * n * 8.0 / 5.0e6;
+                if (t < best) { best = t; pl.bm = c.bm; pl.bn = c.bn; pl.splitk = s_eff; pl.ks_per_split = per; }
+            }
+        return pl;
+    }
     const int64_t fill = cus * 3 / 4;            // "the big tile fills the chip": three quarters of the CUs
     if (tiles_of(256, 256) >= fill) { pl.bm = 256; pl.bn = 256; return pl; }
     if (tiles_of(128, 256) >= fill) { pl.bm = 128; pl.bn = 256; return pl; }   // 8 waves, three LDS stages
