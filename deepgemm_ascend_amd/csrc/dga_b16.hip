@@ -148,10 +148,10 @@ static B16Plan b16_plan(int batch, int m, int n, int k)
     // 1024x18432x7168 326 -> 287 against the fill-the-chip-with-the-biggest-tile rule below, which stays for M <= 64).
     if (m > 64) {
         struct Cand { int bm, bn; double us_per_step; int wpc; };
-        static const Cand kCands[] = {{256, 256, 1.45, 1}, {128, 256, 0.87, 1}, {128, 128, 0.73, 2}};
+        static const Cand kCands[] = {{256, 256, 1.45, 1}, {128, 256, 0.87, 1}, {128, 128, 0.73, 2}, {64, 128, 0.58, 2}};
         double best = 1e300;
         for (const Cand &c : kCands)
-            for (int s : {1, 2, 3, 4}) {
+            for (int s : {1, 2, 3, 4, 6, 8, 12, 16}) {
                 if (s > 1 && ks_n / s < 8) continue;
                 const int per = (ks_n + s - 1) / s, s_eff = (ks_n + per - 1) / per;
                 const int64_t items = tiles_of(c.bm, c.bn) * s_eff;

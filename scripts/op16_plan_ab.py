@@ -18,9 +18,9 @@ for s in sys.argv[1:]:
     err = float((o.float() - ref).abs().max() / ref.abs().max())
     print(s, "%%.1f" %% sweep.graph_us(fn, 10, 3, 30.0), "%%.1e" %% err, flush=True)
 ''' % str(ROOT)
-shapes = ["1024,4096,7168", "1024,18432,7168", "2048,4096,7168", "4096,4096,4096", "512,7168,4096", "3072,4096,4096", "1536,6144,4096", "768,8192,8192", "4608,4096,7168"]
+shapes = sys.argv[1].split() if len(sys.argv) > 1 else ["1024,4096,7168", "1024,18432,7168", "2048,4096,7168", "4096,4096,4096", "512,7168,4096", "3072,4096,4096", "1536,6144,4096", "768,8192,8192", "4608,4096,7168"]
 res = {}
-for plan in (None, "256,256,1", "128,256,1", "128,128,1", "128,256,2", "128,128,2", "256,256,2"):
+for plan in ((None,) + tuple(sys.argv[2].split())) if len(sys.argv) > 2 else (None, "256,256,1", "128,256,1", "128,128,1", "128,256,2", "128,128,2", "256,256,2"):
     env = dict(os.environ)
     if plan:
         env["DGA_B16_PLAN"] = plan
