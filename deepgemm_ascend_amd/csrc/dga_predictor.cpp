@@ -27,7 +27,10 @@ namespace predictor {
 
 constexpr int kFeatures = 16;
 constexpr int kMinCandidates = 4;        // get_best_config.py:587 (min_tiling = 60 on the reference's 16-aligned grid)
-constexpr float kGainThreshold = 0.03f;  // get_best_config.py:606-616 (time_diff_threshold)
+// get_best_config.py:606-616 (time_diff_threshold: 3 % there).  Here 20 %: against round 3's fitted selector the model's picks that
+// promise less than that lose on the device more often than they win (profiles/r03_predictor/validation_on_device.json: the four
+// picks promising >= 20 % ran in 0.84 / 0.88 / 1.02 / 0.90 of the native time, the fifteen below it in 1.04 geomean)
+constexpr float kGainThreshold = 0.20f;
 
 struct Layer { int out = 0, in = 0; std::vector<float> w, b; };
 struct Model {
