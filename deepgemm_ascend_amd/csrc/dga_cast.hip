@@ -8,6 +8,7 @@
 // and the results are byte-exact against it.  Both kernels are HBM streams (read 2 or 4 bytes, write 1 per element).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include "dga_hip.h"
 #include "dga_internal.hpp"
@@ -153,6 +154,39 @@ __global__ void __launch_bounds__(256) cast_1x128_kernel(const void *x, uint8_t 
     }
 }
 
+// The same, U blocks per 16-lane group with all U loads issued before the first is used: U x 16 (32) bytes in flight per lane
+// instead of one load.  Block j of a group is blk + j * stride (stride = a U-th of the blocks), so that each of the U passes of
+// the grid is the contiguous stream the one-block kernel reads.  Whole rows only on the fast path (vec_in, vec_out, K % 128 == 0).
+template <typename T, int U>
+__global__ void __launch_bounds__(256) cast_1x128_unrolled_kernel(const void *x, uint8_t *q, float *sf, int64_t blocks, int64_t stride)
+{
+    const int64_t blk0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    if (blk0 >= stride) return;
+    const int sub = threadIdx.x & 15;
+    float v[U][8];
+    bool live[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const int64_t blk = blk0 + j * stride;
+        live[j] = blk < blocks;
+        if (live[j]) Elem<T>::load8(x, blk * 128 + sub * 8, v[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        if (!live[j]) continue;          // (uniform over the 16-lane group)
+        const int64_t blk = blk0 + j * stride;
+        float amax = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = __builtin_fmaxf(amax, __builtin_fabsf(v[j][e]));
+        amax = row16_max(amax);
+        const float s = amax > 0.f ? amax / 448.f : 1.f;
+        if (sub == 0) sf[blk] = s;
+        uint32_t w0, w1;
+        quant8(v[j], s, w0, w1);
+        *(v2i_c *)(q + blk * 128 + sub * 8) = v2i_c{(int)w0, (int)w1};
+    }
+}
+
 // one workgroup per 128x128 block: thread t holds 64 elements of row t/2 (columns 64*(t&1) ..), the block amax goes
 // through LDS, nothing is read twice.
 template <typename T>
@@ -216,6 +250,23 @@ static int launch_cast(int mode, const void *x, void *q, float *sf, int64_t rows
     // a lane's 8 elements start at element row*k + 8*j: 16-byte aligned for every row iff k % 8 == 0
     const bool vec_in = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (k % 8 == 0);
     const bool vec_out = (reinterpret_cast<uintptr_t>(q) % 8 == 0) && (k % 8 == 0);
+    // 16-bit inputs, large problems: two blocks per 16-lane group (32 bytes in flight per lane): [32768, 7168] bf16 140.7 -> 124.2 us
+    // (5.06 -> 5.73 TB/s; four blocks 129.8; fp32 inputs are faster one block at a time: 195 against 203 / 207 us; scripts/cast_ab.py)
+    static const int unroll = [] { const char *e = std::getenv("DGA_CAST_UNROLL"); return e ? std::atoi(e) : 0; }();
+    const bool two = unroll ? unroll >= 2 : (Elem<T>::kBytes == 2 && rows * kb_n >= 131072);
+    if (mode == 0 && vec_in && vec_out && k % 128 == 0 && two) {
+        const int64_t blocks = rows * kb_n;
+        const int64_t stride = (blocks + 1) / 2;
+        const int64_t grid = (stride * 16 + 255) / 256;
+        if (grid > 0x7FFFFFFFll) return DGA_E_RANGE;
+        if (unroll >= 4)
+            hipLaunchKernelGGL((cast_1x128_unrolled_kernel<T, 4>), dim3(static_cast<unsigned>(((blocks + 3) / 4 * 16 + 255) / 256)), dim3(256), 0,
+                               stream, x, static_cast<uint8_t *>(q), sf, blocks, (blocks + 3) / 4);
+        else
+            hipLaunchKernelGGL((cast_1x128_unrolled_kernel<T, 2>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream, x,
+                               static_cast<uint8_t *>(q), sf, blocks, stride);
+        return record_hip(hipGetLastError());
+    }
     if (mode == 0) {
         const int64_t blocks = rows * kb_n;
         const int64_t grid = (blocks * 16 + 255) / 256;
