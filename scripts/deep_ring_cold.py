@@ -1,5 +1,6 @@
 """Decode shapes cold (operand sets rotated past the Infinity Cache): the tuned tiling against deeper LDS rings (stages 4..6) of the
-same tile, and neighbouring split-K factors.  usage: python scripts/deep_ring_cold.py [iters]"""
+same tile, and neighbouring split-K factors (profiles/r03_deep_ring_cold.txt; the 4..6-stage builds existed only for that
+measurement: today those rows report DGA_E_TILING).  usage: python scripts/deep_ring_cold.py [iters]"""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

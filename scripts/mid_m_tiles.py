@@ -1,3 +1,5 @@
+"""Mid-M shapes over tile / wave-layout / policy / split-K candidates (profiles/r03_mid_m_tiles.txt).  The 128x128 builds with eight
+computing waves (w2x4, w4x2) existed only for that measurement: today those two rows report DGA_E_TILING."""
 import sys; sys.path.insert(0, '/root/repo')
 import torch
 import deepgemm_ascend_amd as dga
