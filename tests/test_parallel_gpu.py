@@ -238,3 +238,38 @@ def test_indexed_gemm_equals_packed_gemm(dga, strict):
         owned[idx] = True
         assert np.array_equal(got[idx], want[i, :masked[i]]), f"group {i}"
     assert (got[~owned] == _bits(torch.tensor([-5.0], dtype=torch.bfloat16))[0]).all()
+
+
+def test_config4_full_size_forward_properties(dga):
+    """BASELINE configs[3] at full size through the sharded forward at world 1 (256 experts x (M <= 128, K = 7168, N = 2048), 32 768
+    tokens on the SURVEY 8(d) recipe), checked by properties that need no CPU reference of that size: (a) a permuted batch gives the
+    same rows bit for bit, through the library path and through the HIP graph; (b) the rows of four sampled experts equal the masked
+    grouped GEMM called directly on those experts' tokens (strict policy on both sides: bit-identical)."""
+    from deepgemm_ascend_amd import parallel
+    dev = torch.device("cuda", 0)
+    g_total, m_max, n, k = 256, 128, 2048, 7168
+    gen = torch.Generator(device=dev).manual_seed(11)
+    eng = parallel.ExpertShardedGroupedGemm(0, 1, g_total, m_max, n, k, dev, None, policy="strict")
+    b, sfb = parallel._quantised_weights(g_total, n, k, gen, dev)
+    eng.set_weights(b, sfb)
+    per = torch.randint(64, m_max + 1, (g_total,), generator=torch.Generator().manual_seed(5))
+    ids = torch.repeat_interleave(torch.arange(g_total), per).to(dev)
+    ids = ids[torch.randperm(ids.numel(), device=dev, generator=gen)].contiguous()
+    T = ids.numel()
+    q, sf = parallel._quantised_tokens(T, k, gen, dev)
+    r1 = eng.forward(q, sf, ids).clone()
+    eng.check()
+    perm = torch.randperm(T, device=dev, generator=gen)
+    r2 = eng.forward(q[perm].contiguous(), sf[perm].contiguous(), ids[perm].contiguous()).clone()
+    eng.check()
+    assert torch.equal(r1[perm].view(torch.int16), r2.view(torch.int16))
+    assert int((r1.view(torch.int16) != 0).any(dim=1).sum()) == T
+    for e in (0, 77, 200, 255):
+        rows = torch.nonzero(ids == e).flatten()
+        mm = rows.numel()
+        a = torch.zeros((1, m_max, k), dtype=torch.uint8, device=dev); a[0, :mm] = q.view(torch.uint8)[rows]
+        sa = torch.ones((1, m_max, k // 128), dtype=torch.float32, device=dev); sa[0, :mm] = sf[rows]
+        out = torch.zeros((1, m_max, n), dtype=torch.bfloat16, device=dev)
+        dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sa), (b[e:e + 1].contiguous(), sfb[e:e + 1].contiguous()), out,
+                                                  torch.tensor([mm], dtype=torch.int32, device=dev), mm, strict=True, sync=True)
+        assert torch.equal(out[0, :mm].view(torch.int16), r1[rows].view(torch.int16)), e
