@@ -1,6 +1,8 @@
 """Fit the dense selector's cost model to a device-timed sweep (harness/sweep.py --cold --heuristic-raster records) and report the
 regret of picking by it: per shape, time of the (tile, split-K) the model prefers / time of the best candidate.
-usage: python scripts/fit_heuristic.py TRAIN_DIR [TRAIN_DIR ...] [--eval DIR [DIR ...]]   (regret on the --eval records, held out)"""
+usage: python scripts/fit_heuristic.py TRAIN_DIR [TRAIN_DIR ...] [--eval DIR [DIR ...]]   (regret on the --eval records, held out)
+--item-floor: a variant with a per-workgroup stream floor on cold short-M items (held-out 1.0213 -> 1.0179, in sample 1.0130 -> 1.0124:
+not adopted in csrc/dga_tiling.cpp)."""
 import glob, json, math, sys
 from pathlib import Path
 import numpy as np
@@ -11,6 +13,9 @@ if "--bf16-exact" in sys.argv:       # the bf16-exact policy's own menu (records
     sys.argv.remove("--bf16-exact")
     TILES = [(0, 0), (128, 256), (0, 1), (128, 128), (64, 256), (64, 128), (0, 2), (32, 128), (0, 3), (0, 4)]
 CUS = 256
+COLD_ITEM_FLOOR = "--item-floor" in sys.argv
+if COLD_ITEM_FLOOR:
+    sys.argv.remove("--item-floor")
 
 
 def load(dirs):
@@ -61,7 +66,10 @@ def predict(theta, m, n, k, c):
     sh = theta[10]                          # slowdown exponent when `share` workgroups run on one CU
     launch, pro, comb, slab_bw, hbm = theta[11], theta[12], theta[13], theta[14], theta[15]
     bm, bn, sk, per, tiles, items, rounds, share = features(m, n, k, c)
-    t_item = per * ckb * share ** sh + pro
+    step = ckb * share ** sh
+    if COLD_ITEM_FLOOR and m <= 256:        # a cold short-M stream: a workgroup pulls its own A and B rows at theta[16] GB/s at most
+        step = max(step, (bm + bn) * 128 / (theta[16] * 1e3))
+    t_item = per * step + pro
     t = launch + rounds * t_item
     tiles_m = -(-m // bm)
     byt = m * k + n * k * (tiles_m if m <= 256 else 1) + 2 * m * n   # a short-M weight stream is cold: every tile row streams B again
