@@ -164,6 +164,8 @@ def live_pmc_traffic(m, n, k, launches=260, skip=200, timeout_s=90):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ):
+        return None, "this process runs under a profiler already: no nested rocprofv3 passes"
     mean = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="dga_pmc_", dir="/tmp")
