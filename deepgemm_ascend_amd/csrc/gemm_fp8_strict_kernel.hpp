@@ -31,6 +31,19 @@ __device__ __forceinline__ float mul_no_fma(float a, float b)
     return a * b;
 }
 
+// 4 x 4 byte transpose of a 16-byte chunk: dword q of the result holds bytes q, 4 + q, 8 + q, 12 + q of the chunk -- the four k
+// values lane group q of the 16x16x4 MFMA feeds over a chunk's four steps, in step order.  Eight v_perm_b32 per chunk at staging
+// time buy a conversion without a per-lane shift, two steps per v_cvt_pk_f32_fp8: next to fp32 MFMAs every vector instruction is
+// paid in matrix-pipe time (scripts/ubench/f32x_ubench: the pipe alone 0.99 of its peak, with a shift + a conversion per operand
+// value 0.68).
+__device__ __forceinline__ v4i transpose_bytes_4x4(v4i w)
+{
+    const uint32_t a = __builtin_amdgcn_perm((uint32_t)w.y, (uint32_t)w.x, 0x05010400u), b = __builtin_amdgcn_perm((uint32_t)w.y, (uint32_t)w.x, 0x07030602u);
+    const uint32_t c = __builtin_amdgcn_perm((uint32_t)w.w, (uint32_t)w.z, 0x05010400u), d = __builtin_amdgcn_perm((uint32_t)w.w, (uint32_t)w.z, 0x07030602u);
+    return v4i{(int)__builtin_amdgcn_perm(c, a, 0x05040100u), (int)__builtin_amdgcn_perm(c, a, 0x07060302u),
+               (int)__builtin_amdgcn_perm(d, b, 0x05040100u), (int)__builtin_amdgcn_perm(d, b, 0x07060302u)};
+}
+
 // TM = m-tiles (16 rows) per wave; workgroup = 2 x 2 waves, tile (32*TM) x 128, one LDS stage, register prefetch.
 // The launcher uses TM = 2 (two workgroups per CU cover each other's barriers: 110 TFLOP/s at 4096^3 against 91 for TM = 4)
 // and TM = 1 where 64-row tiles would leave CUs idle.
@@ -105,12 +118,12 @@ __global__ void __launch_bounds__(256) gemm_fp8_strict_nt_kernel(const GemmParam
 #pragma unroll
         for (int it = 0; it < A_CH; ++it) {
             const int c = it * 256 + tid, row = c >> 3, ch = c & 7;
-            *(v4i *)(lds_a + row * 128 + ((ch ^ swz_a(row)) * 16)) = ra[it];
+            *(v4i *)(lds_a + row * 128 + ((ch ^ swz_a(row)) * 16)) = transpose_bytes_4x4(ra[it]);
         }
 #pragma unroll
         for (int it = 0; it < B_CH; ++it) {
             const int c = it * 256 + tid, row = c >> 3, ch = c & 7;
-            *(v4i *)(lds_b + row * 128 + ((ch ^ swz_a(row)) * 16)) = rb[it];
+            *(v4i *)(lds_b + row * 128 + ((ch ^ swz_a(row)) * 16)) = transpose_bytes_4x4(rb[it]);
         }
         if (tid <= BM) lds_s[tid] = rs;
     };
@@ -123,7 +136,6 @@ __global__ void __launch_bounds__(256) gemm_fp8_strict_nt_kernel(const GemmParam
 
     const int a_row = wm * (16 * TM) + r;   // + 16*mt
     const int b_row = wn * 64 + r;          // + 16*nt
-    const int sh = 8 * q;                   // this lane's byte of every dword: k = 4*step + q
 
     if (p.kb_n > 0) fetch(0);
     for (int kb = 0; kb < p.kb_n; ++kb) {
@@ -139,29 +151,31 @@ __global__ void __launch_bounds__(256) gemm_fp8_strict_nt_kernel(const GemmParam
             for (int j = 0; j < TN; ++j) part[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
         for (int c = 0; c < 8; ++c) {
-            v4i ca[TM], cb[TN];
+            int ca[TM], cb[TN];          // this lane's dword of the chunk: k = 16c + q, + 4, + 8, + 12
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
                 const int row = a_row + 16 * mt;
-                ca[mt] = *(const v4i *)(lds_a + row * 128 + ((c ^ swz_a(row)) * 16));
+                ca[mt] = *(const int *)(lds_a + row * 128 + ((c ^ swz_a(row)) * 16) + 4 * q);
             }
 #pragma unroll
             for (int nt = 0; nt < TN; ++nt) {
                 const int row = b_row + 16 * nt;
-                cb[nt] = *(const v4i *)(lds_b + row * 128 + ((c ^ swz_a(row)) * 16));
+                cb[nt] = *(const int *)(lds_b + row * 128 + ((c ^ swz_a(row)) * 16) + 4 * q);
             }
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {   // step 4c + d of the chain: k = 16c + 4d + q
-                float fa[TM], fb[TN];
+            for (int h = 0; h < 2; ++h) {   // steps 4c + 2h and 4c + 2h + 1 of the chain: one packed conversion per operand value
+                v2f fa[TM], fb[TN];
 #pragma unroll
-                for (int mt = 0; mt < TM; ++mt) fa[mt] = __builtin_amdgcn_cvt_f32_fp8((int)((uint32_t)ca[mt][d] >> sh), 0);
+                for (int mt = 0; mt < TM; ++mt) fa[mt] = h ? __builtin_amdgcn_cvt_pk_f32_fp8(ca[mt], true) : __builtin_amdgcn_cvt_pk_f32_fp8(ca[mt], false);
 #pragma unroll
-                for (int nt = 0; nt < TN; ++nt) fb[nt] = __builtin_amdgcn_cvt_f32_fp8((int)((uint32_t)cb[nt][d] >> sh), 0);
+                for (int nt = 0; nt < TN; ++nt) fb[nt] = h ? __builtin_amdgcn_cvt_pk_f32_fp8(cb[nt], true) : __builtin_amdgcn_cvt_pk_f32_fp8(cb[nt], false);
 #pragma unroll
-                for (int nt = 0; nt < TN; ++nt)
+                for (int d = 0; d < 2; ++d)
 #pragma unroll
-                    for (int mt = 0; mt < TM; ++mt)
-                        part[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[nt], fa[mt], part[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < TM; ++mt)
+                            part[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(d ? fb[nt].y : fb[nt].x, d ? fa[mt].y : fa[mt].x, part[mt][nt], 0, 0, 0);
             }
         }
         // two-level dequant in the oracle's order: s = sfa * sfb (rounded), acc = acc + partial * s (two roundings)
@@ -171,6 +185,7 @@ __global__ void __launch_bounds__(256) gemm_fp8_strict_nt_kernel(const GemmParam
             const float s = mul_no_fma(lds_s[a_row + 16 * mt], sfb_v);
 #pragma unroll
             for (int nt = 0; nt < TN; ++nt) {
+                // (scalar on purpose: v_pk_mul_f32 + v_pk_add_f32 here measured 1181 against 1130 us at 4096^3)
                 acc[mt][nt].x = promote_no_fma(acc[mt][nt].x, part[mt][nt].x, s);
                 acc[mt][nt].y = promote_no_fma(acc[mt][nt].y, part[mt][nt].y, s);
                 acc[mt][nt].z = promote_no_fma(acc[mt][nt].z, part[mt][nt].z, s);
