@@ -95,24 +95,36 @@ __global__ void __launch_bounds__(256) gemm_fp8_strict_nt_kernel(const GemmParam
             if (kc + j < p.k) w[j >> 2] |= (uint32_t)row[kc + j] << (8 * (j & 3));
         return v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
     };
+    // row pointers of this thread's chunks (row clamp, row table, chunk column): once per tile, not once per k block
+    const uint8_t *a_ptr[A_CH], *b_ptr[B_CH];
+    int a_col[A_CH], b_col[B_CH];
+#pragma unroll
+    for (int it = 0; it < A_CH; ++it) {
+        const int c = it * 256 + tid, row = c >> 3;
+        const int mr = m0 + min(row, M - 1 - m0);
+        a_col[it] = (c & 7) * 16;
+        a_ptr[it] = A + (ridx ? ridx[mr] : (int64_t)mr) * p.lda;
+    }
+#pragma unroll
+    for (int it = 0; it < B_CH; ++it) {
+        const int c = it * 256 + tid, row = c >> 3;
+        b_col[it] = (c & 7) * 16;
+        b_ptr[it] = B + (int64_t)(n0 + min(row, p.n - 1 - n0)) * p.ldb;
+    }
+    const float *s_ptr = nullptr;
+    if (tid < BM) {
+        const int mr = min(m0 + tid, M - 1);
+        s_ptr = SFA + (ridx ? ridx[mr] : (int64_t)mr) * p.sfa_ld;
+    } else if (tid == BM) {
+        s_ptr = SFB;   // BM <= 128 < 256 threads
+    }
     auto fetch = [&](int kb) {
         const int k0 = kb * 128;
 #pragma unroll
-        for (int it = 0; it < A_CH; ++it) {
-            const int c = it * 256 + tid, row = c >> 3, ch = c & 7;
-            const int mr = m0 + min(row, M - 1 - m0);
-            ra[it] = fetch_chunk(A + (ridx ? ridx[mr] : (int64_t)mr) * p.lda, k0 + ch * 16);
-        }
+        for (int it = 0; it < A_CH; ++it) ra[it] = fetch_chunk(a_ptr[it], k0 + a_col[it]);
 #pragma unroll
-        for (int it = 0; it < B_CH; ++it) {
-            const int c = it * 256 + tid, row = c >> 3, ch = c & 7;
-            rb[it] = fetch_chunk(B + (int64_t)(n0 + min(row, p.n - 1 - n0)) * p.ldb, k0 + ch * 16);
-        }
-        if (tid < BM) {
-            const int mr = min(m0 + tid, M - 1);
-            rs = SFA[(ridx ? ridx[mr] : (int64_t)mr) * p.sfa_ld + kb];
-        }
-        else if (tid == BM) rs = SFB[kb];   // BM <= 128 < 256 threads
+        for (int it = 0; it < B_CH; ++it) rb[it] = fetch_chunk(b_ptr[it], k0 + b_col[it]);
+        if (s_ptr) rs = s_ptr[kb];
     };
     auto stage = [&]() {
 #pragma unroll
