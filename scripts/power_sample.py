@@ -50,3 +50,38 @@ for name, kw, secs in (("fast 4096^3", {}, 4.0), ("bf16_exact 4096^3", {"policy"
     print(f"{name}: {us:.1f} us per call;", samples[-3:], flush=True)
 time.sleep(1.0)
 print("idle again:", smi(), flush=True)
+# the 16-bit operator path and the grouped weight stream
+x = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16); y = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
+o = torch.empty(4096, 4096, device="cuda", dtype=torch.bfloat16)
+t0 = time.perf_counter()
+cnt, samples = run_for(lambda: dga.catlass_dynamic_matmul(x, y.t(), o), 4.0)
+print(f"bf16 operator 4096^3: {(time.perf_counter() - t0) / cnt * 1e6:.1f} us per call;", samples[-3:], flush=True)
+del x, y, o
+from deepgemm_ascend_amd import parallel
+gen = torch.Generator(device="cuda").manual_seed(1)
+G, MM, N, K = 256, 128, 2048, 7168
+gb, gsb = parallel._quantised_weights(G, N, K, gen, torch.device("cuda"))
+gq, gs = parallel._quantised_tokens(G * MM, K, gen, torch.device("cuda"))
+ga, gsa = gq.view(torch.uint8).view(G, MM, K), gs.view(G, MM, K // 128)
+go = torch.empty((G, MM, N), dtype=torch.bfloat16, device="cuda")
+mm = torch.full((G,), MM, dtype=torch.int32, device="cuda")
+stop_fn = lambda: dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((ga, gsa), (gb, gsb), go, mm, MM)
+
+
+def run_few(fn, seconds):
+    stop = [False]; samples = []
+    def sampler():
+        time.sleep(seconds * 0.4)
+        while not stop[0]:
+            samples.append(smi()); time.sleep(0.25)
+    th = threading.Thread(target=sampler); th.start()
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize(); n += 20
+    stop[0] = True; th.join()
+    return n, samples
+t0 = time.perf_counter()
+cnt, samples = run_few(stop_fn, 4.0)
+print(f"grouped 256 x (128, 7168, 2048): {(time.perf_counter() - t0) / cnt * 1e6:.1f} us per call;", samples[-3:], flush=True)
