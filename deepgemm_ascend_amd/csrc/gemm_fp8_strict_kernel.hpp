@@ -161,26 +161,31 @@ __global__ void __launch_bounds__(256) gemm_fp8_strict_nt_kernel(const GemmParam
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) part[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-        for (int c = 0; c < 8; ++c) {
-            int ca[TM], cb[TN];          // this lane's dword of the chunk: k = 16c + q, + 4, + 8, + 12
+        // chunk c + 1's dwords are read while chunk c's 32 MFMAs are issued (the loop is unrolled: the two register sets alternate)
+        int ca[2][TM], cb[2][TN];      // this lane's dword of a chunk: k = 16c + q, + 4, + 8, + 12
+        auto read_chunk = [&](int c, int (&da)[TM], int (&db)[TN]) {
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
                 const int row = a_row + 16 * mt;
-                ca[mt] = *(const int *)(lds_a + row * 128 + ((c ^ swz_a(row)) * 16) + 4 * q);
+                da[mt] = *(const int *)(lds_a + row * 128 + ((c ^ swz_a(row)) * 16) + 4 * q);
             }
 #pragma unroll
             for (int nt = 0; nt < TN; ++nt) {
                 const int row = b_row + 16 * nt;
-                cb[nt] = *(const int *)(lds_b + row * 128 + ((c ^ swz_a(row)) * 16) + 4 * q);
+                db[nt] = *(const int *)(lds_b + row * 128 + ((c ^ swz_a(row)) * 16) + 4 * q);
             }
+        };
+        read_chunk(0, ca[0], cb[0]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (c + 1 < 8) read_chunk(c + 1, ca[(c + 1) & 1], cb[(c + 1) & 1]);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {   // steps 4c + 2h and 4c + 2h + 1 of the chain: one packed conversion per operand value
                 v2f fa[TM], fb[TN];
 #pragma unroll
-                for (int mt = 0; mt < TM; ++mt) fa[mt] = h ? __builtin_amdgcn_cvt_pk_f32_fp8(ca[mt], true) : __builtin_amdgcn_cvt_pk_f32_fp8(ca[mt], false);
+                for (int mt = 0; mt < TM; ++mt) fa[mt] = h ? __builtin_amdgcn_cvt_pk_f32_fp8(ca[c & 1][mt], true) : __builtin_amdgcn_cvt_pk_f32_fp8(ca[c & 1][mt], false);
 #pragma unroll
-                for (int nt = 0; nt < TN; ++nt) fb[nt] = h ? __builtin_amdgcn_cvt_pk_f32_fp8(cb[nt], true) : __builtin_amdgcn_cvt_pk_f32_fp8(cb[nt], false);
+                for (int nt = 0; nt < TN; ++nt) fb[nt] = h ? __builtin_amdgcn_cvt_pk_f32_fp8(cb[c & 1][nt], true) : __builtin_amdgcn_cvt_pk_f32_fp8(cb[c & 1][nt], false);
 #pragma unroll
                 for (int d = 0; d < 2; ++d)
 #pragma unroll
