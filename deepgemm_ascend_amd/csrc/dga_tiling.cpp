@@ -396,10 +396,13 @@ static const DenseTileCost kDenseTileCost[] = {{256, 256, 1.547}, {128, 256, 0.9
                                                {16, 256, 0.394},  {16, 128, 0.213}};
 static const DenseCostModel kFastModel = {kDenseTileCost, 10, 0.8845, 2.66, 1.31, 3.53, 5.09e6, 8.0e6, 48.6e3};
 // the bf16-exact policy's menu (dga_launch_menu_e.hip: three stages, no loader waves), fitted the same way on its own
-// device-timed sweep (scripts/bx_sweep.py, 214 + 120 shapes): held-out pick / best 1.017 geomean, max 1.32 (the hand-set model
+// device-timed sweep (scripts/bx_sweep.py, 214 + 120 shapes): held-out pick / best 1.019 geomean, max 1.28 (the hand-set model
 // of this policy's first version, fitted to 19 shapes timed through Python: 1.069, max 1.47)
-static const DenseTileCost kBf16xTileCost[] = {{128, 256, 1.566}, {128, 128, 1.165}, {64, 256, 1.235}, {64, 128, 0.710}, {32, 128, 0.447}};
-static const DenseCostModel kBf16xModel = {kBf16xTileCost, 5, 0.619, 2.35, 2.81, 3.21, 5.41e6, 5.40e6, 23.8e3};
+// (refitted after the MFMA results moved to VGPRs -- the Makefile's -amdgpu-mfma-vgpr-form note: the 128x128 / 64x256 / 64x128 / 32x128
+//  builds lost a v_accvgpr_read per MFMA and 14-19 % of their time on mid-M shapes, profiles/r03_vgpr_form.txt)
+static const DenseTileCost kBf16xTileCost[] = {{128, 256, 1.583}, {128, 128, 0.966}, {64, 256, 1.075}, {64, 128, 0.677}, {32, 128, 0.605}};
+static constexpr double kBf16x32RowTallUs = 0.442;   // the 32-row build on a problem of more than 256 rows (warm operands): its own figure
+static const DenseCostModel kBf16xModel = {kBf16xTileCost, 5, 0.529, 1.57, 3.02, 2.98, 5.10e6, 5.35e6, 39.9e3};
 static constexpr uint32_t kDenseSplits[] = {1, 2, 3, 4, 5, 6, 8, 16};   // what the sweeps cover
 static bool tile_has_three_stages(int bm, int bn)
 {
@@ -950,7 +953,8 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out)
     int bm = out->m1, bn = out->n1;
     uint32_t sk = 1;
     for (int i = 0; i < kBf16xModel.n_tiles; ++i) {
-        const DenseTileCost &c = kBf16xModel.tiles[i];
+        DenseTileCost c = kBf16xModel.tiles[i];
+        if (c.bm == 32 && out->m > 256) c.us_per_kblock = kBf16x32RowTallUs;
         for (uint32_t s : kDenseSplits) {
             if (s > 1 && (kb < 4 * s || static_cast<uint64_t>(s) * out->m * out->n * 4 > (1ull << 30))) continue;
             uint32_t s_eff = 1;

@@ -9,6 +9,7 @@ import numpy as np
 from scipy.optimize import least_squares
 
 TILES = [(256, 256), (128, 256), (256, 128), (128, 128), (64, 256), (64, 128), (32, 256), (32, 128), (16, 256), (16, 128)]
+BF16X = "--bf16-exact" in sys.argv
 if "--bf16-exact" in sys.argv:       # the bf16-exact policy's own menu (records of scripts/bx_sweep.py); unused slots stay at their start values
     sys.argv.remove("--bf16-exact")
     TILES = [(0, 0), (128, 256), (0, 1), (128, 128), (64, 256), (64, 128), (0, 2), (32, 128), (0, 3), (0, 4)]
@@ -62,6 +63,8 @@ def features(m, n, k, c):
 
 def predict(theta, m, n, k, c):
     ti = TILES.index((c[0], c[1]))
+    if BF16X and c[0] == 32 and m > 256:    # the decode tile on a tall (warm, compute-bound) problem: its own figure (slot 6)
+        ti = 6
     ckb = theta[ti]                         # us per k block of one workgroup alone on its CU
     sh = theta[10]                          # slowdown exponent when `share` workgroups run on one CU
     launch, pro, comb, slab_bw, hbm = theta[11], theta[12], theta[13], theta[14], theta[15]

@@ -317,8 +317,8 @@ def test_contiguous_rows_share_a_bucketed_key(dga, tmp_path):
 
 
 def test_bf16_exact_policy_has_its_own_tiling(dga):
-    """dga_tiling_bf16_exact: dispatchPolicyTag 7, a tile of THAT policy's menu, and for dense mid-M shapes the 8-wave 128x256
-    build with a K split instead of the fast path's 4-wave pick (profiles/r03_bx_tile_sweep.txt); grouped layouts keep the fast
+    """dga_tiling_bf16_exact: dispatchPolicyTag 7, a tile of THAT policy's menu, picked by the cost model fitted to that menu's
+    own device-timed sweep (profiles/r03_predictor/bf16_exact_fit.txt); grouped layouts keep the fast
     tiling's tile; nothing is written to the tiling cache under the policy's name."""
     menu = {(128, 256), (128, 128), (64, 256), (64, 128), (32, 128)}
     for (m, n, k) in [(4096, 4096, 4096), (4096, 2048, 7168), (1024, 4096, 7168), (512, 4096, 7168), (128, 4096, 7168),
@@ -331,8 +331,8 @@ def test_bf16_exact_policy_has_its_own_tiling(dga):
         assert (t.splitkFactor > 1) == (t.kernelSerial == 4)
         assert dga.workspace_bytes(t) >= (m * n * 4 * t.splitkFactor if t.splitkFactor > 1 else 0)
     assert (dga.tiling(4096, 4096, 4096, policy="bf16_exact").m1, dga.tiling(4096, 4096, 4096, policy="bf16_exact").n1) == (128, 256)
-    mid = dga.tiling(1024, 4096, 7168, policy="bf16_exact")
-    assert (mid.m1, mid.n1) == (128, 256) and mid.splitkFactor == 2
+    mid = dga.tiling(1024, 4096, 7168, policy="bf16_exact")   # 256 tiles of 128x128, one per CU: 57 us against 85 for 128x256 (r03_vgpr_form.txt)
+    assert (mid.m1, mid.n1) == (128, 128) and mid.splitkFactor == 1
     assert dga.tiling(8, 18432, 7168, policy="bf16_exact").m1 == 32
     g = dga.tiling(128, 2048, 7168, groups=256, expected_m=128, policy="bf16_exact")
     f = dga.tiling(128, 2048, 7168, groups=256, expected_m=128)
