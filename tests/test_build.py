@@ -23,7 +23,8 @@ CSRC = ROOT / "deepgemm_ascend_amd" / "csrc"
     ("dga_b16.hip", 20, "gemm_b16_nt_f32_kernel")])
 def test_no_kernel_spills_or_scratch(unit, min_kernels, tile_kernel):
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT / 'include'}", f"-I{CSRC}",
-           "-fno-slp-vectorize", "-x", "hip", "--cuda-device-only", "-S", "-o", "/dev/null",
+           "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1",   # the Makefile's flags: the build that ships
+           "-x", "hip", "--cuda-device-only", "-S", "-o", "/dev/null",
            "-Rpass-analysis=kernel-resource-usage", str(CSRC / unit)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -43,4 +44,7 @@ def test_no_kernel_spills_or_scratch(unit, min_kernels, tile_kernel):
         m = re.search(r"VGPRs: (\d+)", line)
         if m and tile_kernel in (name or ""):
             assert int(m.group(1)) <= 256, name
+        m = re.search(r"AGPRs: (\d+)", line)
+        if m and "gemm_" in (name or ""):
+            assert int(m.group(1)) == 0, f"{name}: MFMA results in AGPRs (a v_accvgpr_read per promoted value in the main loop)"
     assert seen >= min_kernels, seen
