@@ -179,21 +179,28 @@ __global__ void __launch_bounds__(256) gemm_fp8_strict_nt_kernel(const GemmParam
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             if (c + 1 < 8) read_chunk(c + 1, ca[(c + 1) & 1], cb[(c + 1) & 1]);
+            // the chunk's twelve packed conversions first (steps 4c .. 4c + 3: two steps per conversion), then its 32 MFMAs: a
+            // conversion whose result the very next MFMA reads stalls that MFMA behind the vector write (1103 -> 1050 us at 4096^3;
+            // a whole chunk ahead instead costs 20 more registers, the third wave per SIMD with them, and measures 1078)
+            v2f fa[2][TM], fb[2][TN];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {   // steps 4c + 2h and 4c + 2h + 1 of the chain: one packed conversion per operand value
-                v2f fa[TM], fb[TN];
+            for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                for (int mt = 0; mt < TM; ++mt) fa[mt] = h ? __builtin_amdgcn_cvt_pk_f32_fp8(ca[c & 1][mt], true) : __builtin_amdgcn_cvt_pk_f32_fp8(ca[c & 1][mt], false);
+                for (int mt = 0; mt < TM; ++mt) fa[h][mt] = h ? __builtin_amdgcn_cvt_pk_f32_fp8(ca[c & 1][mt], true) : __builtin_amdgcn_cvt_pk_f32_fp8(ca[c & 1][mt], false);
 #pragma unroll
-                for (int nt = 0; nt < TN; ++nt) fb[nt] = h ? __builtin_amdgcn_cvt_pk_f32_fp8(cb[c & 1][nt], true) : __builtin_amdgcn_cvt_pk_f32_fp8(cb[c & 1][nt], false);
+                for (int nt = 0; nt < TN; ++nt) fb[h][nt] = h ? __builtin_amdgcn_cvt_pk_f32_fp8(cb[c & 1][nt], true) : __builtin_amdgcn_cvt_pk_f32_fp8(cb[c & 1][nt], false);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int d = 0; d < 2; ++d)
 #pragma unroll
                     for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
                         for (int mt = 0; mt < TM; ++mt)
-                            part[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(d ? fb[nt].y : fb[nt].x, d ? fa[mt].y : fa[mt].x, part[mt][nt], 0, 0, 0);
-            }
+                            part[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(d ? fb[h][nt].y : fb[h][nt].x, d ? fa[h][mt].y : fa[h][mt].x, part[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // two-level dequant in the oracle's order: s = sfa * sfb (rounded), acc = acc + partial * s (two roundings)
         const float sfb_v = lds_s[BM];
