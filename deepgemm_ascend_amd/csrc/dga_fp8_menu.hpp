@@ -63,10 +63,10 @@ int launch_bf16x(const GemmParams &p, hipStream_t stream);
     extern template int launch_bf16x<GemmCfg<BM, BN, WM, WN, ST>>(const GemmParams &, hipStream_t);
 DGA_MENU_BX(DGA_MENU_EXTERN_BX)
 
-// image build of the bf16-exact policy (gemm_fp8_bf16x_image_kernel.hpp; dga_launch_menu_f.hip): 128 x 256 tile, one wave per
-// SIMD, both operands converted once per workgroup into a bf16 LDS image.  Dense and masked-grouped rasters (split-K too);
+// image builds of the bf16-exact policy (gemm_fp8_bf16x_image_kernel.hpp; dga_launch_menu_f.hip): 128 x 256 tile, both operands
+// converted once per workgroup into a bf16 LDS image; waves = 8 (two per SIMD, 64 x 64 wave tiles) or 4 (one per SIMD, 64 x 128).  Dense and masked-grouped rasters (split-K too);
 // DGA_E_TILING for the contiguous / indexed layouts
-int launch_bf16x_image(const GemmParams &p, hipStream_t stream);
+int launch_bf16x_image(const GemmParams &p, int waves, hipStream_t stream);
 
 // persistent continuous-pipeline build of the 256x256 tile (gemm_fp8_cont_persistent_kernel.hpp, dispatchPolicyTag 6): dense
 // rasters of full tiles only -- launch_cont_persistent returns DGA_E_TILING for anything else

@@ -292,12 +292,17 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     const bool bf16x = tiling->dispatchPolicyTag == DGA_POLICY_BF16_EXACT || bf16x_env;
     const Bf16xVariant *vx = bf16x ? find_bf16x_variant(tiling->m1, tiling->n1) : nullptr;
     if (bf16x && (!vx || clock_stamps)) return DGA_E_TILING;
-    // the 128 x 256 tile's image build (bf16 LDS image converted once per workgroup; same bits as the in-register build):
-    // dense and masked-grouped layouts.  A tiling that names the 2 x 4 wave layout keeps the in-register build;
-    // $DGA_BX_IMAGE = 0 / 1 overrides (A/B runs).
+    // the 128 x 256 tile's image builds (bf16 LDS image converted once per workgroup; same bits as the in-register build; dense
+    // and masked-grouped layouts).  They measured 10 % SLOWER than the in-register build (profiles/r04_bximg_stamps.txt: two
+    // barriers per k block and twice the LDS bytes on a power-bound loop), so they run only when asked for: a tiling with
+    // wavesM = wavesN = 2 takes the 4-wave build, one with two stages the 8-wave build; $DGA_BX_IMAGE = 0 / 4 / 8 overrides.
     static const int bx_image_env = [] { const char *e = std::getenv("DGA_BX_IMAGE"); return e ? std::atoi(e) : -1; }();
-    const bool bx_image = vx && vx->bm == 128 && vx->bn == 256 && !m_indices && !ix &&
-                          (bx_image_env >= 0 ? bx_image_env != 0 : !(tiling->wavesM == 2 && tiling->wavesN == 4));
+    int bx_image = 0;
+    if (vx && vx->bm == 128 && vx->bn == 256 && !m_indices && !ix) {
+        if (bx_image_env >= 0) bx_image = bx_image_env == 4 ? 4 : (bx_image_env ? 8 : 0);
+        else if (tiling->wavesM == 2 && tiling->wavesN == 2) bx_image = 4;
+        else if (tiling->stages == 2 && tiling->wavesM == 2 && tiling->wavesN == 4) bx_image = 8;
+    }
     const Variant *v = find_variant(tiling->m1, tiling->n1, tiling->wavesM, tiling->wavesN, tiling->stages);
     if (!v && !vx) return DGA_E_TILING;
     const int tile_m = vx ? vx->bm : v->bm, tile_n = vx ? vx->bn : v->bn;
@@ -327,7 +332,7 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
             p.partial = slabs;
             GemmParams pk = p;
             pk.groups = s;  // grid = splitk x tiles
-            int rc = vx ? (bx_image ? launch_bf16x_image(pk, stream) : vx->launch(pk, stream)) : v->launch(pk, stream);
+            int rc = vx ? (bx_image ? launch_bf16x_image(pk, bx_image, stream) : vx->launch(pk, stream)) : v->launch(pk, stream);
             if (rc != DGA_OK) return rc;
             const int64_t mn = static_cast<int64_t>(m) * n;
             hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3(static_cast<unsigned>((mn / 8 + 255) / 256 + 1)), dim3(256),
@@ -339,7 +344,7 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     }
     static const int pp_env = [] { const char *e = std::getenv("DGA_PINGPONG"); return e ? std::atoi(e) : -1; }();
     const int policy = pp_env >= 0 ? pp_env : tiling->dispatchPolicyTag;
-    if (vx) return bx_image ? launch_bf16x_image(p, stream) : vx->launch(p, stream);   // bf16-exact: one launch over the whole raster
+    if (vx) return bx_image ? launch_bf16x_image(p, bx_image, stream) : vx->launch(p, stream);   // bf16-exact: one launch over the whole raster
     auto launch_main = [&](const GemmParams &q) -> int {
         if (q.stamps) {
             auto clk = find_clock_build(v, (policy == 2 || policy == DGA_POLICY_CONTINUOUS_PERSISTENT) && v->launch_cont ? 2 : (policy == DGA_POLICY_LOADER_WAVES && v->launch_lc ? policy : 0));

@@ -41,10 +41,10 @@ def main_loop(lines: list[str]) -> list[str]:
         m = re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)", l)
         if m and m.group(1) in labels and labels[m.group(1)] < i:
             a = labels[m.group(1)]
-            if sum("v_mfma" in x for x in lines[a:i]) >= 128 and (best is None or i - a > best[1] - best[0]):
+            if sum("v_mfma" in x for x in lines[a:i]) >= 64 and (best is None or i - a > best[1] - best[0]):
                 best = (a, i)
     if best is None:
-        raise SystemExit("no main loop with 128 MFMAs found")
+        raise SystemExit("no main loop (>= 64 MFMAs) found")
     return [x.strip() for x in lines[best[0]:best[1]] if x.strip() and not x.strip().startswith((";", "."))]
 
 

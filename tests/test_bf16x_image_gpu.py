@@ -5,8 +5,9 @@ The two builds run the same arithmetic -- four chained v_mfma_f32_16x16x32_bf16 
 placement, then the same fp32 promotion (the counterpart of the reference's device K-loop,
 /root/reference/deep_gemm_ascend/framework/csrc/jit/generate_code.hpp:123-369, held to the fp32 golden of
 framework/tests/test.py:19-64) -- so the bar between them is BIT IDENTITY; against the oracle it is the policy's bar
-(tests/test_bf16_exact_gpu.py).  A tiling that names the 2 x 4 wave layout keeps the in-register build; anything else on the
-128 x 256 tile takes the image build.
+(tests/test_bf16_exact_gpu.py).  Two image builds: 8 waves (two per SIMD, 64 x 64 wave tiles: the default of the 128 x 256 tile)
+and 4 waves (one per SIMD, 64 x 128; a tiling that names the 2 x 2 wave layout).  A tiling that names the 2 x 4 layout with three
+LDS stages keeps the in-register build.
 """
 import sys
 from pathlib import Path
@@ -22,13 +23,17 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
+IMAGES = [8, 4]   # waves of the image build under test
+
+
 def _tiling(dga, m, n, k, image, splitk=1, raster=4, groups=1):
+    """image: 0 = in-register build, 4 / 8 = image build with that many waves"""
     t = dga.tiling(m, n, k, groups=groups) if groups > 1 else dga.tiling(m, n, k)
     t.m1, t.n1, t.splitkFactor, t.kernelSerial = 128, 256, splitk, (4 if splitk > 1 else 0)
     t.dispatchPolicyTag = 7
-    t.stages = 3
+    t.stages = 2 if image else 3
     t.swizzleOffset = raster
-    t.wavesM, t.wavesN = (2, 2) if image else (2, 4)
+    t.wavesM, t.wavesN = (2, 2) if image == 4 else (2, 4)
     return t
 
 
@@ -49,35 +54,39 @@ def _run(dga, a, sfa, b, sfb, t):
     (512, 1024, 7168),    # configs[2]'s K
     (64, 256, 8192 + 64),
 ])
-def test_image_build_is_bit_identical_to_the_in_register_build(dga, oracle, m, n, k):
+@pytest.mark.parametrize("waves", IMAGES)
+def test_image_build_is_bit_identical_to_the_in_register_build(dga, oracle, m, n, k, waves):
     a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=m * 13 + n * 5 + k)
-    got_img = _run(dga, a, sfa, b, sfb, _tiling(dga, m, n, k, True))
-    got_reg = _run(dga, a, sfa, b, sfb, _tiling(dga, m, n, k, False))
+    got_img = _run(dga, a, sfa, b, sfb, _tiling(dga, m, n, k, waves))
+    got_reg = _run(dga, a, sfa, b, sfb, _tiling(dga, m, n, k, 0))
     assert np.array_equal(got_img, got_reg), f"{int((got_img != got_reg).sum())} of {got_img.size} outputs differ"
     want = oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, threads=8)
     _assert_bar(oracle, got_img, want, a, sfa, b, sfb, eps=EPS if k >= 128 else EPS_ARBITRARY)
 
 
+@pytest.mark.parametrize("waves", IMAGES)
 @pytest.mark.parametrize("raster", [1, 2, 8])
-def test_rasters(dga, oracle, raster):
+def test_rasters(dga, oracle, raster, waves):
     m, n, k = 640, 1280, 512   # 5 x 5 tiles: the grouped raster's last band is short
     a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=raster)
-    got = _run(dga, a, sfa, b, sfb, _tiling(dga, m, n, k, True, raster=raster))
-    ref = _run(dga, a, sfa, b, sfb, _tiling(dga, m, n, k, False, raster=raster))
+    got = _run(dga, a, sfa, b, sfb, _tiling(dga, m, n, k, waves, raster=raster))
+    ref = _run(dga, a, sfa, b, sfb, _tiling(dga, m, n, k, 0, raster=raster))
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("waves", IMAGES)
 @pytest.mark.parametrize("splitk", [2, 3, 5])
-def test_split_k(dga, oracle, splitk):
+def test_split_k(dga, oracle, splitk, waves):
     m, n, k = 130, 300, 4096 + 128   # 33 k blocks: the last split is short
     a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=splitk)
-    got = _run(dga, a, sfa, b, sfb, _tiling(dga, m, n, k, True, splitk=splitk))
-    ref = _run(dga, a, sfa, b, sfb, _tiling(dga, m, n, k, False, splitk=splitk))
+    got = _run(dga, a, sfa, b, sfb, _tiling(dga, m, n, k, waves, splitk=splitk))
+    ref = _run(dga, a, sfa, b, sfb, _tiling(dga, m, n, k, 0, splitk=splitk))
     assert np.array_equal(got, ref)
     _assert_bar(oracle, got, oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, threads=8), a, sfa, b, sfb)
 
 
-def test_arbitrary_bytes_wild_scales_and_nan(dga, oracle):
+@pytest.mark.parametrize("waves", IMAGES)
+def test_arbitrary_bytes_wild_scales_and_nan(dga, oracle, waves):
     m, n, k = 192, 256, 640
     rng = np.random.default_rng(5)
     a = oracle.random_fp8_bytes((m, k), seed=1)
@@ -85,8 +94,8 @@ def test_arbitrary_bytes_wild_scales_and_nan(dga, oracle):
     a[3, 17] = 0x7F; b[100, 200] = 0xFF
     sfa = np.exp2(rng.uniform(-30, 4, size=(m, 5))).astype(np.float32)
     sfb = np.exp2(rng.uniform(-30, 4, size=(2, 5))).astype(np.float32)
-    got = _run(dga, a, sfa, b, sfb, _tiling(dga, m, n, k, True))
-    ref = _run(dga, a, sfa, b, sfb, _tiling(dga, m, n, k, False))
+    got = _run(dga, a, sfa, b, sfb, _tiling(dga, m, n, k, waves))
+    ref = _run(dga, a, sfa, b, sfb, _tiling(dga, m, n, k, 0))
     nan = (got & 0x7FFF) > 0x7F80
     assert np.array_equal(nan, (ref & 0x7FFF) > 0x7F80)
     assert np.array_equal(got[~nan], ref[~nan])
@@ -94,7 +103,8 @@ def test_arbitrary_bytes_wild_scales_and_nan(dga, oracle):
     _assert_bar(oracle, got, want, a, sfa, b, sfb, eps=EPS_ARBITRARY)
 
 
-def test_every_e4m3_code_converts_exactly(dga, oracle):
+@pytest.mark.parametrize("waves", IMAGES)
+def test_every_e4m3_code_converts_exactly(dga, oracle, waves):
     codes = np.array([c for c in range(256) if (c & 0x7F) != 0x7F], np.uint8)
     m = n = codes.size
     k = 128
@@ -102,7 +112,7 @@ def test_every_e4m3_code_converts_exactly(dga, oracle):
     a[np.arange(m), np.arange(m) % k] = codes
     b = np.repeat(codes[:, None], k, axis=1)
     sfa = np.ones((m, 1), np.float32); sfb = np.ones(((n + 127) // 128, 1), np.float32)
-    got = _run(dga, a, sfa, b, sfb, _tiling(dga, m, n, k, True))
+    got = _run(dga, a, sfa, b, sfb, _tiling(dga, m, n, k, waves))
     assert np.array_equal(got, oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, threads=4))
 
 
@@ -113,13 +123,13 @@ def test_grouped_masked(dga, oracle):
     A, SFA, B, SFB = (np.stack([p[j] for p in parts]) for j in range(4))
     masked = np.array([128, 0, 1, 77, 127, 64], np.int32)
     outs = []
-    for image in (True, False):
+    for image in (8, 0, 4):
         out = torch.full((g, mmax, n), -7.0, dtype=torch.bfloat16, device="cuda")
         t = _tiling(dga, mmax, n, k, image, groups=g)
         dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((_dev(A), _dev(SFA)), (_dev(B), _dev(SFB)), out, _dev(masked),
                                                   expected_m=64, policy="bf16_exact", sync=True, tiling_=t)
         outs.append(_bits(out))
-    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[2], outs[1])
     init = np.full((g, mmax, n), _bits(torch.tensor([-7.0], dtype=torch.bfloat16))[0], np.uint16)
     want = oracle.m_grouped_gemm_fp8_fp8_bf16_nt_masked(A, SFA, B, SFB, init, masked, threads=8)
     for i in range(g):
@@ -137,8 +147,9 @@ def test_baseline_configs_bit_identical_at_full_size(dga, shape):
     m, n, k = bench.WORKLOADS[shape]
     a, sfa, b, sfb = bench.make_dense_inputs(m, n, k, seed=0)
     outs = []
-    for image in (True, False):
+    for image in (8, 0, 4):
         out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
         dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, policy="bf16_exact", sync=True, tiling_=_tiling(dga, m, n, k, image))
         outs.append(out)
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    assert torch.equal(outs[2].view(torch.int16), outs[1].view(torch.int16))
