@@ -17,6 +17,9 @@ Fixtures (SURVEY.md 8c "Golden vectors to commit"):
                                 is imported, numpy's global generator seeded, gen_golden_data(96, 160, 320) run in a scratch
                                 directory; the bytes of input/x1_gm.bin, input/x2_gm.bin and output/golden.bin are stored.
                                 `python tests/golden/make_golden.py ref_gen_golden` writes this one alone.
+  ref_gen_golden_e4m3_96x160x320.npz (viii) the same generator with numpy.random.uniform returning draws from the signed e4m3fn
+                                grid for the duration of the call: a reference-written golden that reaches the FP8 kernels
+                                (`... make_golden.py ref_gen_golden_e4m3`).
 """
 import json
 import sys
@@ -135,10 +138,51 @@ def ref_gen_golden(m=96, n=160, k=320, seed=20251004):
                         source=np.array("deep_gemm_ascend/scripts/gen_golden.py:10-23 gen_golden_data, np.random.seed(seed), numpy " + np.__version__))
 
 
+def ref_gen_golden_e4m3(m=96, n=160, k=320, seed=20251005):
+    """The reference's own golden generator again, this time writing a golden the FP8 kernels can consume: for the duration of
+    gen_golden_data(m, n, k) numpy's `random.uniform` (what gen_golden.py:11-12 draws its operands from) returns draws from the
+    signed e4m3fn grid -- the decode of random bytes, NaN codes excluded -- so x1_gm.bin / x2_gm.bin hold values every one of
+    which is an e4m3 number (exact in the fp16 the generator stores), and golden.bin is the reference's own
+    np.matmul(f32, f32) of them.  Data only is kept: the three file images.  K = 320: two full 128-wide scale blocks and a tail."""
+    import contextlib
+    import io
+    import os
+    import tempfile
+    sys.path.insert(0, str(REF / "deep_gemm_ascend" / "scripts"))
+    import gen_golden as ref   # the reference's module (imported, never copied)
+    tab = O.np_e4m3fn_table()
+    codes = np.array([c for c in range(256) if (c & 0x7F) != 0x7F], np.uint8)
+    rng = np.random.default_rng(seed)
+    real_uniform = np.random.uniform
+
+    def grid_uniform(low, high, size):   # same call shape as gen_golden.py:11-12: uniform(1, 10, [rows, cols])
+        return tab[codes[rng.integers(0, codes.size, size=tuple(size))]].astype(np.float64)
+
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        os.chdir(d)
+        np.random.uniform = grid_uniform
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                ref.gen_golden_data(m, n, k)
+            x1 = np.fromfile("input/x1_gm.bin", dtype=np.float16).reshape(m, k)
+            x2 = np.fromfile("input/x2_gm.bin", dtype=np.float16).reshape(k, n)
+            golden = np.fromfile("output/golden.bin", dtype=np.float32).reshape(m, n)
+        finally:
+            np.random.uniform = real_uniform
+            os.chdir(cwd)
+    np.savez_compressed(HERE / f"ref_gen_golden_e4m3_{m}x{n}x{k}.npz", x1_gm=x1, x2_gm=x2, golden=golden,
+                        meta=np.array([m, n, k, seed], np.int64),
+                        source=np.array("deep_gemm_ascend/scripts/gen_golden.py:10-23 gen_golden_data with numpy.random.uniform returning "
+                                        "draws from the signed e4m3fn grid (default_rng(seed)), numpy " + np.__version__))
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["ref_gen_golden"]:
         ref_gen_golden()
+    elif sys.argv[1:] == ["ref_gen_golden_e4m3"]:
+        ref_gen_golden_e4m3()
     else:
         O.build()
-        table(); c1(); scaled(); grouped(); configs(); op_tiling(); ref_gen_golden()
+        table(); c1(); scaled(); grouped(); configs(); op_tiling(); ref_gen_golden(); ref_gen_golden_e4m3()
     print("fixtures written to", HERE)

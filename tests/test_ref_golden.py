@@ -43,13 +43,14 @@ def test_oracle_mmad_golden_meets_the_reference_verifier(oracle):
     """The oracle's fp32-accumulate CPU path (k ascending) against the reference's BLAS-ordered golden: the file verifier's
     own threshold."""
     x1, x2, golden = _fx()
-    got = oracle.mmad_f32(x1, x2) if hasattr(oracle, "mmad_f32") else None
-    if got is None:
-        acc = np.zeros(golden.shape, np.float32)
-        a32, b32 = x1.astype(np.float32), x2.astype(np.float32)
-        for kk in range(x1.shape[1]):          # fp32 running sum, k ascending (generate_code.hpp:216,320-335)
-            acc += a32[:, kk:kk + 1] * b32[kk:kk + 1, :]
-        got = acc
+    got = oracle.matmul_f32_nn(x1.astype(np.float32), x2.astype(np.float32))   # dga_oracle_matmul_f32_nn: fp32 chain, k ascending
+    assert got.dtype == np.float32 and got.shape == golden.shape
+    # the same chain restated in numpy (generate_code.hpp:216,320-335): the C oracle is that chain, bit for bit
+    acc = np.zeros(golden.shape, np.float32)
+    a32, b32 = x1.astype(np.float32), x2.astype(np.float32)
+    for kk in range(x1.shape[1]):
+        acc += a32[:, kk:kk + 1] * b32[kk:kk + 1, :]
+    assert np.array_equal(got, acc)
     ok, ratio = oracle.verify_isclose(got, golden, rtol=RTOL_FILE)
     assert ok, ratio
 

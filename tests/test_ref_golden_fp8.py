@@ -1,0 +1,122 @@
+"""A golden the reference's OWN generator wrote that reaches the FP8 kernels.
+
+tests/golden/ref_gen_golden_e4m3_96x160x320.npz holds the images of input/x1_gm.bin, input/x2_gm.bin and output/golden.bin as
+/root/reference/deep_gemm_ascend/scripts/gen_golden.py:10-23 wrote them when tests/golden/make_golden.py imported it and let
+numpy.random.uniform return draws from the signed e4m3fn grid for the duration of gen_golden_data(96, 160, 320).  Every operand
+value is therefore an e4m3 number (exact in the fp16 the generator stores), x2 is [K, N] as the reference lays it out, and
+golden.bin is the reference's np.matmul(f32, f32) -- the "reference CPU path (fp32 accumulate)" of north_star, in BLAS order.
+K = 320 = two full 128-wide scale blocks and a 64-wide tail.
+
+What is checked against it
+  * the CPU oracle: the fp32 k-ascending chain on the fp16 files (file verifier's threshold, scripts/verify.py:10-35), and the FP8
+    oracle on the quantised bytes with unit scales -- bf16(oracle) within 1 bf16 ULP of bf16(golden), 2 where the sum cancels to
+    less than 2^-12 of its terms (there the two fp32 summation orders differ by more than a bf16 ULP of the result);
+  * on the GPU, through the C ABI, the three arithmetic policies on the same bytes: strict = the oracle's bits; bf16_exact and
+    fast at their own bars against bf16(golden); and for all three the reference's verifier (framework/tests/test.py:19-21,40-64:
+    rtol 2e-4, atol 1e-9, at most 1e-4 of the elements off) with one bf16 unit in the last place (2^-8 relative) added for the
+    output dtype, as tests/test_ref_golden.py does for the fp16-out operator.
+"""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+FIXTURE = ROOT / "tests" / "golden" / "ref_gen_golden_e4m3_96x160x320.npz"
+RTOL_REF = 2e-4            # framework/tests/test.py:19
+RTOL_BF16_OUT = RTOL_REF + 2.0 ** -8
+
+
+def _fx():
+    d = np.load(FIXTURE)
+    return d["x1_gm"], d["x2_gm"], d["golden"]
+
+
+def _quantise(oracle, x):
+    """fp16 values on the e4m3 grid -> their e4m3fn codes (exact; -0 keeps its sign)"""
+    tab = oracle.np_e4m3fn_table()
+    lut = {}
+    for c in range(256):
+        if (c & 0x7F) != 0x7F:
+            lut[np.float32(tab[c]).tobytes()] = c
+    flat = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+    codes = np.fromiter((lut[v.tobytes()] for v in flat), dtype=np.uint8, count=flat.size)
+    return codes.reshape(x.shape)
+
+
+def _fp8_problem(oracle):
+    x1, x2, golden = _fx()
+    a = _quantise(oracle, x1)                              # [M, K]
+    b = _quantise(oracle, np.ascontiguousarray(x2.T))      # [N, K]: the NT layout of the operator
+    m, k = a.shape
+    n = b.shape[0]
+    sfa = np.ones((m, (k + 127) // 128), np.float32)
+    sfb = np.ones(((n + 127) // 128, (k + 127) // 128), np.float32)
+    return a, sfa, b, sfb, golden
+
+
+def test_fixture_is_what_the_reference_generator_writes(oracle):
+    x1, x2, golden = _fx()
+    assert x1.dtype == np.float16 and x2.dtype == np.float16 and golden.dtype == np.float32
+    assert x1.shape == (96, 320) and x2.shape == (320, 160) and golden.shape == (96, 160)
+    tab = oracle.np_e4m3fn_table()
+    a, b = _quantise(oracle, x1), _quantise(oracle, x2)
+    assert np.array_equal(tab[a].astype(np.float16).view(np.uint16), x1.view(np.uint16))   # every value is an e4m3 number
+    assert np.array_equal(tab[b].astype(np.float16).view(np.uint16), x2.view(np.uint16))
+    assert len(np.unique(a)) > 200 and (x1 < 0).any() and (x1 > 0).any()
+    # gen_golden.py:14-15
+    assert np.array_equal(np.matmul(x1.astype(np.float32), x2.astype(np.float32)).astype(np.float32), golden)
+
+
+def test_oracle_fp32_chain_meets_the_reference_file_verifier(oracle):
+    """dga_oracle_matmul_f32_nn (fp32 products, fp32 running sum, k ascending) against the BLAS-ordered golden at the file
+    verifier's threshold (scripts/verify.py: rtol 1e-6) and at the framework test's (2e-4)."""
+    x1, x2, golden = _fx()
+    got = oracle.matmul_f32_nn(x1.astype(np.float32), x2.astype(np.float32))
+    for rtol in (1e-6, RTOL_REF):
+        ok, ratio = oracle.verify_isclose(got, golden, rtol=rtol)
+        assert ok, (rtol, ratio)
+
+
+def test_fp8_oracle_against_the_reference_golden(oracle):
+    """The FP8 oracle (e4m3 decode, unit block scales, fp32 chain, bf16 rounding) on the quantised files."""
+    a, sfa, b, sfb, golden = _fp8_problem(oracle)
+    got = oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, threads=4)
+    want = oracle.f32_to_bf16_bits(golden)
+    d = oracle.bf16_ulp_diff(got, want)
+    s = oracle.abs_term_sum(a, sfa, b, sfb)
+    cancels = s > np.abs(golden) * 2.0 ** 12
+    assert int(d[~cancels].max()) <= 1, int(d[~cancels].max())
+    assert int(d.max()) <= 2 and int((d > 1).sum()) <= 2, (int(d.max()), int((d > 1).sum()))
+    ok, ratio = oracle.verify_isclose(oracle.bf16_bits_to_f32(got), golden, rtol=RTOL_BF16_OUT)
+    assert ok, ratio
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", ["strict", "bf16_exact", "fast"])
+def test_policies_on_the_reference_golden(dga, oracle, policy):
+    import torch
+    a, sfa, b, sfb, golden = _fp8_problem(oracle)
+    m, n = golden.shape
+    out = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    kw = {"strict": True} if policy == "strict" else ({"policy": "bf16_exact"} if policy == "bf16_exact" else {})
+    dga.gemm_fp8_fp8_bf16_nt((dev(a), dev(sfa)), (dev(b), dev(sfb)), out, sync=True, **kw)
+    got = out.view(torch.int16).cpu().numpy().view(np.uint16)
+    want = oracle.f32_to_bf16_bits(golden)
+    d = oracle.bf16_ulp_diff(got, want)
+    s = oracle.abs_term_sum(a, sfa, b, sfb)
+    ok, ratio = oracle.verify_isclose(oracle.bf16_bits_to_f32(got), golden, rtol=RTOL_BF16_OUT)
+    print(f"{policy}: max ulp vs bf16(golden.bin) {int(d.max())}, beyond 1 ulp {int((d > 1).sum())} of {d.size}; "
+          f"reference verifier (rtol 2e-4 + one bf16 ulp): {'pass' if ok else 'FAIL'}, {ratio:.2e} of the elements off")
+    if policy == "strict":
+        assert np.array_equal(got, oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, threads=4))   # the oracle's bits
+        cancels = s > np.abs(golden) * 2.0 ** 12
+        assert int(d[~cancels].max()) <= 1 and int(d.max()) <= 2
+        assert ok, ratio
+    elif policy == "bf16_exact":
+        from test_bf16_exact_gpu import _assert_bar
+        _assert_bar(oracle, got, want, a, sfa, b, sfb)
+        assert ok, ratio
+    else:
+        oracle.assert_parity(got, want, a, sfa, b, sfb)
