@@ -68,6 +68,12 @@ DGA_MENU_BX(DGA_MENU_EXTERN_BX)
 // DGA_E_TILING for the contiguous / indexed layouts
 int launch_bf16x_image(const GemmParams &p, int waves, hipStream_t stream);
 
+// one-launch workgroup split-K for dense problems of at most 64 rows (gemm_fp8_wsk_kernel.hpp; dga_launch_menu_g.hip; kernelSerial
+// DGA_KERNEL_SPLITK_WORKGROUP): bit-identical to the two-launch split-K with splitkFactor 8.  DGA_E_TILING for anything else
+int launch_wsk(const GemmParams &p, hipStream_t stream);
+int wsk_rows(int m);
+int wsk_max_ntiles(int m);
+
 // persistent continuous-pipeline build of the 256x256 tile (gemm_fp8_cont_persistent_kernel.hpp, dispatchPolicyTag 6): dense
 // rasters of full tiles only -- launch_cont_persistent returns DGA_E_TILING for anything else
 int launch_cont_persistent(const GemmParams &p, hipStream_t stream);

@@ -319,6 +319,15 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     static const int xcd_remap = [] { const char *e = std::getenv("DGA_XCD_REMAP"); return e ? std::atoi(e) : 1; }();
     p.xcd_remap = xcd_remap;
 
+    // ---- workgroup split-K (kernelSerial 6): one launch, the K slices are the waves of a workgroup; dense, M <= 64.  fp8 matrix
+    //      instruction only; a shape it does not take (DGA_E_TILING) falls through to the tiling's tile kernel
+    static const int wsk_env = [] { const char *e = std::getenv("DGA_WSK"); return e ? std::atoi(e) : -1; }();
+    if (!bf16x && !clock_stamps && groups == 1 && !masked_m && !m_indices && !ix &&
+        (wsk_env >= 0 ? wsk_env != 0 : tiling->kernelSerial == DGA_KERNEL_SPLITK_WORKGROUP)) {
+        const int rc = launch_wsk(p, stream);
+        if (rc != DGA_E_TILING) return rc;
+    }
+
     // ---- split-K (kernelSerial 4): partial fp32 slabs + combine; dense only
     if (clock_stamps && (tiling->splitkFactor > 1 || tiling->kernelSerial == DGA_KERNEL_STREAMK_TAIL)) return DGA_E_TILING;
     if (tiling->splitkFactor > 1 && groups == 1 && !masked_m && !m_indices) {

@@ -1,0 +1,49 @@
+// fp8 kernel menu, part G: the one-launch workgroup split-K builds for short-M problems (gemm_fp8_wsk_kernel.hpp,
+// kernelSerial DGA_KERNEL_SPLITK_WORKGROUP): 8 waves = 8 K slices of one output tile, fragments streamed global -> registers,
+// partial tiles combined in LDS.
+#include "dga_fp8_menu_impl.hpp"
+#include "gemm_fp8_wsk_kernel.hpp"
+namespace dga {
+
+template <int TM, int TNMAX, int D, bool KTAIL>
+static int launch_wsk_one(const GemmParams &p, unsigned grid, hipStream_t stream)
+{
+    auto kfn = gemm_fp8_wsk_kernel<TM, TNMAX, D, KTAIL>;
+    constexpr int kLds = 8 * TM * 16 * TNMAX * 16 * 4;
+    static_assert(kLds <= 160 * 1024, "LDS of one CU");
+    static std::once_flag once[64];
+    static hipError_t attr_err[64];
+    int dev = 0;
+    if (int rc = record_hip(hipGetDevice(&dev))) return rc;
+    if (dev < 0 || dev >= 64) return DGA_E_HIP;
+    std::call_once(once[dev], [&] {
+        attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    });
+    if (int rc = record_hip(attr_err[dev])) return rc;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), kLds, stream, p);
+    return record_hip(hipGetLastError());
+}
+
+// rows of the build that takes M rows (0: none) and the n-tiles (16 columns) one of its workgroups may own
+int wsk_rows(int m) { return m <= 16 ? 16 : (m <= 32 ? 32 : (m <= 64 ? 64 : 0)); }
+int wsk_max_ntiles(int m) { return m <= 32 ? 5 : 4; }
+
+int launch_wsk(const GemmParams &p, hipStream_t stream)
+{
+    // dense problems of at most 64 rows, 16-byte K chunks; everything else keeps the tile kernels
+    if (p.groups != 1 || p.masked_m || p.m_indices || p.row_index || p.splitk > 1 || p.tail_sub || p.m > 64 || p.m <= 0 || (p.k % 16) ||
+        p.k <= 0)
+        return DGA_E_TILING;
+    const int nt = (p.n + 15) / 16, tnmax = wsk_max_ntiles(p.m);
+    const int64_t cus = device_cus();
+    // one workgroup per CU where the columns allow it (each owns nt / G n-tiles, balanced to within one), more where a
+    // workgroup would otherwise own more n-tiles than its registers hold
+    int64_t grid = nt < cus ? nt : cus;
+    if ((nt + grid - 1) / grid > tnmax) grid = (nt + tnmax - 1) / tnmax;
+    const bool kt = (p.k % 128) != 0;
+    const unsigned g = static_cast<unsigned>(grid);
+    if (p.m <= 16) return kt ? launch_wsk_one<1, 5, 3, true>(p, g, stream) : launch_wsk_one<1, 5, 3, false>(p, g, stream);
+    if (p.m <= 32) return kt ? launch_wsk_one<2, 5, 2, true>(p, g, stream) : launch_wsk_one<2, 5, 2, false>(p, g, stream);
+    return kt ? launch_wsk_one<4, 4, 2, true>(p, g, stream) : launch_wsk_one<4, 4, 2, false>(p, g, stream);
+}
+}

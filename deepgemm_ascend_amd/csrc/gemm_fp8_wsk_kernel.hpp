@@ -1,0 +1,177 @@
+// One-launch split-K INSIDE a workgroup for short-M ("decode") problems: the 8 waves of a workgroup take the 8 K slices of ONE
+// output tile, each wave streams its slice of A and B straight from global memory into MFMA fragment registers (nothing is
+// shared between the waves while they stream: no LDS, no barrier, no DMA ring), and the eight fp32 partial tiles meet in LDS
+// behind one barrier -- no slab in HBM, no ticket, no combine launch.
+//
+// Reference counterparts: the fused reduce of the Stream-K kernel
+// (/root/reference/aclnn_catlass_dynamic_matmul/op_kernel/kernel/padding_streamk_matmul_kernel.h:92-107), the selection rule
+// (op_host/op_tiling/select_kernel.cpp:303-331) and the single-core split-K kernel types the reference declares
+// (op_kernel/catlass_dynamic_matmul_tiling_key.h:30-36).
+//
+// Why registers instead of the LDS ring: a decode call is bound by bytes in flight per CU and by fixed costs (launch, first
+// round trip, combine launch: profiles/r03_decode_cold.txt).  A wave holds D k blocks of fragments in registers -- 8 waves x D x
+// (16 TM + 16 TN) rows x 128 B = 200-300 KB in flight per CU against the 72 KB of a three-stage LDS ring -- and the 512 KB
+// register file is the one buffer a CU has that is larger than its LDS.
+//
+// Work split.  Workgroup w of G owns n-tiles (16 columns each) [w nt / G, (w + 1) nt / G) -- at most TNMAX of them, balanced to
+// within one, so 18432 columns on 256 CUs are 4 or 5 n-tiles each instead of 288 fixed tiles in two rounds -- and ALL rows
+// (M <= 16 TM).  Wave s owns k blocks [s kbps, (s + 1) kbps), kbps = ceil(kb_n / 8): the same slices, the same per-slice
+// arithmetic (one v_mfma_scale_f32_16x16x128_f8f6f4 per scale block, fp32 promotion) and the same combine order (s ascending) as
+// the two-launch split-K with splitkFactor 8 (gemm_fp8_kernel.hpp + splitk_reduce_bf16_kernel): the outputs are bit-identical
+// to it, which is what tests/test_wsk_gpu.py asserts.
+// A is re-read by every workgroup (from L2: it is M x K bytes in all); the selector (dga_tiling.cpp) takes this kernel only
+// where that stays below the B stream.
+#pragma once
+#include "gemm_fp8_kernel.hpp"
+
+namespace dga {
+
+template <int TM, int TNMAX, int D, bool KTAIL>
+__global__ void __launch_bounds__(512) gemm_fp8_wsk_kernel(const GemmParams p)
+{
+    constexpr int WAVES = 8, BNW = TNMAX * 16, BM = TM * 16;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // [WAVES][BM][BNW] fp32
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kg = lane >> 4;
+    constexpr uint32_t kOutOfRange = 0x80000000u;
+
+    const int M = p.m;
+    const int nt_total = (p.n + 15) >> 4, G = gridDim.x;
+    const int nt0 = (int)(((int64_t)blockIdx.x * nt_total) / G), nt1 = (int)(((int64_t)(blockIdx.x + 1) * nt_total) / G);
+    const int cnt = nt1 - nt0;                      // <= TNMAX (host)
+    if (cnt <= 0) return;
+    const int n0 = nt0 * 16;
+    const int kbps = (p.kb_n + WAVES - 1) / WAVES;
+    const int c0 = wave * kbps, c1 = min(p.kb_n, c0 + kbps);   // this wave's k blocks (empty: c0 >= c1)
+    const int s_eff = (p.kb_n + kbps - 1) / kbps;              // waves that own at least one k block
+
+    auto clamp31 = [](int64_t v) { return (int)(v > 0x7FFFFFFFll ? 0x7FFFFFFFll : (v < 0 ? 0 : v)); };
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.a, 0, clamp31((int64_t)M * p.lda), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.b + (int64_t)n0 * p.ldb), 0, clamp31((int64_t)(p.n - n0) * p.ldb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t sfa_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.sfa, 0, clamp31((int64_t)M * p.sfa_ld * 4), 0x00020000);
+    // the workgroup's columns lie in at most two 128-wide scale blocks (TNMAX * 16 <= 128)
+    static_assert(TNMAX * 16 <= 128, "two sfb blocks per workgroup at most");
+    const int nb0 = n0 >> 7, nb1 = min(nb0 + 1, p.nb_n - 1);
+    const float *sfb0_p = p.sfb + (int64_t)nb0 * p.kb_n, *sfb1_p = p.sfb + (int64_t)nb1 * p.kb_n;
+    const __amdgpu_buffer_rsrc_t sfb_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.sfb, 0, clamp31((int64_t)p.nb_n * p.kb_n * 4), 0x00020000);
+    const int sfb0_off = nb0 * p.kb_n * 4, sfb1_off = nb1 * p.kb_n * 4;
+    (void)sfb0_p; (void)sfb1_p;
+
+    // fragment rows: lane (li, kg) holds bytes [16 kg, +16) and [64 + 16 kg, +16) of row li of its tile's k block
+    uint32_t a_voff[TM], b_voff[TNMAX], sfa_voff[TM];
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+        const int row = mt * 16 + li;
+        a_voff[mt] = row < M ? (uint32_t)row * (uint32_t)p.lda + 16 * kg : kOutOfRange;
+        sfa_voff[mt] = row < M ? (uint32_t)row * (uint32_t)p.sfa_ld * 4u : kOutOfRange;
+    }
+#pragma unroll
+    for (int t = 0; t < TNMAX; ++t) {
+        const int row = t * 16 + li;   // relative to n0
+        b_voff[t] = (t < cnt && n0 + row < p.n) ? (uint32_t)row * (uint32_t)p.ldb + 16 * kg : kOutOfRange;
+    }
+    // which scale block an n-tile lies in (wave-uniform per t)
+    bool second_block[TNMAX];
+#pragma unroll
+    for (int t = 0; t < TNMAX; ++t) second_block[t] = ((n0 + t * 16) >> 7) != nb0;
+
+    struct Stage {
+        v8i a[TM], b[TNMAX];
+        float sfa[TM], sfb0, sfb1;
+    };
+    Stage st[D];
+#ifndef DGA_WSK_B_AUX
+#define DGA_WSK_B_AUX 0   // default policy: a fragment load takes HALF of each 128-byte line, the second half comes from the L1 line the first one filled -- with nt (2) the line is fetched twice: 8x18432x7168 cold 29.9 -> 34.0 us
+#endif
+    auto load16 = [&](const __amdgpu_buffer_rsrc_t &rs, uint32_t vo, int kb, int half, auto auxc) -> v4i {
+        // a lane whose chunk lies beyond K (KTAIL) or whose k block lies beyond the wave's slice reads nothing (zeros)
+        const int k0 = kb * 128 + half * 64;
+        bool ok = kb < c1;
+        if constexpr (KTAIL) ok = ok && (k0 + 16 * kg < p.k);
+        const uint32_t v = ok ? vo : kOutOfRange;
+        return __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)v, k0, decltype(auxc)::value));
+    };
+    auto load_stage = [&](Stage &s, int kb) {
+        const int kbc = min(kb, p.kb_n - 1);
+#pragma unroll
+        for (int t = 0; t < TNMAX; ++t) {
+            const v4i lo = load16(b_rsrc, b_voff[t], kb, 0, std::integral_constant<int, DGA_WSK_B_AUX>{}), hi = load16(b_rsrc, b_voff[t], kb, 1, std::integral_constant<int, DGA_WSK_B_AUX>{});
+            s.b[t] = v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        }
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            const v4i lo = load16(a_rsrc, a_voff[mt], kb, 0, std::integral_constant<int, 0>{}), hi = load16(a_rsrc, a_voff[mt], kb, 1, std::integral_constant<int, 0>{});
+            s.a[mt] = v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            s.sfa[mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sfa_rsrc, (int)sfa_voff[mt], kbc * 4, 0));
+        }
+        s.sfb0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sfb_rsrc, 0, sfb0_off + kbc * 4, 0));
+        s.sfb1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sfb_rsrc, 0, sfb1_off + kbc * 4, 0));
+    };
+
+    v4f acc[TM][TNMAX];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TNMAX; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int d = 0; d < D; ++d) load_stage(st[d], c0 + d);
+    for (int kb = c0; kb < c1; kb += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (kb + d < c1) {   // (wave-uniform)
+#pragma unroll
+                for (int t = 0; t < TNMAX; ++t) {
+                    if (t < cnt) {
+                        const float sb = second_block[t] ? st[d].sfb1 : st[d].sfb0;
+#pragma unroll
+                        for (int mt = 0; mt < TM; ++mt) {
+                            const v4f pr = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(st[d].b[t], st[d].a[mt], v4f{0.f, 0.f, 0.f, 0.f},
+                                                                                           0, 0, 0, 0, 0, 0);
+                            const float s = st[d].sfa[mt] * sb;   // two-level scale: sfa[m, kb] * sfb[n / 128, kb]
+                            acc[mt][t].x = __builtin_fmaf(pr.x, s, acc[mt][t].x);
+                            acc[mt][t].y = __builtin_fmaf(pr.y, s, acc[mt][t].y);
+                            acc[mt][t].z = __builtin_fmaf(pr.z, s, acc[mt][t].z);
+                            acc[mt][t].w = __builtin_fmaf(pr.w, s, acc[mt][t].w);
+                        }
+                    }
+                }
+            }
+            load_stage(st[d], kb + d + D);   // (beyond the slice: every lane out of range, nothing is fetched)
+        }
+    }
+
+    // ---- the eight partial tiles meet in LDS: slab[wave][m][n] fp32; lane (li, kg) owns row m = 16 mt + li, columns 16 t + 4 kg + [0, 4)
+    float *slab = (float *)smem;
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int t = 0; t < TNMAX; ++t)
+            *(v4f *)(slab + ((size_t)wave * BM + mt * 16 + li) * BNW + t * 16 + 4 * kg) = acc[mt][t];
+    __syncthreads();
+    // s ascending = k ascending, as splitk_reduce_bf16_kernel sums its slabs
+    const bool vec_ok = ((p.ldc & 3) == 0) && ((((uintptr_t)p.out) & 7) == 0);
+    for (int g = tid; g < BM * (BNW / 4); g += 512) {
+        const int m = g / (BNW / 4), nl = (g % (BNW / 4)) * 4;
+        if (m >= M || nl >= cnt * 16) continue;
+        v4f v = *(const v4f *)(slab + (size_t)m * BNW + nl);
+        for (int s = 1; s < s_eff; ++s) v += *(const v4f *)(slab + ((size_t)s * BM + m) * BNW + nl);
+        const v2bf h0 = __builtin_convertvector(v2f{v.x, v.y}, v2bf), h1 = __builtin_convertvector(v2f{v.z, v.w}, v2bf);
+        uint16_t *dst = p.out + (int64_t)m * p.ldc + n0 + nl;
+        if (vec_ok && n0 + nl + 4 <= p.n) {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            *(v2i *)dst = v2i{__builtin_bit_cast(int, h0), __builtin_bit_cast(int, h1)};
+        } else {
+            const uint32_t w0 = __builtin_bit_cast(uint32_t, h0), w1 = __builtin_bit_cast(uint32_t, h1);
+            const uint16_t e[4] = {(uint16_t)(w0 & 0xFFFFu), (uint16_t)(w0 >> 16), (uint16_t)(w1 & 0xFFFFu), (uint16_t)(w1 >> 16)};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (n0 + nl + q < p.n) dst[q] = e[q];
+        }
+    }
+}
+
+}  // namespace dga

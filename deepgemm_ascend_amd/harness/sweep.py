@@ -101,6 +101,9 @@ def candidates(m, n, k, rasters=None):
                         # 256x256, more than one wave of tiles with a small remainder: also with the quarter-tile tail
                         if (bm, bn) == (256, 256) and sk == 1 and blocks > 256 and 0 < blocks % 256 <= 64:
                             out.append({"m1": bm, "n1": bn, "raster": rr, "stages": st, "splitk": sk, "policy": pol, "tail": 1})
+    # short-M: the one-launch workgroup split-K kernel (csrc/gemm_fp8_wsk_kernel.hpp, kernelSerial 6): 8 waves = 8 K slices
+    if m <= 64 and k % 16 == 0 and k > 0:
+        out.append({"m1": 16 if m <= 16 else (32 if m <= 32 else 64), "n1": 128, "raster": 1, "stages": 2, "splitk": 1, "policy": 0, "wsk": 1})
     return out
 
 
@@ -323,7 +326,7 @@ def benchmark_shape(shape, out_dir: Path, rank=0, num_processes=1, iters=10, ras
         t = dga.tiling(m, n, k)
         t.m1, t.n1, t.swizzleOffset = p["m1"], p["n1"], p["raster"]
         t.stages, t.wavesM, t.wavesN, t.dispatchPolicyTag = p["stages"], 0, 0, p["policy"]
-        t.splitkFactor = p["splitk"]; t.kernelSerial = 5 if p.get("tail") else (4 if p["splitk"] > 1 else 0)
+        t.splitkFactor = p["splitk"]; t.kernelSerial = 6 if p.get("wsk") else (5 if p.get("tail") else (4 if p["splitk"] > 1 else 0))
         def fn():
             c = sets[turn[0] % len(sets)]
             turn[0] += 1
@@ -478,7 +481,7 @@ def main(argv=None):
                 blocks = -(-m // p["m1"]) * -(-n // p["n1"]) * p["splitk"]
                 if p.get("tail"):   # whole waves + the last partial wave in quarter tiles
                     blocks = blocks - blocks % 256 + 4 * (blocks % 256)
-                f.write(f"{m},{n},{k},{p['m1']},{p['n1']},128,{5 if p.get('tail') else (4 if p['splitk'] > 1 else 0)},0,0,0,{blocks},"
+                f.write(f"{m},{n},{k},{p['m1']},{p['n1']},128,{6 if p.get('wsk') else (5 if p.get('tail') else (4 if p['splitk'] > 1 else 0))},0,0,0,{blocks},"
                         f"{p['splitk']},{p['stages']},{p['raster']},0,0,{p['policy']}\n")
 
 

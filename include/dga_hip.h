@@ -47,7 +47,10 @@ enum { DGA_PADDING_NONE = 0, DGA_PADDING_ND = 1, DGA_PADDING_BLOCK_ND = 2, DGA_P
  * (op_kernel/kernel/kernel_utils.h:31-37, select_kernel.cpp:270-331):
  *   0 Common, 1 Small, 2 PaddingCommon (never chosen on CDNA4), 4 StreamK/split-K. */
 enum { DGA_KERNEL_COMMON = 0, DGA_KERNEL_SMALL = 1, DGA_KERNEL_PADDING_COMMON = 2, DGA_KERNEL_STREAMK = 4,
-       DGA_KERNEL_STREAMK_TAIL = 5 /* whole waves of 256x256 tiles, the last partial wave covered by 128x128 tiles */ };
+       DGA_KERNEL_STREAMK_TAIL = 5 /* whole waves of 256x256 tiles, the last partial wave covered by 128x128 tiles */,
+       DGA_KERNEL_SPLITK_WORKGROUP = 6 /* M <= 64: the 8 waves of a workgroup are the 8 K slices of one output tile, partial tiles
+                                          combined in LDS -- one launch, no slab (the reference's single-core split-K kernel types,
+                                          op_kernel/catlass_dynamic_matmul_tiling_key.h:30-36); the bits of split-K with factor 8 */ };
 
 /* dispatchPolicyTag of the fp8 tile kernels (the reference's field selects a catlass dispatch policy,
  * op_tiling/tiling_params.h:19-66; here it selects the main-loop schedule or the exact-arithmetic kernel):
