@@ -131,8 +131,11 @@ def make_dense_inputs(m, n, k, seed):
     return qa.contiguous(), sa.contiguous().float(), qb.contiguous(), sb.contiguous().float()
 
 
+TRAFFIC_FILES = ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")   # newest first
+
+
 def pmc_traffic_source():
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in TRAFFIC_FILES:
         if (ROOT / "profiles" / name).exists():
             return f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel (a committed measurement, not this run)"
     return None
@@ -142,7 +145,7 @@ def pmc_traffic(workload: str):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r0N_traffic.json: FETCH_SIZE and
     WRITE_SIZE collected in separate passes and corrected as MI355X_MICROARCH.md prescribes).  PMC counters cannot be
     read from inside this process, so this is the figure of the profiled run of the same kernel, not of this run."""
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in TRAFFIC_FILES:
         try:
             d = json.loads((ROOT / "profiles" / name).read_text())
             return int(d[workload]["traffic_bytes"])
@@ -734,6 +737,7 @@ def main():
         bx = res["policies"].get("bf16_exact", {}).get("roofline")
         if isinstance(bx, dict) and args.workload == "dense_4096":
             bx["traffic"] = pmc_traffic("dense_bf16_exact")
+            bx["traffic_source"] = "committed: " + str(pmc_traffic_source())
             bx["algorithmic_bytes"] = res["roofline"]["algorithmic_bytes"]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -767,6 +771,7 @@ def main():
                                    "value": round(2.0 * pm * pn * pk / us / 1e6, 2), "unit": "TFLOP/s",
                                    "roofline": roofline_mfma(dga, pa, psfa, pb, psfb, pout, pt, pm, pn, pk, us, cus)}
             res["dsv3_prefill"]["roofline"]["traffic"] = pmc_traffic("dsv3_prefill")
+            res["dsv3_prefill"]["roofline"]["traffic_source"] = "committed: " + str(pmc_traffic_source())
             if rank == 0 and not args.no_parity:
                 dga.gemm_fp8_fp8_bf16_nt((pa, psfa), (pb, psfb), pout, sync=True)
                 res["dsv3_prefill"]["parity"] = parity_vs_strict(dga, pa, psfa, pb, psfb, pout)
@@ -788,6 +793,7 @@ def main():
             grouped = grouped_leg(args, rank, world, dist)
             if isinstance(grouped.get("roofline"), dict) and world == 1 and args.groups == 256 and args.grouped_mask == "full":
                 grouped["roofline"]["traffic"] = pmc_traffic("grouped")
+                grouped["roofline"]["traffic_source"] = "committed: " + str(pmc_traffic_source())
             res["grouped"] = grouped
         except Exception as e:  # the primary metric must still be reported
             res["grouped"] = {"error": repr(e)}

@@ -33,6 +33,7 @@ from .api import (  # noqa: F401
     predictor_load,
     predictor_loaded,
     predictor_unload,
+    release_scratch,
     select_kernel_with_predictor,
     platform_mi355x,
     run_mmad_bench,

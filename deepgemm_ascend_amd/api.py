@@ -87,6 +87,20 @@ def _scratch(kind: str, device, need: int, stream: Optional[int] = None) -> Tupl
     return buf.data_ptr(), buf.numel()
 
 
+def release_scratch(retired_only: bool = True) -> int:
+    """Frees the outgrown scratch buffers (`retired_only`) or every scratch buffer of the process; returns the bytes released.
+    Worst case held per (device, stream): the selector bounds split-K slabs to 256 MiB (dga_tiling.cpp kMaxSlabBytes) and the
+    odd-K padding copies to the operands' size, and growth is geometric, so at most ~1.5x the largest workspace ever asked for
+    on that stream -- plus the retired ones until this is called.  Only call it when no captured HIP graph that ran a GEMM
+    through this module will be replayed again (a graph holds the address of the buffer it was captured with)."""
+    n = sum(b.numel() for b in _RETIRED)
+    _RETIRED.clear()
+    if not retired_only:
+        n += sum(b.numel() for b in _WORKSPACES.values())
+        _WORKSPACES.clear()
+    return int(n)
+
+
 _WS_BYTES = {}     # bytes of a Tiling -> dga_workspace_bytes of it (pure function of the struct)
 
 

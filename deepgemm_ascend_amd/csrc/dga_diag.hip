@@ -157,7 +157,10 @@ extern "C" int dga_mfma_ceiling(int mode, int launches, void *scratch, size_t sc
     float ms = 0.f;
     int rc = DGA_OK;
     for (int i = 0; i < launches && rc == DGA_OK; ++i) {   // the last launch is the one reported (sustained clocks)
-        if (i == launches - 1) rc = dga::record_hip(hipEventRecord(e0, s));
+        if (i == launches - 1) {
+            rc = dga::record_hip(hipEventRecord(e0, s));
+            if (rc != DGA_OK) break;   // (the launch's own status below must not overwrite a failed start stamp)
+        }
         if (mode == 0) hipLaunchKernelGGL(dga::mfma_ceiling_kernel<0>, dim3(cus), dim3(512), 0, s, seed, out, iters);
         else hipLaunchKernelGGL(dga::mfma_ceiling_kernel<1>, dim3(cus), dim3(512), 0, s, seed, out, iters);
         rc = dga::record_hip(hipGetLastError());

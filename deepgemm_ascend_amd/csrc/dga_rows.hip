@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) route_pos_kernel(const int64_t *ids, int6
 // ---- capacity-bounded slot assignment: the host-sync-free routing of the sharded forward --------------------------
 // Row r carries an int32 key (an expert id).  bucket(key) names a destination with room for `cap` rows; the row gets
 // the next free slot of its bucket by one atomic, dest[r] = bucket * cap + slot.  A key outside [0, key_div * key_mul)
-// (unused payload rows carry -1) gets dest -1 silently; a full bucket gets dest -1 and raises *overflow.
+// (unused payload rows carry -1) gets dest -1 silently; a full bucket gets dest -1 and adds one to *overflow per dropped row.
 //   key_sub == 0:  bucket = key / key_div                       tag = key % key_div
 //   key_sub  > 0:  bucket = ((key % key_div) / key_sub) * key_mul + key / key_div     (chunk-major, then rank)
 // Source side of the dispatch: key_div = experts per rank, bucket = (chunk, destination rank), cap = rows per pair and
@@ -141,9 +141,10 @@ __global__ void __launch_bounds__(ROUTE_THREADS) route_slots_kernel(const uint8_
         if (c > 0) {
             const int old = atomicAdd(counts + b, c);
             base[b] = old;
-            if (old + c > cap) {   // the tail of this block's rows does not fit: give the slots back, flag it
-                atomicSub(counts + b, min(c, old + c - cap));
-                atomicOr(overflow, 1);
+            if (old + c > cap) {   // the tail of this block's rows does not fit: give the slots back, count the dropped rows
+                const int dropped = min(c, old + c - cap);
+                atomicSub(counts + b, dropped);
+                atomicAdd(overflow, dropped);
             }
         }
     }

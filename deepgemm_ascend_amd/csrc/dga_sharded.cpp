@@ -34,6 +34,10 @@ int derive(const dga_sharded_shape_t &s, Derived &d)
 {
     if (s.world < 1 || s.rank < 0 || s.rank >= s.world || s.groups_total < 1 || s.m_max < 1 || s.n < 1 || s.k < 1) return DGA_E_SHAPE;
     if (s.groups_total % s.world) return DGA_E_SHAPE;             // experts must divide evenly over the ranks
+    // a payload row is [K fp8 bytes][scales as floats][int32 header]: with more than one rank the routing steps read the
+    // header (and the indexed GEMM the scales) in place, which needs K % 4 == 0 -- said here, not by a failing step halfway
+    // through a forward (a single rank has no payload rows: any K)
+    if (s.world > 1 && (s.k % 4) != 0) return DGA_E_SHAPE;
     d.gl = s.groups_total / s.world;
     int chunks = s.chunks;
     if (chunks <= 0) chunks = (s.world > 1 && d.gl % 2 == 0 && d.gl >= 8) ? 2 : 1;
@@ -59,7 +63,7 @@ int derive(const dga_sharded_shape_t &s, Derived &d)
     d.rows = d.per * chunks;
     d.indexed = s.indexed != 0;
     // the tile loads address a row's scales as floats inside the payload row, and everything with 32-bit byte offsets
-    if (d.indexed && s.world > 1 && ((s.k % 4) != 0 || d.rows * d.row_bytes >= 0x7FFFFFFFll)) d.indexed = false;
+    if (d.indexed && s.world > 1 && d.rows * d.row_bytes >= 0x7FFFFFFFll) d.indexed = false;
     if (d.indexed && s.world == 1 && d.max_tokens * static_cast<int64_t>(s.k) >= 0x7FFFFFFFll) d.indexed = false;
     return DGA_OK;
 }
@@ -117,7 +121,7 @@ int build_plan(const dga_sharded_shape_t &s, const Derived &d, std::vector<dga_s
     return DGA_OK;
 }
 
-// four bytes of `value` at base + r * stride (byte stores: the header sits behind K fp8 bytes, K need not be a multiple of 4)
+// four bytes of `value` at base + r * stride (byte stores)
 __global__ void fill_i32_strided_kernel(uint8_t *base, int64_t stride, int64_t rows, int32_t value)
 {
     const int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;

@@ -404,6 +404,9 @@ static const DenseTileCost kBf16xTileCost[] = {{128, 256, 1.583}, {128, 128, 0.9
 static constexpr double kBf16x32RowTallUs = 0.442;   // the 32-row build on a problem of more than 256 rows (warm operands): its own figure
 static const DenseCostModel kBf16xModel = {kBf16xTileCost, 5, 0.529, 1.57, 3.02, 2.98, 5.10e6, 5.35e6, 39.9e3};
 static constexpr uint32_t kDenseSplits[] = {1, 2, 3, 4, 5, 6, 8, 16};   // what the sweeps cover
+// fp32 split-K slabs a tiling may ask for: the caller keeps one grow-only workspace per stream (api._scratch), so this bounds
+// the scratch a serving process pins per stream through tiling choices alone (+ the odd-K padding copies of its operands)
+static constexpr uint64_t kMaxSlabBytes = 256ull << 20;
 static bool tile_has_three_stages(int bm, int bn)
 {
     for (int i = 0; i < variant_count(); ++i) {
@@ -500,7 +503,7 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
             if (!c) continue;
             if (c->bn == 256 && c->bm <= 32 && t.m > 256) continue;   // never the best of a tall problem (1 shape of 381), and their warm builds differ
             for (uint32_t sk : kDenseSplits) {
-                if (sk > 1 && (kb < 4 * sk || static_cast<uint64_t>(sk) * t.m * t.n * 4 > (1ull << 30))) continue;  // >= 4 k blocks per split, slabs <= 1 GiB
+                if (sk > 1 && (kb < 4 * sk || static_cast<uint64_t>(sk) * t.m * t.n * 4 > kMaxSlabBytes)) continue;  // >= 4 k blocks per split, slabs <= 256 MiB
                 uint32_t s_eff = 1;
                 double us = dense_cost_us(kFastModel, t.m, t.n, t.k, *c, sk, tile_has_three_stages(c->bm, c->bn) ? 3 : 2, pf.coreNum,
                                           static_cast<uint32_t>(pf.l1Size), &s_eff);
@@ -956,7 +959,7 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out)
         DenseTileCost c = kBf16xModel.tiles[i];
         if (c.bm == 32 && out->m > 256) c.us_per_kblock = kBf16x32RowTallUs;
         for (uint32_t s : kDenseSplits) {
-            if (s > 1 && (kb < 4 * s || static_cast<uint64_t>(s) * out->m * out->n * 4 > (1ull << 30))) continue;
+            if (s > 1 && (kb < 4 * s || static_cast<uint64_t>(s) * out->m * out->n * 4 > kMaxSlabBytes)) continue;
             uint32_t s_eff = 1;
             double us = dense_cost_us(kBf16xModel, out->m, out->n, out->k, c, s, 3, cus, 160 * 1024, &s_eff);
             us *= 1.0 + 1e-3 * (c.bm > static_cast<int>(out->m) ? (c.bm - static_cast<int>(out->m)) / 16.0 : 0.0);

@@ -96,7 +96,7 @@ def _route_slots(keys, key_stride, key_off, rows, buckets, cap, counts, dest, ov
         if hi >= (key_mul if key_sub else buckets) or bucket >= buckets:
             continue
         if cnt[bucket] >= cap:
-            overflow[0] = 1
+            overflow[0] += 1
             continue
         d[r] = bucket * cap + cnt[bucket]
         cnt[bucket] += 1
@@ -114,8 +114,12 @@ class ExpertShardedGroupedGemm:
     def __init__(self, rank: int, world: int, groups_total: int, m_max: int, n: int, k: int, device,
                  dist=None, compute: Optional[Callable] = None, chunks: Optional[int] = None,
                  capacity_factor: Optional[float] = None, max_tokens: Optional[int] = None, strict: bool = False,
-                 indexed: Optional[bool] = None, policy: Optional[str] = None):
+                 indexed: Optional[bool] = None, policy: Optional[str] = None, overlap: Optional[bool] = None):
         from . import _lib, api
+        import os as _os
+        # world > 1 on the device: overlap the exchanges with the GEMM on side streams through the library's executor.  OFF by
+        # default until it has run against RCCL with more than one rank (see forward()).
+        self.overlap = bool(int(_os.environ.get("DGA_SHARDED_OVERLAP", "0"))) if overlap is None else bool(overlap)
         assert groups_total % world == 0, "experts must divide evenly over ranks"
         self.rank, self.world, self.dist = rank, world, dist
         self.G = groups_total
@@ -224,12 +228,21 @@ class ExpertShardedGroupedGemm:
         if dev.type == "cuda" and self._side is None:
             self._side = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
 
-    def check(self):
-        """Synchronises and raises if a capacity was exceeded since the last check (rows of a full bucket are dropped)."""
-        if int(self.overflow.item()):
+    def dropped_tokens(self) -> int:
+        """Synchronises; the number of token rows THIS rank dropped since the last call (a full (chunk, rank) pair slice on the
+        sending side, a full expert on the receiving side: their output rows are zeros) -- one device counter that every
+        routing step of forward() adds to and nothing reads inside forward().  Reading clears it."""
+        n = int(self.overflow.item())
+        if n:
             self.overflow.zero_()
-            raise ValueError(f"capacity exceeded: an expert received more than m_max = {self.m_max} rows, or a "
-                             f"(chunk, rank) pair more than its {getattr(self, 'C', self.m_max)} reserved rows")
+        return n
+
+    def check(self):
+        """Synchronises and raises if a capacity was exceeded since the last check / dropped_tokens() call."""
+        n = self.dropped_tokens()
+        if n:
+            raise ValueError(f"capacity exceeded: {n} token row(s) dropped -- an expert received more than m_max = {self.m_max} "
+                             f"rows, or a (chunk, rank) pair more than its {getattr(self, 'C', self.m_max)} reserved rows")
 
     # ------------------------------------------------------------------ the library's executor (device tensors)
     def _forward_library(self, tok_q, tok_sf, expert_ids, expected_m, overlap: bool):
@@ -398,11 +411,18 @@ class ExpertShardedGroupedGemm:
             if phase_us is not None and cuda:
                 e = torch.cuda.Event(enable_timing=True); e.record(); events.append((name, e))
 
-        if cuda and self.compute is None and phase_us is None:
+        # world > 1: the library's three-stream executor (dispatch stream -> GEMM on the caller's stream -> combine stream, the
+        # collectives called back on ExternalStreams) has never met a real multi-rank collective -- tests/test_parallel_rccl.py
+        # needs two GPUs and this pool's boxes have one.  Until that test has run once, the default at world > 1 is the SAME
+        # plan interpreted here on ONE stream (no cross-stream ordering to get wrong); overlap=True (or $DGA_SHARDED_OVERLAP=1)
+        # asks for the executor, and the RCCL test runs both.
+        use_library = cuda and self.compute is None and phase_us is None and (self.world == 1 or self.overlap)
+        if use_library:
             res = self._forward_library(tok_q, tok_sf, expert_ids, expected_m, overlap=True)
         else:
             marks("start")
-            res = self._forward_interpreted(tok_q, tok_sf, expert_ids, expected_m, marks, overlap=phase_us is None)
+            res = self._forward_interpreted(tok_q, tok_sf, expert_ids, expected_m, marks,
+                                            overlap=phase_us is None and (self.overlap or not cuda))
         if phase_us is not None and cuda:
             torch.cuda.synchronize()
             for (_, e0), (name, e1) in zip(events[:-1], events[1:]):
@@ -573,12 +593,18 @@ def bench_grouped(rank, world, dist, steps=10, warmup=3, groups_total=256, m_max
     for _ in range(warmup):
         eng.forward(tok_q, tok_sf, expert_ids)
     sync()
-    eng.check()
+    dropped_warm = eng.dropped_tokens()
     t0 = time.perf_counter()
     for _ in range(steps):
         eng.forward(tok_q, tok_sf, expert_ids)
     sync()
     e2e = (time.perf_counter() - t0) / steps
+    # rows this rank dropped in the timed steps (a full pair slice / a full expert): read once, after the clock stopped
+    dropped = eng.dropped_tokens()
+    if dist is not None and world > 1:
+        dd = torch.tensor([float(dropped), float(dropped_warm)], device=dev, dtype=torch.float64)
+        dist.all_reduce(dd, op=dist.ReduceOp.SUM)
+        dropped, dropped_warm = int(dd[0]), int(dd[1])
     # end-to-end self-check that needs no remote weights: a token's result row does not depend on where the token sits in the
     # batch (other slot, other chunk, other position in the exchange buffers), bit for bit
     forward_check = None
@@ -663,6 +689,9 @@ def bench_grouped(rank, world, dist, steps=10, warmup=3, groups_total=256, m_max
         "tok_per_s_with_alltoall": round(total_tokens / e2e, 1),
         "ms_gemm": round(gemm * 1e3, 4), "ms_end_to_end": round(e2e * 1e3, 4),
         "ms_end_to_end_graph": round(e2e_graph * 1e3, 4) if e2e_graph else None,
+        "dropped_tokens": {"timed_steps": int(dropped), "per_forward": round(dropped / max(steps, 1), 2), "warmup_steps": int(dropped_warm),
+                           "note": "token rows that found a full (chunk, rank) pair slice or a full expert, summed over ranks; "
+                                   "their output rows are zeros (0 = the capacity held)"},
         "forward_check": forward_check, "phase_us": phases, "phase_us_per_rank": phases_per_rank, "chunks": eng.chunks, "indexed_rows": bool(eng.indexed),
         "pair_capacity_rows": getattr(eng, "C", None), "capacity_factor": capacity_factor if world > 1 else None,
         "roofline": roof,

@@ -299,7 +299,7 @@ int dga_route_tokens(const int64_t *expert_ids, int64_t tokens, int groups, int6
  *   bucket = hi                                        (key_sub == 0)
  *   bucket = (lo / key_sub) * key_mul + hi             (key_sub > 0: expert chunk, then destination rank)
  * dest[r] = bucket * cap + (next free slot of the bucket, one atomic), or -1 for an unused row / an unknown bucket; a
- * full bucket gives -1 and ORs 1 into *overflow (device int32, sticky -- the caller clears and inspects it).
+ * full bucket gives -1 and adds 1 to *overflow per dropped row (device int32 counter, sticky -- the caller reads and clears it).
  * counts (device int32[buckets]) end as the rows placed per bucket (zeroed first when zero_counts != 0); tags != NULL:
  * the int32 at tags + dest[r] * tag_stride_bytes receives lo (the payload header the receiving rank routes by).
  * Slot order inside a bucket is the atomics' arrival order.  No reference counterpart (row 8(e)).
@@ -365,7 +365,7 @@ typedef struct dga_sharded_buffers_t {
     void *send, *recv, *osend, *oback;
     int64_t *slot, *rdest, *row_of_slot;
     int32_t *pair_cnt, *masked_m;
-    int32_t *overflow;        /* sticky device flag: a full expert / pair slice dropped a row (the caller clears and inspects it) */
+    int32_t *overflow;        /* sticky device counter of rows dropped by a full expert / pair slice (the caller reads and clears it) */
     void *packed_a; float *packed_sfa; void *packed_out;
     const void *b;            /* resident weights of this rank: [groups_local, n, k] e4m3fn */
     const float *sfb;         /* [groups_local, ceil(n/128), ceil(k/128)] */

@@ -1,4 +1,5 @@
-"""Launch the grouped masked-M GEMM a few times (for rocprofv3 runs)."""
+"""Launch the grouped masked-M GEMM (BASELINE configs[3]: 256 x (M <= 128, K = 7168, N = 2048)) a few times, for rocprofv3 runs.
+usage: prof_grouped.py [launches] [full|random]   -- `random`: masked_m ~ randint(0, 129), SURVEY.md 8(d)'s second mask"""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -12,7 +13,9 @@ def rf(shape):
 a = rf((G, MMAX, K)); b = rf((G, N, K))
 sfa = torch.rand((G, MMAX, K // 128), device="cuda") + 0.5; sfb = torch.rand((G, N // 128, K // 128), device="cuda") + 0.5
 out = torch.zeros((G, MMAX, N), dtype=torch.bfloat16, device="cuda")
-masked = torch.full((G,), MMAX, dtype=torch.int32, device="cuda")
+mask = sys.argv[2] if len(sys.argv) > 2 else "full"
+masked = (torch.full((G,), MMAX, dtype=torch.int32, device="cuda") if mask == "full" else
+          torch.randint(0, MMAX + 1, (G,), dtype=torch.int32, device="cuda", generator=g))
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10):
     dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), out, masked, MMAX)
 torch.cuda.synchronize()

@@ -107,7 +107,11 @@ def test_tokens_beyond_an_experts_capacity_come_back_as_zero_rows(dga, oracle, i
     assert (got[dropped] == 0).all()
     want = _want(oracle, q, sf, ids, b, sfb)
     assert np.array_equal(got[~dropped], want[~dropped])
-    with pytest.raises(ValueError):
+    # the device counter says how many rows were dropped (read and cleared by dropped_tokens(); check() raises on it)
+    assert eng.dropped_tokens() == int(dropped.sum())
+    assert eng.dropped_tokens() == 0
+    eng.forward(torch.from_numpy(q).cuda(), torch.from_numpy(sf).cuda(), torch.from_numpy(ids).cuda())
+    with pytest.raises(ValueError, match=f"{int(dropped.sum())} token row"):
         eng.check()
 
 

@@ -1,9 +1,9 @@
 """GPU, >= 2 devices: the sharded forward under the REAL collective (RCCL through torch.distributed "nccl"), world 2, one
 process per GPU.  Skipped on a one-GPU box (the gpurun boxes): there the exchange is emulated in-process
-(tests/test_parallel_gpu.py).  What it checks when it can run: the indexed forward (GEMM reading the receive buffer in place,
-three streams around the collectives) equals the packed forward byte for byte, both equal the oracle's rows under the strict
-policy, twice in a row (static buffers reused) -- the evidence parallel.py waits for before `indexed` becomes the default at
-world > 1."""
+(tests/test_parallel_gpu.py).  What it checks when it can run: the default single-stream forward AND the library's three-stream
+executor (overlap=True), each with the indexed rows (GEMM reading the receive buffer in place) and with the packed layout, one
+and two chunks -- all equal the oracle's rows under the strict policy byte for byte, twice in a row (static buffers reused).
+This is the evidence parallel.py waits for before `overlap` and `indexed` become the defaults at world > 1."""
 import os
 import socket
 import subprocess
@@ -41,16 +41,19 @@ for r in range(world):
 q, sf, ids = toks[rank]
 gl = G // world
 outs = {}
-for indexed in (True, False):
-    for chunks in (1, 2):
-        eng = ExpertShardedGroupedGemm(rank, world, G, MMAX, N, K, "cuda", dist, strict=True, max_tokens=128, indexed=indexed,
-                                       chunks=chunks)
-        eng.set_weights(torch.from_numpy(b[rank * gl:(rank + 1) * gl]).cuda(), torch.from_numpy(sfb[rank * gl:(rank + 1) * gl]).cuda())
-        for _ in range(2):
-            res = eng.forward(torch.from_numpy(q).cuda(), torch.from_numpy(sf).cuda(), torch.from_numpy(ids).cuda())
-        torch.cuda.synchronize()
-        eng.check()
-        outs[(indexed, chunks)] = res.view(torch.int16).cpu().numpy().view(np.uint16)
+# overlap False = the world > 1 default (the plan interpreted on one stream); True = the library's three-stream executor with
+# the collectives called back on its streams (opt-in until this very test has run on a two-GPU box)
+for overlap in (False, True):
+    for indexed in (True, False):
+        for chunks in (1, 2):
+            eng = ExpertShardedGroupedGemm(rank, world, G, MMAX, N, K, "cuda", dist, strict=True, max_tokens=128, indexed=indexed,
+                                           chunks=chunks, overlap=overlap)
+            eng.set_weights(torch.from_numpy(b[rank * gl:(rank + 1) * gl]).cuda(), torch.from_numpy(sfb[rank * gl:(rank + 1) * gl]).cuda())
+            for _ in range(2):
+                res = eng.forward(torch.from_numpy(q).cuda(), torch.from_numpy(sf).cuda(), torch.from_numpy(ids).cuda())
+            torch.cuda.synchronize()
+            assert eng.dropped_tokens() == 0
+            outs[(overlap, indexed, chunks)] = res.view(torch.int16).cpu().numpy().view(np.uint16)
 want = np.zeros((len(ids), N), np.uint16)
 for g in np.unique(ids):
     rows = np.nonzero(ids == g)[0]

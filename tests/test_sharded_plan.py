@@ -87,7 +87,10 @@ def test_shape_errors_and_indexed_limits():
     assert _plan(groups_total=250)[0] == -2              # experts must divide over the ranks
     assert _plan(rank=8)[0] == -2
     assert _plan(chunks=3)[0] == -2                      # 32 experts per rank do not split into 3 chunks
-    rc, lay, _ = _plan(indexed=1, k=7170)                # K % 4 != 0: the scales inside a payload row would be misaligned
-    assert rc == 0 and lay.indexed == 0
+    # K % 4 != 0 with more than one rank: the header / the scales inside a payload row would be misaligned -- refused by the
+    # layout, not by a routing step halfway through a forward; a single rank has no payload rows and takes any K
+    assert _plan(indexed=1, k=7170)[0] == -2 and _plan(indexed=0, k=130)[0] == -2
+    rc, lay, _ = _plan(world=1, rank=0, indexed=0, k=130)
+    assert rc == 0
     rc, lay, _ = _plan(indexed=1, max_tokens=400000, capacity_factor=0.0, m_max=16384)   # > 2 GiB of payload rows: 32-bit tile offsets
     assert rc == 0 and lay.indexed == 0
