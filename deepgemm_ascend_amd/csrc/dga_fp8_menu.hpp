@@ -68,6 +68,9 @@ DGA_MENU_BX(DGA_MENU_EXTERN_BX)
 // DGA_E_TILING for the contiguous / indexed layouts
 int launch_bf16x_image(const GemmParams &p, int waves, hipStream_t stream);
 
+// loader-wave build of the 128 x 256 tile for rows that start at any byte (K % 16 != 0, no padded copy; dga_launch_menu_d.hip)
+int launch_unaligned(const GemmParams &p, hipStream_t stream);
+
 // one-launch workgroup split-K for dense problems of at most 64 rows (gemm_fp8_wsk_kernel.hpp; dga_launch_menu_g.hip; kernelSerial
 // DGA_KERNEL_SPLITK_WORKGROUP): bit-identical to the two-launch split-K with splitkFactor 8.  DGA_E_TILING for anything else
 int launch_wsk(const GemmParams &p, hipStream_t stream);

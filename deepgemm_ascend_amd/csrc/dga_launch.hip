@@ -260,6 +260,32 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
         ws_used = at + bytes;
         return ws + at;
     };
+    // ---- PaddingCommon (kernelSerial 2): K % 16 != 0 WITHOUT the padded copies -- the loader waves of the 128 x 256 tile fetch
+    //      the rows where they lie (any byte alignment), realign them in registers and write the LDS image themselves (the
+    //      reference's kernel of that name fuses its re-layout with the matmul the same way:
+    //      op_kernel/kernel/padding_common_matmul_kernel.h:33-107).  Dense, fp8 matrix instruction; anything it does not take
+    //      (DGA_E_TILING) goes on to the padding pass below.  It measured 15-40 % slower than padding pass + aligned tile
+    //      (profiles/r04_odd_k_fused.txt: a misaligned 128-byte row piece costs two line requests on every re-read), so the
+    //      selector never asks for it; it runs when the tiling names it, when $DGA_UNALIGNED = 1, or when the caller gave no
+    //      workspace for the padded copies (the alternative there is the element-wise kernel, orders of magnitude slower).
+    static const int unal_env = [] { const char *e = std::getenv("DGA_UNALIGNED"); return e ? std::atoi(e) : -1; }();
+    static const int bf16x_env0 = [] { const char *e = std::getenv("DGA_BF16_EXACT"); return e ? std::atoi(e) : 0; }();
+    if (k > 0 && (k % 16) != 0 && !ix && groups == 1 && !masked_m && !m_indices && !clock_stamps && !bf16x_env0 &&
+        tiling->dispatchPolicyTag != DGA_POLICY_BF16_EXACT &&
+        (unal_env >= 0 ? unal_env != 0
+                       : (tiling->kernelSerial == DGA_KERNEL_PADDING_COMMON ||
+                          // no room for the padded copies: in place through the loader waves instead of the element-wise kernel
+                          !workspace || workspace_bytes < (((static_cast<size_t>(m) * p.kb_n * 128 + 255) & ~size_t(255)) +
+                                                           static_cast<size_t>(n) * p.kb_n * 128 + 256)))) {
+        GemmParams q = p;
+        q.tiles_m = (m + 127) / 128;
+        q.tiles_n = (n + 255) / 256;
+        q.raster_group = tiling->swizzleOffset ? tiling->swizzleOffset : 1;
+        static const int xcd_remap_u = [] { const char *e = std::getenv("DGA_XCD_REMAP"); return e ? std::atoi(e) : 1; }();
+        q.xcd_remap = xcd_remap_u;
+        const int rc = launch_unaligned(q, stream);
+        if (rc != DGA_E_TILING) return rc;
+    }
     if (k > 0 && (k % 16) != 0 && !ix) {   // (indexed rows are read where they lie: odd K takes the element-wise kernel)
         const int kp = p.kb_n * 128;
         const int64_t rows_a = static_cast<int64_t>(groups) * m, rows_b = static_cast<int64_t>(b_groups) * n;

@@ -40,6 +40,30 @@ int launch_persistent(const GemmParams &p, hipStream_t stream)
     return (p.k % 128) ? launch_persistent_one<Cfg, true>(p, stream) : launch_persistent_one<Cfg, false>(p, stream);
 }
 
+// The loader-wave build of the 128 x 256 tile whose loaders take rows that start at any byte (K % 16 != 0 without a padded copy;
+// gemm_fp8_kernel.hpp UNAL): dense problems only.
+int launch_unaligned(const GemmParams &p, hipStream_t stream)
+{
+    typedef GemmCfg<128, 256, 2, 2, 3, 4> Cfg;
+    if (p.groups != 1 || p.masked_m || p.m_indices || p.row_index || p.tail_sub || p.stamps) return DGA_E_TILING;
+    // 32-bit byte offsets from the matrices' first bytes
+    if (static_cast<int64_t>(p.m) * p.lda >= 0x7FFFFFFFll || static_cast<int64_t>(p.n) * p.ldb >= 0x7FFFFFFFll) return DGA_E_TILING;
+    auto kfn = gemm_fp8_blockscaled_nt_kernel<Cfg, 0, true, false, 0, true>;
+    static std::once_flag once[64];
+    static hipError_t attr_err[64];
+    int dev = 0;
+    if (int rc = record_hip(hipGetDevice(&dev))) return rc;
+    if (dev < 0 || dev >= 64) return DGA_E_HIP;
+    std::call_once(once[dev], [&] {
+        attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    });
+    if (int rc = record_hip(attr_err[dev])) return rc;
+    const unsigned grid = p.launch_tiles > 0 ? static_cast<unsigned>(p.launch_tiles) : static_cast<unsigned>(p.groups) * p.tiles_m * p.tiles_n;
+    if (grid == 0) return DGA_OK;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p);
+    return record_hip(hipGetLastError());
+}
+
 int launch_cont_persistent(const GemmParams &p, hipStream_t stream)
 {
     typedef GemmCfg<256, 256, 4, 2, 2> Cfg;

@@ -140,9 +140,15 @@ struct LoopClock {
 // MATH = 0: the fp8 matrix instruction (one v_mfma_scale_f32_16x16x128_f8f6f4 per 128-wide scale block).
 // MATH = 1 (PP = 0, three LDS stages): the bf16-exact policy -- the e4m3 bytes are up-converted to bf16 in registers (exact)
 //         and a scale block is four chained v_mfma_f32_16x16x32_bf16, whose sums are fp32-class (see the loop below).
-template <class Cfg, int PP, bool KTAIL, bool CLK = false, int MATH = 0>
+// UNAL (loader-wave builds, plain loop, dense): the operands' rows start at ANY byte (K % 16 != 0, no padded copy): the loader waves
+//         fetch them to registers with dword-aligned loads, realign (v_alignbyte), zero the bytes beyond K and ds_write the same
+//         swizzled image the LDS-DMA would have written -- the computing waves are unchanged.  The counterpart of the reference's
+//         PaddingCommon kernel, which fuses the re-layout with the matmul
+//         (/root/reference/aclnn_catlass_dynamic_matmul/op_kernel/kernel/padding_common_matmul_kernel.h:33-107).
+template <class Cfg, int PP, bool KTAIL, bool CLK = false, int MATH = 0, bool UNAL = false>
 __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const GemmParams p)
 {
+    static_assert(!UNAL || (Cfg::kLC && PP == 0 && MATH == 0 && KTAIL), "unaligned rows: loader waves, plain loop, fp8 matrix instruction");
     LoopClock<CLK> loop_clock;
     constexpr int BM = Cfg::kBM, BN = Cfg::kBN, WN = Cfg::kWN;
     constexpr int NT = Cfg::NT, TM = Cfg::TM, TN = Cfg::TN;
@@ -252,14 +258,21 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
 #else
         a_voff[it] = row < M - m0 ? (ridx ? (uint32_t)ridx[m0 + rr] : (uint32_t)rr) * (uint32_t)p.lda + a_col : kOutOfRange;
 #endif
+        if constexpr (UNAL)   // byte offset from the dword at or below the matrix's first byte (rows start at any byte, and so may the matrix)
+            a_voff[it] = row < M - m0 ? (uint32_t)(m0 + row) * (uint32_t)p.lda + a_col + (uint32_t)((uintptr_t)A & 3) : kOutOfRange;
     }
 #pragma unroll
     for (int it = 0; it < Cfg::B_ITERS; ++it) {
         const int row = (it * DNT + dtid) >> 3;
         b_voff[it] = (uint32_t)min(row, p.n - 1 - n0) * (uint32_t)p.ldb + b_col;
+        if constexpr (UNAL) b_voff[it] = (uint32_t)(n0 + min(row, p.n - 1 - n0)) * (uint32_t)p.ldb + b_col + (uint32_t)((uintptr_t)B & 3);
     }
-    const v4i a_rsrc = ridx ? make_rsrc(A, p.a_bytes) : make_rsrc(A + (int64_t)m0 * p.lda, (int64_t)(M - m0) * p.lda);
-    const v4i b_rsrc = make_rsrc(B + (int64_t)n0 * p.ldb, (int64_t)(p.n - n0) * p.ldb);
+    // (UNAL: from the dword at or below the matrix's first byte -- the per-lane offsets above count from there -- to the end of
+    //  the dword that holds its last byte)
+    const v4i a_rsrc = UNAL ? make_rsrc(A - ((uintptr_t)A & 3), ((int64_t)((uintptr_t)A & 3) + (int64_t)M * p.lda + 3) & ~(int64_t)3)
+                            : (ridx ? make_rsrc(A, p.a_bytes) : make_rsrc(A + (int64_t)m0 * p.lda, (int64_t)(M - m0) * p.lda));
+    const v4i b_rsrc = UNAL ? make_rsrc(B - ((uintptr_t)B & 3), ((int64_t)((uintptr_t)B & 3) + (int64_t)p.n * p.ldb + 3) & ~(int64_t)3)
+                            : make_rsrc(B + (int64_t)n0 * p.ldb, (int64_t)(p.n - n0) * p.ldb);
     // scale slots: [0,BM) = sfa rows of this tile, [BM, BM+8) = sfb blocks of this tile, rest = padding
     const float *sc_src[Cfg::SC_ITERS];
 #pragma unroll
@@ -930,7 +943,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         // first fills: the B and scale pieces go out before the A pieces, so that in the indexed form the row-table loads
         // behind a_voff have the B issue to hide under (per stage the piece count is what the vmcnt waits rely on,
         // not the order inside a stage)
-        if (!LC || loader) {
+        if ((!LC || loader) && !UNAL) {
 #pragma unroll
             for (int d = 0; d < STG - 1; ++d) {
 #pragma unroll
@@ -944,7 +957,86 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         loop_clock.tick();
         int stage = 0, fill = STG - 1;   // stage being consumed / stage being refilled (with k block kb + STG - 1)
         const bool wave_has_rows = m0 + wm * (BM / Cfg::kWM) < M;  // wave-uniform (wm comes from readfirstlane)
-        if constexpr (LC) {
+        if constexpr (LC && UNAL) {
+            if (loader) {
+                // ---- loader wave, rows that start at any byte.  The LDS-DMA (and a plain buffer load) takes a source address
+                // of ANY alignment at full rate on this part (scripts/ubench/probe_unaligned_dma.hip ->
+                // profiles/r04_probe_unaligned_dma.txt: 16 misalignments exact, 5.7-6.0 TB/s each), so every k block but one
+                // is fetched exactly as in the aligned build, with byte offsets from the matrix's first byte.  The one block
+                // that holds K's ragged end (K % 16 != 0: the chunk that straddles K would bring the NEXT row's first bytes
+                // into the image) goes through registers: buffer_load_dwordx4, the bytes at and beyond K zeroed, ds_write_b128
+                // to the address the DMA would have written.  The scales always go by LDS-DMA.
+                constexpr int NP = Cfg::A_ITERS + Cfg::B_ITERS;
+                const int64_t a_mis = (int64_t)((uintptr_t)A & 3), b_mis = (int64_t)((uintptr_t)B & 3);
+                const __amdgpu_buffer_rsrc_t ua = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)(A - a_mis), 0, (int)min((a_mis + (int64_t)M * p.lda + 3) & ~(int64_t)3, (int64_t)0x7FFFFFFC), 0x00020000);
+                const __amdgpu_buffer_rsrc_t ub = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)(B - b_mis), 0, (int)min((b_mis + (int64_t)p.n * p.ldb + 3) & ~(int64_t)3, (int64_t)0x7FFFFFFC), 0x00020000);
+                const int ragged_kb = (p.k & 15) ? p.k / 128 : -1;    // the k block that holds the straddling chunk
+                bool drained = false;                                 // the ragged block is behind us: no batch counting any more
+                auto fill_stage = [&](int stg, int kbr) {
+                    if (kbr != ragged_kb) {
+#pragma unroll
+                        for (int idx = Cfg::A_ITERS; idx < Cfg::LOADS_PER_STAGE; ++idx) issue_one(idx, stg, kbr);
+#pragma unroll
+                        for (int idx = 0; idx < Cfg::A_ITERS; ++idx) issue_one(idx, stg, kbr);
+                        return;
+                    }
+                    // five dwords from the dword-aligned address at or below the chunk (each load a whole aligned dword, range-checked
+                    // on its own: a 16-byte load that ends past num_records comes back as zeros altogether -- measured), shifted into
+                    // place by v_alignbyte
+                    const int k0 = kbr * 128;
+                    uint32_t r[NP][5];
+#pragma unroll
+                    for (int idx = 0; idx < NP; ++idx) {
+                        const bool isa = idx < Cfg::A_ITERS;
+                        const uint32_t vo = isa ? a_voff[idx] : b_voff[idx - Cfg::A_ITERS];
+                        const bool live = vo != kOutOfRange && k0 + (isa ? a_col : b_col) < p.k;
+                        const uint32_t al = live ? (vo & ~3u) + (uint32_t)k0 : kOutOfRange;
+                        // (builtin loads, not asm: the compiler must know when these registers are valid -- with asm loads it is free
+                        //  to copy an output register before the hand-placed wait, and did: one run in three came out wrong)
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) r[idx][j] = __builtin_amdgcn_raw_buffer_load_b32(isa ? ua : ub, (int)(al + 4 * j), 0, 0);
+                    }
+#pragma unroll
+                    for (int idx = 0; idx < NP; ++idx) {
+                        const bool isa = idx < Cfg::A_ITERS;
+                        const uint32_t sh = (isa ? a_voff[idx] : b_voff[idx - Cfg::A_ITERS]) & 3u;
+                        const int valid = p.k - (k0 + (isa ? a_col : b_col));   // bytes of this chunk inside the row
+                        v4i w;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            uint32_t x = __builtin_amdgcn_alignbyte(r[idx][j + 1], r[idx][j], sh);
+                            const int nb = valid - 4 * j;
+                            if (nb < 4) x = nb <= 0 ? 0u : (x & ((1u << (8 * nb)) - 1u));
+                            w[j] = (int)x;
+                        }
+                        const int it = isa ? idx : idx - Cfg::A_ITERS;
+                        *(v4i *)(smem + stg * Cfg::STAGE_BYTES + (isa ? 0 : Cfg::A_BYTES) + dwave * 1024 + it * DNT * 16 + lane * 16) = w;
+                    }
+#pragma unroll
+                    for (int idx = NP; idx < Cfg::LOADS_PER_STAGE; ++idx) issue_one(idx, stg, kbr);   // its scales
+                    drained = true;
+                };
+#pragma unroll
+                for (int d = 0; d < STG - 1; ++d) fill_stage(d, kb_begin + d);
+                for (int kb = kb_begin; kb < kb_end; ++kb) {
+                    if (drained) {
+                        wait_vmcnt<0>();
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the ragged block's image stores
+                    } else {
+                        wait_vmcnt<(STG - 2) * Cfg::LOADS_PER_STAGE>();
+                    }
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    fill_stage(fill, kb + STG - 1);
+                    fill = fill + 1 == STG ? 0 : fill + 1;
+                }
+                wait_vmcnt<0>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                return;
+            }
+        } else if constexpr (LC) {
             if (loader) {
                 // loader wave: per k block, wait until the oldest batch in flight has landed, meet the computing waves at
                 // the barrier (they have left the stage that is refilled next), send the whole refill in one burst

@@ -31,7 +31,6 @@ __global__ void __launch_bounds__(512) gemm_fp8_wsk_kernel(const GemmParams p)
 {
     constexpr int WAVES = 8, BNW = TNMAX * 16, BM = TM * 16;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // [WAVES][BM][BNW] fp32
-    typedef unsigned v4u __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kg = lane >> 4;

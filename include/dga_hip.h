@@ -45,7 +45,8 @@ enum { DGA_PADDING_NONE = 0, DGA_PADDING_ND = 1, DGA_PADDING_BLOCK_ND = 2, DGA_P
 
 /* kernelSerial menu, same numbering as the reference
  * (op_kernel/kernel/kernel_utils.h:31-37, select_kernel.cpp:270-331):
- *   0 Common, 1 Small, 2 PaddingCommon (never chosen on CDNA4), 4 StreamK/split-K. */
+ *   0 Common, 1 Small, 2 PaddingCommon (K % 16 != 0 read in place by the loader waves of the 128 x 256 tile: the re-layout fused
+ *   with the matmul as in the reference's kernel of that name; without it odd K takes a padding pass), 4 StreamK/split-K. */
 enum { DGA_KERNEL_COMMON = 0, DGA_KERNEL_SMALL = 1, DGA_KERNEL_PADDING_COMMON = 2, DGA_KERNEL_STREAMK = 4,
        DGA_KERNEL_STREAMK_TAIL = 5 /* whole waves of 256x256 tiles, the last partial wave covered by 128x128 tiles */,
        DGA_KERNEL_SPLITK_WORKGROUP = 6 /* M <= 64: the 8 waves of a workgroup are the 8 K slices of one output tile, partial tiles
