@@ -197,7 +197,7 @@ def lib() -> ctypes.CDLL:
                 raise DGALibraryError(f"{LIB_PATH} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
-        if L.dga_abi_version() != 3:
+        if L.dga_abi_version() != 4:
             raise DGALibraryError("ABI version mismatch")
         _lib = L
     return _lib

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define DGA_ABI_VERSION 3
+#define DGA_ABI_VERSION 4
 
 /* ---- status codes (reference: DGA_HOST_ASSERT throws DGAException,
  *      deep_gemm_ascend/framework/csrc/utils/exception.hpp:9-33; op hooks return
