@@ -318,10 +318,9 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
             const int it = idx - Cfg::A_ITERS;
             uint32_t voff = b_voff[it];
             if constexpr (KTAIL) voff = (k0 + b_col < p.k) ? voff : kOutOfRange;
-            // bf16-exact builds on a weight stream (masked grouped layout: every weight byte is read once, by one CU): the
-            // non-temporal policy, as the persistent fast-path builds use it (gemm_fp8_persistent_kernel.hpp)
-            if (MATH == 1 && p.b_nt) dma16_nt(voff, b_rsrc, (uint32_t)k0, sa + Cfg::A_BYTES + it * DNT * 16);
-            else dma16(voff, b_rsrc, (uint32_t)k0, sa + Cfg::A_BYTES + it * DNT * 16);
+            // (the non-temporal policy on the bf16-exact builds' weight stream measured no difference: 1096 against 1107 us on
+            //  256 x (128, 7168, 2048) -- that kernel is bound by its matrix rate there, profiles/r04_grouped_policy_perf.txt)
+            dma16(voff, b_rsrc, (uint32_t)k0, sa + Cfg::A_BYTES + it * DNT * 16);
         } else {
             const int it = idx - Cfg::A_ITERS - Cfg::B_ITERS;
             dma4(sc_src[it] + min(kb, p.kb_n - 1), lds0 + stage * Cfg::STAGE_BYTES + Cfg::A_BYTES + Cfg::B_BYTES +
