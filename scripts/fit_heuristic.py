@@ -25,10 +25,10 @@ def load(dirs):
         for f in glob.glob(str(Path(d) / "shape_*_rank_*.jsonl")):
             for line in open(f):
                 r = json.loads(line)
-                if r["negative"] or r["time"] <= 0:
+                if "parameters" not in r or r.get("negative") or r.get("time", 0) <= 0:   # (checkpoint files match the glob too)
                     continue
                 p = r["parameters"]
-                if p.get("tail"):
+                if p.get("tail") or p.get("wsk"):   # other kernels than the tile menu
                     continue
                 key = (r["M"], r["N"], r["K"])
                 c = (p["m1"], p["n1"], p["splitk"])
