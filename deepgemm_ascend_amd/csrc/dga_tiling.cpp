@@ -675,6 +675,19 @@ public:
     {
         std::lock_guard<std::mutex> lk(mu_);
         auto it = data_.find(key_of(t.m, t.n, t.k, t.groups, t.contiguous ? 1u : 0u));
+        bool bucketed = false;
+        if (it == data_.end() && t.groups <= 1 && !t.contiguous && t.m >= 1 && t.m <= 128) {
+            // a decode batch is any M <= 128 on a handful of (N, K): what a short-M tiling depends on is the tile height that covers M
+            // and the (N, K) stream, so a miss falls back to the swept row of the same (N, K) at the next row count of the decode
+            // grid (harness/sweep.py --cold over M in {1, 4, 8, 16, 32, 48, 64, 96, 128}: profiles/r04_sweep_decode)
+            static constexpr uint32_t kDecodeRows[] = {1, 4, 8, 16, 32, 48, 64, 96, 128};
+            for (uint32_t mb : kDecodeRows) {
+                if (mb < t.m) continue;
+                it = data_.find(key_of(mb, t.n, t.k, 1u, 0u));
+                if (it != data_.end() && it->second.stages != 0) { bucketed = true; break; }
+                it = data_.end();
+            }
+        }
         if (it == data_.end()) return false;
         const Entry &e = it->second;
         t.m1 = e.m1; t.n1 = e.n1; t.k1 = e.k1; t.kernelSerial = e.serial;
@@ -683,6 +696,8 @@ public:
         t.stages = static_cast<uint8_t>(e.stages); t.wavesM = static_cast<uint8_t>(e.waves_m);
         t.wavesN = static_cast<uint8_t>(e.waves_n); t.dispatchPolicyTag = static_cast<uint8_t>(e.policy);
         if (e.raster) t.swizzleOffset = static_cast<uint8_t>(e.raster);
+        if (bucketed && t.m1 && t.n1)   // the neighbour's grid is not this problem's
+            t.blockDim = ((t.m + t.m1 - 1) / t.m1) * ((t.n + t.n1 - 1) / t.n1) * std::max<uint32_t>(1, t.splitkFactor);
         *swept = e.stages != 0;
         *timed_policy = e.has_policy;
         return true;
