@@ -35,6 +35,7 @@ from .api import (  # noqa: F401
     predictor_unload,
     release_scratch,
     select_kernel_with_predictor,
+    select_tiling_strategy,
     platform_mi355x,
     run_mmad_bench,
     run_mmad_custom,

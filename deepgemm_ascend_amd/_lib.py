@@ -111,6 +111,10 @@ SIGNATURES = {
     "dga_predictor_unload": (None, []),
     "dga_predictor_loaded": (c_int, []),
     "dga_predict_time_us": (c_int, [POINTER(Problem), POINTER(Tiling), POINTER(ctypes.c_float)]),
+    "dga_select_tiling_strategy": (c_int, [POINTER(ctypes.c_float), POINTER(ctypes.c_int32), c_int, c_int, c_int, ctypes.c_float, c_int,
+                                           ctypes.c_uint64, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "dga_select_kernel_with_predictor_ex": (c_int, [POINTER(Problem), POINTER(Tiling), POINTER(ctypes.c_float), POINTER(ctypes.c_float),
+                                                    c_int, c_int]),
     "dga_select_kernel_with_predictor": (c_int, [POINTER(Problem), POINTER(Tiling), POINTER(ctypes.c_float),
                                                  POINTER(ctypes.c_float)]),
     "dga_tiling_cache_open": (c_int, [c_char_p]),

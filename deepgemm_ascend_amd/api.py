@@ -256,15 +256,40 @@ def predict_time_us(m: int, n: int, k: int, t: Tiling) -> float:
     return us.value
 
 
-def select_kernel_with_predictor(m: int, n: int, k: int):
+SELECTION_METHODS = {"greedy": 0, "topk_median": 1, "topk_dbscan": 2}   # get_best_config.py:431-525
+
+
+def select_kernel_with_predictor(m: int, n: int, k: int, method: str = "greedy", topk: int = 10):
     """SelectKernelWithPredictor: (tiling, predicted_us, native_us); falls back to the heuristic tiling when the model
-    is absent, the candidate list is short or the promised gain is below 3 % (get_best_config.py:587-621)."""
+    is absent, the candidate list is short or the promised gain is below the threshold (get_best_config.py:587-621).  `method` /
+    `topk`: the reference predictor's selection strategy (select_tiling_strategy, get_best_config.py:431-525)."""
+    _require(method in SELECTION_METHODS, f"method: one of {sorted(SELECTION_METHODS)}")
     t = Tiling()
     p = _problem(m, n, k)
     a, b = ctypes.c_float(0), ctypes.c_float(0)
-    _lib.check(_lib.lib().dga_select_kernel_with_predictor(ctypes.byref(p), ctypes.byref(t), ctypes.byref(a),
-                                                           ctypes.byref(b)), "select_kernel_with_predictor")
+    _lib.check(_lib.lib().dga_select_kernel_with_predictor_ex(ctypes.byref(p), ctypes.byref(t), ctypes.byref(a), ctypes.byref(b),
+                                                              SELECTION_METHODS[method], int(topk)), "select_kernel_with_predictor")
     return t, a.value, b.value
+
+
+def select_tiling_strategy(preds, tiles, method: str = "greedy", topk: int = 10, dbscan_eps: float = 0.8, dbscan_min_samples: int = 2,
+                           random_state: int = 0):
+    """select_tiling_strategy (get_best_config.py:431-525) on predicted times `preds` [count] and tile triples `tiles` [count][3]
+    (mTile, nTile, kTile): returns (picked index, members of the winning cluster -- topk_dbscan only, else []).  The reference draws a
+    random member of that cluster; this library takes its fastest (random_state = 0) or member random_state % size."""
+    import numpy as np
+    _require(method in SELECTION_METHODS, f"method: one of {sorted(SELECTION_METHODS)}")
+    pr = np.ascontiguousarray(preds, dtype=np.float32)
+    tl = np.ascontiguousarray(tiles, dtype=np.int32).reshape(-1, 3) if tiles is not None else np.zeros((pr.size, 3), np.int32)
+    _require(tl.shape[0] == pr.size, "one tile triple per prediction")
+    picked, cnt = ctypes.c_int(-1), ctypes.c_int(0)
+    members = (ctypes.c_int * max(1, pr.size))()
+    _lib.check(_lib.lib().dga_select_tiling_strategy(pr.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                                     tl.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), int(pr.size),
+                                                     SELECTION_METHODS[method], int(topk), float(dbscan_eps), int(dbscan_min_samples),
+                                                     int(random_state), ctypes.byref(picked), members, ctypes.byref(cnt)),
+               "select_tiling_strategy")
+    return picked.value, [members[i] for i in range(cnt.value)]
 
 
 def platform_mi355x() -> Platform:

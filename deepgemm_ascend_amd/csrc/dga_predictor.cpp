@@ -7,6 +7,7 @@
 // folded), the candidate list is the compiled variant menu x stages x split-K x schedule (the same list the sweep
 // driver times, harness/sweep.py candidates()), and no Python runs in the operator path.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -258,11 +259,114 @@ int dga_predict_time_us(const dga_problem_t *problem, const dga_tiling_t *tiling
     return DGA_OK;
 }
 
+// select_tiling_strategy (get_best_config.py:431-525): which of the candidates to take, given the model's time for each.
+//   greedy       the smallest predicted time;
+//   topk_median  the median position of the topk smallest;
+//   topk_dbscan  DBSCAN (eps, min_samples; scikit-learn's semantics: a point with >= min_samples points within eps, itself
+//                included, is a core point; clusters grow depth-first from core points in index order, a border point joins the
+//                first cluster that reaches it) over the standardised rows [time, mTile, nTile, kTile] of the topk; every cluster
+//                scores 0.7 * median time / best median + 0.3 * largest size / size; the best-scoring cluster wins (no cluster at
+//                all: the fastest candidate).
+// The reference then takes a uniformly random member of that cluster (random.Random(random_state).choice).  A tiling pick has to
+// be the same on every call and every rank, so here random_state == 0 takes the cluster's FASTEST member and random_state != 0
+// the member at position random_state % size (in order of predicted time) -- the one deliberate deviation; cluster_members
+// returns the whole cluster so that a caller (and the parity test) sees what the reference would have drawn from.
+int dga_select_tiling_strategy(const float *preds, const int32_t *tiles, int count, int method, int topk, float dbscan_eps,
+                               int dbscan_min_samples, uint64_t random_state, int *picked_index, int *cluster_members, int *cluster_count)
+{
+    if (!preds || !picked_index || (method == DGA_PICK_TOPK_DBSCAN && !tiles)) return DGA_E_NULL;
+    if (count <= 0 || method < DGA_PICK_GREEDY || method > DGA_PICK_TOPK_DBSCAN) return DGA_E_SHAPE;
+    if (cluster_count) *cluster_count = 0;
+    std::vector<int> order(count);
+    for (int i = 0; i < count; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return preds[a] < preds[b]; });
+    const int tk = std::max(1, std::min(topk, count));
+    if (method == DGA_PICK_GREEDY) { *picked_index = order[0]; return DGA_OK; }
+    if (method == DGA_PICK_TOPK_MEDIAN) { *picked_index = order[tk / 2]; return DGA_OK; }
+    // ---- topk_dbscan
+    std::vector<std::array<float, 4>> f(tk);
+    for (int i = 0; i < tk; ++i) {
+        const int idx = order[i];
+        f[i] = {preds[idx], static_cast<float>(tiles[3 * idx]), static_cast<float>(tiles[3 * idx + 1]), static_cast<float>(tiles[3 * idx + 2])};
+    }
+    for (int c = 0; c < 4; ++c) {   // (x - mean) / std, population std, a constant column left as it is
+        double mean = 0, var = 0;
+        for (int i = 0; i < tk; ++i) mean += f[i][c];
+        mean /= tk;
+        for (int i = 0; i < tk; ++i) var += (f[i][c] - mean) * (f[i][c] - mean);
+        double sd = std::sqrt(var / tk);
+        if (sd < 1e-6) sd = 1.0;
+        for (int i = 0; i < tk; ++i) f[i][c] = static_cast<float>((f[i][c] - mean) / sd);
+    }
+    std::vector<std::vector<int>> nb(tk);
+    for (int i = 0; i < tk; ++i)
+        for (int j = 0; j < tk; ++j) {
+            double d2 = 0;
+            for (int c = 0; c < 4; ++c) d2 += (static_cast<double>(f[i][c]) - f[j][c]) * (static_cast<double>(f[i][c]) - f[j][c]);
+            if (std::sqrt(d2) <= dbscan_eps) nb[i].push_back(j);
+        }
+    std::vector<int> label(tk, -1);
+    int labels = 0;
+    for (int s0 = 0; s0 < tk; ++s0) {
+        if (label[s0] != -1 || static_cast<int>(nb[s0].size()) < dbscan_min_samples) continue;
+        std::vector<int> stack;
+        int i = s0;
+        for (;;) {
+            if (label[i] == -1) {
+                label[i] = labels;
+                if (static_cast<int>(nb[i].size()) >= dbscan_min_samples)
+                    for (int j : nb[i])
+                        if (label[j] == -1) stack.push_back(j);
+            }
+            if (stack.empty()) break;
+            i = stack.back();
+            stack.pop_back();
+        }
+        ++labels;
+    }
+    if (labels == 0) { *picked_index = order[0]; return DGA_OK; }
+    std::vector<float> med(labels);
+    std::vector<int> size(labels, 0);
+    for (int l = 0; l < labels; ++l) {
+        std::vector<float> t;
+        for (int i = 0; i < tk; ++i)
+            if (label[i] == l) t.push_back(preds[order[i]]);
+        std::sort(t.begin(), t.end());
+        size[l] = static_cast<int>(t.size());
+        med[l] = (t.size() & 1) ? t[t.size() / 2] : (t[t.size() / 2 - 1] + t[t.size() / 2]) * 0.5f;   // numpy.median of float32
+    }
+    const double min_med = std::max<double>(*std::min_element(med.begin(), med.end()), 1e-6);
+    const int max_size = std::max(1, *std::max_element(size.begin(), size.end()));
+    int best = 0;
+    double best_score = 0;
+    for (int l = 0; l < labels; ++l) {
+        const double score = 0.7 * (static_cast<double>(med[l]) / min_med) + 0.3 * (static_cast<double>(max_size) / size[l]);
+        if (l == 0 || score < best_score) { best = l; best_score = score; }   // (ties: the lower label, as the reference's sort)
+    }
+    std::vector<int> members;   // in order of predicted time (= their order in the topk)
+    for (int i = 0; i < tk; ++i)
+        if (label[i] == best) members.push_back(order[i]);
+    if (cluster_count) *cluster_count = static_cast<int>(members.size());
+    if (cluster_members)
+        for (size_t i = 0; i < members.size(); ++i) cluster_members[i] = members[i];
+    *picked_index = members[random_state ? static_cast<size_t>(random_state % members.size()) : 0];
+    return DGA_OK;
+}
+
 // SelectKernelWithPredictor (select_kernel.cpp:380-388, commented out in the reference): native tiling first, then
-// the model's greedy pick over the candidate list unless a fallback applies.
+// the model's pick over the candidate list -- by `method` (dga_select_tiling_strategy; the reference's default is greedy) --
+// unless a fallback applies.
+int dga_select_kernel_with_predictor_ex(const dga_problem_t *problem, dga_tiling_t *out, float *predicted_us, float *native_us,
+                                        int method, int topk);
 int dga_select_kernel_with_predictor(const dga_problem_t *problem, dga_tiling_t *out, float *predicted_us, float *native_us)
 {
+    return dga_select_kernel_with_predictor_ex(problem, out, predicted_us, native_us, DGA_PICK_GREEDY, 10);
+}
+int dga_select_kernel_with_predictor_ex(const dga_problem_t *problem, dga_tiling_t *out, float *predicted_us, float *native_us,
+                                        int method, int topk)
+{
     if (!problem || !out) return DGA_E_NULL;
+    if (method < DGA_PICK_GREEDY || method > DGA_PICK_TOPK_DBSCAN) return DGA_E_SHAPE;
     int rc = dga_select_kernel(problem, nullptr, out);
     if (rc != DGA_OK) return rc;
     if (predicted_us) *predicted_us = 0.f;
@@ -278,14 +382,20 @@ int dga_select_kernel_with_predictor(const dga_problem_t *problem, dga_tiling_t 
     if (predicted_us) *predicted_us = t_native;
     const std::vector<Cand> cands = candidates(problem->m, problem->n, problem->k);
     if (static_cast<int>(cands.size()) < kMinCandidates) return DGA_OK;  // fallback 1: too few candidates
-    float best = 0.f;
-    const Cand *pick = nullptr;
-    for (const Cand &c : cands) {
-        feature_row(problem->m, problem->n, problem->k, c, f);
-        const float t = forward(*mo, f);
-        if (!pick || t < best) { best = t; pick = &c; }
+    std::vector<float> times(cands.size());
+    std::vector<int32_t> tile3(3 * cands.size());
+    for (size_t i = 0; i < cands.size(); ++i) {
+        feature_row(problem->m, problem->n, problem->k, cands[i], f);
+        times[i] = forward(*mo, f);
+        tile3[3 * i] = cands[i].m1; tile3[3 * i + 1] = cands[i].n1; tile3[3 * i + 2] = 128 * cands[i].splitk;   // (kTile's role: the K a workgroup walks per pass)
     }
-    if (!pick || !(best <= (1.f - kGainThreshold) * t_native)) return DGA_OK;  // fallback 2: gain below the threshold
+    int picked = -1;
+    if (dga_select_tiling_strategy(times.data(), tile3.data(), static_cast<int>(cands.size()), method, topk, 0.8f, 2, 0, &picked, nullptr,
+                                   nullptr) != DGA_OK || picked < 0)
+        return DGA_OK;
+    const Cand *pick = &cands[static_cast<size_t>(picked)];
+    const float best = times[static_cast<size_t>(picked)];
+    if (!(best <= (1.f - kGainThreshold) * t_native)) return DGA_OK;  // fallback 2: gain below the threshold
     out->m1 = static_cast<uint16_t>(pick->m1); out->n1 = static_cast<uint16_t>(pick->n1); out->k1 = 128;
     out->stages = static_cast<uint8_t>(pick->stages);
     // schedule of the 256x256 tile: the continuous pipeline wins every A/B at sustained clocks by 1-6 % (scripts/

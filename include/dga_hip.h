@@ -173,6 +173,17 @@ int dga_predictor_load(const char *path);
 void dga_predictor_unload(void);
 int dga_predictor_loaded(void);
 int dga_predict_time_us(const dga_problem_t *problem, const dga_tiling_t *tiling, float *us);
+/* Selection strategies of the predictor (get_best_config.py:431-525 select_tiling_strategy): greedy, topk_median, topk_dbscan.
+ * preds[count] = predicted times, tiles[count][3] = (mTile, nTile, kTile) of every candidate (used by topk_dbscan only).
+ * *picked_index = the candidate taken; topk_dbscan also returns the winning cluster (cluster_members[<= count], *cluster_count;
+ * both nullable) -- the reference draws a random member of it (random.Random(random_state).choice), this library takes its fastest
+ * member (random_state == 0) or member random_state % size, so that a pick is reproducible. */
+enum { DGA_PICK_GREEDY = 0, DGA_PICK_TOPK_MEDIAN = 1, DGA_PICK_TOPK_DBSCAN = 2 };
+int dga_select_tiling_strategy(const float *preds, const int32_t *tiles, int count, int method, int topk, float dbscan_eps,
+                               int dbscan_min_samples, uint64_t random_state, int *picked_index, int *cluster_members, int *cluster_count);
+/* dga_select_kernel_with_predictor with the strategy named (method: DGA_PICK_*, topk as in the reference: 10). */
+int dga_select_kernel_with_predictor_ex(const dga_problem_t *problem, dga_tiling_t *out, float *predicted_us, float *native_us,
+                                        int method, int topk);
 int dga_select_kernel_with_predictor(const dga_problem_t *problem, dga_tiling_t *out, float *predicted_us,
                                      float *native_us);
 

@@ -20,6 +20,9 @@ Fixtures (SURVEY.md 8c "Golden vectors to commit"):
   ref_gen_golden_e4m3_96x160x320.npz (viii) the same generator with numpy.random.uniform returning draws from the signed e4m3fn
                                 grid for the duration of the call: a reference-written golden that reaches the FP8 kernels
                                 (`... make_golden.py ref_gen_golden_e4m3`).
+  select_strategy_vectors.json  (ix) picks of the reference predictor's selection strategies (greedy / topk_median / topk_dbscan):
+                                get_best_config.py's TilingPredictor.select_tiling_strategy imported and called on seeded lists
+                                (`... make_golden.py select_strategy`).
 """
 import json
 import sys
@@ -177,12 +180,68 @@ def ref_gen_golden_e4m3(m=96, n=160, k=320, seed=20251005):
                                         "draws from the signed e4m3fn grid (default_rng(seed)), numpy " + np.__version__))
 
 
+def select_strategy():
+    """Golden picks of the reference predictor's selection strategies: TilingPredictor.select_tiling_strategy
+    (get_best_config/get_best_config.py:431-525) imported and called on seeded candidate lists.  greedy / topk_median: the picked
+    index.  topk_dbscan: the winning CLUSTER (the reference returns random.Random(random_state).choice of it; the module's `random`
+    is replaced for the call by a recorder that captures the list it is asked to choose from) -- or the fallback index when no
+    cluster forms."""
+    sys.path.insert(0, str(REF / "get_best_config"))
+    import get_best_config as gbc   # the reference's module (imported, never copied)
+    rng = np.random.default_rng(20251006)
+    captured = []
+
+    class Recorder:
+        def __init__(self, seed=None):
+            pass
+
+        def choice(self, seq):
+            captured.append(list(seq))
+            return seq[0]
+
+    class FakeRandom:
+        Random = Recorder
+
+    cases = []
+    tile_values = [16, 32, 48, 64, 96, 128, 192, 256]
+    for n in (1, 2, 3, 8, 15, 40, 120):
+        for rep in range(4):
+            # a few performance plateaus (tiles that behave alike) plus scattered outliers, no two times equal
+            centres = rng.uniform(20, 400, size=max(1, n // 6 + 1))
+            preds = np.array([c * rng.uniform(0.97, 1.03) for c in rng.choice(centres, size=n)], np.float32)
+            preds += np.arange(n, dtype=np.float32) * 1e-3
+            tiles = [[int(rng.choice(tile_values)), int(rng.choice(tile_values)), int(rng.choice([64, 128, 256, 512, 1024]))] for _ in range(n)]
+            params = [{"mTile": t[0], "nTile": t[1], "kTile": t[2]} for t in tiles]
+            for method, topk, eps, ms in (("greedy", 10, 0.8, 2), ("topk_median", 1, 0.8, 2), ("topk_median", 5, 0.8, 2),
+                                          ("topk_median", 10, 0.8, 2), ("topk_median", 20, 0.8, 2), ("topk_dbscan", 5, 0.8, 2),
+                                          ("topk_dbscan", 10, 0.8, 2), ("topk_dbscan", 20, 0.5, 2), ("topk_dbscan", 20, 1.5, 3),
+                                          ("topk_dbscan", 60, 0.8, 2), ("topk_dbscan", 60, 1.2, 4)):
+                del captured[:]
+                real = gbc.random
+                gbc.random = FakeRandom
+                try:
+                    got, t = gbc.TilingPredictor.select_tiling_strategy(None, params, preds, method=method, topk=topk, random_state=7,
+                                                                        dbscan_eps=eps, dbscan_min_samples=ms)
+                finally:
+                    gbc.random = real
+                idx = params.index(got) if captured == [] else None
+                # (params may hold equal dicts: identify the pick by its predicted time, which is unique)
+                idx = int(np.nonzero(preds == np.float32(t))[0][0]) if captured == [] else None
+                cases.append({"preds": [float(x) for x in preds], "tiles": tiles, "method": method, "topk": topk, "eps": eps,
+                              "min_samples": ms, "index": idx, "cluster": [int(i) for i in captured[0]] if captured else None})
+    (HERE / "select_strategy_vectors.json").write_text(json.dumps(
+        {"source": "get_best_config/get_best_config.py:431-525 TilingPredictor.select_tiling_strategy, numpy " + np.__version__,
+         "cases": cases}))
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["ref_gen_golden"]:
+    if sys.argv[1:] == ["select_strategy"]:
+        select_strategy()
+    elif sys.argv[1:] == ["ref_gen_golden"]:
         ref_gen_golden()
     elif sys.argv[1:] == ["ref_gen_golden_e4m3"]:
         ref_gen_golden_e4m3()
     else:
         O.build()
-        table(); c1(); scaled(); grouped(); configs(); op_tiling(); ref_gen_golden(); ref_gen_golden_e4m3()
+        table(); c1(); scaled(); grouped(); configs(); op_tiling(); ref_gen_golden(); ref_gen_golden_e4m3(); select_strategy()
     print("fixtures written to", HERE)
