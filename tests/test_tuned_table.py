@@ -16,6 +16,18 @@ def _rows():
         return list(csv.DictReader(f))
 
 
+@pytest.fixture
+def table(dga, tmp_path):
+    """The shipped table loaded from a scratch copy (other tests of the process open / clear the cache; a cache opened from a path
+    appends its misses to that file, which must not be the shipped one)."""
+    import shutil
+    copy = tmp_path / "mi355x.csv"
+    shutil.copy(TABLE, copy)
+    dga.tiling_cache_open(str(copy))
+    yield dga
+    dga.tiling_cache_open(None)
+
+
 def test_table_is_well_formed(dga):
     rows = _rows()
     assert len(rows) >= 100
@@ -29,7 +41,8 @@ def test_table_is_well_formed(dga):
 
 
 @pytest.mark.parametrize("m,bucket", [(24, 32), (17, 32), (50, 64), (100, 128), (5, 8), (2, 4), (128, 128)])
-def test_decode_rows_fall_back_to_the_next_swept_row_count(dga, m, bucket):
+def test_decode_rows_fall_back_to_the_next_swept_row_count(table, m, bucket):
+    dga = table
     n, k = 18432, 7168
     want = next(r for r in _rows() if (int(r["m"]), int(r["n"]), int(r["k"]), int(r["groups"])) == (bucket, n, k, 1))
     t = dga.tiling(m, n, k)
@@ -38,7 +51,8 @@ def test_decode_rows_fall_back_to_the_next_swept_row_count(dga, m, bucket):
     assert t.blockDim == ((m + t.m1 - 1) // t.m1) * ((n + t.n1 - 1) // t.n1) * t.splitkFactor
 
 
-def test_no_fallback_beyond_the_grid_or_off_its_shapes(dga):
+def test_no_fallback_beyond_the_grid_or_off_its_shapes(table):
+    dga = table
     t_sel = dga.tiling(24, 5120, 3328)        # an (N, K) the sweep never saw: the fitted selector's pick, whatever it is
     assert t_sel.m1 in (16, 32, 64) and t_sel.n1 in (128, 256)
     t_big = dga.tiling(129, 18432, 7168)      # M > 128: not a decode row
