@@ -62,6 +62,7 @@ static void tiling_sweep(unsigned seed, int count)
         float pus = 0.f, nus = 0.f;
         p.dtype = DGA_DT_FP8_E4M3FN;
         (void)dga_select_kernel_with_predictor(&p, &ts, &pus, &nus);
+        (void)dga_select_kernel_with_predictor_ex(&p, &ts, &pus, &nus, static_cast<int>(rng() % 3), static_cast<int>(rng() % 40));
     }
 }
 
@@ -126,6 +127,36 @@ int main()
         (void)dga_tiling_cache_open(tmp("no/such/dir/cache.csv").c_str());
         CHECK(dga_tiling_cache_open(nullptr) == DGA_OK);
         std::remove(f.c_str()); std::remove(ref.c_str()); std::remove(junk.c_str());
+    }
+
+    // ---- the predictor's selection strategies on random lists (ties, one element, topk beyond the list, degenerate columns)
+    {
+        std::mt19937 rng(11);
+        for (int it = 0; it < 4000; ++it) {
+            const int n = 1 + static_cast<int>(rng() % 90);
+            std::vector<float> preds(n);
+            std::vector<int32_t> tiles(3 * n);
+            for (int i = 0; i < n; ++i) {
+                preds[i] = (it % 7 == 0) ? 5.0f : 1.0f + static_cast<float>(rng() % 1000) * ((it % 3) ? 0.37f : 0.0f);   // equal times too
+                tiles[3 * i] = 16 << (rng() % 5); tiles[3 * i + 1] = (it % 5 == 0) ? 128 : 16 << (rng() % 5); tiles[3 * i + 2] = 64 << (rng() % 5);
+            }
+            for (int method = 0; method <= 2; ++method) {
+                int picked = -1, cnt = -1;
+                std::vector<int> members(n, -1);
+                const int topk = static_cast<int>(rng() % 130) - 3;
+                const int rc = dga_select_tiling_strategy(preds.data(), tiles.data(), n, method, topk, 0.1f + (rng() % 30) * 0.1f, 1 + static_cast<int>(rng() % 5),
+                                                          rng() % 9, &picked, members.data(), &cnt);
+                CHECK(rc == DGA_OK && picked >= 0 && picked < n && cnt >= 0 && cnt <= n);
+                for (int i = 0; i < cnt; ++i) CHECK(members[i] >= 0 && members[i] < n);
+            }
+        }
+        int picked = 0;
+        float one = 1.f;
+        CHECK(dga_select_tiling_strategy(nullptr, nullptr, 1, 0, 1, 0.8f, 2, 0, &picked, nullptr, nullptr) != DGA_OK);
+        CHECK(dga_select_tiling_strategy(&one, nullptr, 1, DGA_PICK_TOPK_DBSCAN, 1, 0.8f, 2, 0, &picked, nullptr, nullptr) != DGA_OK);
+        CHECK(dga_select_tiling_strategy(&one, nullptr, 0, 0, 1, 0.8f, 2, 0, &picked, nullptr, nullptr) != DGA_OK);
+        CHECK(dga_select_tiling_strategy(&one, nullptr, 1, 9, 1, 0.8f, 2, 0, &picked, nullptr, nullptr) != DGA_OK);
+        CHECK(dga_select_tiling_strategy(&one, nullptr, 1, DGA_PICK_GREEDY, 1, 0.8f, 2, 0, &picked, nullptr, nullptr) == DGA_OK && picked == 0);
     }
 
     // ---- predictor: default file, truncated copies, garbage
