@@ -1,0 +1,442 @@
+// bf16-exact policy (dispatchPolicyTag 7), A-image build: 128 x 256 tile, 8 waves (2 x 4, wave tile 64 x 64, two per SIMD).
+//
+// The first step VERDICT r3 asked for, built after the both-operand image (gemm_fp8_bf16x_image_kernel.hpp) had lost: only the
+// A-matrix tile -- the operand four waves of a tile row share, i.e. the one whose fragments the in-register build converts four times
+// over -- goes through a bf16 LDS image written once per workgroup; the B-matrix fragments (shared by two waves) are converted in
+// registers as in the MATH = 1 loop of gemm_fp8_kernel.hpp.  Same arithmetic, bit for bit (four chained v_mfma_f32_16x16x32_bf16 per
+// scale block with the same k placement, the same fp32 promotion): the CDNA4 counterpart of the reference's device K-loop
+// (/root/reference/deep_gemm_ascend/framework/csrc/jit/generate_code.hpp:123-369) held to the fp32 golden of
+// framework/tests/test.py:19-64.  Per MFMA the vector pipe sees 1 promotion FMA + 1 B conversion + 0.25 image conversions (2.25
+// instructions; in-register build 3, both-image build 1.75) and ONE barrier per k block (both-image build: two).
+//
+// Per k block kb (64 MFMA gaps per wave, u = 4 t + q, tile t = 4 nt + mt: n-tile outer, m-tile inner):
+//   * A fragments (4 m-tiles x 4 MFMAs x 16 B per lane = 64 AGPRs) are HELD for the block and replaced IN PLACE as they die: A[mt]
+//     sees its last MFMA in tile (mt, 3) and is re-read from the next block's image during the following tile (A[3] during the next
+//     block's first tile), ds_read_b128 straight into AGPRs;
+//   * the image of block kb + 1 (stage (kb + 1) & 1 of two) is converted and written on gaps 2..17 from registers fetched a block
+//     earlier (buffer_load_dwordx4; 2 pieces per thread), which are refilled with block kb + 2 at once;
+//   * B: e4m3 bytes by LDS-DMA into a two-stage ring; the refill of the stage block kb has left (B(kb + 2)) is issued right behind
+//     the barrier, so it has a whole k block to land; fragments B(nt + 1) are converted during n-tile nt into the other register set
+//     (the last n-tile converts the NEXT block's B(0)), raw halves reloaded as the conversions release them;
+//   * the ONE barrier X sits in front of n-tile 2 (gap 32): behind it the next block's A image is complete, its B stage has landed
+//     (counted vmcnt: the newer register fetches stay in flight), and nobody reads B(kb)'s stage any more.
+// LDS: A image 2 x 32 KB + B ring 2 x (32 KB + 2 KB of scales) = 132 KB.
+// Every memory wait of the loop is placed by hand.  The compiler cannot count the LDS-DMA (inline asm), so any vmcnt it derives for
+// a load it does know is too strict by the DMAs in flight: with the scales fetched by buffer loads it drained the B refill at every
+// block's end (1170 of 4460 ticks per k block, profiles/r04_aimage.txt).  So the scales ride the B refill as a fifth DMA and are
+// read back from LDS, the A pieces are fetched by inline-asm buffer loads, and the loop holds no memory instruction the compiler
+// knows: vmcnt(6) in front of a piece's first conversion (the other piece and five DMAs are younger), vmcnt(2) in front of X (the
+// block's two pieces are younger than the refill X waits for).  A fragment reads and image stores are inline asm too, with lgkmcnt
+// waits from the static schedule (BxAImageCfg::wait_for_gap); the B raw and scale reads are ordinary LDS loads the compiler tracks.
+// An asm load with a wait the compiler does not see is only safe if nothing touches its registers in between (a copy the register
+// allocator slips in would read them early): scripts/check_bximg_waits.py walks the compiled loop and checks exactly that, for both
+// counters.
+#pragma once
+#include "gemm_fp8_bf16x_image_kernel.hpp"
+
+namespace dga {
+
+struct BxAImageCfg {
+    static constexpr int kBM = 128, kBN = 256, NT = 512, kWM = 2, kWN = 4, TM = 4, TN = 4;
+    static constexpr int A_IMG = 128 * 256, B_STAGE = 256 * 128;
+    static constexpr int SC_STAGE = 2048;                            // 512 scale slots: [0, 128) sfa rows, [128, 136) sfb blocks
+    static constexpr int SC0 = 2 * A_IMG + 2 * B_STAGE;
+    static constexpr int LDS_BYTES = SC0 + 2 * SC_STAGE;             // A image 0 | A image 1 | B stage 0 | B stage 1 | scales 0 | 1
+    static constexpr int A_PIECES = 2, PIECE_ROWS = 64, B_DMA = 4;   // per thread: 2 register fetches of A, 4 LDS-DMA pieces of B
+    static constexpr int G = 64, XGAP = 32, CA0 = 2;
+    static constexpr int SGAP = 40;                                  // the next block's scales are read on gaps SGAP .. SGAP + 4
+    // LDS operations riding on gap u, in issue order:
+    // [A[3] re-read (u < 4)][image store][B raw read][A in-place read (u >= 52)][scale read]
+    static constexpr bool gap_converts(int u) { return u >= CA0 && u < CA0 + 8 * A_PIECES; }
+    static constexpr int gap_ci(int u) { return (u - CA0) & 7; }
+    static constexpr int gap_piece(int u) { return (u - CA0) >> 3; }
+    static constexpr bool gap_stores(int u) { return gap_converts(u) && (gap_ci(u) & 3) == 3; }
+    static constexpr bool gap_reads_a3(int u) { return u < 4; }
+    static constexpr bool gap_reads_braw(int u) { return (u & 7) == 7; }
+    static constexpr bool gap_reads_a_next(int u) { return u >= 52; }
+    static constexpr bool gap_reads_scale(int u) { return u >= SGAP && u < SGAP + 5; }
+    static constexpr int gap_ops(int u)
+    {
+        return gap_reads_a3(u) + gap_stores(u) + gap_reads_braw(u) + gap_reads_a_next(u) + gap_reads_scale(u);
+    }
+    static constexpr int ops_before(int u) { int n = 0; for (int v = 0; v < u; ++v) n += gap_ops(v); return n; }
+    // lgkmcnt in front of MFMA(u) so that A[mt][q] (first use: n-tile 0) has landed; >= 16: nothing to wait for.  The barrier at
+    // XGAP drains everything, so only the reads behind it can be in flight at the top of a block.
+    static constexpr int wait_for_gap(int u)
+    {
+        const int t = u >> 2, q = u & 3, nt = t >> 2, mt = t & 3;
+        if (nt != 0) return 99;
+        const int issued = ops_before(u), per_block = ops_before(G);
+        if (mt == 3) return issued - (ops_before(q) + 0 + 1);                                    // read on gap q of this block
+        const int v = 52 + 4 * mt + q;                                                          // read on gap v of the previous block
+        return issued + per_block - (ops_before(v) + gap_stores(v) + gap_reads_braw(v) + 1);
+    }
+};
+
+template <bool KTAIL, bool CLK = false>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+gemm_fp8_bf16x_aimage_kernel(const GemmParams p)
+{
+    using Cfg = BxAImageCfg;
+    constexpr int BM = Cfg::kBM, BN = Cfg::kBN, TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::NT;
+    LoopClock<CLK> loop_clock;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 15, kg = lane >> 4;
+
+    // ---- tile id (as gemm_fp8_blockscaled_nt_kernel: dense, masked grouped, split-K)
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    int tile;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        tile = p.xcd_remap ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3) : bid;
+    }
+    const int tiles_per_group = p.tiles_m * p.tiles_n;
+    const int split = p.splitk > 1 ? tile / tiles_per_group : 0;
+    const int g = p.splitk > 1 ? 0 : tile / tiles_per_group;
+    const int t_in = tile - (p.splitk > 1 ? split : g) * tiles_per_group;
+    int tm, tn;
+    {
+        const int gm = p.raster_group;
+        const int per = gm * p.tiles_n;
+        const int band = t_in / per;
+        const int first = band * gm;
+        const int rows = min(p.tiles_m - first, gm);
+        const int loc = t_in - band * per;
+        tm = first + loc % rows;
+        tn = loc / rows;
+    }
+    const int M = p.masked_m ? min(p.masked_m[g], p.m) : p.m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    if (m0 >= M) return;
+    const int kb_begin = p.splitk > 1 ? split * p.kb_per_split : 0;
+    const int kb_end = p.splitk > 1 ? min(p.kb_n, kb_begin + p.kb_per_split) : p.kb_n;
+    if (kb_begin >= kb_end) return;
+    const int kb_last = kb_end - 1;
+
+    const uint8_t *A = p.a + (int64_t)g * p.a_gs;
+    const uint8_t *B = p.b + (int64_t)g * p.b_gs;
+    const float *SFA = p.sfa + (int64_t)g * p.sfa_gs;
+    const float *SFB = p.sfb + (int64_t)g * p.sfb_gs;
+    uint16_t *C = p.out + (int64_t)g * p.c_gs;
+    constexpr uint32_t kOutOfRange = 0x80000000u;
+    auto clamp31 = [](int64_t v) { return (int)(v > 0x7FFFFFFFll ? 0x7FFFFFFFll : (v < 0 ? 0 : v)); };
+
+    // ---- A: register fetch -> conversion -> image (thread = row wrow of a 64-row piece, 16-byte chunk wc)
+    const int wrow = tid >> 3, wc = tid & 7;
+    uint32_t a_voff = (uint32_t)wrow * (uint32_t)p.lda + 16 * wc;
+    const uint32_t a_step = 64u * (uint32_t)p.lda;
+    const v4i a_rsrc = make_rsrc(A + (int64_t)m0 * p.lda, (int64_t)(M - m0) * p.lda);
+    // (inline asm: see the header -- the wait is placed by hand, DGA_BXA_WAIT_PIECE below)
+#ifdef DGA_BXA_NOALOAD   // diagnostic: nothing is fetched
+#define DGA_BXA_LOAD_ASM(dst, vo, k0) asm volatile("" : "=v"(dst) : "v"(vo), "s"(a_rsrc), "s"(k0))
+#else
+#define DGA_BXA_LOAD_ASM(dst, vo, k0) \
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(vo), "s"(a_rsrc), "s"(k0) : "memory")
+#endif
+#define DGA_BXA_LOAD_PIECE(dst, pc, kb)                                                 \
+    do {                                                                                \
+        const int k0_ = (kb) * 128;                                                     \
+        uint32_t vo_ = a_voff + (pc) * a_step;                                          \
+        if constexpr (KTAIL) vo_ = (k0_ + 16 * wc < p.k) ? vo_ : kOutOfRange;           \
+        v4i piece_;                                                                     \
+        DGA_BXA_LOAD_ASM(piece_, vo_, k0_);                                             \
+        (dst) = piece_;                                                                 \
+    } while (0)
+    auto unit = [](int c, int j, int l) { return rotl1_4((8 * (c >> 2) + 4 * j + (c & 3)) ^ l); };
+    uint32_t a_wr0 = Cfg::A_IMG + wrow * 256 + unit(wc, 0, wrow & 15) * 16;      // (stage 1; toggles per k block)
+    uint32_t a_wr1 = Cfg::A_IMG + wrow * 256 + unit(wc, 1, wrow & 15) * 16;
+    v4i cv[2];
+    auto convert_a = [&](const v4i &raw, int ci) {
+        const int w = raw[ci >> 1];
+        cv[ci >> 2][ci & 3] = (ci & 1) ? __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true))
+                                       : __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false));
+    };
+    auto store_half = [&](auto pcc, auto jc) __attribute__((always_inline)) {
+        constexpr int pc = decltype(pcc)::value, j = decltype(jc)::value;
+        const uint32_t base = j ? a_wr1 : a_wr0;
+        const v4i data = cv[j];
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(base), "v"(data), "n"(pc * 64 * 256) : "memory");
+    };
+#define DGA_BXA_READ(dst, addr, off)                                                                             \
+    do {                                                                                                         \
+        v4i frag_;                                                                                               \
+        const uint32_t addr_ = (addr);                                                                           \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(frag_) : "v"(addr_), "n"(off) : "memory");           \
+        (dst) = frag_;                                                                                           \
+    } while (0)
+    uint32_t a_rd[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a_rd[q] = (wm * 64 + li) * 256 + rotl1_4((4 * q + kg) ^ li) * 16;   // + mt * 4096; stage toggles
+
+    // ---- B: LDS-DMA pieces (chunk id c = it * 512 + tid -> row c >> 3 of the tile, source chunk (c & 7) ^ swz_b(row))
+    const int b_col = ((tid & 7) ^ swz_b(tid >> 3)) * 16;
+    uint32_t b_voff[Cfg::B_DMA];
+#pragma unroll
+    for (int it = 0; it < Cfg::B_DMA; ++it) {
+        const int row = (it * NT + tid) >> 3;
+        b_voff[it] = (uint32_t)min(row, p.n - 1 - n0) * (uint32_t)p.ldb + b_col;
+    }
+    const v4i b_rsrc = make_rsrc(B + (int64_t)n0 * p.ldb, (int64_t)(p.n - n0) * p.ldb);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    auto issue_b = [&](int it, int stage, int kb) {
+        const int k0 = kb * 128;
+        uint32_t voff = b_voff[it];
+        if constexpr (KTAIL) voff = (k0 + b_col < p.k) ? voff : kOutOfRange;
+#ifdef DGA_BXA_NOBDMA   // diagnostic: the B tile is never fetched
+        asm volatile("" ::"v"(voff), "s"(k0));
+        return;
+#endif
+        dma16(voff, b_rsrc, (uint32_t)k0, lds0 + 2 * Cfg::A_IMG + stage * Cfg::B_STAGE + it * NT * 16 + wave * 1024);
+    };
+    // scales of a k block: slot tid of the stage's 512 (sfa of the tile's 128 rows, sfb of its n blocks; the rest re-fetch sfb)
+    const float *sc_src = tid < BM ? SFA + (int64_t)min(m0 + tid, M - 1) * p.sfa_ld
+                                   : SFB + (int64_t)min(n0 / 128 + min(tid - BM, 7), p.nb_n - 1) * p.kb_n;
+    auto issue_scales = [&](int stage, int kb) {
+#ifndef DGA_BXA_NOSCALE
+        dma4(sc_src + kb, lds0 + Cfg::SC0 + stage * Cfg::SC_STAGE + wave * 256);
+#endif
+    };
+    const int sa_off = Cfg::SC0 + (wm * 64 + li) * 4, sb_off = Cfg::SC0 + (BM + (wn * 64) / 128) * 4;
+    // raw fragment bytes of n-tile nt: row = wn * 64 + 32 (nt >> 1) + 8 (li >> 2) + 4 (nt & 1) + (li & 3) (gemm_fp8_kernel.hpp)
+    const int b_row = wn * 64 + 8 * (li >> 2) + (li & 3);
+    const int b_off0 = 2 * Cfg::A_IMG + b_row * 128 + ((kg ^ swz_b(b_row)) * 16);
+    const int b_off1 = 2 * Cfg::A_IMG + b_row * 128 + (((kg + 4) ^ swz_b(b_row)) * 16);
+    auto b_frag_off = [](int nt) { return (nt >> 1) * 4096 + (nt & 1) * 512; };
+    auto convert_b = [](const v4i (&raw)[2], v4i (&dst)[4], int c) {
+        const int w = raw[(c >> 1) >> 2][(c >> 1) & 3];
+        dst[c >> 2][c & 3] = (c & 1) ? __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true))
+                                     : __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false));
+    };
+
+    v4f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+    v4f part[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) part[i] = v4f{0.f, 0.f, 0.f, 0.f};
+    v4i Ah[TM][4], bfx[2][4], braw[2], araw[Cfg::A_PIECES];
+    float s_cur[TM], s_old[TM], s_nxt[TM], sfb_nxt = 0.f;
+
+    // ---- prologue: A image of block kb_begin in stage 0, B(kb_begin) and B(kb_begin + 1) on their way, first fragments converted
+#pragma unroll
+    for (int pc = 0; pc < Cfg::A_PIECES; ++pc) DGA_BXA_LOAD_PIECE(araw[pc], pc, kb_begin);
+#pragma unroll
+    for (int it = 0; it < Cfg::B_DMA; ++it) issue_b(it, 0, kb_begin);
+    issue_scales(0, kb_begin);
+#pragma unroll
+    for (int it = 0; it < Cfg::B_DMA; ++it) issue_b(it, 1, min(kb_begin + 1, kb_last));
+    issue_scales(1, min(kb_begin + 1, kb_last));
+    wait_vmcnt<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    a_wr0 ^= Cfg::A_IMG; a_wr1 ^= Cfg::A_IMG;   // block kb_begin's image goes to stage 0
+    bximg::static_for<0, Cfg::A_PIECES>([&](auto pcc) __attribute__((always_inline)) {
+        constexpr int pc = decltype(pcc)::value;
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) convert_a(araw[pc], ci);
+        store_half(pcc, std::integral_constant<int, 0>{});
+        store_half(pcc, std::integral_constant<int, 1>{});
+        asm volatile("s_nop 0" ::: "memory");
+        DGA_BXA_LOAD_PIECE(araw[pc], pc, min(kb_begin + 1, kb_last));
+    });
+    a_wr0 ^= Cfg::A_IMG; a_wr1 ^= Cfg::A_IMG;
+    wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+#ifdef DGA_BXA_NOSCALE
+        const float sfb0 = 0.5f;
+#else
+        const float sfb0 = *(const float *)(smem + sb_off);
+#endif
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+#ifdef DGA_BXA_NOSCALE
+            s_cur[mt] = sfb0;
+#else
+            s_cur[mt] = *(const float *)(smem + sa_off + mt * 64) * sfb0;
+#endif
+            s_old[mt] = 0.f;
+            s_nxt[mt] = 0.f;
+        }
+    }
+    // A[0..2] of the first block in the order the loop's tail issues them (A[3] is read by the first block's own gaps 0..3)
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) DGA_BXA_READ(Ah[mt][q], a_rd[q], mt * 4096);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Ah[3][q] = v4i{0, 0, 0, 0};
+    braw[0] = *(const v4i *)(smem + b_off0);
+    braw[1] = *(const v4i *)(smem + b_off1);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) convert_b(braw, bfx[0], c);
+    braw[0] = *(const v4i *)(smem + b_off0 + b_frag_off(1));
+    braw[1] = *(const v4i *)(smem + b_off1 + b_frag_off(1));
+    DGA_STAMP_DECL
+    DGA_STAMP_CLOCK(6, 7);
+    DGA_STAMP_START();
+    loop_clock.tick();
+
+    int cur = 0;   // B stage being consumed (the A image stage toggles inside a_rd / a_wr)
+    for (int kb = kb_begin; kb < kb_end; ++kb) {
+        const int kb_fetch = min(kb + 2, kb_last);
+        const uint8_t *sc = smem + cur * Cfg::B_STAGE, *sn = smem + (cur ^ 1) * Cfg::B_STAGE;
+        const uint8_t *ssn = smem + (cur ^ 1) * Cfg::SC_STAGE;   // the next block's scales (landed with its B stage)
+        asm volatile("" : "+v"(a_voff));
+        bximg::static_for<0, Cfg::G>([&](auto uc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value;
+            constexpr int t = u >> 2, q = u & 3, nt = t >> 2, mt = t & 3, gq = u & 15;
+            if constexpr (u == Cfg::XGAP) {
+                // X: the next block's A image is written, its B stage and scales have landed (the two A pieces fetched since stay
+                // in flight; the first block's batch was issued in the prologue and has landed)
+                DGA_STAMP(0);
+                wait_vmcnt<2>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef DGA_BXA_NOBAR   // diagnostic: the waves run free
+                __builtin_amdgcn_s_barrier();
+#endif
+                asm volatile("" ::: "memory");
+                DGA_STAMP(1);
+            }
+            if constexpr (Cfg::wait_for_gap(u) < 16) {
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(Cfg::wait_for_gap(u)) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            part[t & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(v8bf, bfx[nt & 1][q]), __builtin_bit_cast(v8bf, Ah[mt][q]),
+                q == 0 ? v4f{0.f, 0.f, 0.f, 0.f} : part[t & 3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // A[3] of THIS block: re-read in place behind its last MFMA of the previous block (tile (3, 3))
+            if constexpr (Cfg::gap_reads_a3(u)) DGA_BXA_READ(Ah[3][q], a_rd[q], 3 * 4096);
+            // the A image of block kb + 1: one conversion per gap, a store after every fourth, the registers refilled with kb + 2
+            if constexpr (Cfg::gap_converts(u)) {
+                constexpr int pc = Cfg::gap_piece(u), ci = Cfg::gap_ci(u);
+                if constexpr (ci == 0) {   // the piece fetched a block ago: younger are the other piece and the refill's five DMAs
+                    wait_vmcnt<6>();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                convert_a(araw[pc], ci);
+                if constexpr (ci == 3) store_half(std::integral_constant<int, pc>{}, std::integral_constant<int, 0>{});
+                if constexpr (ci == 7) {
+                    store_half(std::integral_constant<int, pc>{}, std::integral_constant<int, 1>{});
+                    DGA_BXA_LOAD_PIECE(araw[pc], pc, kb_fetch);
+                }
+            }
+            if constexpr (u == Cfg::CA0 + 8 * Cfg::A_PIECES) a_wr0 ^= Cfg::A_IMG;
+            if constexpr (u == Cfg::CA0 + 8 * Cfg::A_PIECES + 1) a_wr1 ^= Cfg::A_IMG;
+            if constexpr (u >= 4 && u < 8) a_rd[q] ^= Cfg::A_IMG;   // (behind A[3]'s re-read: from here on the NEXT block's image)
+            // B(kb + 2) into the stage this block has left, right behind the barrier
+            if constexpr (u > Cfg::XGAP && u <= Cfg::XGAP + Cfg::B_DMA) issue_b(u - Cfg::XGAP - 1, cur, kb_fetch);
+            if constexpr (u == Cfg::XGAP + Cfg::B_DMA + 1) issue_scales(cur, kb_fetch);
+            // B(nt + 1) -> bfx[(nt + 1) & 1], one conversion per gap; raw halves reloaded with B(nt + 2) as they are released
+            // (n-tiles 2, 3: the next block's B(0), B(1) from the stage that landed before X)
+            convert_b(braw, bfx[(nt + 1) & 1], gq);
+            if constexpr (gq == 7 || gq == 15) {
+                constexpr int nn = nt + 2;
+                const uint8_t *src = nn < TN ? sc : sn;
+                constexpr int off = (nn < TN ? nn : nn - TN);
+                if constexpr (gq == 7) braw[0] = *(const v4i *)(src + b_off0 + b_frag_off(off));
+                else braw[1] = *(const v4i *)(src + b_off1 + b_frag_off(off));
+            }
+            // A[mt] of the NEXT block, in place, behind its last MFMA (tile (mt, 3)); A[3] follows on the next block's gaps 0..3
+            if constexpr (Cfg::gap_reads_a_next(u)) DGA_BXA_READ(Ah[(u - 52) >> 2][q], a_rd[q], ((u - 52) >> 2) * 4096);
+            // the next block's scales
+#ifndef DGA_BXA_NOSCALE   // diagnostic: constant scales, no scale traffic
+            if constexpr (u >= Cfg::SGAP && u < Cfg::SGAP + 4) s_nxt[u - Cfg::SGAP] = *(const float *)(ssn + sa_off + (u - Cfg::SGAP) * 64);
+            if constexpr (u == Cfg::SGAP + 4) sfb_nxt = *(const float *)(ssn + sb_off);
+#endif
+            // promotion of tile t - 2 (the first two tiles promote the previous block's last two)
+            {
+                constexpr int j = t >= 2 ? t - 2 : 14 + t, jn = j >> 2, jm = j & 3;
+                const float sv = t >= 2 ? s_cur[jm] : s_old[jm];
+                acc[jm][jn][q] = __builtin_fmaf(part[j & 3][q], sv, acc[jm][jn][q]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        DGA_STAMP(4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            s_old[i] = s_cur[i];
+#ifndef DGA_BXA_NOSCALE
+            s_cur[i] = s_nxt[i] * sfb_nxt;
+#endif
+        }
+        cur ^= 1;
+    }
+    wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 14; j < 16; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[j & 3][j >> 2][q] = __builtin_fmaf(part[j & 3][q], s_old[j & 3], acc[j & 3][j >> 2][q]);
+    DGA_STAMP_CLOCK(6, 7);
+    DGA_STAMP_FLUSH();
+    loop_clock.tick();
+    loop_clock.flush(p.stamps, blockIdx.x * (NT / 64) + wave, lane);
+#undef DGA_BXA_READ
+#undef DGA_BXA_LOAD_PIECE
+#undef DGA_BXA_LOAD_ASM
+
+    // ---- epilogue: lane owns row m, columns n_base + 32 j + [0, 8)
+    const int m_row = m0 + wm * 64 + li;
+    const int n_base = n0 + wn * 64 + 8 * kg;
+    if (p.splitk > 1) {
+        float *slab = p.partial + (int64_t)split * p.m * p.n;
+        const bool v_ok = (p.n & 3) == 0;
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            const int m = m_row + mt * 16;
+            if (m >= M) continue;
+            float *prow = slab + (int64_t)m * p.n;
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) {
+                const int n = n_base + 32 * (nt >> 1) + 4 * (nt & 1);
+                if (v_ok && n + 4 <= p.n) {
+                    *(v4f *)(prow + n) = acc[mt][nt];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < p.n) prow[n + q] = acc[mt][nt][q];
+                }
+            }
+        }
+        return;
+    }
+    const bool vec_ok = ((p.ldc & 7) == 0) && ((((uintptr_t)C) & 15) == 0);
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+        const int m = m_row + mt * 16;
+        if (m >= M) continue;
+        uint16_t *crow = C + (int64_t)m * p.ldc;
+#pragma unroll
+        for (int j = 0; j < TN / 2; ++j) {
+            const int n = n_base + 32 * j;
+            const v4f lo = acc[mt][2 * j], hi = acc[mt][2 * j + 1];
+            const v2bf h0 = __builtin_convertvector(v2f{lo.x, lo.y}, v2bf);
+            const v2bf h1 = __builtin_convertvector(v2f{lo.z, lo.w}, v2bf);
+            const v2bf h2 = __builtin_convertvector(v2f{hi.x, hi.y}, v2bf);
+            const v2bf h3 = __builtin_convertvector(v2f{hi.z, hi.w}, v2bf);
+            const v4i pk = v4i{__builtin_bit_cast(int, h0), __builtin_bit_cast(int, h1),
+                               __builtin_bit_cast(int, h2), __builtin_bit_cast(int, h3)};
+            if (vec_ok && n + 8 <= p.n) {
+                *(v4i *)(crow + n) = pk;
+            } else {
+                const uint16_t *e = (const uint16_t *)&pk;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (n + q < p.n) crow[n + q] = e[q];
+            }
+        }
+    }
+}
+
+}  // namespace dga

@@ -19,7 +19,7 @@ from scripts.policy_perf import time_us  # noqa: E402
 def tiling(m, n, k, image, raster=4):
     t = dga.tiling(m, n, k)
     t.m1, t.n1, t.splitkFactor, t.kernelSerial = 128, 256, 1, 0
-    t.dispatchPolicyTag, t.stages, t.swizzleOffset = 7, (2 if image else 3), raster
+    t.dispatchPolicyTag, t.stages, t.swizzleOffset = 7, {0: 3, 1: 4}.get(image, 2), raster
     t.wavesM, t.wavesN = (2, 2) if image == 4 else (2, 4)
     return t
 
@@ -32,12 +32,12 @@ def main():
         out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
         row = {}
         for rep in range(2):
-            for image in (0, 8, 4):
+            for image in (0, 8, 4, 1):
                 for raster in ((1, 2, 4, 8, 16) if "--rasters" in sys.argv else (4,)):
                     t = tiling(m, n, k, image, raster)
                     fn = lambda: dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, policy="bf16_exact", tiling_=t)
                     us = time_us(fn, 200, 400)
-                    key = f"{'image%d' % image if image else 'in_register'}_r{raster}"
+                    key = f"{('a_image' if image == 1 else 'image%d' % image) if image else 'in_register'}_r{raster}"
                     row.setdefault(key, []).append(round(us, 2))
                     print(name, key, f"{us:.2f} us  {2.0 * m * n * k / us / 1e6:.0f} TFLOP/s", flush=True)
         res[name] = row

@@ -3,9 +3,10 @@
 The kernel issues its fragment reads (ds_read_b128 into AGPRs) and image stores as inline asm and places the
 `s_waitcnt lgkmcnt(N)` itself from a compile-time schedule; the compiler neither sees the reads nor orders the MFMAs
 against the waits (only the sched_barrier does).  This script compiles the translation unit to ISA, walks the main loop of
-every instantiation twice (steady state) and checks, instruction by instruction, that no v_mfma reads an AGPR whose
+every instantiation twice (steady state) and checks, instruction by instruction, that no instruction reads a register whose
 ds_read is still counted in lgkmcnt -- LDS operations of one wave complete in order, so after `lgkmcnt(N)` everything but
-the N youngest has landed.  It also checks that the image stores' data registers are not rewritten by the instruction
+the N youngest has landed -- or whose buffer load is still counted in vmcnt (the A-image build fetches its pieces by inline
+asm as well: csrc/gemm_fp8_bf16x_aimage_kernel.hpp).  It also checks that the image stores' data registers are not rewritten by the instruction
 right behind the store (the >64-bit store-data hazard the hazard recognizer cannot see inside an asm).
 
     python scripts/check_bximg_waits.py        # exit code 0 = every instantiation passes
@@ -50,22 +51,38 @@ def main_loop(lines: list[str]) -> list[str]:
 
 def check(name: str, body: list[str]) -> int:
     pending: list[set[str]] = []   # in-flight LDS operations, oldest first; a store is an empty set
+    vm: list[set[str]] = []        # in-flight vector-memory loads (vmcnt, in order too); an LDS-DMA is an empty set
     errors = 0
     n_mfma = n_wait = 0
     for rep in range(2):
         for idx, ins in enumerate(body):
             op, _, rest = ins.partition(" ")
             args = [a for a in rest.split(",")] if rest else []
-            if op == "ds_read_b128":
+            if op.startswith("ds_read"):
                 pending.append(regs(args[0]))
-            elif op == "ds_write_b128":
+            elif op.startswith("ds_write"):
                 pending.append(set())
                 nxt = body[idx + 1] if idx + 1 < len(body) else ""
                 nop, _, nrest = nxt.partition(" ")
                 if nop.startswith("v_") and nrest and regs(nrest.split(",")[0]) & regs(args[1]):
                     print(f"{name}: store data rewritten by the next instruction: {ins} ; {nxt}")
                     errors += 1
+            elif op.startswith("buffer_load") or op.startswith("global_load"):
+                to_lds = " lds" in ins or "_lds_" in op   # LDS-DMA: no destination register
+                src = set()
+                for a in args if to_lds else args[1:]:
+                    src |= regs(a)
+                if src & (set().union(*vm, *pending) if (vm or pending) else set()):
+                    print(f"{name}: {op} takes an address from a register still in flight: {ins}")
+                    errors += 1
+                vm.append(set() if to_lds else regs(args[0]))
             elif op == "s_waitcnt":
+                m = re.search(r"vmcnt\((\d+)\)", rest)
+                if m:
+                    keep = int(m.group(1))
+                    vm = vm[len(vm) - keep:] if keep < len(vm) else vm
+                    if keep == 0:
+                        vm = []
                 m = re.search(r"lgkmcnt\((\d+)\)", rest)
                 if m:
                     n_wait += rep
@@ -81,14 +98,24 @@ def check(name: str, body: list[str]) -> int:
                 src = set()
                 for a in args[1:3]:
                     src |= regs(a)
-                inflight = set().union(*pending) if pending else set()
+                inflight = set().union(*pending, *vm) if (pending or vm) else set()
                 if src & inflight:
                     print(f"{name}: MFMA reads a fragment still in flight (pass {rep}, loop instr {idx}): {ins}")
+                    errors += 1
+            elif op.startswith("v_") or op.startswith("buffer_store") or op.startswith("global_store"):
+                # any other consumer of a register whose load is still counted (a copy the compiler slipped in front of the wait)
+                src = set()
+                for a in (args[1:] if op.startswith("v_") else args):
+                    src |= regs(a)
+                inflight = set().union(*pending, *vm) if (pending or vm) else set()
+                if src & inflight:
+                    print(f"{name}: {op} reads a register still in flight (pass {rep}, loop instr {idx}): {ins}")
                     errors += 1
             if len(pending) > 15:
                 # more than the counter can tell apart: a later wait of N <= 15 is still exact, nothing to flag
                 pass
-    print(f"{name}: {n_mfma} MFMAs, {n_wait} lgkmcnt waits per k block, {errors} problem(s)")
+    n_vm = sum(1 for x in body if x.startswith(("buffer_load", "global_load")))
+    print(f"{name}: {n_mfma} MFMAs, {n_wait} lgkmcnt waits, {n_vm} vector-memory loads per k block, {errors} problem(s)")
     return errors
 
 
@@ -101,7 +128,7 @@ def main() -> int:
     errors = 0
     for chunk in text.split(".globl")[1:]:
         name = chunk.split("\n", 1)[0].strip()
-        if "bf16x_image_kernel" not in name or "v_mfma" not in chunk:
+        if ("bf16x_image_kernel" not in name and "bf16x_aimage_kernel" not in name) or "v_mfma" not in chunk:
             continue
         errors += check(name, main_loop(chunk.split("\n")))
     return 1 if errors else 0

@@ -13,7 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "gemm_fp8_bf16x_image_kernel.hpp"
+#include "gemm_fp8_bf16x_aimage_kernel.hpp"
 using namespace dga;
 int main(int argc, char **argv)
 {
@@ -22,7 +22,11 @@ int main(int argc, char **argv)
 #ifndef BXI_WAVES
 #define BXI_WAVES 8
 #endif
+#ifdef BXI_AIMAGE   // the A-image build (gemm_fp8_bf16x_aimage_kernel.hpp): head = gaps 0..31, X, tail = gaps 32..63 (Y, body: none)
+    typedef BxAImageCfg Cfg;
+#else
     typedef BxImageCfg<BXI_WAVES> Cfg;
+#endif
     GemmParams p{};
     std::vector<uint8_t> ha((size_t)m * k), hb((size_t)n * k);
     srand(1);
@@ -42,7 +46,11 @@ int main(int argc, char **argv)
     const int grid = p.tiles_m * p.tiles_n, waves = Cfg::NT / 64;
     hipMalloc(&st, (size_t)grid * waves * 8 * 8); hipMemset(st, 0, (size_t)grid * waves * 8 * 8);
     p.stamps = st;
+#ifdef BXI_AIMAGE
+    auto kfn = gemm_fp8_bf16x_aimage_kernel<false>;
+#else
     auto kfn = gemm_fp8_bf16x_image_kernel<Cfg, false>;
+#endif
     hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < warm; ++i) hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, 0, p);
@@ -58,7 +66,7 @@ int main(int argc, char **argv)
         ct += (double)h[(size_t)w * 8 + 6]; crt += (double)h[(size_t)w * 8 + 7];
     }
     const double nw = (double)grid * waves;
-    printf("image build 128x256, %d waves, on %dx%dx%d: %.1f us per launch (stamped build, %d warm launches)\n", BXI_WAVES, m, n, k, ms * 1000 / 20, warm);
+    printf("image build 128x256, %d waves, on %dx%dx%d: %.1f us per launch (stamped build, %d warm launches)\n", Cfg::NT / 64, m, n, k, ms * 1000 / 20, warm);
     printf("  per k block: head %.0f  Y %.0f  body %.0f  X %.0f  tail %.0f  = %.0f ticks (matrix pipe alone: 2048 per SIMD)\n", seg[0] / nw / kb,
            seg[1] / nw / kb, seg[2] / nw / kb, seg[3] / nw / kb, seg[4] / nw / kb, (seg[0] + seg[1] + seg[2] + seg[3] + seg[4]) / nw / kb);
     printf("  whole wave: %.0f ticks, clock %.3f GHz, %.1f us\n", ct / nw, ct / crt * 0.1, crt / nw / 100.0);

@@ -7,7 +7,8 @@ placement, then the same fp32 promotion (the counterpart of the reference's devi
 framework/tests/test.py:19-64) -- so the bar between them is BIT IDENTITY; against the oracle it is the policy's bar
 (tests/test_bf16_exact_gpu.py).  Two image builds: 8 waves (two per SIMD, 64 x 64 wave tiles: the default of the 128 x 256 tile)
 and 4 waves (one per SIMD, 64 x 128; a tiling that names the 2 x 2 wave layout).  A tiling that names the 2 x 4 layout with three
-LDS stages keeps the in-register build.
+LDS stages keeps the in-register build.  A third build shares only the A-matrix tile through the image (gemm_fp8_bf16x_aimage_kernel.hpp,
+8 waves; B-matrix fragments converted in registers; a 2 x 4 tiling with stages = 4): `waves` = 1 below.
 """
 import sys
 from pathlib import Path
@@ -23,15 +24,15 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-IMAGES = [8, 4]   # waves of the image build under test
+IMAGES = [8, 4, 1]   # waves of the image build under test (1 = the A-image build)
 
 
 def _tiling(dga, m, n, k, image, splitk=1, raster=4, groups=1):
-    """image: 0 = in-register build, 4 / 8 = image build with that many waves"""
+    """image: 0 = in-register build, 4 / 8 = image build with that many waves, 1 = A-image build"""
     t = dga.tiling(m, n, k, groups=groups) if groups > 1 else dga.tiling(m, n, k)
     t.m1, t.n1, t.splitkFactor, t.kernelSerial = 128, 256, splitk, (4 if splitk > 1 else 0)
     t.dispatchPolicyTag = 7
-    t.stages = 2 if image else 3
+    t.stages = {0: 3, 1: 4}.get(image, 2)
     t.swizzleOffset = raster
     t.wavesM, t.wavesN = (2, 2) if image == 4 else (2, 4)
     return t
@@ -123,13 +124,13 @@ def test_grouped_masked(dga, oracle):
     A, SFA, B, SFB = (np.stack([p[j] for p in parts]) for j in range(4))
     masked = np.array([128, 0, 1, 77, 127, 64], np.int32)
     outs = []
-    for image in (8, 0, 4):
+    for image in (8, 0, 4, 1):
         out = torch.full((g, mmax, n), -7.0, dtype=torch.bfloat16, device="cuda")
         t = _tiling(dga, mmax, n, k, image, groups=g)
         dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((_dev(A), _dev(SFA)), (_dev(B), _dev(SFB)), out, _dev(masked),
                                                   expected_m=64, policy="bf16_exact", sync=True, tiling_=t)
         outs.append(_bits(out))
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[2], outs[1])
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[2], outs[1]) and np.array_equal(outs[3], outs[1])
     init = np.full((g, mmax, n), _bits(torch.tensor([-7.0], dtype=torch.bfloat16))[0], np.uint16)
     want = oracle.m_grouped_gemm_fp8_fp8_bf16_nt_masked(A, SFA, B, SFB, init, masked, threads=8)
     for i in range(g):
@@ -147,9 +148,10 @@ def test_baseline_configs_bit_identical_at_full_size(dga, shape):
     m, n, k = bench.WORKLOADS[shape]
     a, sfa, b, sfb = bench.make_dense_inputs(m, n, k, seed=0)
     outs = []
-    for image in (8, 0, 4):
+    for image in (8, 0, 4, 1):
         out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
         dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, policy="bf16_exact", sync=True, tiling_=_tiling(dga, m, n, k, image))
         outs.append(out)
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
     assert torch.equal(outs[2].view(torch.int16), outs[1].view(torch.int16))
+    assert torch.equal(outs[3].view(torch.int16), outs[1].view(torch.int16))
