@@ -57,6 +57,7 @@ class Problem(ctypes.Structure):
 
 
 PROBLEM_CONTIGUOUS_M = 1
+ROWS_A_ZERO_PADDED, ROWS_B_ZERO_PADDED = 1, 2   # dga_gemm_fp8_fp8_bf16_nt_strided flags
 CONTIGUOUS_M_ALIGNMENT = 128
 
 
@@ -123,6 +124,8 @@ SIGNATURES = {
     "dga_workspace_bytes": (c_size_t, [POINTER(Tiling)]),
     "dga_gemm_fp8_fp8_bf16_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                          POINTER(Tiling), c_void_p, c_size_t, c_void_p]),
+    "dga_gemm_fp8_fp8_bf16_nt_strided": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int,
+                                                 c_int, c_int, POINTER(Tiling), c_void_p, c_size_t, c_void_p]),
     "dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                           c_int, c_int, c_int, c_int, c_int, POINTER(Tiling),
                                                           c_void_p, c_size_t, c_void_p]),
@@ -131,6 +134,8 @@ SIGNATURES = {
                                                               c_void_p, c_size_t, c_void_p]),
     "dga_cast_to_fp8_1x128": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "dga_cast_to_fp8_128x128": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "dga_cast_to_fp8_1x128_ld": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
+    "dga_cast_to_fp8_128x128_ld": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "dga_catlass_dynamic_matmul_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_void_p, c_void_p]),
     "dga_catlass_dynamic_matmul": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                                            c_void_p]),
@@ -201,7 +206,7 @@ def lib() -> ctypes.CDLL:
                 raise DGALibraryError(f"{LIB_PATH} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
-        if L.dga_abi_version() != 4:
+        if L.dga_abi_version() != 5:
             raise DGALibraryError("ABI version mismatch")
         _lib = L
     return _lib

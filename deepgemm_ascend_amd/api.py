@@ -360,8 +360,15 @@ def bench_params_fill(m: int, n: int, k: int, params6: Sequence[int]) -> list:
 
 def gemm_fp8_fp8_bf16_nt(lhs: Tuple[torch.Tensor, torch.Tensor], rhs: Tuple[torch.Tensor, torch.Tensor],
                          out: torch.Tensor, tiling_: Optional[Tiling] = None, sync: bool = False,
-                         strict: bool = False, policy: Optional[str] = None) -> None:
+                         strict: bool = False, policy: Optional[str] = None,
+                         zero_padded: Optional[Tuple[bool, bool]] = None) -> None:
     """out[M,N] (bf16, written in place) = (A[M,K] fp8, sfa[M,ceil(K/128)]) x (B[N,K] fp8, sfb[ceil(N/128),ceil(K/128)])^T.
+
+    A and B may be row-strided views (unit inner stride; a row stride that is K or a multiple of 16 bytes): rows that start on
+    16-byte boundaries are read where they lie.  For K % 16 != 0 that also needs zeros from byte K to the next 16-byte boundary
+    of each row -- true of what per_token_cast_to_fp8 / per_block_cast_to_fp8(..., aligned_rows=True) return (they mark their
+    results), or promised by the caller with zero_padded=(a_is, b_is); an operand without the promise is re-laid out by the
+    padding pass, alone (dga_gemm_fp8_fp8_bf16_nt_strided).
 
     strict=True (= policy="strict") runs the exact-arithmetic kernel (dispatchPolicyTag 3): fp32 products and sums in the
     reference CPU path's own order, bit-identical to the oracle, at the fp32 matrix rate.  policy="bf16_exact"
@@ -391,8 +398,15 @@ def gemm_fp8_fp8_bf16_nt(lhs: Tuple[torch.Tensor, torch.Tensor], rhs: Tuple[torc
         _fail(f"sfa must be [{m},{kb}]")
     if sfb.dim() != 2 or sfb.shape[0] != nb or sfb.shape[1] != kb:
         _fail(f"sfb must be [{nb},{kb}]")
-    if not (a.is_contiguous() and b.is_contiguous() and sfa.is_contiguous() and sfb.is_contiguous() and out.is_contiguous()):
-        _fail("operands must be contiguous")
+    if not (sfa.is_contiguous() and sfb.is_contiguous() and out.is_contiguous()):
+        _fail("scales and out must be contiguous")
+    if (k > 1 and (a.stride(1) != 1 or b.stride(1) != 1)) or (m > 1 and a.stride(0) < k) or (n > 1 and b.stride(0) < k):
+        _fail("operands must be row-major with unit inner stride (row-strided views are accepted)")
+    lda = a.stride(0) if m > 1 else k
+    ldb = b.stride(0) if n > 1 else k
+    strided = lda != k or ldb != k
+    if zero_padded is None:
+        zero_padded = (bool(getattr(a, "_dga_zero_padded", False)), bool(getattr(b, "_dga_zero_padded", False)))
     with _device_guard(a, b, sfa, sfb, out):
         index = out.device.index
         if tiling_ is None:
@@ -401,8 +415,14 @@ def gemm_fp8_fp8_bf16_nt(lhs: Tuple[torch.Tensor, torch.Tensor], rhs: Tuple[torc
             tiling_ = _with_policy(tiling_, strict, policy)
         stream = _stream_of(index)
         ws_ptr, ws_bytes = _workspace(tiling_, out.device, stream)
-        rc = _lib.lib().dga_gemm_fp8_fp8_bf16_nt(a.data_ptr(), sfa.data_ptr(), b.data_ptr(), sfb.data_ptr(),
-                                                 out.data_ptr(), m, n, k, ctypes.byref(tiling_), ws_ptr, ws_bytes, stream)
+        if strided:
+            flags = (_lib.ROWS_A_ZERO_PADDED if zero_padded[0] else 0) | (_lib.ROWS_B_ZERO_PADDED if zero_padded[1] else 0)
+            rc = _lib.lib().dga_gemm_fp8_fp8_bf16_nt_strided(a.data_ptr(), lda, sfa.data_ptr(), b.data_ptr(), ldb, sfb.data_ptr(),
+                                                             out.data_ptr(), m, n, k, flags, ctypes.byref(tiling_), ws_ptr,
+                                                             ws_bytes, stream)
+        else:
+            rc = _lib.lib().dga_gemm_fp8_fp8_bf16_nt(a.data_ptr(), sfa.data_ptr(), b.data_ptr(), sfb.data_ptr(),
+                                                     out.data_ptr(), m, n, k, ctypes.byref(tiling_), ws_ptr, ws_bytes, stream)
         if rc:
             _lib.check(rc, "gemm_fp8_fp8_bf16_nt")
         if sync:
@@ -599,29 +619,42 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(lhs, rhs, out: torch.Tensor, m_ind
 _CAST_DT = {torch.float32: _lib.DT_FP32, torch.bfloat16: _lib.DT_BF16, torch.float16: _lib.DT_FP16}
 
 
-def _cast(fn_name: str, x: torch.Tensor, block_rows: int):
+def _cast(fn_name: str, x: torch.Tensor, block_rows: int, aligned_rows: bool = False):
     _require(x.dim() == 2 and x.is_contiguous(), "x must be a contiguous [rows, k] tensor")
     _require(x.dtype in _CAST_DT, "x must be float32, bfloat16 or float16")
     rows, k = x.shape
-    q = torch.empty((rows, k), dtype=torch.uint8, device=x.device)
+    ldq = (k + 127) // 128 * 128 if aligned_rows else k   # whole 128-byte lines: a row's k blocks never straddle two
+    q = torch.empty((rows, ldq), dtype=torch.uint8, device=x.device)
     sf = torch.empty(((rows + block_rows - 1) // block_rows, (k + 127) // 128), dtype=torch.float32, device=x.device)
     with _device_guard(x):
-        rc = getattr(_lib.lib(), fn_name)(x.data_ptr(), _CAST_DT[x.dtype], rows, k, q.data_ptr(), sf.data_ptr(),
-                                          _stream_ptr(x))
+        if ldq != k:
+            rc = getattr(_lib.lib(), fn_name + "_ld")(x.data_ptr(), _CAST_DT[x.dtype], rows, k, q.data_ptr(), ldq, sf.data_ptr(),
+                                                      _stream_ptr(x))
+        else:
+            rc = getattr(_lib.lib(), fn_name)(x.data_ptr(), _CAST_DT[x.dtype], rows, k, q.data_ptr(), sf.data_ptr(),
+                                              _stream_ptr(x))
         _lib.check(rc, fn_name)
-    return q.view(torch.float8_e4m3fn), sf
+    q = q.view(torch.float8_e4m3fn)
+    if ldq != k:
+        q = q[:, :k]
+        q._dga_zero_padded = True   # (a Python attribute: views and copies made from it do not carry the promise)
+    return q, sf
 
 
-def per_token_cast_to_fp8(x: torch.Tensor):
+def per_token_cast_to_fp8(x: torch.Tensor, aligned_rows: bool = False):
     """Activation quantiser: x [rows,k] -> (e4m3fn [rows,k], fp32 scales [rows, ceil(k/128)]), one scale per 1x128
-    block: scale = amax/448, q = RNE-satfinite(x/scale) (the A-operand format of gemm_fp8_fp8_bf16_nt)."""
-    return _cast("dga_cast_to_fp8_1x128", x, 1)
+    block: scale = amax/448, q = RNE-satfinite(x/scale) (the A-operand format of gemm_fp8_fp8_bf16_nt).
+    aligned_rows=True: the result is a [rows, k] view of rows round_up(k, 128) bytes apart with zero tails, which
+    gemm_fp8_fp8_bf16_nt reads in place whatever k is (no padding pass for k % 16 != 0; 1279 x 5003 x 7681: 80.6 -> 65.8 us.
+    Rows only 16-byte aligned are read in place too but gain nothing: a 128-byte row piece that straddles two cache lines
+    costs two requests on every re-read, profiles/r04_odd_k_rows.txt)."""
+    return _cast("dga_cast_to_fp8_1x128", x, 1, aligned_rows)
 
 
-def per_block_cast_to_fp8(x: torch.Tensor):
+def per_block_cast_to_fp8(x: torch.Tensor, aligned_rows: bool = False):
     """Weight quantiser: x [rows,k] -> (e4m3fn [rows,k], fp32 scales [ceil(rows/128), ceil(k/128)]), one scale per
-    128x128 block (the B-operand format)."""
-    return _cast("dga_cast_to_fp8_128x128", x, 128)
+    128x128 block (the B-operand format).  aligned_rows: as per_token_cast_to_fp8."""
+    return _cast("dga_cast_to_fp8_128x128", x, 128, aligned_rows)
 
 
 def route_tokens(expert_ids: torch.Tensor, groups: int):

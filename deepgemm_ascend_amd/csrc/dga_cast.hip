@@ -123,7 +123,7 @@ template <> struct Elem<F16Tag> {
 // are contiguous per 16-lane group (256 / 512 bytes in, 128 bytes out).
 template <typename T>
 __global__ void __launch_bounds__(256) cast_1x128_kernel(const void *x, uint8_t *q, float *sf, int64_t rows, int64_t k,
-                                                         int64_t kb_n, bool vec_in, bool vec_out)
+                                                         int64_t kb_n, bool vec_in, bool vec_out, int64_t ldq)
 {
     const int64_t blk = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
     if (blk >= rows * kb_n) return;  // whole 16-lane groups leave together
@@ -145,12 +145,14 @@ __global__ void __launch_bounds__(256) cast_1x128_kernel(const void *x, uint8_t 
     if (sub == 0) sf[blk] = s;
     uint32_t w0, w1;
     quant8(v, s, w0, w1);
-    if (vec_out && c0 + 8 <= k) {
-        *(v2i_c *)(q + base) = v2i_c{(int)w0, (int)w1};
+    // (columns at and beyond k were read as 0 and quantise to the zero byte: they fill the row's tail up to ldq)
+    const int64_t qbase = row * ldq + c0;
+    if (vec_out && c0 + 8 <= ldq) {
+        *(v2i_c *)(q + qbase) = v2i_c{(int)w0, (int)w1};
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (c0 + j < k) q[base + j] = (uint8_t)(((j < 4 ? w0 : w1) >> (8 * (j & 3))) & 0xFF);
+            if (c0 + j < ldq) q[qbase + j] = (uint8_t)(((j < 4 ? w0 : w1) >> (8 * (j & 3))) & 0xFF);
     }
 }
 
@@ -191,7 +193,7 @@ __global__ void __launch_bounds__(256) cast_1x128_unrolled_kernel(const void *x,
 // through LDS, nothing is read twice.
 template <typename T>
 __global__ void __launch_bounds__(256) cast_128x128_kernel(const void *x, uint8_t *q, float *sf, int64_t rows, int64_t k,
-                                                           int64_t kb_n, bool vec_in, bool vec_out)
+                                                           int64_t kb_n, bool vec_in, bool vec_out, int64_t ldq)
 {
     __shared__ float red[4];
     const int64_t rb = blockIdx.x / kb_n, kb = blockIdx.x - rb * kb_n;
@@ -233,28 +235,29 @@ __global__ void __launch_bounds__(256) cast_128x128_kernel(const void *x, uint8_
         for (int j = 0; j < 8; ++j) e[j] = v[g8 * 8 + j];
         uint32_t w0, w1;
         quant8(e, s, w0, w1);
-        if (vec_out && c + 8 <= k) {
-            *(v2i_c *)(q + base) = v2i_c{(int)w0, (int)w1};
+        const int64_t qbase = row * ldq + c;
+        if (vec_out && c + 8 <= ldq) {
+            *(v2i_c *)(q + qbase) = v2i_c{(int)w0, (int)w1};
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (c + j < k) q[base + j] = (uint8_t)(((j < 4 ? w0 : w1) >> (8 * (j & 3))) & 0xFF);
+                if (c + j < ldq) q[qbase + j] = (uint8_t)(((j < 4 ? w0 : w1) >> (8 * (j & 3))) & 0xFF);
         }
     }
 }
 
 template <typename T>
-static int launch_cast(int mode, const void *x, void *q, float *sf, int64_t rows, int64_t k, hipStream_t stream)
+static int launch_cast(int mode, const void *x, void *q, float *sf, int64_t rows, int64_t k, int64_t ldq, hipStream_t stream)
 {
     const int64_t kb_n = (k + 127) / 128;
     // a lane's 8 elements start at element row*k + 8*j: 16-byte aligned for every row iff k % 8 == 0
     const bool vec_in = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (k % 8 == 0);
-    const bool vec_out = (reinterpret_cast<uintptr_t>(q) % 8 == 0) && (k % 8 == 0);
+    const bool vec_out = (reinterpret_cast<uintptr_t>(q) % 8 == 0) && (ldq % 8 == 0);
     // 16-bit inputs, large problems: two blocks per 16-lane group (32 bytes in flight per lane): [32768, 7168] bf16 140.7 -> 124.2 us
     // (5.06 -> 5.73 TB/s; four blocks 129.8; fp32 inputs are faster one block at a time: 195 against 203 / 207 us; scripts/cast_ab.py)
     static const int unroll = [] { const char *e = std::getenv("DGA_CAST_UNROLL"); return e ? std::atoi(e) : 0; }();
     const bool two = unroll ? unroll >= 2 : (Elem<T>::kBytes == 2 && rows * kb_n >= 131072);
-    if (mode == 0 && vec_in && vec_out && k % 128 == 0 && two) {
+    if (mode == 0 && vec_in && vec_out && k % 128 == 0 && ldq == k && two) {
         const int64_t blocks = rows * kb_n;
         const int64_t stride = (blocks + 1) / 2;
         const int64_t grid = (stride * 16 + 255) / 256;
@@ -272,26 +275,26 @@ static int launch_cast(int mode, const void *x, void *q, float *sf, int64_t rows
         const int64_t grid = (blocks * 16 + 255) / 256;
         if (grid > 0x7FFFFFFFll) return DGA_E_RANGE;
         hipLaunchKernelGGL(cast_1x128_kernel<T>, dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream, x,
-                           static_cast<uint8_t *>(q), sf, rows, k, kb_n, vec_in, vec_out);
+                           static_cast<uint8_t *>(q), sf, rows, k, kb_n, vec_in, vec_out, ldq);
     } else {
         const int64_t grid = ((rows + 127) / 128) * kb_n;
         if (grid > 0x7FFFFFFFll) return DGA_E_RANGE;
         hipLaunchKernelGGL(cast_128x128_kernel<T>, dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream, x,
-                           static_cast<uint8_t *>(q), sf, rows, k, kb_n, vec_in, vec_out);
+                           static_cast<uint8_t *>(q), sf, rows, k, kb_n, vec_in, vec_out, ldq);
     }
     return record_hip(hipGetLastError());
 }
 
-static int run_cast(int mode, const void *x, int x_dtype, int64_t rows, int64_t k, void *q, float *sf, void *stream)
+static int run_cast(int mode, const void *x, int x_dtype, int64_t rows, int64_t k, void *q, int64_t ldq, float *sf, void *stream)
 {
-    if (rows < 0 || k < 0) return DGA_E_SHAPE;
+    if (rows < 0 || k < 0 || ldq < k || ldq > (k + 127) / 128 * 128) return DGA_E_SHAPE;
     if (rows == 0 || k == 0) return DGA_OK;
     if (!x || !q || !sf) return DGA_E_NULL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (x_dtype) {
-        case DGA_DT_FP32: return launch_cast<float>(mode, x, q, sf, rows, k, st);
-        case DGA_DT_BF16: return launch_cast<Bf16Tag>(mode, x, q, sf, rows, k, st);
-        case DGA_DT_FP16: return launch_cast<F16Tag>(mode, x, q, sf, rows, k, st);
+        case DGA_DT_FP32: return launch_cast<float>(mode, x, q, sf, rows, k, ldq, st);
+        case DGA_DT_BF16: return launch_cast<Bf16Tag>(mode, x, q, sf, rows, k, ldq, st);
+        case DGA_DT_FP16: return launch_cast<F16Tag>(mode, x, q, sf, rows, k, ldq, st);
         default: return DGA_E_DTYPE;
     }
 }
@@ -302,12 +305,22 @@ extern "C" {
 
 int dga_cast_to_fp8_1x128(const void *x, int x_dtype, int64_t rows, int64_t k, void *q, float *sf, void *stream)
 {
-    return dga::run_cast(0, x, x_dtype, rows, k, q, sf, stream);
+    return dga::run_cast(0, x, x_dtype, rows, k, q, k, sf, stream);
 }
 
 int dga_cast_to_fp8_128x128(const void *x, int x_dtype, int64_t rows, int64_t k, void *q, float *sf, void *stream)
 {
-    return dga::run_cast(1, x, x_dtype, rows, k, q, sf, stream);
+    return dga::run_cast(1, x, x_dtype, rows, k, q, k, sf, stream);
+}
+
+int dga_cast_to_fp8_1x128_ld(const void *x, int x_dtype, int64_t rows, int64_t k, void *q, int64_t ldq, float *sf, void *stream)
+{
+    return dga::run_cast(0, x, x_dtype, rows, k, q, ldq, sf, stream);
+}
+
+int dga_cast_to_fp8_128x128_ld(const void *x, int x_dtype, int64_t rows, int64_t k, void *q, int64_t ldq, float *sf, void *stream)
+{
+    return dga::run_cast(1, x, x_dtype, rows, k, q, ldq, sf, stream);
 }
 
 }  // extern "C"

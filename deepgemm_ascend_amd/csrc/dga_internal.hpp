@@ -17,11 +17,16 @@ struct Fp8Indexed {
     int64_t ldc;                // bf16 elements between rows of the flat destination
     int64_t rows;               // rows of the flat A source (bounds the buffer descriptor)
 };
+// row-strided dense form (dga_gemm_fp8_fp8_bf16_nt_strided): bytes between the rows of A and of B, DGA_ROWS_* flags
+struct Fp8Strided {
+    int64_t lda, ldb;
+    int flags;
+};
 // the fp8 launcher behind the C-ABI GEMM entry points (dga_launch.hip); clock_stamps: see dga_diag.hip
 int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, void *out, const int32_t *masked_m,
             const int32_t *m_indices, int b_groups, int groups, int m, int n, int k, int expected_m,
             const dga_tiling_t *tiling, void *workspace, size_t workspace_bytes, hipStream_t stream,
-            unsigned long long *clock_stamps, const Fp8Indexed *ix);
+            unsigned long long *clock_stamps, const Fp8Indexed *ix, const Fp8Strided *sd = nullptr);
 // compiled fp8 kernel menu (dga_launch.hip)
 int variant_count();
 void variant_info(int i, int *bm, int *bn, int *wm, int *wn, int *lds);
@@ -33,6 +38,9 @@ void prefer_loader_waves(dga_tiling_t &t, bool upgrade_plain = true);
 // two operands in one launch (rows1 == 0: one)
 int pad_rows(const void *src0, void *dst0, int64_t rows0, const void *src1, void *dst1, int64_t rows1, int64_t src_row_bytes,
              int64_t dst_row_bytes, hipStream_t stream);
+// the same with the sources' own row strides (bytes between rows, >= src_row_bytes)
+int pad_rows_strided(const void *src0, int64_t stride0, void *dst0, int64_t rows0, const void *src1, int64_t stride1, void *dst1,
+                     int64_t rows1, int64_t src_row_bytes, int64_t dst_row_bytes, hipStream_t stream);
 // dense 256x256 tilings: turn a small last partial wave into a K-split tail (dga_tiling.cpp)
 void apply_tail_split(dga_tiling_t &t, uint32_t cus);
 }  // namespace dga

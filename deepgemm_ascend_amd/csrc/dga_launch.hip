@@ -152,7 +152,7 @@ static int (*find_clock_build(const Variant *v, int policy))(const GemmParams &,
 int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, void *out,
             const int32_t *masked_m, const int32_t *m_indices, int b_groups, int groups, int m, int n, int k,
             int expected_m, const dga_tiling_t *tiling, void *workspace, size_t workspace_bytes,
-            hipStream_t stream, unsigned long long *clock_stamps, const Fp8Indexed *ix)
+            hipStream_t stream, unsigned long long *clock_stamps, const Fp8Indexed *ix, const Fp8Strided *sd)
 {
     if (m < 0 || n < 0 || k < 0 || groups < 0 || b_groups < 0) return DGA_E_SHAPE;
     if (groups == 0 || m == 0 || n == 0) return DGA_OK;  // empty problem: nothing to write
@@ -199,6 +199,12 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     p.sfa_gs = static_cast<int64_t>(m) * p.kb_n;
     p.sfb_gs = static_cast<int64_t>(p.nb_n) * p.kb_n;
     p.sfa_ld = p.kb_n;
+    if (sd) {  // dense operands with their own row strides: 16-byte aligned rows are read where they lie (below)
+        if (groups != 1 || b_groups != 1 || masked_m || m_indices || ix || clock_stamps) return DGA_E_SHAPE;
+        if (sd->lda < k || sd->ldb < k) return DGA_E_SHAPE;
+        if ((sd->lda != k && (sd->lda & 15)) || (sd->ldb != k && (sd->ldb & 15))) return DGA_E_ALIGN;
+        p.lda = sd->lda; p.ldb = sd->ldb;
+    }
     if (ix) {  // one flat source / destination for every group, rows named by the index
         if (!ix->row_index || ix->lda < k || ix->ldc < n || ix->sfa_ld < p.kb_n || ix->rows < 0) return DGA_E_SHAPE;
         p.row_index = ix->row_index;
@@ -270,7 +276,7 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     //      workspace for the padded copies (the alternative there is the element-wise kernel, orders of magnitude slower).
     static const int unal_env = [] { const char *e = std::getenv("DGA_UNALIGNED"); return e ? std::atoi(e) : -1; }();
     static const int bf16x_env0 = [] { const char *e = std::getenv("DGA_BF16_EXACT"); return e ? std::atoi(e) : 0; }();
-    if (k > 0 && (k % 16) != 0 && !ix && groups == 1 && !masked_m && !m_indices && !clock_stamps && !bf16x_env0 &&
+    if (k > 0 && (k % 16) != 0 && !ix && !sd && groups == 1 && !masked_m && !m_indices && !clock_stamps && !bf16x_env0 &&
         tiling->dispatchPolicyTag != DGA_POLICY_BF16_EXACT &&
         (unal_env >= 0 ? unal_env != 0
                        : (tiling->kernelSerial == DGA_KERNEL_PADDING_COMMON ||
@@ -286,6 +292,32 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
         const int rc = launch_unaligned(q, stream);
         if (rc != DGA_E_TILING) return rc;
     }
+    if (sd && k > 0) {
+        // Row-strided operands: an operand whose rows start on 16-byte boundaries, are at least round_up(K, 16) bytes apart and --
+        // when K % 16 != 0 -- carry zeros from byte K to that boundary (DGA_ROWS_*_ZERO_PADDED: the caller's promise; the
+        // quantisers' _ld forms write them) is read in place; the other one, if any, goes through the padding pass alone.
+        const int k16 = (k + 15) & ~15;
+        auto in_place = [&](const void *base, int64_t ld, int flag) {
+            return (reinterpret_cast<uintptr_t>(base) & 15) == 0 && (ld & 15) == 0 && ld >= k16 && ((k % 16) == 0 || (sd->flags & flag));
+        };
+        const bool a_ok = in_place(p.a, p.lda, DGA_ROWS_A_ZERO_PADDED), b_ok = in_place(p.b, p.ldb, DGA_ROWS_B_ZERO_PADDED);
+        bool ready = a_ok && b_ok;
+        if (!ready) {
+            const int kp = p.kb_n * 128;
+            uint8_t *pa = a_ok ? nullptr : carve(static_cast<size_t>(m) * kp);
+            uint8_t *pb = b_ok ? nullptr : carve(static_cast<size_t>(n) * kp);
+            if ((a_ok || pa) && (b_ok || pb)) {
+                const int st = pad_rows_strided(a_ok ? nullptr : p.a, p.lda, pa, a_ok ? 0 : m, b_ok ? nullptr : p.b, p.ldb, pb,
+                                                b_ok ? 0 : n, k, kp, stream);
+                if (st != DGA_OK) return st;
+                if (!a_ok) { p.a = pa; p.lda = kp; }
+                if (!b_ok) { p.b = pb; p.ldb = kp; }
+                ready = true;
+            }
+            // no (or too small a) workspace: the element-wise kernel below still computes the right answer
+        }
+        if (ready) { p.k = k16; k = k16; }   // (the tile kernels zero-fill from there to the end of the last k block)
+    } else
     if (k > 0 && (k % 16) != 0 && !ix) {   // (indexed rows are read where they lie: odd K takes the element-wise kernel)
         const int kp = p.kb_n * 128;
         const int64_t rows_a = static_cast<int64_t>(groups) * m, rows_b = static_cast<int64_t>(b_groups) * n;
@@ -305,8 +337,8 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
 
     // LDS-DMA kernel: 16-byte chunks (K % 16 == 0, 16-byte aligned bases) and 32-bit in-tile byte offsets
     const bool fast_ok = (k % 16 == 0) && k > 0 && ((reinterpret_cast<uintptr_t>(p.a) & 15) == 0) &&
-                         ((reinterpret_cast<uintptr_t>(p.b) & 15) == 0) && (p.lda % 16 == 0) &&
-                         (static_cast<int64_t>(p.lda) * 257 < 0x7FFFFFFFll);
+                         ((reinterpret_cast<uintptr_t>(p.b) & 15) == 0) && (p.lda % 16 == 0) && (p.ldb % 16 == 0) &&
+                         (static_cast<int64_t>(p.lda) * 257 < 0x7FFFFFFFll) && (static_cast<int64_t>(p.ldb) * 257 < 0x7FFFFFFFll);
     if (!fast_ok) {
         // K not a multiple of the 16-byte DMA chunk and no workspace to pad into (or k == 0): element-wise kernel
         dim3 grid((n + 15) / 16, (m + 15) / 16, groups);
@@ -433,6 +465,15 @@ int dga_gemm_fp8_fp8_bf16_nt(const void *a, const float *sfa, const void *b, con
 {
     return dga::run_fp8(a, sfa, b, sfb, out, nullptr, nullptr, 1, 1, m, n, k, 0, tiling, workspace, workspace_bytes,
                         static_cast<hipStream_t>(stream), nullptr, nullptr);
+}
+
+int dga_gemm_fp8_fp8_bf16_nt_strided(const void *a, int64_t lda, const float *sfa, const void *b, int64_t ldb, const float *sfb,
+                                     void *out, int m, int n, int k, int flags, const dga_tiling_t *tiling, void *workspace,
+                                     size_t workspace_bytes, void *stream)
+{
+    const dga::Fp8Strided sd{lda, ldb, flags};
+    return dga::run_fp8(a, sfa, b, sfb, out, nullptr, nullptr, 1, 1, m, n, k, 0, tiling, workspace, workspace_bytes,
+                        static_cast<hipStream_t>(stream), nullptr, nullptr, &sd);
 }
 
 int dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked(const void *a, const float *sfa, const void *b, const float *sfb,

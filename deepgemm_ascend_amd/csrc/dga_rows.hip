@@ -223,6 +223,7 @@ struct PadOperand {
     const uint8_t *src;
     uint8_t *dst;
     int64_t rows;
+    int64_t stride;   // bytes between source rows (>= the row's own bytes)
 };
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef uint32_t v4u_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -241,10 +242,10 @@ __global__ void __launch_bounds__(256) pad_rows_kernel(PadOperand o0, PadOperand
     const int valid = src_row_bytes - c0;   // bytes of this row at and after c0
     v4u w = {0u, 0u, 0u, 0u};
     if (valid > 0) {
-        const uint8_t *s = o.src + r * src_row_bytes + c0;
+        const uint8_t *s = o.src + r * o.stride + c0;
         const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(s) & 3);
         const uint32_t *al = reinterpret_cast<const uint32_t *>(s - sh);
-        const uint8_t *end = o.src + o.rows * src_row_bytes;
+        const uint8_t *end = o.src + (o.rows - 1) * o.stride + src_row_bytes;
         uint32_t d[5];
         if (reinterpret_cast<const uint8_t *>(al + 5) <= end) {
             const v4u q = *reinterpret_cast<const v4u_a4 *>(al);
@@ -267,8 +268,14 @@ __global__ void __launch_bounds__(256) pad_rows_kernel(PadOperand o0, PadOperand
 int pad_rows(const void *src0, void *dst0, int64_t rows0, const void *src1, void *dst1, int64_t rows1, int64_t src_row_bytes,
              int64_t dst_row_bytes, hipStream_t stream)
 {
+    return pad_rows_strided(src0, src_row_bytes, dst0, rows0, src1, src_row_bytes, dst1, rows1, src_row_bytes, dst_row_bytes, stream);
+}
+
+int pad_rows_strided(const void *src0, int64_t stride0, void *dst0, int64_t rows0, const void *src1, int64_t stride1, void *dst1,
+                     int64_t rows1, int64_t src_row_bytes, int64_t dst_row_bytes, hipStream_t stream)
+{
     if (rows0 < 0 || rows1 < 0 || src_row_bytes < 0 || dst_row_bytes < src_row_bytes || (dst_row_bytes & 15) ||
-        dst_row_bytes > 0x7FFFFFF0ll)
+        dst_row_bytes > 0x7FFFFFF0ll || (rows0 && stride0 < src_row_bytes) || (rows1 && stride1 < src_row_bytes))
         return DGA_E_SHAPE;
     if (((reinterpret_cast<uintptr_t>(dst0) | reinterpret_cast<uintptr_t>(dst1)) & 15) != 0) return DGA_E_ALIGN;
     const int64_t cpr = dst_row_bytes >> 4;
@@ -277,8 +284,8 @@ int pad_rows(const void *src0, void *dst0, int64_t rows0, const void *src1, void
     if ((rows0 && (!src0 || !dst0)) || (rows1 && (!src1 || !dst1))) return DGA_E_NULL;
     if ((chunks + 255) / 256 > 0x7FFFFFFFll) return DGA_E_RANGE;
     hipLaunchKernelGGL(pad_rows_kernel, dim3(static_cast<unsigned>((chunks + 255) / 256)), dim3(256), 0, stream,
-                       PadOperand{static_cast<const uint8_t *>(src0), static_cast<uint8_t *>(dst0), rows0},
-                       PadOperand{static_cast<const uint8_t *>(src1), static_cast<uint8_t *>(dst1), rows1}, chunks0, chunks,
+                       PadOperand{static_cast<const uint8_t *>(src0), static_cast<uint8_t *>(dst0), rows0, stride0},
+                       PadOperand{static_cast<const uint8_t *>(src1), static_cast<uint8_t *>(dst1), rows1, stride1}, chunks0, chunks,
                        static_cast<int>(src_row_bytes), static_cast<int>(dst_row_bytes));
     return record_hip(hipGetLastError());
 }

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define DGA_ABI_VERSION 4
+#define DGA_ABI_VERSION 5
 
 /* ---- status codes (reference: DGA_HOST_ASSERT throws DGAException,
  *      deep_gemm_ascend/framework/csrc/utils/exception.hpp:9-33; op hooks return
@@ -209,6 +209,23 @@ int dga_gemm_fp8_fp8_bf16_nt(const void *a, const float *sfa, const void *b, con
                              int m, int n, int k, const dga_tiling_t *tiling, void *workspace,
                              size_t workspace_bytes, void *stream);
 
+/* The same with the operands' own row strides (bytes between rows: lda, ldb >= K, each either K or a multiple of 16; out and the
+ * scales stay contiguous) -- what a framework hands over when its tensors are views of padded buffers (the reference's Python
+ * entry takes torch tensors, strides and all: deep_gemm_ascend/framework/csrc/python_api.cpp:18).  An operand whose rows start
+ * on 16-byte boundaries is read in place.  For K % 16 != 0 that needs the bytes from K to the next 16-byte boundary of every row to
+ * be zero, which the caller states per operand with DGA_ROWS_A_ZERO_PADDED / DGA_ROWS_B_ZERO_PADDED (dga_cast_to_fp8_*_ld writes
+ * such rows; make the stride a multiple of 128 where possible -- rows that start inside a cache line cost two line requests per
+ * 128-byte piece and give the gain back, profiles/r04_odd_k_rows.txt); an operand without the promise goes through the padding
+ * pass ALONE -- weights padded once at load time leave only
+ * the activations to re-lay out, and operands that both come from the _ld quantisers need no pass at all (the reference fuses
+ * its re-layout into the matmul launch instead: op_kernel/kernel/padding_common_matmul_kernel.h:33-107).
+ * DGA_E_ALIGN: a stride that is neither K nor a multiple of 16; DGA_E_SHAPE: a stride below K. */
+#define DGA_ROWS_A_ZERO_PADDED 1
+#define DGA_ROWS_B_ZERO_PADDED 2
+int dga_gemm_fp8_fp8_bf16_nt_strided(const void *a, int64_t lda, const float *sfa, const void *b, int64_t ldb, const float *sfb,
+                                     void *out, int m, int n, int k, int flags, const dga_tiling_t *tiling, void *workspace,
+                                     size_t workspace_bytes, void *stream);
+
 /* m_grouped_gemm_fp8_fp8_bf16_nt_masked: G independent problems
  *   a [G,m_max,K], sfa [G,m_max,KB], b [G,N,K], sfb [G,NB,KB], out [G,m_max,N];
  *   only rows < masked_m[g] (device int32[G]) of out[g] are written.  masked_m is read on the device while the call
@@ -262,6 +279,11 @@ int dga_m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(const void *a, const float *sf
  * files from numpy (scripts/gen_data.py:10-30); it has no quantiser. */
 int dga_cast_to_fp8_1x128(const void *x, int x_dtype, int64_t rows, int64_t k, void *q, float *sf, void *stream);
 int dga_cast_to_fp8_128x128(const void *x, int x_dtype, int64_t rows, int64_t k, void *q, float *sf, void *stream);
+/* The same writing rows ldq bytes apart (k <= ldq <= 128 * ceil(k/128)) with ZEROS from byte k to the end of each row: with
+ * ldq = round_up(k, 128) (whole cache lines; round_up(k, 16) is the minimum) the result is an operand
+ * dga_gemm_fp8_fp8_bf16_nt_strided reads in place (DGA_ROWS_*_ZERO_PADDED). */
+int dga_cast_to_fp8_1x128_ld(const void *x, int x_dtype, int64_t rows, int64_t k, void *q, int64_t ldq, float *sf, void *stream);
+int dga_cast_to_fp8_128x128_ld(const void *x, int x_dtype, int64_t rows, int64_t k, void *q, int64_t ldq, float *sf, void *stream);
 
 /* ---- the framework's 28-int Config (deep_gemm_ascend/framework/csrc/jit/get_best_config.hpp) ---- */
 

@@ -1,30 +1,30 @@
-"""One decode shape under the cold-cache protocol (operand sets rotated past the Infinity Cache), the tuned table's tiling:
-launch-to-launch time by HIP events, and -- run under `rocprofv3 --kernel-trace --stats` -- the split between the tile kernel
-and the split-K combine kernel.  usage: python scripts/decode_breakdown.py M N K [iters]"""
+"""Where a cold short-M call spends its time: run under `rocprofv3 --kernel-trace --stats` -- per-kernel durations of the tile
+kernel and the split-K combine for M = 16 / 64 / 128 on two weight shapes, operand sets rotated past the Infinity Cache.
+Usage: rocprofv3 --kernel-trace --stats -d gpurun_out/prof_decode -- python3 scripts/decode_breakdown.py [M ...]"""
 import sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-import torch
-import bench
-import deepgemm_ascend_amd as dga
 
-m, n, k = (int(x) for x in sys.argv[1:4])
-iters = int(sys.argv[4]) if len(sys.argv) > 4 else 120
-a, sfa, b, sfb = bench.make_dense_inputs(max(m, 128), n, k, seed=0)
-a, sfa = a[:m].contiguous(), sfa[:m].contiguous()
-opbytes = m * k + n * k + 2 * m * n
-sets = max(3, -(-320 * 2 ** 20 // opbytes))
-copies = [(a.clone(), sfa.clone(), b.clone(), sfb.clone(), torch.empty((m, n), dtype=torch.bfloat16, device="cuda")) for _ in range(sets)]
-t = dga.tiling(m, n, k)
-fns = [(lambda c=c: dga.gemm_fp8_fp8_bf16_nt((c[0], c[1]), (c[2], c[3]), c[4], tiling_=t)) for c in copies]
-for i in range(3 * sets):
-    fns[i % sets]()
-torch.cuda.synchronize()
-e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-e0.record()
-for i in range(iters):
-    fns[i % sets]()
-e1.record(); torch.cuda.synchronize()
-us = e0.elapsed_time(e1) * 1e3 / iters
-print(f"{m}x{n}x{k}: tile {t.m1}x{t.n1} stages {t.stages} split-K {t.splitkFactor} policy {t.dispatchPolicyTag}: cold {us:.1f} us per call "
-      f"({opbytes / us / 1e3:.0f} GB/s of operands; {sets} operand sets)")
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import deepgemm_ascend_amd as dga  # noqa: E402
+from scripts.wsk_cold import operand_sets, time_cold  # noqa: E402
+
+
+def main():
+    ms = [int(x) for x in sys.argv[1:]] or [16, 64, 128]
+    for n, k in ((7168, 18432), (4096, 7168)):
+        for m in ms:
+            sets = operand_sets(m, n, k)
+            t = dga.tiling(m, n, k)
+            fn = lambda s: dga.gemm_fp8_fp8_bf16_nt((s[0], s[1]), (s[2], s[3]), s[4], tiling_=t)
+            us = time_cold(fn, sets, iters=40)
+            print(f"M={m} N={n} K={k}: {t.m1}x{t.n1} split {t.splitkFactor} serial {t.kernelSerial} policy {t.dispatchPolicyTag} "
+                  f"stages {t.stages}: {us:.2f} us per call (events, {len(sets)} sets)", flush=True)
+            del sets
+            torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
