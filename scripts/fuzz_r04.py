@@ -1,5 +1,6 @@
-"""Randomised bit-identity campaign for round 4's three kernels (each against the path it would replace), through the operator:
-  image     bf16-exact image builds (8 and 4 waves) == the in-register build            dense and masked-grouped, any M N K % 16 == 0
+"""Randomised bit-identity campaign for round 4's kernels (each against the path it would replace), through the operator:
+  image     bf16-exact image builds (8 and 4 waves, A-image) == the in-register build   dense, any M N K % 16 == 0
+  strided   row-strided / aligned-row operands, every policy == the contiguous call     any M N K, strides, promises
   wsk       one-launch workgroup split-K (kernelSerial 6) == two-launch split-K 8       M <= 64
   unaligned odd K read in place (kernelSerial 2) == padding pass + the same tile        K % 16 != 0
 Usage: python scripts/fuzz_r04.py [cases per kernel = 150] [seed = 0]; exit code 1 on the first mismatch (the case is printed)."""
@@ -50,13 +51,13 @@ def main():
         sk = int(rng.choice([1, 1, 2, 3]))
         raster = int(rng.choice([1, 2, 4, 8]))
         outs = []
-        for image in (0, 8, 4):
+        for image in (0, 8, 4, 1):
             t = dga.tiling(m, n, k)
             t.m1, t.n1, t.splitkFactor, t.kernelSerial, t.dispatchPolicyTag = 128, 256, sk, (4 if sk > 1 else 0), 7
-            t.stages, t.swizzleOffset = (2 if image else 3), raster
+            t.stages, t.swizzleOffset = {0: 3, 1: 4}.get(image, 2), raster
             t.wavesM, t.wavesN = (2, 2) if image == 4 else (2, 4)
             outs.append(run(a, sfa, b, sfb, t, policy="bf16_exact"))
-        if not (same(outs[0], outs[1]) and same(outs[0], outs[2])):
+        if not (same(outs[0], outs[1]) and same(outs[0], outs[2]) and same(outs[0], outs[3])):
             print(f"MISMATCH image: m={m} n={n} k={k} splitk={sk} raster={raster} case {i} seed {seed}")
             return 1
         done["image"] += 1
@@ -85,6 +86,25 @@ def main():
             print(f"MISMATCH unaligned: m={m} n={n} k={k} case {i} seed {seed}")
             return 1
         done["unaligned"] += 1
+        # ---- row-strided operands (this case's odd K, and a K % 16 == 0 one every other round), auto tiling, a policy per round
+        if i % 2:
+            k = (k + 15) // 16 * 16
+            a, sfa, b, sfb = data(m, n, k, gen)
+        kw = [{}, {"policy": "bf16_exact"}, {"strict": True}][i % 3]
+        ref = run(a, sfa, b, sfb, None, **kw)
+        lds = [((k + 15) // 16 + int(rng.integers(0, 9))) * 16 for _ in range(2)]
+        views = []
+        for x, ld in ((a, lds[0]), (b, lds[1])):
+            buf = torch.randint(0, 256, (x.shape[0], ld), dtype=torch.uint8, device="cuda", generator=gen)
+            buf[:, :k] = x
+            buf[:, k:(k + 15) // 16 * 16] = 0
+            views.append(buf[:, :k])
+        zp = [(True, True), (False, False), (True, False), (False, True)][int(rng.integers(0, 4))]
+        ops = [views[j] if (zp[j] or rng.integers(0, 2)) else (a, b)[j] for j in range(2)]
+        if not same(run(ops[0], sfa, ops[1], sfb, None, zero_padded=zp, **kw), ref):
+            print(f"MISMATCH strided: m={m} n={n} k={k} lds={lds} zero_padded={zp} policy={kw} case {i} seed {seed}")
+            return 1
+        done["strided"] = done.get("strided", 0) + 1
         if i % 25 == 24:
             print(f"{i + 1} rounds: {done}", flush=True)
     print(f"fuzz ok: {done} (seed {seed})")
