@@ -384,6 +384,13 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     static const int wsk_env = [] { const char *e = std::getenv("DGA_WSK"); return e ? std::atoi(e) : -1; }();
     if (!bf16x && !clock_stamps && groups == 1 && !masked_m && !m_indices && !ix &&
         (wsk_env >= 0 ? wsk_env != 0 : tiling->kernelSerial == DGA_KERNEL_SPLITK_WORKGROUP)) {
+        // M <= 32: the LDS-DMA staged build (whole-line requests, hand-counted vmcnt); a tiling with stages = 1 names the register
+        // build (fragments global -> registers), which also takes 32 < M <= 64.  $DGA_WSK_DMA = 0 / 1 overrides.
+        static const int wsk_dma_env = [] { const char *e = std::getenv("DGA_WSK_DMA"); return e ? std::atoi(e) : -1; }();
+        if (wsk_dma_env >= 0 ? wsk_dma_env != 0 : tiling->stages != 1) {
+            const int rc = launch_wsk_dma(p, stream);
+            if (rc != DGA_E_TILING) return rc;
+        }
         const int rc = launch_wsk(p, stream);
         if (rc != DGA_E_TILING) return rc;
     }

@@ -24,6 +24,45 @@ static int launch_wsk_one(const GemmParams &p, unsigned grid, hipStream_t stream
     return record_hip(hipGetLastError());
 }
 
+template <int TM, int TN, int D, bool KTAIL>
+static int launch_wskd_one(const GemmParams &p, unsigned grid, hipStream_t stream)
+{
+    auto kfn = gemm_fp8_wskd_kernel<TM, TN, D, KTAIL>;
+    constexpr int kLds = 8 * D * ((TM + TN) * 16 * 128 + 256);
+    static_assert(kLds <= 160 * 1024, "LDS of one CU");
+    static std::once_flag once[64];
+    static hipError_t attr_err[64];
+    int dev = 0;
+    if (int rc = record_hip(hipGetDevice(&dev))) return rc;
+    if (dev < 0 || dev >= 64) return DGA_E_HIP;
+    std::call_once(once[dev], [&] {
+        attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    });
+    if (int rc = record_hip(attr_err[dev])) return rc;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), kLds, stream, p);
+    return record_hip(hipGetLastError());
+}
+
+// the LDS-DMA staged builds (M <= 32): one workgroup per CU (or per n-tile where there are fewer), each walking its n-tiles TN at a time
+int launch_wsk_dma(const GemmParams &p, hipStream_t stream)
+{
+    if (p.groups != 1 || p.masked_m || p.m_indices || p.row_index || p.splitk > 1 || p.tail_sub || p.m > 32 || p.m <= 0 || (p.k % 16) ||
+        p.k <= 0 || (reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.b) & 15) || (p.lda & 15) || (p.ldb & 15) ||
+        static_cast<int64_t>(p.m) * p.lda >= 0x7FFFFFFFll)
+        return DGA_E_TILING;
+    const int nt = (p.n + 15) / 16;
+    const int64_t cus = device_cus();
+    const unsigned g = static_cast<unsigned>(nt < cus ? nt : cus);
+    const bool kt = (p.k % 128) != 0;
+    if (p.m > 16) return kt ? launch_wskd_one<2, 2, 2, true>(p, g, stream) : launch_wskd_one<2, 2, 2, false>(p, g, stream);
+    // n-tiles per workgroup -> the build that walks them in the fewest passes (every pass re-streams the A rows and pays a round
+    // trip); at equal passes the narrower one (deeper ring)
+    const int per = static_cast<int>((nt + g - 1) / g);
+    if (per <= 1) return kt ? launch_wskd_one<1, 1, 4, true>(p, g, stream) : launch_wskd_one<1, 1, 4, false>(p, g, stream);
+    if ((per + 2) / 3 < (per + 1) / 2) return kt ? launch_wskd_one<1, 3, 2, true>(p, g, stream) : launch_wskd_one<1, 3, 2, false>(p, g, stream);
+    return kt ? launch_wskd_one<1, 2, 3, true>(p, g, stream) : launch_wskd_one<1, 2, 3, false>(p, g, stream);
+}
+
 // rows of the build that takes M rows (0: none) and the n-tiles (16 columns) one of its workgroups may own
 int wsk_rows(int m) { return m <= 16 ? 16 : (m <= 32 ? 32 : (m <= 64 ? 64 : 0)); }
 int wsk_max_ntiles(int m) { return m <= 32 ? 5 : 4; }

@@ -581,6 +581,20 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
     t.swizzleOffset = static_cast<uint8_t>(std::min<uint32_t>(gm, 255));
     t.ldsBytes = menu_lds_bytes(t);   // of the build that will run (stage count and wave grid are settled by now)
     prefer_loader_waves(t);
+    // Decode rows (M <= 16) on a weight matrix of up to 10240 rows with 2048 <= K <= 18432: the one-launch workgroup split-K on
+    // per-wave LDS-DMA rings (kernelSerial 6, stages 3 names that build; csrc/gemm_fp8_wsk_kernel.hpp).  Cold, it was the fastest
+    // kernel on 64 of the 68 such shapes of the decode grids, by 3-34 % (profiles/r04_sweep_wskd/table.txt): no combine launch, no
+    // slab.  Wider matrices need three or more passes per workgroup (each re-streams the A rows), shorter K leaves the eight waves
+    // a k block or two each, more rows double the A share of every stage: the tile kernels keep those.
+    // $DGA_NO_WSK_PICK = 1 keeps the tile kernels (A/B scripts).
+    static const bool no_wsk = [] { const char *e = std::getenv("DGA_NO_WSK_PICK"); return e && std::atoi(e) != 0; }();
+    if (!no_wsk && groups == 1 && !contiguous && t.m <= 16 && (t.k % 16) == 0 && kb >= 16 && kb <= 144 && t.n <= 10240) {
+        t.kernelSerial = DGA_KERNEL_SPLITK_WORKGROUP;
+        t.m1 = 16; t.n1 = 128; t.k1 = 128;
+        t.splitkFactor = 1; t.stages = 3; t.wavesM = 0; t.wavesN = 0; t.dispatchPolicyTag = DGA_POLICY_PLAIN; t.swizzleOffset = 1;
+        t.blockDim = std::min<uint32_t>(ceil_div(t.n, 16), pf.coreNum);
+        t.ldsBytes = 8u * 3u * ((1u + 2u) * 2048u + 256u);
+    }
 }
 
 // ---- CSV-backed (m,n,k)-keyed cache ---------------------------------------------------------

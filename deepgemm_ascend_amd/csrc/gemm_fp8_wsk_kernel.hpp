@@ -173,4 +173,178 @@ __global__ void __launch_bounds__(512) gemm_fp8_wsk_kernel(const GemmParams p)
     }
 }
 
+// ---- the same split with the operands staged through LDS-DMA -------------------------------------------------------------------
+// What sank the register build on cold weights (profiles/r04_decode_cold.txt): a fragment load takes HALF of a 128-byte line per
+// row and request, and its loads are ones the compiler counts.  Here every wave owns a private ring of D stages in LDS -- a stage =
+// the 16 TM rows of A and 16 TN rows of B of one k block, 128 bytes each, plus their scales -- filled by LDS-DMA (whole lines: a
+// wave-instruction moves 8 rows x 128 bytes) and read back as fragments by ordinary ds_read_b128.  Nothing is shared between the
+// waves while they stream (no barrier); every vector-memory instruction of the loop is inline-asm DMA, so the only vmcnt waits are
+// the hand-placed ones (one per k block: the oldest stage has landed, the D - 1 younger ones stay in flight).  The LDS image is the
+// tile kernels': chunk c of row r at chunk position c ^ ((r >> 1) & 7), conflict-free for the fragment reads.
+// A workgroup owns the n-tiles [w nt / G, (w + 1) nt / G) as above and walks them TN at a time; each pass re-streams the A rows
+// (from L2).  Same slices, same per-slice arithmetic, same combine order: bit-identical to the register build and to the
+// two-launch split-K with splitkFactor 8.  LDS: 8 waves x D x (2 (TM + TN) KB + 256 B); the partial tiles meet in the rings.
+template <int TM, int TN, int D, bool KTAIL>
+__global__ void __launch_bounds__(512) gemm_fp8_wskd_kernel(const GemmParams p)
+{
+    constexpr int WAVES = 8, BM = TM * 16, BNW = TN * 16, ROWS = BM + BNW;
+    constexpr int L = ROWS / 8 + 1;                          // DMA instructions per stage: 8 rows each, + the scales
+    constexpr int STAGE = ROWS * 128 + 256, RING = D * STAGE;
+    static_assert(WAVES * RING <= 160 * 1024 && BM * BNW * 4 <= RING, "LDS of one CU; a wave's partial tile fits its own ring");
+    static_assert((D - 1) * L < 64, "vmcnt");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kg = lane >> 4;
+    constexpr uint32_t kOutOfRange = 0x80000000u;
+
+    const int M = p.m;
+    const int nt_total = (p.n + 15) >> 4, G = gridDim.x;
+    const int nt0 = (int)(((int64_t)blockIdx.x * nt_total) / G), nt1 = (int)(((int64_t)(blockIdx.x + 1) * nt_total) / G);
+    if (nt1 <= nt0) return;
+    const int kbps = (p.kb_n + WAVES - 1) / WAVES;
+    const int c0 = wave * kbps, c1 = min(p.kb_n, c0 + kbps);   // this wave's k blocks (empty: c0 >= c1)
+    const int s_eff = (p.kb_n + kbps - 1) / kbps;              // waves that own at least one k block
+
+    uint8_t *ring = smem + wave * RING;
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(lptr_t)smem + wave * RING;
+    // DMA sources.  Instruction j of a stage fills image rows 8 j .. 8 j + 7: lane -> row 8 j + (lane >> 3), source chunk
+    // (lane & 7) ^ x(row).  Rows [0, BM) are A rows, rows [BM, ROWS) the pass's B rows.
+    const int d_row = lane >> 3;
+    const v4i a_rsrc = make_rsrc(p.a, (int64_t)M * p.lda);
+    uint32_t a_voff[BM / 8];
+    int col[2];   // (the swizzle looks at the row inside its 16-row tile: instruction j's column depends on j & 1 only)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) col[j] = ((lane & 7) ^ swz_a((8 * j + d_row) & 15)) * 16;
+#pragma unroll
+    for (int j = 0; j < BM / 8; ++j) {
+        const int row = 8 * j + d_row;
+        a_voff[j] = row < M ? (uint32_t)row * (uint32_t)p.lda + col[j & 1] : kOutOfRange;
+    }
+    // fragment reads: lane (li, kg) takes chunks kg and 4 + kg of row li of its tile
+    const int f_off0 = li * 128 + ((kg ^ swz_a(li)) * 16), f_off1 = li * 128 + (((4 + kg) ^ swz_a(li)) * 16);
+    // scales of a stage: one 4-byte DMA per lane -- lanes [0, BM): sfa of row `lane`; lanes BM, BM + 1: the two sfb blocks of the
+    // pass; the other lanes re-fetch the first sfb word
+    const float *sfa_src = p.sfa + (int64_t)min(lane, M - 1) * p.sfa_ld;
+
+    for (int ntc = nt0; ntc < nt1; ntc += TN) {
+        const int cnt = min(TN, nt1 - ntc), n0 = ntc * 16;
+        const v4i b_rsrc = make_rsrc(p.b + (int64_t)n0 * p.ldb, (int64_t)(p.n - n0) * p.ldb);
+        uint32_t b_voff[BNW / 8];
+#pragma unroll
+        for (int j = 0; j < BNW / 8; ++j) {
+            const int row = 8 * j + d_row;   // relative to n0
+            b_voff[j] = (row < cnt * 16 && n0 + row < p.n) ? (uint32_t)row * (uint32_t)p.ldb + col[j & 1] : kOutOfRange;
+        }
+        const int nb0 = n0 >> 7, nb1 = min(nb0 + 1, p.nb_n - 1);
+        const float *sc_src = lane < BM ? sfa_src : p.sfb + (int64_t)(lane == BM + 1 ? nb1 : nb0) * p.kb_n;
+        bool second_block[TN];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) second_block[t] = ((n0 + t * 16) >> 7) != nb0;
+
+        // one stage: k block kb of the wave's slice into ring stage `stg`; beyond the slice every lane is out of range (zeros
+        // land, nothing is fetched) so that the number of instructions in flight stays what the waits assume
+        auto issue_stage = [&](int stg, int kb) {
+            const uint32_t base = ring_lds + stg * STAGE;
+            const int k0 = kb * 128;
+            const bool live = kb < c1;
+            bool ok2[2] = {live, live};
+            if constexpr (KTAIL) {
+                ok2[0] = live && (k0 + col[0] < p.k);
+                ok2[1] = live && (k0 + col[1] < p.k);
+            }
+#pragma unroll
+            for (int j = 0; j < ROWS / 8; ++j) {
+                uint32_t vo = j < BM / 8 ? a_voff[j < BM / 8 ? j : 0] : b_voff[j >= BM / 8 ? j - BM / 8 : 0];
+                vo = ok2[j & 1] ? vo : kOutOfRange;
+                dma16(vo, j < BM / 8 ? a_rsrc : b_rsrc, (uint32_t)k0, base + j * 1024);
+            }
+            dma4(sc_src + min(kb, p.kb_n - 1), base + ROWS * 128);
+        };
+
+        v4f acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < D; ++d) issue_stage(d, c0 + d);
+        for (int kb = c0; kb < c1; kb += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (kb + d < c1) {   // (wave-uniform; once false it stays false, so no later wait depends on the skipped refill)
+                    wait_vmcnt<(D - 1) * L>();   // stage d has landed; the D - 1 younger stages stay in flight
+                    const uint8_t *st = ring + d * STAGE;
+                    v8i af[TM], bf[TN];
+                    float sfa_r[TM];
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt) {
+                        const v4i lo = *(const v4i *)(st + mt * 2048 + f_off0), hi = *(const v4i *)(st + mt * 2048 + f_off1);
+                        af[mt] = v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                        sfa_r[mt] = *(const float *)(st + ROWS * 128 + (mt * 16 + li) * 4);
+                    }
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) {
+                        const v4i lo = *(const v4i *)(st + (TM + t) * 2048 + f_off0), hi = *(const v4i *)(st + (TM + t) * 2048 + f_off1);
+                        bf[t] = v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    }
+                    const float sfb0 = *(const float *)(st + ROWS * 128 + BM * 4), sfb1 = *(const float *)(st + ROWS * 128 + BM * 4 + 4);
+                    // the stage is in registers: refill it (the reads must have returned before the DMA may overwrite it)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    issue_stage(d, kb + d + D);
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) {
+                        if (t < cnt) {
+                            const float sb = second_block[t] ? sfb1 : sfb0;
+#pragma unroll
+                            for (int mt = 0; mt < TM; ++mt) {
+                                const v4f pr = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[t], af[mt], v4f{0.f, 0.f, 0.f, 0.f},
+                                                                                               0, 0, 0, 0, 0, 0);
+                                const float s = sfa_r[mt] * sb;   // two-level scale: sfa[m, kb] * sfb[n / 128, kb]
+                                acc[mt][t].x = __builtin_fmaf(pr.x, s, acc[mt][t].x);
+                                acc[mt][t].y = __builtin_fmaf(pr.y, s, acc[mt][t].y);
+                                acc[mt][t].z = __builtin_fmaf(pr.z, s, acc[mt][t].z);
+                                acc[mt][t].w = __builtin_fmaf(pr.w, s, acc[mt][t].w);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        wait_vmcnt<0>();   // the refills beyond the slice (zeros) have landed: the ring is this wave's to reuse
+
+        // ---- the eight partial tiles meet in LDS, each in its wave's own ring: slab[m][n] fp32; lane (li, kg) owns row
+        //      m = 16 mt + li, columns 16 t + 4 kg + [0, 4)
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+            for (int t = 0; t < TN; ++t) *(v4f *)((float *)ring + (mt * 16 + li) * BNW + t * 16 + 4 * kg) = acc[mt][t];
+        __syncthreads();
+        // s ascending = k ascending, as splitk_reduce_bf16_kernel sums its slabs
+        const bool vec_ok = ((p.ldc & 3) == 0) && ((((uintptr_t)p.out) & 7) == 0);
+        for (int g = tid; g < BM * (BNW / 4); g += 512) {
+            const int m = g / (BNW / 4), nl = (g % (BNW / 4)) * 4;
+            if (m >= M || nl >= cnt * 16) continue;
+            v4f v = *(const v4f *)((const float *)smem + m * BNW + nl);
+            for (int s = 1; s < s_eff; ++s) v += *(const v4f *)((const float *)(smem + s * RING) + m * BNW + nl);
+            const v2bf h0 = __builtin_convertvector(v2f{v.x, v.y}, v2bf), h1 = __builtin_convertvector(v2f{v.z, v.w}, v2bf);
+            uint16_t *dst = p.out + (int64_t)m * p.ldc + n0 + nl;
+            if (vec_ok && n0 + nl + 4 <= p.n) {
+                typedef int v2i __attribute__((ext_vector_type(2)));
+                *(v2i *)dst = v2i{__builtin_bit_cast(int, h0), __builtin_bit_cast(int, h1)};
+            } else {
+                const uint32_t w0 = __builtin_bit_cast(uint32_t, h0), w1 = __builtin_bit_cast(uint32_t, h1);
+                const uint16_t e[4] = {(uint16_t)(w0 & 0xFFFFu), (uint16_t)(w0 >> 16), (uint16_t)(w1 & 0xFFFFu), (uint16_t)(w1 >> 16)};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (n0 + nl + q < p.n) dst[q] = e[q];
+            }
+        }
+        if (ntc + TN < nt1) {   // the next pass refills the rings: every wave has read the partial tiles, and this wave's stores
+            __syncthreads();    // (counted in vmcnt like the DMA) are out of the way of the next pass's waits
+            wait_vmcnt<0>();
+        }
+    }
+}
+
 }  // namespace dga

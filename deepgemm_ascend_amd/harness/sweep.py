@@ -103,7 +103,10 @@ def candidates(m, n, k, rasters=None):
                             out.append({"m1": bm, "n1": bn, "raster": rr, "stages": st, "splitk": sk, "policy": pol, "tail": 1})
     # short-M: the one-launch workgroup split-K kernel (csrc/gemm_fp8_wsk_kernel.hpp, kernelSerial 6): 8 waves = 8 K slices
     if m <= 64 and k % 16 == 0 and k > 0:
-        out.append({"m1": 16 if m <= 16 else (32 if m <= 32 else 64), "n1": 128, "raster": 1, "stages": 2, "splitk": 1, "policy": 0, "wsk": 1})
+        # (stages names the build: 1 = fragments global -> registers, 3 = per-wave LDS-DMA rings, M <= 32)
+        out.append({"m1": 16 if m <= 16 else (32 if m <= 32 else 64), "n1": 128, "raster": 1, "stages": 1, "splitk": 1, "policy": 0, "wsk": 1})
+        if m <= 32:
+            out.append({"m1": 16 if m <= 16 else 32, "n1": 128, "raster": 1, "stages": 3, "splitk": 1, "policy": 0, "wsk": 2})
     return out
 
 
@@ -274,7 +277,7 @@ INFINITY_CACHE = 256 << 20
 
 
 def benchmark_shape(shape, out_dir: Path, rank=0, num_processes=1, iters=10, rasters=None, prewarm_s=0.15, only_policy=None,
-                    cold=False):
+                    cold=False, versus_tuned=False):
     """cold: time the candidates of a short-M shape on operand sets rotated past the Infinity Cache (SURVEY.md 8(d)'s
     protocol).  Re-launching on one set keeps a decode shape's 20-140 MB of weights in the 256 MiB cache, which favours
     tilings that leave CUs idle (fewer, longer streams): 64x4096x7168 picks 16x128 without split-K warm (16.2 us) and pays
@@ -282,6 +285,15 @@ def benchmark_shape(shape, out_dir: Path, rank=0, num_processes=1, iters=10, ras
     import deepgemm_ascend_amd as dga
     m, n, k = shape
     cands = candidates(m, n, k, rasters)
+    if versus_tuned:   # a supplementary sweep of the kernels outside the tile menu against the operator's current pick
+        t0 = dga.tiling(m, n, k)
+        pick = {"m1": int(t0.m1), "n1": int(t0.n1), "raster": int(t0.swizzleOffset), "stages": int(t0.stages),
+                "splitk": int(t0.splitkFactor), "policy": int(t0.dispatchPolicyTag)}
+        if t0.kernelSerial == 6:
+            pick["wsk"] = 2 if t0.stages != 1 else 1
+        elif t0.kernelSerial == 5:
+            pick["tail"] = 1
+        cands = [pick] + [c for c in cands if c.get("wsk") and c != pick]
     if only_policy is not None:   # a supplementary sweep of one dispatch policy (merged into an earlier run's records)
         cands = [c for c in cands if c["policy"] == only_policy]
         if not cands:
@@ -433,6 +445,8 @@ def main(argv=None):
     ap.add_argument("--heuristic-raster", action="store_true",
                     help="one raster per candidate (the heuristic's) instead of the raster sweep")
     ap.add_argument("--only-policy", type=int, default=None, help="time only the candidates of this dispatchPolicyTag")
+    ap.add_argument("--versus-tuned", action="store_true",
+                    help="time only the operator's current pick and the workgroup split-K builds (a supplementary sweep)")
     ap.add_argument("--cold", action="store_true",
                     help=f"shapes with M <= {COLD_MAX_M}: rotate operand sets past the Infinity Cache (decode weights are never warm)")
     ap.add_argument("--grouped", action="store_true",
@@ -465,7 +479,7 @@ def main(argv=None):
     winners = []
     for shape in shapes:
         best = benchmark_shape(shape, out_dir, a.rank, a.num_processes, a.iters, [0] if a.heuristic_raster else None,
-                               a.prewarm_ms / 1e3, a.only_policy, a.cold)
+                               a.prewarm_ms / 1e3, a.only_policy, a.cold, a.versus_tuned)
         if best:
             us, p = best
             m, n, k = shape

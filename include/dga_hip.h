@@ -51,7 +51,9 @@ enum { DGA_KERNEL_COMMON = 0, DGA_KERNEL_SMALL = 1, DGA_KERNEL_PADDING_COMMON = 
        DGA_KERNEL_STREAMK_TAIL = 5 /* whole waves of 256x256 tiles, the last partial wave covered by 128x128 tiles */,
        DGA_KERNEL_SPLITK_WORKGROUP = 6 /* M <= 64: the 8 waves of a workgroup are the 8 K slices of one output tile, partial tiles
                                           combined in LDS -- one launch, no slab (the reference's single-core split-K kernel types,
-                                          op_kernel/catlass_dynamic_matmul_tiling_key.h:30-36); the bits of split-K with factor 8 */ };
+                                          op_kernel/catlass_dynamic_matmul_tiling_key.h:30-36); the bits of split-K with factor 8.
+                                          M <= 32: operands staged through per-wave LDS-DMA rings (tiling.stages = 1 names the
+                                          older build that streams fragments global -> registers instead) */ };
 
 /* dispatchPolicyTag of the fp8 tile kernels (the reference's field selects a catlass dispatch policy,
  * op_tiling/tiling_params.h:19-66; here it selects the main-loop schedule or the exact-arithmetic kernel):

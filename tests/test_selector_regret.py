@@ -42,6 +42,8 @@ def test_dense_selector_regret_on_the_held_out_sweep(dga, tmp_path, monkeypatch)
     reg, missing = [], 0
     for (m, n, k), cs in shapes.items():
         t = dga.select_kernel(m, n, k)
+        if t.kernelSerial == 6:   # the workgroup split-K (decode rows): not a candidate of this sweep's tile menu; its own cold
+            continue              # sweep against the tile kernels is profiles/r04_sweep_wskd/table.txt
         key = (t.m1, t.n1, 3 if t.stages == 3 else 2, max(1, t.splitkFactor), fold(t.dispatchPolicyTag), t.kernelSerial == 5)
         if key not in cs:
             missing += 1

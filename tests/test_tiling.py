@@ -63,7 +63,10 @@ def test_mi355x_selection_is_launchable(dga):
         assert (t.m1, t.n1) in menu and t.k1 == 128
         assert t.ldsBytes <= pf.l1Size and t.m1 * t.n1 * 4 <= pf.l0CSize
         tiles = -(-shape[0] // t.m1) * -(-shape[1] // t.n1)
-        if t.kernelSerial == 5:   # whole waves of 256x256 tiles + the last partial wave in quarter tiles
+        if t.kernelSerial == 6:   # workgroup split-K (decode rows): one workgroup per CU, each walking its share of the n-tiles
+            assert shape[0] <= 16 and (t.m1, t.n1, t.splitkFactor, t.stages) == (16, 128, 1, 3)
+            assert t.blockDim == min(-(-shape[1] // 16), pf.coreNum)
+        elif t.kernelSerial == 5:   # whole waves of 256x256 tiles + the last partial wave in quarter tiles
             assert (t.m1, t.n1, t.splitkFactor) == (256, 256, 1) and 0 < tiles % 256 <= 64
             assert t.blockDim == tiles - tiles % 256 + 4 * (tiles % 256)
         else:
@@ -78,6 +81,10 @@ def test_mi355x_selection_is_launchable(dga):
     tg = dga.select_kernel(128, 2048, 7168, groups=256, expected_m=128)
     assert tg.groups == 256 and tg.m1 == 128 and tg.blockDim == 256 * (2048 // tg.n1)
     assert dga.select_kernel(0, 128, 128).blockDim == 0
+    # decode rows: the one-launch workgroup split-K where it won its cold sweep (M <= 16, N <= 10240, 2048 <= K <= 18432)
+    assert dga.select_kernel(8, 7168, 18432).kernelSerial == 6 and dga.select_kernel(16, 4096, 7168).kernelSerial == 6
+    assert dga.select_kernel(32, 4096, 7168).kernelSerial != 6 and dga.select_kernel(8, 18432, 7168).kernelSerial != 6
+    assert dga.select_kernel(8, 7168, 1536).kernelSerial != 6
 
 
 def test_non_nt_layout_rejected(dga):

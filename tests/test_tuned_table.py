@@ -37,7 +37,9 @@ def test_table_is_well_formed(dga):
         assert key not in seen, f"duplicate row {key}"
         seen.add(key)
         assert int(r["m1"]) in (16, 32, 64, 128, 256) and int(r["n1"]) in (128, 256) and int(r["stages"]) in (2, 3)
-        assert int(r["kernelSerial"]) in (0, 1, 4, 5) and int(r["splitkFactor"]) >= 1   # the selectable-only kernels (2, 6) are never tabled
+        assert int(r["kernelSerial"]) in (0, 1, 4, 5, 6) and int(r["splitkFactor"]) >= 1   # (2, odd K in place, is never tabled)
+        if int(r["kernelSerial"]) == 6:   # the workgroup split-K on LDS-DMA rings: decode rows only (profiles/r04_sweep_wskd)
+            assert int(r["m"]) <= 32 and int(r["stages"]) == 3 and int(r["splitkFactor"]) == 1 and r["groups"] == "1"
 
 
 @pytest.mark.parametrize("m,bucket", [(24, 32), (17, 32), (50, 64), (100, 128), (5, 8), (2, 4), (128, 128)])

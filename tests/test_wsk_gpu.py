@@ -1,5 +1,7 @@
 """The one-launch workgroup split-K kernel for short-M problems (csrc/gemm_fp8_wsk_kernel.hpp, kernelSerial 6): the 8 waves of a
-workgroup are the 8 K slices of one output tile, fragments streamed global -> registers, partial tiles combined in LDS.
+workgroup are the 8 K slices of one output tile, partial tiles combined in LDS.  Two builds: fragments streamed global ->
+registers (M <= 64; a tiling with stages = 1 names it), and -- M <= 32, the default there -- operands staged through per-wave
+LDS-DMA rings (whole-line requests, hand-counted vmcnt).
 
 Reference counterparts: the Stream-K kernel's fused reduce
 (/root/reference/aclnn_catlass_dynamic_matmul/op_kernel/kernel/padding_streamk_matmul_kernel.h:92-107) and the single-core
@@ -24,11 +26,14 @@ def _bits(t):
 
 
 def _run(dga, a, sfa, b, sfb, wsk):
+    """wsk: False = two-launch split-K 8; True / "dma" = kernelSerial 6 as the dispatcher builds it (LDS-DMA rings up to 32 rows);
+    "reg" = the register build"""
     m, k = a.shape
     n = b.shape[0]
     t = dga.tiling(m, n, k)
     if wsk:
         t.kernelSerial, t.splitkFactor = 6, 1
+        t.stages = 1 if wsk == "reg" else 3
     else:
         t.kernelSerial, t.splitkFactor = 4, 8
         t.m1, t.n1, t.stages, t.wavesM, t.wavesN, t.dispatchPolicyTag = 64, 128, 3, 1, 4, 0
@@ -41,13 +46,18 @@ def _run(dga, a, sfa, b, sfb, wsk):
     (1, 80, 1024), (8, 512, 2048), (16, 1000, 4096 + 16), (17, 333, 1040), (32, 4096, 1024), (33, 640, 3072),
     (64, 1024, 1152), (64, 256, 128),      # one k block: seven of the eight waves have nothing to do
     (5, 48, 16), (48, 7168, 7168), (13, 72, 8192 + 48),
+    (16, 16 * 256 + 16, 2048),            # 257 n-tiles: one workgroup walks two
+    (9, 16 * 700 + 5, 1024 + 32),         # 2.7 n-tiles per workgroup: passes of 2 + 1, the last column tile cut
+    (32, 16 * 600, 1152), (24, 40, 128 * 9),
 ])
 def test_against_two_launch_split_k_and_the_oracle(dga, oracle, m, n, k):
     a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=m + n + k)
     da, dsfa, db, dsfb = _dev(a), _dev(sfa), _dev(b), _dev(sfb)
-    got = _run(dga, da, dsfa, db, dsfb, True)
+    got = _run(dga, da, dsfa, db, dsfb, "dma")
     ref = _run(dga, da, dsfa, db, dsfb, False)
     assert np.array_equal(got, ref), f"{int((got != ref).sum())} of {got.size} outputs differ from the two-launch split-K"
+    got_reg = _run(dga, da, dsfa, db, dsfb, "reg")
+    assert np.array_equal(got_reg, ref), f"register build: {int((got_reg != ref).sum())} of {got.size} outputs differ"
     want = oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, threads=8)
     oracle.assert_parity(got, want, a, sfa, b, sfb)
 
@@ -66,6 +76,7 @@ def test_decode_shapes_at_full_size(dga, m, n, k):
     got = _run(dga, a, sfa, b, sfb, True)
     ref = _run(dga, a, sfa, b, sfb, False)
     assert np.array_equal(got, ref)
+    assert np.array_equal(_run(dga, a, sfa, b, sfb, "reg"), ref)
 
 
 def test_shapes_it_does_not_take_fall_through(dga, oracle):
