@@ -63,6 +63,8 @@ def main():
         done["image"] += 1
         # ---- workgroup split-K
         m = int(rng.integers(1, 65)); n = int(rng.integers(1, 3000)); k = int(rng.integers(1, 600)) * 16
+        if i % 3 == 0:   # more than one n-tile per workgroup: the multi-pass LDS-DMA builds (M <= 32)
+            n = int(rng.integers(4097, 15000)); k = int(rng.integers(1, 200)) * 16
         a, sfa, b, sfb = data(m, n, k, gen)
         t6 = dga.tiling(m, n, k); t6.kernelSerial, t6.splitkFactor = 6, 1
         t4 = dga.tiling(m, n, k); t4.kernelSerial, t4.splitkFactor = 4, 8
