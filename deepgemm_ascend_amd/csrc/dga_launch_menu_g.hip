@@ -24,11 +24,11 @@ static int launch_wsk_one(const GemmParams &p, unsigned grid, hipStream_t stream
     return record_hip(hipGetLastError());
 }
 
-template <int TM, int TN, int D, bool KTAIL>
+template <int TM, int TN, int D, bool KTAIL, int WAVES = 8>
 static int launch_wskd_one(const GemmParams &p, unsigned grid, hipStream_t stream)
 {
-    auto kfn = gemm_fp8_wskd_kernel<TM, TN, D, KTAIL>;
-    constexpr int kLds = 8 * D * ((TM + TN) * 16 * 128 + 256);
+    auto kfn = gemm_fp8_wskd_kernel<TM, TN, D, KTAIL, WAVES>;
+    constexpr int kLds = WAVES * D * ((TM + TN) * 16 * 128 + (TM * 16 + 2 + 63) / 64 * 256);
     static_assert(kLds <= 160 * 1024, "LDS of one CU");
     static std::once_flag once[64];
     static hipError_t attr_err[64];
@@ -39,14 +39,15 @@ static int launch_wskd_one(const GemmParams &p, unsigned grid, hipStream_t strea
         attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     });
     if (int rc = record_hip(attr_err[dev])) return rc;
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), kLds, stream, p);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WAVES * 64), kLds, stream, p);
     return record_hip(hipGetLastError());
 }
 
-// the LDS-DMA staged builds (M <= 32): one workgroup per CU (or per n-tile where there are fewer), each walking its n-tiles TN at a time
-int launch_wsk_dma(const GemmParams &p, hipStream_t stream)
+// the LDS-DMA staged builds: one workgroup per CU (or per n-tile where there are fewer), each walking its n-tiles TN at a time.
+// waves = 8: M <= 32, eight K slices; waves = 4: M <= 64, four K slices (the bits of split-K with factor 4).
+int launch_wsk_dma(const GemmParams &p, int waves, hipStream_t stream)
 {
-    if (p.groups != 1 || p.masked_m || p.m_indices || p.row_index || p.splitk > 1 || p.tail_sub || p.m > 32 || p.m <= 0 || (p.k % 16) ||
+    if (p.groups != 1 || p.masked_m || p.m_indices || p.row_index || p.splitk > 1 || p.tail_sub || p.m > (waves == 4 ? 64 : 32) || p.m <= 0 || (p.k % 16) ||
         p.k <= 0 || (reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.b) & 15) || (p.lda & 15) || (p.ldb & 15) ||
         static_cast<int64_t>(p.m) * p.lda >= 0x7FFFFFFFll)
         return DGA_E_TILING;
@@ -54,6 +55,16 @@ int launch_wsk_dma(const GemmParams &p, hipStream_t stream)
     const int64_t cus = device_cus();
     const unsigned g = static_cast<unsigned>(nt < cus ? nt : cus);
     const bool kt = (p.k % 128) != 0;
+    if (waves == 4) {
+        const int per4 = static_cast<int>((nt + g - 1) / g);
+        if (p.m <= 32) {
+            if (per4 <= 2 || per4 % 4 == 1 || per4 % 4 == 2)   // (passes of 4 would leave one at most half full)
+                return kt ? launch_wskd_one<2, 2, 4, true, 4>(p, g, stream) : launch_wskd_one<2, 2, 4, false, 4>(p, g, stream);
+            return kt ? launch_wskd_one<2, 4, 3, true, 4>(p, g, stream) : launch_wskd_one<2, 4, 3, false, 4>(p, g, stream);
+        }
+        if (per4 <= 1) return kt ? launch_wskd_one<4, 1, 3, true, 4>(p, g, stream) : launch_wskd_one<4, 1, 3, false, 4>(p, g, stream);
+        return kt ? launch_wskd_one<4, 2, 3, true, 4>(p, g, stream) : launch_wskd_one<4, 2, 3, false, 4>(p, g, stream);
+    }
     if (p.m > 16) return kt ? launch_wskd_one<2, 2, 2, true>(p, g, stream) : launch_wskd_one<2, 2, 2, false>(p, g, stream);
     // n-tiles per workgroup -> the build that walks them in the fewest passes (every pass re-streams the A rows and pays a round
     // trip); at equal passes the narrower one (deeper ring)

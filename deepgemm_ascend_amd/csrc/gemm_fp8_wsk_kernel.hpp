@@ -183,13 +183,15 @@ __global__ void __launch_bounds__(512) gemm_fp8_wsk_kernel(const GemmParams p)
 // tile kernels': chunk c of row r at chunk position c ^ ((r >> 1) & 7), conflict-free for the fragment reads.
 // A workgroup owns the n-tiles [w nt / G, (w + 1) nt / G) as above and walks them TN at a time; each pass re-streams the A rows
 // (from L2).  Same slices, same per-slice arithmetic, same combine order: bit-identical to the register build and to the
-// two-launch split-K with splitkFactor 8.  LDS: 8 waves x D x (2 (TM + TN) KB + 256 B); the partial tiles meet in the rings.
-template <int TM, int TN, int D, bool KTAIL>
-__global__ void __launch_bounds__(512) gemm_fp8_wskd_kernel(const GemmParams p)
+// two-launch split-K with splitkFactor WAVES.  LDS: WAVES x D x (2 (TM + TN) KB + 256 B); the partial tiles meet in the rings.
+// WAVES = 8 (M <= 32) or 4 (M <= 64: half as many K slices, twice the ring per wave -- what 64 rows of A per stage need).
+template <int TM, int TN, int D, bool KTAIL, int WAVES = 8>
+__global__ void __launch_bounds__(WAVES * 64) gemm_fp8_wskd_kernel(const GemmParams p)
 {
-    constexpr int WAVES = 8, BM = TM * 16, BNW = TN * 16, ROWS = BM + BNW;
-    constexpr int L = ROWS / 8 + 1;                          // DMA instructions per stage: 8 rows each, + the scales
-    constexpr int STAGE = ROWS * 128 + 256, RING = D * STAGE;
+    constexpr int BM = TM * 16, BNW = TN * 16, ROWS = BM + BNW, NT = WAVES * 64;
+    constexpr int SCI = (BM + 2 + 63) / 64;                  // scale DMA instructions per stage (BM sfa rows + 2 sfb words, 64 per instruction)
+    constexpr int L = ROWS / 8 + SCI;                        // DMA instructions per stage: 8 rows each, + the scales
+    constexpr int STAGE = ROWS * 128 + SCI * 256, RING = D * STAGE;
     static_assert(WAVES * RING <= 160 * 1024 && BM * BNW * 4 <= RING, "LDS of one CU; a wave's partial tile fits its own ring");
     static_assert((D - 1) * L < 64, "vmcnt");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -223,9 +225,8 @@ __global__ void __launch_bounds__(512) gemm_fp8_wskd_kernel(const GemmParams p)
     }
     // fragment reads: lane (li, kg) takes chunks kg and 4 + kg of row li of its tile
     const int f_off0 = li * 128 + ((kg ^ swz_a(li)) * 16), f_off1 = li * 128 + (((4 + kg) ^ swz_a(li)) * 16);
-    // scales of a stage: one 4-byte DMA per lane -- lanes [0, BM): sfa of row `lane`; lanes BM, BM + 1: the two sfb blocks of the
-    // pass; the other lanes re-fetch the first sfb word
-    const float *sfa_src = p.sfa + (int64_t)min(lane, M - 1) * p.sfa_ld;
+    // scales of a stage: one 4-byte DMA per lane and instruction -- slots [0, BM): sfa of row `slot`; slots BM, BM + 1: the two
+    // sfb blocks of the pass; the other slots re-fetch the first sfb word
 
     for (int ntc = nt0; ntc < nt1; ntc += TN) {
         const int cnt = min(TN, nt1 - ntc), n0 = ntc * 16;
@@ -237,7 +238,12 @@ __global__ void __launch_bounds__(512) gemm_fp8_wskd_kernel(const GemmParams p)
             b_voff[j] = (row < cnt * 16 && n0 + row < p.n) ? (uint32_t)row * (uint32_t)p.ldb + col[j & 1] : kOutOfRange;
         }
         const int nb0 = n0 >> 7, nb1 = min(nb0 + 1, p.nb_n - 1);
-        const float *sc_src = lane < BM ? sfa_src : p.sfb + (int64_t)(lane == BM + 1 ? nb1 : nb0) * p.kb_n;
+        const float *sc_src[SCI];
+#pragma unroll
+        for (int i = 0; i < SCI; ++i) {
+            const int slot = i * 64 + lane;
+            sc_src[i] = slot < BM ? p.sfa + (int64_t)min(slot, M - 1) * p.sfa_ld : p.sfb + (int64_t)(slot == BM + 1 ? nb1 : nb0) * p.kb_n;
+        }
         bool second_block[TN];
 #pragma unroll
         for (int t = 0; t < TN; ++t) second_block[t] = ((n0 + t * 16) >> 7) != nb0;
@@ -259,7 +265,8 @@ __global__ void __launch_bounds__(512) gemm_fp8_wskd_kernel(const GemmParams p)
                 vo = ok2[j & 1] ? vo : kOutOfRange;
                 dma16(vo, j < BM / 8 ? a_rsrc : b_rsrc, (uint32_t)k0, base + j * 1024);
             }
-            dma4(sc_src + min(kb, p.kb_n - 1), base + ROWS * 128);
+#pragma unroll
+            for (int i = 0; i < SCI; ++i) dma4(sc_src[i] + min(kb, p.kb_n - 1), base + ROWS * 128 + i * 256);
         };
 
         v4f acc[TM][TN];
@@ -322,7 +329,7 @@ __global__ void __launch_bounds__(512) gemm_fp8_wskd_kernel(const GemmParams p)
         __syncthreads();
         // s ascending = k ascending, as splitk_reduce_bf16_kernel sums its slabs
         const bool vec_ok = ((p.ldc & 3) == 0) && ((((uintptr_t)p.out) & 7) == 0);
-        for (int g = tid; g < BM * (BNW / 4); g += 512) {
+        for (int g = tid; g < BM * (BNW / 4); g += NT) {
             const int m = g / (BNW / 4), nl = (g % (BNW / 4)) * 4;
             if (m >= M || nl >= cnt * 16) continue;
             v4f v = *(const v4f *)((const float *)smem + m * BNW + nl);
