@@ -387,9 +387,8 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
         // M <= 32: the LDS-DMA staged build (whole-line requests, hand-counted vmcnt); a tiling with stages = 1 names the register
         // build (fragments global -> registers), which also takes 32 < M <= 64.  $DGA_WSK_DMA = 0 / 1 overrides.
         static const int wsk_dma_env = [] { const char *e = std::getenv("DGA_WSK_DMA"); return e ? std::atoi(e) : -1; }();
-        // stages = 4 names the 4-wave builds (four K slices, M <= 64); beyond 32 rows they are the only LDS-DMA builds
         if (wsk_dma_env >= 0 ? wsk_dma_env != 0 : tiling->stages != 1) {
-            const int rc = launch_wsk_dma(p, (tiling->stages == 4 || m > 32) ? 4 : 8, stream);
+            const int rc = launch_wsk_dma(p, stream);
             if (rc != DGA_E_TILING) return rc;
         }
         const int rc = launch_wsk(p, stream);

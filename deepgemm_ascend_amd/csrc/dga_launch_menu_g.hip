@@ -43,11 +43,13 @@ static int launch_wskd_one(const GemmParams &p, unsigned grid, hipStream_t strea
     return record_hip(hipGetLastError());
 }
 
-// the LDS-DMA staged builds: one workgroup per CU (or per n-tile where there are fewer), each walking its n-tiles TN at a time.
-// waves = 8: M <= 32, eight K slices; waves = 4: M <= 64, four K slices (the bits of split-K with factor 4).
-int launch_wsk_dma(const GemmParams &p, int waves, hipStream_t stream)
+// the LDS-DMA staged builds (M <= 32): one workgroup per CU (or per n-tile where there are fewer), each walking its n-tiles TN at a time.
+// (4-wave forms for up to 64 rows -- four K slices, twice the ring per wave -- were built and measured too: within 5 % of the tile
+//  kernels on 7 of 72 cold shapes, 10-100 % behind elsewhere, profiles/r04_sweep_wskd/table_m64.txt; they are not in the menu.  The
+//  kernel keeps its WAVES parameter.)
+int launch_wsk_dma(const GemmParams &p, hipStream_t stream)
 {
-    if (p.groups != 1 || p.masked_m || p.m_indices || p.row_index || p.splitk > 1 || p.tail_sub || p.m > (waves == 4 ? 64 : 32) || p.m <= 0 || (p.k % 16) ||
+    if (p.groups != 1 || p.masked_m || p.m_indices || p.row_index || p.splitk > 1 || p.tail_sub || p.m > 32 || p.m <= 0 || (p.k % 16) ||
         p.k <= 0 || (reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.b) & 15) || (p.lda & 15) || (p.ldb & 15) ||
         static_cast<int64_t>(p.m) * p.lda >= 0x7FFFFFFFll)
         return DGA_E_TILING;
@@ -55,16 +57,6 @@ int launch_wsk_dma(const GemmParams &p, int waves, hipStream_t stream)
     const int64_t cus = device_cus();
     const unsigned g = static_cast<unsigned>(nt < cus ? nt : cus);
     const bool kt = (p.k % 128) != 0;
-    if (waves == 4) {
-        const int per4 = static_cast<int>((nt + g - 1) / g);
-        if (p.m <= 32) {
-            if (per4 <= 2 || per4 % 4 == 1 || per4 % 4 == 2)   // (passes of 4 would leave one at most half full)
-                return kt ? launch_wskd_one<2, 2, 4, true, 4>(p, g, stream) : launch_wskd_one<2, 2, 4, false, 4>(p, g, stream);
-            return kt ? launch_wskd_one<2, 4, 3, true, 4>(p, g, stream) : launch_wskd_one<2, 4, 3, false, 4>(p, g, stream);
-        }
-        if (per4 <= 1) return kt ? launch_wskd_one<4, 1, 3, true, 4>(p, g, stream) : launch_wskd_one<4, 1, 3, false, 4>(p, g, stream);
-        return kt ? launch_wskd_one<4, 2, 3, true, 4>(p, g, stream) : launch_wskd_one<4, 2, 3, false, 4>(p, g, stream);
-    }
     if (p.m > 16) return kt ? launch_wskd_one<2, 2, 2, true>(p, g, stream) : launch_wskd_one<2, 2, 2, false>(p, g, stream);
     // n-tiles per workgroup -> the build that walks them in the fewest passes (every pass re-streams the A rows and pays a round
     // trip); at equal passes the narrower one (deeper ring)

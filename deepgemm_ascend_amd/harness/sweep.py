@@ -103,12 +103,10 @@ def candidates(m, n, k, rasters=None):
                             out.append({"m1": bm, "n1": bn, "raster": rr, "stages": st, "splitk": sk, "policy": pol, "tail": 1})
     # short-M: the one-launch workgroup split-K kernel (csrc/gemm_fp8_wsk_kernel.hpp, kernelSerial 6): 8 waves = 8 K slices
     if m <= 64 and k % 16 == 0 and k > 0:
-        # (stages names the build: 1 = fragments global -> registers, 3 = per-wave LDS-DMA rings (8 waves, M <= 32), 4 = the same on 4 waves)
+        # (stages names the build: 1 = fragments global -> registers, 3 = per-wave LDS-DMA rings, M <= 32)
         out.append({"m1": 16 if m <= 16 else (32 if m <= 32 else 64), "n1": 128, "raster": 1, "stages": 1, "splitk": 1, "policy": 0, "wsk": 1})
         if m <= 32:
             out.append({"m1": 16 if m <= 16 else 32, "n1": 128, "raster": 1, "stages": 3, "splitk": 1, "policy": 0, "wsk": 2})
-        if m > 16:
-            out.append({"m1": 32 if m <= 32 else 64, "n1": 128, "raster": 1, "stages": 4, "splitk": 1, "policy": 0, "wsk": 3})
     return out
 
 
@@ -292,7 +290,7 @@ def benchmark_shape(shape, out_dir: Path, rank=0, num_processes=1, iters=10, ras
         pick = {"m1": int(t0.m1), "n1": int(t0.n1), "raster": int(t0.swizzleOffset), "stages": int(t0.stages),
                 "splitk": int(t0.splitkFactor), "policy": int(t0.dispatchPolicyTag)}
         if t0.kernelSerial == 6:
-            pick["wsk"] = 1 if t0.stages == 1 else (3 if (t0.stages == 4 or m > 32) else 2)
+            pick["wsk"] = 2 if (t0.stages != 1 and m <= 32) else 1
         elif t0.kernelSerial == 5:
             pick["tail"] = 1
         cands = [pick] + [c for c in cands if c.get("wsk") and c != pick]

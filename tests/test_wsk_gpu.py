@@ -27,13 +27,13 @@ def _bits(t):
 
 def _run(dga, a, sfa, b, sfb, wsk, split=8):
     """wsk: False = two-launch split-K `split`; True / "dma" = kernelSerial 6 as the dispatcher builds it (8-wave LDS-DMA rings up to
-    32 rows); "reg" = the register build; "dma4" = the 4-wave LDS-DMA builds (four K slices, M <= 64)"""
+    32 rows); "reg" = the register build"""
     m, k = a.shape
     n = b.shape[0]
     t = dga.tiling(m, n, k)
     if wsk:
         t.kernelSerial, t.splitkFactor = 6, 1
-        t.stages = {"reg": 1, "dma4": 4}.get(wsk, 3)
+        t.stages = 1 if wsk == "reg" else 3
     else:
         t.kernelSerial, t.splitkFactor = 4, split
         t.m1, t.n1, t.stages, t.wavesM, t.wavesN, t.dispatchPolicyTag = 64, 128, 3, 1, 4, 0
@@ -49,23 +49,16 @@ def _run(dga, a, sfa, b, sfb, wsk, split=8):
     (16, 16 * 256 + 16, 2048),            # 257 n-tiles: one workgroup walks two
     (9, 16 * 700 + 5, 1024 + 32),         # 2.7 n-tiles per workgroup: passes of 2 + 1, the last column tile cut
     (32, 16 * 600, 1152), (24, 40, 128 * 9),
-    (64, 16 * 300, 2048 + 16), (40, 16 * 1300 + 3, 1024), (20, 16 * 900, 640), (30, 16 * 1600, 512),   # 4-wave builds: 1 / 2..6 n-tiles per workgroup
+    (64, 16 * 300, 2048 + 16), (40, 16 * 1300 + 3, 1024), (20, 16 * 900, 640), (30, 16 * 1600, 512),
 ])
 def test_against_two_launch_split_k_and_the_oracle(dga, oracle, m, n, k):
     a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=m + n + k)
     da, dsfa, db, dsfb = _dev(a), _dev(sfa), _dev(b), _dev(sfb)
     got = _run(dga, da, dsfa, db, dsfb, "dma")
     ref = _run(dga, da, dsfa, db, dsfb, False)
-    if m > 32:   # beyond 32 rows the dispatcher's LDS-DMA build is the 4-wave one: four K slices
-        assert np.array_equal(got, _run(dga, da, dsfa, db, dsfb, False, split=4))
-    else:
-        assert np.array_equal(got, ref), f"{int((got != ref).sum())} of {got.size} outputs differ from the two-launch split-K"
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} of {got.size} outputs differ from the two-launch split-K"
     got_reg = _run(dga, da, dsfa, db, dsfb, "reg")
     assert np.array_equal(got_reg, ref), f"register build: {int((got_reg != ref).sum())} of {got.size} outputs differ"
-    # the 4-wave builds: four K slices = the bits of split-K with factor 4
-    got4 = _run(dga, da, dsfa, db, dsfb, "dma4")
-    ref4 = _run(dga, da, dsfa, db, dsfb, False, split=4)
-    assert np.array_equal(got4, ref4), f"4-wave build: {int((got4 != ref4).sum())} of {got4.size} outputs differ from split-K 4"
     want = oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, threads=8)
     oracle.assert_parity(got, want, a, sfa, b, sfb)
 
@@ -83,9 +76,8 @@ def test_decode_shapes_at_full_size(dga, m, n, k):
     sfb = torch.rand(((n + 127) // 128, kb), device="cuda", generator=gen) + 0.5
     got = _run(dga, a, sfa, b, sfb, True)
     ref = _run(dga, a, sfa, b, sfb, False)
-    assert np.array_equal(got, ref if m <= 32 else _run(dga, a, sfa, b, sfb, False, split=4))
+    assert np.array_equal(got, ref)
     assert np.array_equal(_run(dga, a, sfa, b, sfb, "reg"), ref)
-    assert np.array_equal(_run(dga, a, sfa, b, sfb, "dma4"), _run(dga, a, sfa, b, sfb, False, split=4))
 
 
 def test_shapes_it_does_not_take_fall_through(dga, oracle):
