@@ -252,8 +252,10 @@ __global__ void __launch_bounds__(WAVES * 64) gemm_fp8_wskd_kernel(const GemmPar
         // land, nothing is fetched) so that the number of instructions in flight stays what the waits assume
         auto issue_stage = [&](int stg, int kb) {
             const uint32_t base = ring_lds + stg * STAGE;
-            const int k0 = kb * 128;
             const bool live = kb < c1;
+            // (starting the workgroups' slices at different k blocks -- so that they do not all ask for the same A lines at once -- changes
+            //  nothing: 16 x 7168 x 18432 31.8 against 32.0 us; A costs its bytes, not a hot spot)
+            const int k0 = kb * 128;
             bool ok2[2] = {live, live};
             if constexpr (KTAIL) {
                 ok2[0] = live && (k0 + col[0] < p.k);
