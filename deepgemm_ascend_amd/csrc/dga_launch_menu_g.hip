@@ -57,6 +57,8 @@ int launch_wsk_dma(const GemmParams &p, hipStream_t stream)
     const int64_t cus = device_cus();
     const unsigned g = static_cast<unsigned>(nt < cus ? nt : cus);
     const bool kt = (p.k % 128) != 0;
+    // (fewer workgroups with three n-tiles each -- a third less A traffic per B byte -- measured worse: 8 x 7168 x 18432 27.9 -> 34.9 us;
+    //  every CU streaming counts for more than the A bytes)
     if (p.m > 16) return kt ? launch_wskd_one<2, 2, 2, true>(p, g, stream) : launch_wskd_one<2, 2, 2, false>(p, g, stream);
     // n-tiles per workgroup -> the build that walks them in the fewest passes (every pass re-streams the A rows and pays a round
     // trip); at equal passes the narrower one (deeper ring)
