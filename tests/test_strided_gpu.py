@@ -45,6 +45,8 @@ POLICIES = [{}, {"policy": "bf16_exact"}, {"strict": True}]
     (333, 520, 777, 784, 800),        # K odd
     (1, 8, 5, 16, 16),                # less than one chunk
     (130, 257, 7681, 7696, 7696),     # the reference list's K
+    (8, 520, 2056, 2064, 2176),       # decode rows: the selector's one-launch workgroup split-K reads the strided rows too
+    (16, 4100, 4096, 4096 + 128, 4096 + 16),
 ])
 def test_strided_operands_give_the_contiguous_call_s_bytes(dga, oracle, m, n, k, lda, ldb, kw):
     a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=m + 3 * n + 7 * k)
