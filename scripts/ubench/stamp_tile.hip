@@ -5,7 +5,7 @@
 //   barrier the k block's one barrier: "this stage landed everywhere" (in a loader-wave build this is where a late refill shows)
 //   frags   first fragments + scales out of the LDS
 //   pipe    the MFMA / promotion pipeline (+ B-fragment reads, + the refill issue in builds without loader waves)
-// usage: stamp_tile M N K [warm launches]
+// usage: stamp_tile M N K [warm launches] [split-K factor: the tile kernel of a two-launch split-K call, slabs written, no combine]
 #define DGA_STAMPS 1
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -29,6 +29,7 @@ int main(int argc, char **argv)
 {
     const int m = argc > 1 ? atoi(argv[1]) : 4096, n = argc > 2 ? atoi(argv[2]) : 2048, k = argc > 3 ? atoi(argv[3]) : 7168;
     const int warm = argc > 4 ? atoi(argv[4]) : 3000;
+    const int splitk = argc > 5 ? atoi(argv[5]) : 1;
     typedef GemmCfg<CFG_BM, CFG_BN, CFG_WM, CFG_WN, CFG_ST, CFG_LC> Cfg;
     GemmParams p{};
     std::vector<uint8_t> ha((size_t)m * k), hb((size_t)n * k);
@@ -46,7 +47,16 @@ int main(int argc, char **argv)
     p.lda = k; p.ldb = k; p.ldc = n; p.groups = 1; p.b_groups = 1; p.sfa_ld = kb; p.splitk = 1;
     p.tiles_m = (m + Cfg::kBM - 1) / Cfg::kBM; p.tiles_n = (n + Cfg::kBN - 1) / Cfg::kBN;
     p.raster_group = 4; p.xcd_remap = 1;
-    const int grid = p.tiles_m * p.tiles_n, waves = Cfg::NT / 64, cwaves = Cfg::kWM * Cfg::kWN;
+    const int kb_total = kb;
+    if (splitk > 1) {
+        p.splitk = splitk;
+        p.kb_per_split = (kb + splitk - 1) / splitk;
+        float *slab;
+        hipMalloc(&slab, (size_t)splitk * m * n * 4);
+        p.partial = slab;
+    }
+    const int kb_wave = splitk > 1 ? p.kb_per_split : kb_total;   // k blocks one wave walks
+    const int grid = p.tiles_m * p.tiles_n * splitk, waves = Cfg::NT / 64, cwaves = Cfg::kWM * Cfg::kWN;
     hipMalloc(&st, (size_t)grid * waves * 8 * 8); hipMemset(st, 0, (size_t)grid * waves * 8 * 8);
     p.stamps = st;
     auto kfn = gemm_fp8_blockscaled_nt_kernel<Cfg, 0, false, false, CFG_MATH>;
@@ -68,8 +78,8 @@ int main(int argc, char **argv)
     const double nw = (double)grid * cwaves;
     printf("tile %dx%d waves %dx%d%s stages %d on %dx%dx%d: %.1f us per launch (stamped build, %d warm launches)\n", Cfg::kBM, Cfg::kBN,
            Cfg::kWM, Cfg::kWN, Cfg::kLC ? "+loaders" : "", Cfg::STAGES, m, n, k, ms * 1000 / 20, warm);
-    printf("  per k block: wait %.0f  barrier %.0f  frags %.0f  pipe %.0f  = %.0f ticks (matrix pipe alone: %d)\n", seg[1] / nw / kb,
-           seg[2] / nw / kb, seg[3] / nw / kb, seg[4] / nw / kb, (seg[1] + seg[2] + seg[3] + seg[4]) / nw / kb,
+    printf("  per k block: wait %.0f  barrier %.0f  frags %.0f  pipe %.0f  = %.0f ticks (matrix pipe alone: %d)\n", seg[1] / nw / kb_wave,
+           seg[2] / nw / kb_wave, seg[3] / nw / kb_wave, seg[4] / nw / kb_wave, (seg[1] + seg[2] + seg[3] + seg[4]) / nw / kb_wave,
            Cfg::TM * Cfg::TN * (CFG_MATH ? 64 : 32) * cwaves / 4);
     printf("  main loop: %.0f ticks, clock %.3f GHz, %.1f us\n", ct / nw, ct / crt * 0.1, crt / nw / 100.0);
     if (cwaves == 8)   // the two waves of a SIMD: first-dispatched half against second-dispatched half
@@ -79,8 +89,8 @@ int main(int argc, char **argv)
                 if (w % waves < cwaves && ((w % waves) >= 4) == half)
                     for (int q = 0; q < 6; ++q) sg[q] += (double)h[(size_t)w * 8 + q];
             const double hw = (double)grid * 4;
-            printf("  waves %s: wait %.0f  barrier %.0f  frags %.0f  pipe %.0f\n", half ? "4-7" : "0-3", sg[1] / hw / kb, sg[2] / hw / kb,
-                   sg[3] / hw / kb, sg[4] / hw / kb);
+            printf("  waves %s: wait %.0f  barrier %.0f  frags %.0f  pipe %.0f\n", half ? "4-7" : "0-3", sg[1] / hw / kb_wave, sg[2] / hw / kb_wave,
+                   sg[3] / hw / kb_wave, sg[4] / hw / kb_wave);
         }
     return 0;
 }
