@@ -74,7 +74,8 @@ int launch_unaligned(const GemmParams &p, hipStream_t stream);
 // one-launch workgroup split-K for dense problems of at most 64 rows (gemm_fp8_wsk_kernel.hpp; dga_launch_menu_g.hip; kernelSerial
 // DGA_KERNEL_SPLITK_WORKGROUP): bit-identical to the two-launch split-K with splitkFactor 8.  DGA_E_TILING for anything else
 int launch_wsk(const GemmParams &p, hipStream_t stream);
-int launch_wsk_dma(const GemmParams &p, hipStream_t stream);   // the LDS-DMA staged builds (M <= 32); DGA_E_TILING: not a problem they take
+// the LDS-DMA staged builds (M <= 32); math 1 = the bf16-exact policy's arithmetic; DGA_E_TILING: not a problem they take
+int launch_wsk_dma(const GemmParams &p, hipStream_t stream, int math = 0);
 int wsk_rows(int m);
 int wsk_max_ntiles(int m);
 

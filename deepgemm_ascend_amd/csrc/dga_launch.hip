@@ -382,6 +382,11 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     // ---- workgroup split-K (kernelSerial 6): one launch, the K slices are the waves of a workgroup; dense, M <= 64.  fp8 matrix
     //      instruction only; a shape it does not take (DGA_E_TILING) falls through to the tiling's tile kernel
     static const int wsk_env = [] { const char *e = std::getenv("DGA_WSK"); return e ? std::atoi(e) : -1; }();
+    if (bf16x && !clock_stamps && groups == 1 && !masked_m && !m_indices && !ix &&
+        (wsk_env >= 0 ? wsk_env != 0 : tiling->kernelSerial == DGA_KERNEL_SPLITK_WORKGROUP)) {
+        const int rc = launch_wsk_dma(p, stream, 1);   // the bf16-exact policy has the LDS-DMA build only (M <= 32)
+        if (rc != DGA_E_TILING) return rc;
+    }
     if (!bf16x && !clock_stamps && groups == 1 && !masked_m && !m_indices && !ix &&
         (wsk_env >= 0 ? wsk_env != 0 : tiling->kernelSerial == DGA_KERNEL_SPLITK_WORKGROUP)) {
         // M <= 32: the LDS-DMA staged build (whole-line requests, hand-counted vmcnt); a tiling with stages = 1 names the register

@@ -24,10 +24,10 @@ static int launch_wsk_one(const GemmParams &p, unsigned grid, hipStream_t stream
     return record_hip(hipGetLastError());
 }
 
-template <int TM, int TN, int D, bool KTAIL, int WAVES = 8>
+template <int TM, int TN, int D, bool KTAIL, int WAVES = 8, int MATH = 0>
 static int launch_wskd_one(const GemmParams &p, unsigned grid, hipStream_t stream)
 {
-    auto kfn = gemm_fp8_wskd_kernel<TM, TN, D, KTAIL, WAVES>;
+    auto kfn = gemm_fp8_wskd_kernel<TM, TN, D, KTAIL, WAVES, MATH>;
     constexpr int kLds = WAVES * D * ((TM + TN) * 16 * 128 + (TM * 16 + 2 + 63) / 64 * 256);
     static_assert(kLds <= 160 * 1024, "LDS of one CU");
     static std::once_flag once[64];
@@ -47,7 +47,8 @@ static int launch_wskd_one(const GemmParams &p, unsigned grid, hipStream_t strea
 // (4-wave forms for up to 64 rows -- four K slices, twice the ring per wave -- were built and measured too: within 5 % of the tile
 //  kernels on 7 of 72 cold shapes, 10-100 % behind elsewhere, profiles/r04_sweep_wskd/table_m64.txt; they are not in the menu.  The
 //  kernel keeps its WAVES parameter.)
-int launch_wsk_dma(const GemmParams &p, hipStream_t stream)
+template <int MATH>
+static int launch_wsk_dma_math(const GemmParams &p, hipStream_t stream)
 {
     if (p.groups != 1 || p.masked_m || p.m_indices || p.row_index || p.splitk > 1 || p.tail_sub || p.m > 32 || p.m <= 0 || (p.k % 16) ||
         p.k <= 0 || (reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.b) & 15) || (p.lda & 15) || (p.ldb & 15) ||
@@ -59,13 +60,18 @@ int launch_wsk_dma(const GemmParams &p, hipStream_t stream)
     const bool kt = (p.k % 128) != 0;
     // (fewer workgroups with three n-tiles each -- a third less A traffic per B byte -- measured worse: 8 x 7168 x 18432 27.9 -> 34.9 us;
     //  every CU streaming counts for more than the A bytes)
-    if (p.m > 16) return kt ? launch_wskd_one<2, 2, 2, true>(p, g, stream) : launch_wskd_one<2, 2, 2, false>(p, g, stream);
+    if (p.m > 16) return kt ? launch_wskd_one<2, 2, 2, true, 8, MATH>(p, g, stream) : launch_wskd_one<2, 2, 2, false, 8, MATH>(p, g, stream);
     // n-tiles per workgroup -> the build that walks them in the fewest passes (every pass re-streams the A rows and pays a round
     // trip); at equal passes the narrower one (deeper ring)
     const int per = static_cast<int>((nt + g - 1) / g);
-    if (per <= 1) return kt ? launch_wskd_one<1, 1, 4, true>(p, g, stream) : launch_wskd_one<1, 1, 4, false>(p, g, stream);
-    if ((per + 2) / 3 < (per + 1) / 2) return kt ? launch_wskd_one<1, 3, 2, true>(p, g, stream) : launch_wskd_one<1, 3, 2, false>(p, g, stream);
-    return kt ? launch_wskd_one<1, 2, 3, true>(p, g, stream) : launch_wskd_one<1, 2, 3, false>(p, g, stream);
+    if (per <= 1) return kt ? launch_wskd_one<1, 1, 4, true, 8, MATH>(p, g, stream) : launch_wskd_one<1, 1, 4, false, 8, MATH>(p, g, stream);
+    if ((per + 2) / 3 < (per + 1) / 2) return kt ? launch_wskd_one<1, 3, 2, true, 8, MATH>(p, g, stream) : launch_wskd_one<1, 3, 2, false, 8, MATH>(p, g, stream);
+    return kt ? launch_wskd_one<1, 2, 3, true, 8, MATH>(p, g, stream) : launch_wskd_one<1, 2, 3, false, 8, MATH>(p, g, stream);
+}
+
+int launch_wsk_dma(const GemmParams &p, hipStream_t stream, int math)
+{
+    return math ? launch_wsk_dma_math<1>(p, stream) : launch_wsk_dma_math<0>(p, stream);
 }
 
 // rows of the build that takes M rows (0: none) and the n-tiles (16 columns) one of its workgroups may own

@@ -1002,6 +1002,17 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out)
     out->swizzleOffset = 4;
     const uint64_t tiles = static_cast<uint64_t>((out->m + bm - 1) / bm) * ((out->n + bn - 1) / bn);
     out->blockDim = static_cast<uint32_t>(tiles * sk);
+    // Decode rows: the workgroup split-K on LDS-DMA rings runs this policy's arithmetic too (gemm_fp8_wskd_kernel<..., MATH = 1>), and
+    // since the stream pays for neither the conversions nor the bf16 matrix rate it takes the fast policy's time: cold, 20-44 % ahead
+    // of this policy's tile kernels on 103 of 120 decode shapes (profiles/r04_wskd_cold_bf16x.txt) -- up to 16 rows wherever a wave
+    // gets at least one k block and the matrix has at most 65536 rows, up to 32 rows on matrices of at most 8192.
+    static const bool no_wsk = [] { const char *e = std::getenv("DGA_NO_WSK_PICK"); return e && std::atoi(e) != 0; }();
+    if (!no_wsk && ((out->m <= 16 && kb >= 8 && out->n <= 65536) || (out->m <= 32 && kb >= 12 && out->n <= 8192))) {
+        out->kernelSerial = DGA_KERNEL_SPLITK_WORKGROUP;
+        out->m1 = out->m <= 16 ? 16 : 32; out->n1 = 128;
+        out->splitkFactor = 1; out->stages = 3; out->swizzleOffset = 1;
+        out->blockDim = std::min<uint32_t>((out->n + 15) / 16, cus);
+    }
     return DGA_OK;
 }
 

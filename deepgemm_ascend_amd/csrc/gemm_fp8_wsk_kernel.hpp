@@ -185,7 +185,11 @@ __global__ void __launch_bounds__(512) gemm_fp8_wsk_kernel(const GemmParams p)
 // (from L2).  Same slices, same per-slice arithmetic, same combine order: bit-identical to the register build and to the
 // two-launch split-K with splitkFactor WAVES.  LDS: WAVES x D x (2 (TM + TN) KB + 256 B); the partial tiles meet in the rings.
 // WAVES = 8 (M <= 32) or 4 (M <= 64: half as many K slices, twice the ring per wave -- what 64 rows of A per stage need).
-template <int TM, int TN, int D, bool KTAIL, int WAVES = 8>
+// MATH = 1: the bf16-exact policy's arithmetic (dispatchPolicyTag 7) on the same rings -- the fragments are up-converted in
+// registers (v_cvt_scalef32_pk_bf16_fp8, exact) and a scale block is four chained v_mfma_f32_16x16x32_bf16 with the k placement of
+// the tile kernel's MATH = 1 loop (gemm_fp8_kernel.hpp): bit-identical to that policy's two-launch split-K.  The stream pays for
+// neither the conversions nor the second matrix rate.
+template <int TM, int TN, int D, bool KTAIL, int WAVES = 8, int MATH = 0>
 __global__ void __launch_bounds__(WAVES * 64) gemm_fp8_wskd_kernel(const GemmParams p)
 {
     constexpr int BM = TM * 16, BNW = TN * 16, ROWS = BM + BNW, NT = WAVES * 64;
@@ -301,13 +305,38 @@ __global__ void __launch_bounds__(WAVES * 64) gemm_fp8_wskd_kernel(const GemmPar
                     // the stage is in registers: refill it (the reads must have returned before the DMA may overwrite it)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     issue_stage(d, kb + d + D);
+                    // MATH = 1: conversion c (0..15) of a fragment: dword c >> 1 of its 32 bytes, half c & 1 -> dword c & 3 of MFMA c >> 2
+                    typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+                    v4i afx[MATH ? TM : 1][4], bfx[MATH ? TN : 1][4];
+                    if constexpr (MATH == 1) {
+                        auto convert = [](const v8i &raw, v4i (&dst)[4]) {
+#pragma unroll
+                            for (int c = 0; c < 16; ++c) {
+                                const int w = raw[c >> 1];
+                                dst[c >> 2][c & 3] = (c & 1) ? __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true))
+                                                             : __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false));
+                            }
+                        };
+#pragma unroll
+                        for (int mt = 0; mt < TM; ++mt) convert(af[mt], afx[mt]);
+#pragma unroll
+                        for (int t = 0; t < TN; ++t) convert(bf[t], bfx[t]);
+                    }
 #pragma unroll
                     for (int t = 0; t < TN; ++t) {
                         if (t < cnt) {
                             const float sb = second_block[t] ? sfb1 : sfb0;
 #pragma unroll
                             for (int mt = 0; mt < TM; ++mt) {
-                                const v4f pr = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[t], af[mt], v4f{0.f, 0.f, 0.f, 0.f},
+                                v4f pr;
+                                if constexpr (MATH == 1) {
+                                    pr = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q)
+                                        pr = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, bfx[t][q]),
+                                                                                     __builtin_bit_cast(v8bf, afx[mt][q]), pr, 0, 0, 0);
+                                } else
+                                pr = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[t], af[mt], v4f{0.f, 0.f, 0.f, 0.f},
                                                                                                0, 0, 0, 0, 0, 0);
                                 const float s = sfa_r[mt] * sb;   // two-level scale: sfa[m, kb] * sfb[n / 128, kb]
                                 acc[mt][t].x = __builtin_fmaf(pr.x, s, acc[mt][t].x);

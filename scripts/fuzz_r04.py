@@ -72,6 +72,10 @@ def main():
         if not same(run(a, sfa, b, sfb, t6), run(a, sfa, b, sfb, t4)):
             print(f"MISMATCH wsk: m={m} n={n} k={k} case {i} seed {seed}")
             return 1
+        if m <= 32 and i % 2:   # the same rings with the bf16-exact policy's arithmetic == that policy's two-launch split-K 8
+            if not same(run(a, sfa, b, sfb, t6, policy="bf16_exact"), run(a, sfa, b, sfb, t4, policy="bf16_exact")):
+                print(f"MISMATCH wsk bf16-exact: m={m} n={n} k={k} case {i} seed {seed}")
+                return 1
         done["wsk"] += 1
         # ---- odd K in place
         m, n = int(rng.integers(1, 600)), int(rng.integers(1, 900))

@@ -60,6 +60,8 @@ def test_bf16_exact_tiling_regret_on_its_held_out_sweep(dga, tmp_path):
     reg, missing = [], 0
     for (m, n, k), cs in shapes.items():
         t = dga.tiling(m, n, k, policy="bf16_exact")
+        if t.kernelSerial == 6:   # decode rows on the workgroup split-K: outside this sweep's menu (profiles/r04_wskd_cold_bf16x.txt)
+            continue
         key = (t.m1, t.n1, max(1, t.splitkFactor))
         if key not in cs:
             missing += 1

@@ -332,7 +332,10 @@ def test_bf16_exact_policy_has_its_own_tiling(dga):
                       (64, 7168, 18432), (8, 18432, 7168), (300, 200, 256), (1279, 5003, 7681)]:
         t = dga.tiling(m, n, k, policy="bf16_exact")
         assert t.dispatchPolicyTag == dga.api.POLICY_BF16_EXACT and (t.m, t.n, t.k) == (m, n, k)
-        if k % 16 == 0:
+        if t.kernelSerial == 6:   # decode rows: the workgroup split-K with this policy's arithmetic
+            assert m <= 32 and (t.m1, t.n1, t.splitkFactor, t.stages) == (16 if m <= 16 else 32, 128, 1, 3)
+            assert t.blockDim == min(-(-n // 16), 256)
+        elif k % 16 == 0:
             assert (t.m1, t.n1) in menu, (m, n, k, t.m1, t.n1)
             assert t.blockDim == -(-m // t.m1) * -(-n // t.n1) * t.splitkFactor
         assert (t.splitkFactor > 1) == (t.kernelSerial == 4)
@@ -340,7 +343,8 @@ def test_bf16_exact_policy_has_its_own_tiling(dga):
     assert (dga.tiling(4096, 4096, 4096, policy="bf16_exact").m1, dga.tiling(4096, 4096, 4096, policy="bf16_exact").n1) == (128, 256)
     mid = dga.tiling(1024, 4096, 7168, policy="bf16_exact")   # 256 tiles of 128x128, one per CU: 57 us against 85 for 128x256 (r03_vgpr_form.txt)
     assert (mid.m1, mid.n1) == (128, 128) and mid.splitkFactor == 1
-    assert dga.tiling(8, 18432, 7168, policy="bf16_exact").m1 == 32
+    assert dga.tiling(8, 18432, 7168, policy="bf16_exact").kernelSerial == 6 and dga.tiling(32, 4096, 7168, policy="bf16_exact").kernelSerial == 6
+    assert dga.tiling(48, 18432, 7168, policy="bf16_exact").m1 in (32, 64) and dga.tiling(32, 18432, 7168, policy="bf16_exact").kernelSerial != 6
     g = dga.tiling(128, 2048, 7168, groups=256, expected_m=128, policy="bf16_exact")
     f = dga.tiling(128, 2048, 7168, groups=256, expected_m=128)
     assert g.dispatchPolicyTag == dga.api.POLICY_BF16_EXACT and (g.m1, g.n1) == (f.m1, f.n1)

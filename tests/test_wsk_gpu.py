@@ -25,7 +25,7 @@ def _bits(t):
     return t.view(torch.int16).cpu().numpy().view(np.uint16)
 
 
-def _run(dga, a, sfa, b, sfb, wsk, split=8):
+def _run(dga, a, sfa, b, sfb, wsk, split=8, policy=None):
     """wsk: False = two-launch split-K `split`; True / "dma" = kernelSerial 6 as the dispatcher builds it (8-wave LDS-DMA rings up to
     32 rows); "reg" = the register build"""
     m, k = a.shape
@@ -38,7 +38,7 @@ def _run(dga, a, sfa, b, sfb, wsk, split=8):
         t.kernelSerial, t.splitkFactor = 4, split
         t.m1, t.n1, t.stages, t.wavesM, t.wavesN, t.dispatchPolicyTag = 64, 128, 3, 1, 4, 0
     out = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device="cuda")
-    dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, sync=True, tiling_=t)
+    dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, sync=True, tiling_=t, policy=policy)
     return _bits(out)
 
 
@@ -78,6 +78,23 @@ def test_decode_shapes_at_full_size(dga, m, n, k):
     ref = _run(dga, a, sfa, b, sfb, False)
     assert np.array_equal(got, ref)
     assert np.array_equal(_run(dga, a, sfa, b, sfb, "reg"), ref)
+
+
+@pytest.mark.parametrize("m,n,k", [
+    (1, 80, 1024), (8, 512, 2048), (16, 1000, 4096 + 16), (17, 333, 1040), (32, 4096, 1024), (5, 48, 16),
+    (16, 16 * 256 + 16, 2048), (9, 16 * 700 + 5, 1024 + 32), (32, 16 * 600, 1152), (13, 72, 8192 + 48),
+])
+def test_bf16_exact_policy_on_the_same_rings(dga, oracle, m, n, k):
+    """dispatchPolicyTag 7 with kernelSerial 6 (M <= 32): bit-identical to that policy's two-launch split-K 8, and inside the
+    policy's bar against the oracle."""
+    from test_bf16_exact_gpu import _assert_bar, EPS, EPS_ARBITRARY
+    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=2 * m + n + k)
+    da, dsfa, db, dsfb = _dev(a), _dev(sfa), _dev(b), _dev(sfb)
+    got = _run(dga, da, dsfa, db, dsfb, "dma", policy="bf16_exact")
+    ref = _run(dga, da, dsfa, db, dsfb, False, policy="bf16_exact")
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} of {got.size} outputs differ from the two-launch split-K"
+    want = oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, threads=8)
+    _assert_bar(oracle, got, want, a, sfa, b, sfb, eps=EPS if k >= 128 else EPS_ARBITRARY)
 
 
 def test_shapes_it_does_not_take_fall_through(dga, oracle):
