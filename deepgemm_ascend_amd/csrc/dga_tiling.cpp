@@ -978,6 +978,19 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out)
     int rc = dga_tiling(problem, out);
     if (rc != DGA_OK) return rc;
     out->dispatchPolicyTag = DGA_POLICY_BF16_EXACT;
+    // Masked grouped layout: this policy's loop multiplies every row of its tile (no per-m-tile skipping as in the fast kernels), so the
+    // tile height follows the caller's hint where it says the experts are nearly empty -- rows present 0..16: 832 -> 597 us on
+    // 256 x (128, 7168, 2048) with 32 x 128 tiles, 0..32: 886 -> 628, 0..64: 938 -> 734 with 64 x 256 (scripts/grouped_decode_bf16x.py,
+    // profiles/r04_grouped_decode_bf16x.txt).  A hint that is too low costs time only (every further tile row of an expert streams its
+    // weights again), never rows: the raster still covers m_max.
+    if (std::max<uint32_t>(1, out->groups) > 1 && !out->contiguous && problem->expected_m > 0 && problem->expected_m <= 64 && out->m > 64 &&
+        out->k >= 128 && (out->k % 16) == 0) {
+        out->m1 = problem->expected_m <= 32 ? 32 : 64;
+        out->n1 = problem->expected_m <= 32 ? 128 : 256;
+        out->stages = 3; out->wavesM = 0; out->wavesN = 0; out->splitkFactor = 1; out->kernelSerial = DGA_KERNEL_COMMON;
+        out->blockDim = out->groups * ((out->m + out->m1 - 1) / out->m1) * ((out->n + out->n1 - 1) / out->n1);
+        return DGA_OK;
+    }
     if (std::max<uint32_t>(1, out->groups) > 1 || out->contiguous || !out->m || !out->n || out->k < 128 || (out->k % 16)) return DGA_OK;
     using namespace dga::tiling;
     const uint32_t cus = dga::device_cus(), kb = (out->k + 127) / 128;
