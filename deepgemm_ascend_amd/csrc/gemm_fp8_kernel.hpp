@@ -849,6 +849,24 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         DGA_STAMP_START();
         loop_clock.tick();
         int cur = 0, nxt = 1, fill = 2;
+        // A wave whose rows all lie at or beyond M -- the masked grouped layout with an expert that has fewer rows than the tile is
+        // tall, a dense problem's ragged last tile row -- multiplies nothing: it keeps its share of the refill DMA and the barriers,
+        // and its SIMD partner gets the issue slots (256 x (128, 7168, 2048), random masks, two runs each on one box: 888 / 904 -> 853 / 870 us;
+        // full mask unchanged, 983 -> 988).
+        const bool rows_present = m0 + wm * (BM / Cfg::kWM) < M;   // (wave-uniform)
+        if (!rows_present) {
+            for (int kb = kb_begin; kb < kb_end; ++kb) {
+                wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int idx = 0; idx < NL; ++idx) issue_one(idx, fill, kb + 2);
+                const int f = cur;
+                cur = nxt; nxt = fill; fill = f;
+            }
+            wait_vmcnt<0>();
+            return;
+        }
         for (int kb = kb_begin; kb < kb_end; ++kb) {
             wait_vmcnt<0>();                         // this wave's pieces of block kb + 1 (issued a block ago) have landed
             DGA_STAMP(1);
