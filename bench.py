@@ -476,6 +476,19 @@ def shape_list_leg(dga, iters=20):
                          "policy": int(t.dispatchPolicyTag), "us": round(us, 2), "us_eager": round(us_eager, 2), "timing": timing, "tflops": round(flops / us / 1e6, 1),
                          "gbps": round(byt / us / 1e3, 1), "bound": bound, "frac": round(max(t_mfma, t_hbm) / us, 4),
                          "parity_ok": bool(ok), "frac_gt_2ulp": frac})
+            if m <= 128 and k % 16 == 0:
+                # the short-M rows under the in-contract policy (bf16-exact arithmetic, its own tiling): decode rows stream their weights,
+                # so the exact arithmetic costs them little -- up to 16-32 rows it runs on the same one-launch kernel as the fast policy
+                tb = dga.tiling(m, n, k, policy="bf16_exact")
+                fb = lambda: dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, tiling_=tb, policy="bf16_exact")
+                fb(); torch.cuda.synchronize()
+                okb, fracb = sweep.is_correct(golden, out, s_abs, policy="bf16_exact", short_k=k < 128)
+                try:
+                    usb = _graph_us(fb, n_it)
+                except Exception:
+                    usb = _prewarmed_us(fb, n_it, 30.0)
+                rows[-1].update({"us_in_contract": round(usb, 2), "in_contract_kernel": int(tb.kernelSerial), "in_contract_parity_ok": bool(okb),
+                                 "in_contract_frac_gt_2ulp": fracb})
             if k % 16:
                 # the same bytes in rows round_up(K, 16) apart with zero tails (what the quantisers' aligned_rows forms write):
                 # read in place, no padding pass -- both operands, and the weights alone (padded once at load time)
@@ -500,7 +513,8 @@ def shape_list_leg(dga, iters=20):
         except Exception as e:
             rows.append({"m": m, "n": n, "k": k, "error": repr(e)})
     return {"source": "framework/benchmark/benchmark.py:24-44 (the reference's sweep shape list)", "protocol": "warm, auto tiling, fast policy; us = device time per call (the calls captured into a HIP graph and replayed), "
-                        "us_eager = launch interval of the same calls issued one by one from Python (host-bound below ~6 us); K % 16 != 0 rows: "
+                        "us_eager = launch interval of the same calls issued one by one from Python (host-bound below ~6 us); M <= 128 rows: us_in_contract = the "
+                        "bf16-exact policy with its own tiling (in_contract_kernel 6 = the one-launch workgroup split-K); K % 16 != 0 rows: "
                         "us = contiguous operands (padding pass + tile kernel), us_rows_aligned = both operands in 16-byte aligned zero-tailed rows "
                         "(read in place), us_weights_aligned = only the weights",
             "shapes": rows}
