@@ -82,7 +82,6 @@ gemm_fp8_bf16x_aimage_kernel(const GemmParams p)
     LoopClock<CLK> loop_clock;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
-    typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
