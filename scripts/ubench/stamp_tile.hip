@@ -30,9 +30,11 @@ int main(int argc, char **argv)
     const int m = argc > 1 ? atoi(argv[1]) : 4096, n = argc > 2 ? atoi(argv[2]) : 2048, k = argc > 3 ? atoi(argv[3]) : 7168;
     const int warm = argc > 4 ? atoi(argv[4]) : 3000;
     const int splitk = argc > 5 ? atoi(argv[5]) : 1;
+    const int groups = argc > 6 ? atoi(argv[6]) : 1;      // masked grouped layout: `groups` problems of M x N x K ...
+    const int rows = argc > 7 ? atoi(argv[7]) : m;        // ... with masked_m[g] = rows
     typedef GemmCfg<CFG_BM, CFG_BN, CFG_WM, CFG_WN, CFG_ST, CFG_LC> Cfg;
     GemmParams p{};
-    std::vector<uint8_t> ha((size_t)m * k), hb((size_t)n * k);
+    std::vector<uint8_t> ha((size_t)m * k), hb((size_t)n * k * groups);
     srand(1);
     for (auto &v : ha) { v = rand() & 0xFF; if ((v & 0x7F) == 0x7F) v &= 0x80; if ((v & 0x78) > 0x60) v &= 0xBF; }
     for (auto &v : hb) { v = rand() & 0xFF; if ((v & 0x7F) == 0x7F) v &= 0x80; if ((v & 0x78) > 0x60) v &= 0xBF; }
@@ -46,6 +48,12 @@ int main(int argc, char **argv)
     p.a = a; p.sfa = sfa; p.b = b; p.sfb = sfb; p.out = out; p.m = m; p.n = n; p.k = k; p.kb_n = kb; p.nb_n = nb;
     p.lda = k; p.ldb = k; p.ldc = n; p.groups = 1; p.b_groups = 1; p.sfa_ld = kb; p.splitk = 1;
     p.tiles_m = (m + Cfg::kBM - 1) / Cfg::kBM; p.tiles_n = (n + Cfg::kBN - 1) / Cfg::kBN;
+    if (groups > 1) {   // every group multiplies the same A and scales with its own B
+        p.groups = groups; p.b_groups = groups; p.a_gs = 0; p.sfa_gs = 0; p.sfb_gs = 0; p.b_gs = (int64_t)n * k; p.c_gs = 0;
+        std::vector<int> hm(groups, rows);
+        int *dm; hipMalloc(&dm, groups * 4); hipMemcpy(dm, hm.data(), groups * 4, hipMemcpyHostToDevice);
+        p.masked_m = dm;
+    }
     p.raster_group = 4; p.xcd_remap = 1;
     const int kb_total = kb;
     if (splitk > 1) {
@@ -56,7 +64,7 @@ int main(int argc, char **argv)
         p.partial = slab;
     }
     const int kb_wave = splitk > 1 ? p.kb_per_split : kb_total;   // k blocks one wave walks
-    const int grid = p.tiles_m * p.tiles_n * splitk, waves = Cfg::NT / 64, cwaves = Cfg::kWM * Cfg::kWN;
+    const int grid = p.tiles_m * p.tiles_n * splitk * groups, waves = Cfg::NT / 64, cwaves = Cfg::kWM * Cfg::kWN;
     hipMalloc(&st, (size_t)grid * waves * 8 * 8); hipMemset(st, 0, (size_t)grid * waves * 8 * 8);
     p.stamps = st;
     auto kfn = gemm_fp8_blockscaled_nt_kernel<Cfg, 0, false, false, CFG_MATH>;
