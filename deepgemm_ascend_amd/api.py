@@ -17,6 +17,7 @@ PyTorch is used only for device memory and the current stream.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -127,7 +128,11 @@ POLICY_BF16_EXACT = 7
 #   "fast"        the fp8 matrix instruction (whatever schedule the tiling names) -- the throughput form
 #   "bf16_exact"  e4m3 -> bf16 in registers (exact), bf16 matrix instruction: exact products, fp32-class block sums
 #   "strict"      fp32-input matrix instruction in the oracle's own order: bit-identical to the reference CPU path
-ARITHMETIC_POLICIES = {"fast": None, "bf16_exact": POLICY_BF16_EXACT, "strict": POLICY_STRICT}
+#   "auto"        "bf16_exact" where it is nearly free -- the decode rows the one-launch workgroup split-K takes (the weights are
+#                 streamed, the exact arithmetic rides along: +2..+15 %) -- and "fast" everywhere else; dense calls without an
+#                 explicit tiling only.  $DGA_DEFAULT_POLICY names the policy of calls that pass none (default: "fast").
+ARITHMETIC_POLICIES = {"fast": None, "bf16_exact": POLICY_BF16_EXACT, "strict": POLICY_STRICT, "auto": None}
+_DEFAULT_POLICY = os.environ.get("DGA_DEFAULT_POLICY") or None
 
 
 def _with_policy(t: Tiling, strict: bool, policy: Optional[str] = None) -> Tiling:
@@ -176,11 +181,21 @@ def _planned(index: int, m: int, n: int, k: int, groups: int, expected_m: int, c
              policy: Optional[str]) -> Tiling:
     """tiling(...) + the arithmetic policy's tag, remembered per problem: the C side's (m,n,k) cache answers the same question, but
     through two ctypes calls and a struct copy per GEMM.  Dropped whenever the cache file, the cache or the predictor changes."""
+    if policy is None and not strict:
+        policy = _DEFAULT_POLICY
     key = (index, m, n, k, groups, expected_m, contiguous, strict, policy)
     t = _PLANS.get(key)
     if t is None:
         if len(_PLANS) > 4096:
             _PLANS.clear()
+        if policy == "auto":   # the exact arithmetic where the decode kernel carries it, the fast path elsewhere
+            tb = tiling(m, n, k, policy="bf16_exact") if groups == 1 and not contiguous else None
+            if tb is not None and tb.kernelSerial == 6:   # DGA_KERNEL_SPLITK_WORKGROUP
+                t = tb
+            else:
+                t = tiling(m, n, k, groups=groups, expected_m=expected_m, contiguous=contiguous)
+            _PLANS[key] = t
+            return t
         t = tiling(m, n, k, groups=groups, expected_m=expected_m, contiguous=contiguous, policy=policy if policy == "bf16_exact" else None)
         t = _PLANS[key] = _with_policy(t, strict, policy)
     return t

@@ -97,6 +97,20 @@ def test_bf16_exact_policy_on_the_same_rings(dga, oracle, m, n, k):
     _assert_bar(oracle, got, want, a, sfa, b, sfb, eps=EPS if k >= 128 else EPS_ARBITRARY)
 
 
+def test_policy_auto_is_exact_where_the_decode_kernel_carries_it(dga, oracle):
+    """policy="auto": the bf16-exact arithmetic on the rows the workgroup split-K takes, the fast policy elsewhere (same bytes as
+    naming the policy)."""
+    for (m, n, k), exact in (((8, 512, 2048), True), ((16, 4096, 7168), True), ((256, 512, 1024), False), ((64, 18432, 1024), False)):
+        a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=m + k)
+        ops = ((_dev(a), _dev(sfa)), (_dev(b), _dev(sfb)))
+        outs = {}
+        for pol in ("auto", "bf16_exact", "fast"):
+            out = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device="cuda")
+            dga.gemm_fp8_fp8_bf16_nt(*ops, out, sync=True, policy=pol)
+            outs[pol] = _bits(out)
+        assert np.array_equal(outs["auto"], outs["bf16_exact" if exact else "fast"]), (m, n, k)
+
+
 def test_shapes_it_does_not_take_fall_through(dga, oracle):
     """M > 64 with kernelSerial 6 runs the tiling's tile kernel (same answer as without the request)."""
     m, n, k = 96, 256, 512
