@@ -1008,6 +1008,14 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out)
             if (us < best) { best = us; bm = c.bm; bn = c.bn; sk = s_eff; }
         }
     }
+    // Short-M rows on the tiles of which two workgroups share a CU (64x128, 32x128: 75 / 63 KB of LDS): the fitted model stops splitting
+    // once every CU has a workgroup, but these rows are streams and the second workgroup per CU is more bytes in flight -- cold,
+    // 64 x 7168 x 18432 48.2 -> 40.1 us and 64 x 7168 x 16384 43.9 -> 36.3 with 8 splits instead of 4, 128 x 4096 x 7168 23.9 -> 22.5
+    // (scripts/bf16x_decode_sweep.py).  Double the split while the grid stays within two workgroups per CU and a split keeps >= 4 k blocks.
+    if (out->m <= 128 && bn == 128 && bm <= 64 && kb >= 16) {   // (K < 2048: 64 x 24576 x 1536 is best unsplit)
+        const uint64_t tiles0 = static_cast<uint64_t>((out->m + bm - 1) / bm) * ((out->n + bn - 1) / bn);
+        while (tiles0 * sk * 2 <= 2ull * cus && kb / (2 * sk) >= 4 && static_cast<uint64_t>(2 * sk) * out->m * out->n * 4 <= kMaxSlabBytes) sk *= 2;
+    }
     out->m1 = static_cast<uint16_t>(bm); out->n1 = static_cast<uint16_t>(bn);
     out->splitkFactor = static_cast<uint16_t>(sk);
     out->kernelSerial = sk > 1 ? DGA_KERNEL_STREAMK : DGA_KERNEL_COMMON;
