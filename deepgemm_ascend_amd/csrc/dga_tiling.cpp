@@ -991,7 +991,12 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out)
         out->blockDim = out->groups * ((out->m + out->m1 - 1) / out->m1) * ((out->n + out->n1 - 1) / out->n1);
         return DGA_OK;
     }
-    if (std::max<uint32_t>(1, out->groups) > 1 || out->contiguous || !out->m || !out->n || out->k < 128 || (out->k % 16)) return DGA_OK;
+    if (std::max<uint32_t>(1, out->groups) > 1 || out->contiguous || !out->m || !out->n || out->k < 128 || (out->k % 16)) {
+        // grouped layouts keep the fast tiling's tile -- but not its wave layout: 2 x 2 waves would name this policy's 4-wave IMAGE build
+        // (dga_launch.hip), 4-10 % behind the in-register build on the grouped stream and without its row skipping
+        out->wavesM = out->wavesN = 0;
+        return DGA_OK;
+    }
     using namespace dga::tiling;
     const uint32_t cus = dga::device_cus(), kb = (out->k + 127) / 128;
     double best = 1e300;

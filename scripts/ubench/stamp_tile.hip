@@ -48,8 +48,17 @@ int main(int argc, char **argv)
     p.a = a; p.sfa = sfa; p.b = b; p.sfb = sfb; p.out = out; p.m = m; p.n = n; p.k = k; p.kb_n = kb; p.nb_n = nb;
     p.lda = k; p.ldb = k; p.ldc = n; p.groups = 1; p.b_groups = 1; p.sfa_ld = kb; p.splitk = 1;
     p.tiles_m = (m + Cfg::kBM - 1) / Cfg::kBM; p.tiles_n = (n + Cfg::kBN - 1) / Cfg::kBN;
-    if (groups > 1) {   // every group multiplies the same A and scales with its own B
-        p.groups = groups; p.b_groups = groups; p.a_gs = 0; p.sfa_gs = 0; p.sfb_gs = 0; p.b_gs = (int64_t)n * k; p.c_gs = 0;
+    if (groups > 1) {   // every group has its own A, B and output (argv[8] = 1: one A for all -- L2-resident)
+        const bool shared_a = argc > 8 && atoi(argv[8]) == 1;
+        uint8_t *ag = a; uint16_t *og = out;
+        if (!shared_a) {
+            hipMalloc(&ag, (size_t)groups * m * k);
+            for (int g = 0; g < groups; ++g) hipMemcpy(ag + (size_t)g * m * k, a, (size_t)m * k, hipMemcpyDeviceToDevice);
+            hipMalloc(&og, (size_t)groups * m * n * 2);
+            p.a = ag; p.out = og;
+        }
+        p.groups = groups; p.b_groups = groups; p.a_gs = shared_a ? 0 : (int64_t)m * k; p.sfa_gs = 0; p.sfb_gs = 0; p.b_gs = (int64_t)n * k;
+        p.c_gs = shared_a ? 0 : (int64_t)m * n;
         std::vector<int> hm(groups, rows);
         int *dm; hipMalloc(&dm, groups * 4); hipMemcpy(dm, hm.data(), groups * 4, hipMemcpyHostToDevice);
         p.masked_m = dm;

@@ -348,5 +348,6 @@ def test_bf16_exact_policy_has_its_own_tiling(dga):
     g = dga.tiling(128, 2048, 7168, groups=256, expected_m=128, policy="bf16_exact")
     f = dga.tiling(128, 2048, 7168, groups=256, expected_m=128)
     assert g.dispatchPolicyTag == dga.api.POLICY_BF16_EXACT and (g.m1, g.n1) == (f.m1, f.n1)
+    assert (g.wavesM, g.wavesN) != (2, 2) and g.stages == 3   # (2 x 2 waves / two stages would name the policy's slower image builds)
     assert dga.tiling(4096, 4096, 4096).dispatchPolicyTag != dga.api.POLICY_BF16_EXACT      # the cache entry is the fast path's
     assert dga.tiling(4096, 4096, 4096, policy="strict").dispatchPolicyTag == dga.api.POLICY_STRICT
