@@ -351,17 +351,18 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     const Bf16xVariant *vx = bf16x ? find_bf16x_variant(tiling->m1, tiling->n1) : nullptr;
     if (bf16x && (!vx || clock_stamps)) return DGA_E_TILING;
     // the 128 x 256 tile's image builds (bf16 LDS image converted once per workgroup; same bits as the in-register build; dense
-    // and masked-grouped layouts).  They measured 10 % SLOWER than the in-register build (profiles/r04_bximg_stamps.txt: two
-    // barriers per k block and twice the LDS bytes on a power-bound loop), so they run only when asked for: a tiling with
-    // wavesM = wavesN = 2 takes the 4-wave build, one with two stages the 8-wave build, one with four (two A image stages + two
-    // B stages) the A-image build (gemm_fp8_bf16x_aimage_kernel.hpp); $DGA_BX_IMAGE = 0 / 1 (A image) / 4 / 8 overrides.
+    // and masked-grouped layouts).  Both-operand images measured 10 % SLOWER than the in-register build, the A-only image ties it
+    // (profiles/r04_bximg_stamps.txt, r04_aimage.txt), so they run only when NAMED: tiling.stages = 4 (A image), 5 (both operands, 8
+    // waves), 6 (both operands, 4 waves), or $DGA_BX_IMAGE = 1 / 8 / 4 (0: never).  (Stage counts no tile build has, so that a fast-path
+    // tiling that is handed this policy's tag -- 2 x 2 waves, two stages -- cannot name one by accident: it did, for a while, on every
+    // grouped call of the policy.)
     static const int bx_image_env = [] { const char *e = std::getenv("DGA_BX_IMAGE"); return e ? std::atoi(e) : -1; }();
     int bx_image = 0;
     if (vx && vx->bm == 128 && vx->bn == 256 && !m_indices && !ix) {
         if (bx_image_env >= 0) bx_image = bx_image_env == 4 ? 4 : (bx_image_env == 1 ? 1 : (bx_image_env ? 8 : 0));
-        else if (tiling->wavesM == 2 && tiling->wavesN == 2) bx_image = 4;
-        else if (tiling->stages == 2 && tiling->wavesM == 2 && tiling->wavesN == 4) bx_image = 8;
-        else if (tiling->stages == 4 && tiling->wavesM == 2 && tiling->wavesN == 4) bx_image = 1;
+        else if (tiling->stages == 4) bx_image = 1;
+        else if (tiling->stages == 5) bx_image = 8;
+        else if (tiling->stages == 6) bx_image = 4;
     }
     const Variant *v = find_variant(tiling->m1, tiling->n1, tiling->wavesM, tiling->wavesN, tiling->stages);
     if (!v && !vx) return DGA_E_TILING;

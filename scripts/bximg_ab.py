@@ -19,8 +19,8 @@ from scripts.policy_perf import time_us  # noqa: E402
 def tiling(m, n, k, image, raster=4):
     t = dga.tiling(m, n, k)
     t.m1, t.n1, t.splitkFactor, t.kernelSerial = 128, 256, 1, 0
-    t.dispatchPolicyTag, t.stages, t.swizzleOffset = 7, {0: 3, 1: 4}.get(image, 2), raster
-    t.wavesM, t.wavesN = (2, 2) if image == 4 else (2, 4)
+    t.dispatchPolicyTag, t.stages, t.swizzleOffset = 7, {0: 3, 1: 4, 8: 5, 4: 6}[image], raster
+    t.wavesM, t.wavesN = 2, 4
     return t
 
 

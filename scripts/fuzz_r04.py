@@ -54,8 +54,8 @@ def main():
         for image in (0, 8, 4, 1):
             t = dga.tiling(m, n, k)
             t.m1, t.n1, t.splitkFactor, t.kernelSerial, t.dispatchPolicyTag = 128, 256, sk, (4 if sk > 1 else 0), 7
-            t.stages, t.swizzleOffset = {0: 3, 1: 4}.get(image, 2), raster
-            t.wavesM, t.wavesN = (2, 2) if image == 4 else (2, 4)
+            t.stages, t.swizzleOffset = {0: 3, 1: 4, 8: 5, 4: 6}[image], raster
+            t.wavesM, t.wavesN = 2, 4
             outs.append(run(a, sfa, b, sfb, t, policy="bf16_exact"))
         if not (same(outs[0], outs[1]) and same(outs[0], outs[2]) and same(outs[0], outs[3])):
             print(f"MISMATCH image: m={m} n={n} k={k} splitk={sk} raster={raster} case {i} seed {seed}")

@@ -15,7 +15,7 @@ for mask, masked in (("full", torch.full((G,), MMAX, dtype=torch.int32, device="
                      ("random", torch.randint(0, 129, (G,), dtype=torch.int32, device="cuda", generator=g))):
     rows = int(masked.sum()); byt = G * N * K + rows * (K + 4 * (K // 128) + 2 * N)
     ref = None
-    for name, st, wv in (("in-register", 3, (2, 4)), ("a-image", 4, (2, 4)), ("image8", 2, (2, 4)), ("image4", 2, (2, 2))):
+    for name, st, wv in (("in-register", 3, (2, 4)), ("a-image", 4, (2, 4)), ("image8", 5, (2, 4)), ("image4", 6, (2, 4))):
         t = dga.tiling(MMAX, N, K, groups=G, expected_m=MMAX, policy="bf16_exact")
         t.m1, t.n1, t.stages, t.wavesM, t.wavesN = 128, 256, st, wv[0], wv[1]
         out = torch.zeros((G, MMAX, N), dtype=torch.bfloat16, device="cuda")

@@ -6,9 +6,10 @@ placement, then the same fp32 promotion (the counterpart of the reference's devi
 /root/reference/deep_gemm_ascend/framework/csrc/jit/generate_code.hpp:123-369, held to the fp32 golden of
 framework/tests/test.py:19-64) -- so the bar between them is BIT IDENTITY; against the oracle it is the policy's bar
 (tests/test_bf16_exact_gpu.py).  Two image builds: 8 waves (two per SIMD, 64 x 64 wave tiles: the default of the 128 x 256 tile)
-and 4 waves (one per SIMD, 64 x 128; a tiling that names the 2 x 2 wave layout).  A tiling that names the 2 x 4 layout with three
-LDS stages keeps the in-register build.  A third build shares only the A-matrix tile through the image (gemm_fp8_bf16x_aimage_kernel.hpp,
-8 waves; B-matrix fragments converted in registers; a 2 x 4 tiling with stages = 4): `waves` = 1 below.
+and 4 waves (one per SIMD, 64 x 128).  A third build shares only the A-matrix tile through the image
+(gemm_fp8_bf16x_aimage_kernel.hpp, 8 waves; B-matrix fragments converted in registers): `waves` = 1 below.  The builds run only when
+a tiling NAMES them through a stage count no tile build has (4 = A image, 5 / 6 = both operands on 8 / 4 waves); every other tiling
+of the policy -- 2 x 2 waves and two stages included -- keeps the in-register build.
 """
 import sys
 from pathlib import Path
@@ -32,9 +33,9 @@ def _tiling(dga, m, n, k, image, splitk=1, raster=4, groups=1):
     t = dga.tiling(m, n, k, groups=groups) if groups > 1 else dga.tiling(m, n, k)
     t.m1, t.n1, t.splitkFactor, t.kernelSerial = 128, 256, splitk, (4 if splitk > 1 else 0)
     t.dispatchPolicyTag = 7
-    t.stages = {0: 3, 1: 4}.get(image, 2)
+    t.stages = {0: 3, 1: 4, 8: 5, 4: 6}[image]   # (stage counts no tile build has name the image builds)
     t.swizzleOffset = raster
-    t.wavesM, t.wavesN = (2, 2) if image == 4 else (2, 4)
+    t.wavesM, t.wavesN = 2, 4
     return t
 
 
