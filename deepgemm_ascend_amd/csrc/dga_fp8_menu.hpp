@@ -67,6 +67,8 @@ DGA_MENU_BX(DGA_MENU_EXTERN_BX)
 // converted once per workgroup into a bf16 LDS image; waves = 8 (two per SIMD, 64 x 64 wave tiles) or 4 (one per SIMD, 64 x 128).  Dense and masked-grouped rasters (split-K too);
 // DGA_E_TILING for the contiguous / indexed layouts
 int launch_bf16x_image(const GemmParams &p, int waves, hipStream_t stream);
+// the persistent form of the 128 x 256 in-register build (dense / masked grouped rasters); DGA_E_TILING: not a launch it takes
+int launch_bf16x_persistent(const GemmParams &p, hipStream_t stream);
 
 // loader-wave build of the 128 x 256 tile for rows that start at any byte (K % 16 != 0, no padded copy; dga_launch_menu_d.hip)
 int launch_unaligned(const GemmParams &p, hipStream_t stream);

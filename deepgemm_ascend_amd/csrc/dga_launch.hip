@@ -426,7 +426,23 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     }
     static const int pp_env = [] { const char *e = std::getenv("DGA_PINGPONG"); return e ? std::atoi(e) : -1; }();
     const int policy = pp_env >= 0 ? pp_env : tiling->dispatchPolicyTag;
-    if (vx) return bx_image ? launch_bf16x_image(p, bx_image, stream) : vx->launch(p, stream);   // bf16-exact: one launch over the whole raster
+    if (vx) {   // bf16-exact: one launch over the whole raster
+        if (bx_image) return launch_bf16x_image(p, bx_image, stream);
+        // the 128 x 256 tile's persistent form (gemm_fp8_bf16x_persistent_kernel.hpp; same bits).  The dispatcher hides most of a tile
+        // boundary already, so it pays little -- masked grouped 256 x (128, 7168, 2048): full mask 1010 -> 998 us, random masks
+        // 856 -> 835; 4096^3 114.1 -> 113.4; configs[2], 1.75 tiles per CU, 97.3 -> 98.5 (profiles/r04_bf16x_persistent_ab.txt) --
+        // and runs on the masked grouped layout and on dense rasters that give every CU the same number of tiles.  tiling.stages = 7
+        // names it, 8 names the one-tile build, $DGA_BF16X_PERSIST = 0 / 1 overrides.
+        static const int bxp_env = [] { const char *e = std::getenv("DGA_BF16X_PERSIST"); return e ? std::atoi(e) : -1; }();
+        const int64_t tiles = static_cast<int64_t>(p.groups) * p.tiles_m * p.tiles_n, cus = static_cast<int64_t>(device_cus());
+        const bool pays = tiles > cus && (masked_m || tiles % cus == 0);
+        if (vx->bm == 128 && vx->bn == 256 && !clock_stamps &&
+            (bxp_env >= 0 ? bxp_env != 0 : (tiling->stages == 7 || (tiling->stages != 8 && pays)))) {
+            const int rc = launch_bf16x_persistent(p, stream);
+            if (rc != DGA_E_TILING) return rc;
+        }
+        return vx->launch(p, stream);
+    }
     auto launch_main = [&](const GemmParams &q) -> int {
         if (q.stamps) {
             auto clk = find_clock_build(v, (policy == 2 || policy == DGA_POLICY_CONTINUOUS_PERSISTENT) && v->launch_cont ? 2 : (policy == DGA_POLICY_LOADER_WAVES && v->launch_lc ? policy : 0));
