@@ -13,6 +13,9 @@
 // Dense and masked grouped rasters; K of at least two k blocks; no split-K, no indexed rows, no contiguous layout (those keep the
 // one-tile build).  A wave whose rows all lie at or beyond M multiplies nothing in that tile (it keeps its share of the refill DMA
 // and the barriers); when its next tile has rows again it sets its fragments up from the stage that tile's block 0 has landed in.
+// (Tried and dropped: per-wave loop variants that multiply only the 1, 2 or 4 m-tiles holding rows.  Same bits, but with four variants
+//  of the 64-gap body in one function the full-schedule loop -- 239 of 256 VGPRs on its own -- lost 13 % (4096^3 120 -> 136 us) and the
+//  short ones did not reach the tile-height hint of dga_tiling_bf16_exact (0..16 rows per expert: 773 us against 617).)
 // Counterpart in the reference: its kernel is persistent by construction -- one block per AI core walks the tiles of its section
 // with double-buffered L1 across them (/root/reference/deep_gemm_ascend/framework/csrc/jit/generate_code.hpp:160-198).
 #pragma once
