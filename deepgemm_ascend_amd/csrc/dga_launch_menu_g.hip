@@ -43,6 +43,25 @@ static int launch_wskd_one(const GemmParams &p, unsigned grid, hipStream_t strea
     return record_hip(hipGetLastError());
 }
 
+template <int TM, int TN, int D, bool KTAIL, int MATH>
+static int launch_wskc_one(const GemmParams &p, unsigned grid, hipStream_t stream)
+{
+    auto kfn = gemm_fp8_wskc_kernel<TM, TN, D, KTAIL, MATH>;
+    constexpr int kLds = 8 * (D * ((TM + TN) * 16 * 128 + (TM * 16 + 2 + 63) / 64 * 256) + TM * 16 * TN * 16 * 4);
+    static_assert(kLds <= 160 * 1024, "LDS of one CU");
+    static std::once_flag once[64];
+    static hipError_t attr_err[64];
+    int dev = 0;
+    if (int rc = record_hip(hipGetDevice(&dev))) return rc;
+    if (dev < 0 || dev >= 64) return DGA_E_HIP;
+    std::call_once(once[dev], [&] {
+        attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    });
+    if (int rc = record_hip(attr_err[dev])) return rc;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), kLds, stream, p);
+    return record_hip(hipGetLastError());
+}
+
 // the LDS-DMA staged builds (M <= 32): one workgroup per CU (or per n-tile where there are fewer), each walking its n-tiles TN at a time.
 // (4-wave forms for up to 64 rows -- four K slices, twice the ring per wave -- were built and measured too: within 5 % of the tile
 //  kernels on 7 of 72 cold shapes, 10-100 % behind elsewhere, profiles/r04_sweep_wskd/table_m64.txt; they are not in the menu.  The
@@ -64,6 +83,17 @@ static int launch_wsk_dma_math(const GemmParams &p, hipStream_t stream)
     // n-tiles per workgroup -> the build that walks them in the fewest passes (every pass re-streams the A rows and pays a round
     // trip); at equal passes the narrower one (deeper ring)
     const int per = static_cast<int>((nt + g - 1) / g);
+    // more n-tiles per workgroup than one pass holds: the continuous-ring builds (gemm_fp8_wskc_kernel: the refill runs on across
+    // the passes).  Three tiles per pass where that saves a pass without leaving a single tile to the last one, two otherwise
+    // (cold, M = 8: 18432 x 7168 30.8 -> 28.7 us, 16384 x 7168 26.6 -> 24.7, 28672 x 4096 31.3 -> 27.9; $DGA_WSK_CONT = 0 keeps the
+    // pass-by-pass build).
+    static const int cont_env = [] { const char *e = std::getenv("DGA_WSK_CONT"); return e ? std::atoi(e) : 1; }();
+    const int p2 = (per + 1) / 2, p3 = (per + 2) / 3;
+    if (cont_env && per >= 4) {
+        if (p3 < p2 && per % 3 != 1)
+            return kt ? launch_wskc_one<1, 3, 2, true, MATH>(p, g, stream) : launch_wskc_one<1, 3, 2, false, MATH>(p, g, stream);
+        return kt ? launch_wskc_one<1, 2, 2, true, MATH>(p, g, stream) : launch_wskc_one<1, 2, 2, false, MATH>(p, g, stream);
+    }
     if (per <= 1) return kt ? launch_wskd_one<1, 1, 4, true, 8, MATH>(p, g, stream) : launch_wskd_one<1, 1, 4, false, 8, MATH>(p, g, stream);
     if ((per + 2) / 3 < (per + 1) / 2) return kt ? launch_wskd_one<1, 3, 2, true, 8, MATH>(p, g, stream) : launch_wskd_one<1, 3, 2, false, 8, MATH>(p, g, stream);
     return kt ? launch_wskd_one<1, 2, 3, true, 8, MATH>(p, g, stream) : launch_wskd_one<1, 2, 3, false, 8, MATH>(p, g, stream);

@@ -588,12 +588,15 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
     // a k block or two each, more rows double the A share of every stage: the tile kernels keep those.
     // $DGA_NO_WSK_PICK = 1 keeps the tile kernels (A/B scripts).
     static const bool no_wsk = [] { const char *e = std::getenv("DGA_NO_WSK_PICK"); return e && std::atoi(e) != 0; }();
-    if (!no_wsk && groups == 1 && !contiguous && t.m <= 16 && (t.k % 16) == 0 && kb >= 16 && kb <= 144 && t.n <= 10240) {
+    // (wider matrices, up to 32768 rows with K >= 4096, take its continuous-ring build: 3-7 % ahead on 16384 / 18432 x 7168 and
+    //  28672 x 4096, profiles/r04_sweep_wskd/table_wide.txt)
+    if (!no_wsk && groups == 1 && !contiguous && t.m <= 16 && (t.k % 16) == 0 && kb >= 16 && kb <= 144 &&
+        (t.n <= 10240 || (t.n <= 32768 && kb >= 32))) {
         t.kernelSerial = DGA_KERNEL_SPLITK_WORKGROUP;
         t.m1 = 16; t.n1 = 128; t.k1 = 128;
-        t.splitkFactor = 1; t.stages = 3; t.wavesM = 0; t.wavesN = 0; t.dispatchPolicyTag = DGA_POLICY_PLAIN; t.swizzleOffset = 1;
+        t.splitkFactor = 1; t.stages = 3; t.wavesM = 1; t.wavesN = 4; t.dispatchPolicyTag = DGA_POLICY_PLAIN; t.swizzleOffset = 1;
         t.blockDim = std::min<uint32_t>(ceil_div(t.n, 16), pf.coreNum);
-        t.ldsBytes = 8u * 3u * ((1u + 2u) * 2048u + 256u);
+        t.ldsBytes = menu_lds_bytes(t);   // (of the 16 x 128 tile a shape the kernel does not take falls back to: what a cache file gives back)
     }
 }
 

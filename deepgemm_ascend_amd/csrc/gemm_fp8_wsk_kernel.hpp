@@ -385,4 +385,205 @@ __global__ void __launch_bounds__(WAVES * 64) gemm_fp8_wskd_kernel(const GemmPar
     }
 }
 
+// ---- the LDS-DMA build for workgroups that walk MORE than TN n-tiles: one continuous ring ------------------------------------------
+// gemm_fp8_wskd_kernel drains its rings at the end of every pass (the partial tiles meet IN the rings) and starts the next pass with
+// nothing in flight: three passes on an 18432-row matrix are three first round trips, which is why it only ties the tile kernels
+// there.  Here the partial tiles have a slab of their own behind the rings and the refill never stops: a wave's stages are the
+// flattened (pass, k block) sequence, the stage a wave has just read is refilled with the block D positions further on -- the same
+// pass or the next -- and a pass boundary costs the two barriers around the combine, not a round trip.  Everything else (image,
+// hand-counted vmcnt, slices, arithmetic, combine order) is gemm_fp8_wskd_kernel's: the same bits.  The global stores of a combine
+// are counted in vmcnt like the DMA; they only make the next waits stricter (vector-memory operations retire in order).
+template <int TM, int TN, int D, bool KTAIL, int MATH = 0>
+__global__ void __launch_bounds__(512) gemm_fp8_wskc_kernel(const GemmParams p)
+{
+    constexpr int WAVES = 8, BM = TM * 16, BNW = TN * 16, ROWS = BM + BNW, NT = WAVES * 64;
+    constexpr int SCI = (BM + 2 + 63) / 64, L = ROWS / 8 + SCI;
+    constexpr int STAGE = ROWS * 128 + SCI * 256, RING = D * STAGE, SLAB = BM * BNW * 4;
+    static_assert(WAVES * (RING + SLAB) <= 160 * 1024, "LDS of one CU");
+    static_assert((D - 1) * L < 64, "vmcnt");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kg = lane >> 4;
+    constexpr uint32_t kOutOfRange = 0x80000000u;
+
+    const int M = p.m;
+    const int nt_total = (p.n + 15) >> 4, G = gridDim.x;
+    const int nt0 = (int)(((int64_t)blockIdx.x * nt_total) / G), nt1 = (int)(((int64_t)(blockIdx.x + 1) * nt_total) / G);
+    if (nt1 <= nt0) return;
+    const int npass = (nt1 - nt0 + TN - 1) / TN;
+    const int kbps = (p.kb_n + WAVES - 1) / WAVES;
+    const int c0 = wave * kbps, c1 = min(p.kb_n, c0 + kbps);
+    const int len = max(0, c1 - c0);                            // k blocks of this wave's slice
+    const int s_eff = (p.kb_n + kbps - 1) / kbps;
+
+    uint8_t *ring = smem + wave * RING;
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(lptr_t)smem + wave * RING;
+    float *slab = (float *)(smem + WAVES * RING);               // [wave][m][n] fp32
+    const int d_row = lane >> 3;
+    const v4i a_rsrc = make_rsrc(p.a, (int64_t)M * p.lda);
+    uint32_t a_voff[BM / 8];
+    int col[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) col[j] = ((lane & 7) ^ swz_a((8 * j + d_row) & 15)) * 16;
+#pragma unroll
+    for (int j = 0; j < BM / 8; ++j) {
+        const int row = 8 * j + d_row;
+        a_voff[j] = row < M ? (uint32_t)row * (uint32_t)p.lda + col[j & 1] : kOutOfRange;
+    }
+    const int f_off0 = li * 128 + ((kg ^ swz_a(li)) * 16), f_off1 = li * 128 + (((4 + kg) ^ swz_a(li)) * 16);
+
+    // ---- the refill cursor: pass ip, k block ik of the slice, ring stage istg; D positions ahead of the multiplication
+    int ip = 0, ik = 0, istg = 0;
+    v4i b_rsrc = a_rsrc;
+    uint32_t b_voff[BNW / 8];
+    const float *sc_src[SCI];
+    auto set_issue_pass = [&](int pass) {
+        const int ntc = nt0 + pass * TN, cnt = min(TN, nt1 - ntc), n0 = ntc * 16;
+        b_rsrc = make_rsrc(p.b + (int64_t)n0 * p.ldb, (int64_t)(p.n - n0) * p.ldb);
+#pragma unroll
+        for (int j = 0; j < BNW / 8; ++j) {
+            const int row = 8 * j + d_row;
+            b_voff[j] = (row < cnt * 16 && n0 + row < p.n) ? (uint32_t)row * (uint32_t)p.ldb + col[j & 1] : kOutOfRange;
+        }
+        const int nb0 = n0 >> 7, nb1 = min(nb0 + 1, p.nb_n - 1);
+#pragma unroll
+        for (int i = 0; i < SCI; ++i) {
+            const int slot = i * 64 + lane;
+            sc_src[i] = slot < BM ? p.sfa + (int64_t)min(slot, M - 1) * p.sfa_ld : p.sfb + (int64_t)(slot == BM + 1 ? nb1 : nb0) * p.kb_n;
+        }
+    };
+    // the next stage of the sequence (past its end: every lane out of range -- zeros land, nothing is fetched -- so that the
+    // number of instructions in flight stays what the waits assume)
+    auto issue_next = [&]() {
+        const uint32_t base = ring_lds + istg * STAGE;
+        const bool live = ip < npass;
+        const int kb = c0 + ik, k0 = kb * 128;
+        bool ok2[2] = {live, live};
+        if constexpr (KTAIL) {
+            ok2[0] = live && (k0 + col[0] < p.k);
+            ok2[1] = live && (k0 + col[1] < p.k);
+        }
+#pragma unroll
+        for (int j = 0; j < ROWS / 8; ++j) {
+            uint32_t vo = j < BM / 8 ? a_voff[j < BM / 8 ? j : 0] : b_voff[j >= BM / 8 ? j - BM / 8 : 0];
+            vo = ok2[j & 1] ? vo : kOutOfRange;
+            dma16(vo, j < BM / 8 ? a_rsrc : b_rsrc, (uint32_t)k0, base + j * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < SCI; ++i) dma4(sc_src[i] + min(kb, p.kb_n - 1), base + ROWS * 128 + i * 256);
+        istg = istg + 1 == D ? 0 : istg + 1;
+        if (live && ++ik == len) {
+            ik = 0;
+            if (++ip < npass) set_issue_pass(ip);
+        }
+    };
+    set_issue_pass(0);
+    if (len > 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) issue_next();
+    }
+
+    int cstg = 0;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int ntc = nt0 + pass * TN, cnt = min(TN, nt1 - ntc), n0 = ntc * 16;
+        const int nb0 = n0 >> 7;
+        bool second_block[TN];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) second_block[t] = ((n0 + t * 16) >> 7) != nb0;
+        v4f acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < len; ++i) {
+            wait_vmcnt<(D - 1) * L>();   // the oldest stage has landed; the D - 1 younger ones stay in flight
+            const uint8_t *st = ring + cstg * STAGE;
+            v8i af[TM], bf[TN];
+            float sfa_r[TM];
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const v4i lo = *(const v4i *)(st + mt * 2048 + f_off0), hi = *(const v4i *)(st + mt * 2048 + f_off1);
+                af[mt] = v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                sfa_r[mt] = *(const float *)(st + ROWS * 128 + (mt * 16 + li) * 4);
+            }
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const v4i lo = *(const v4i *)(st + (TM + t) * 2048 + f_off0), hi = *(const v4i *)(st + (TM + t) * 2048 + f_off1);
+                bf[t] = v8i{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+            const float sfb0 = *(const float *)(st + ROWS * 128 + BM * 4), sfb1 = *(const float *)(st + ROWS * 128 + BM * 4 + 4);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage is in registers: refill it
+            issue_next();
+            cstg = cstg + 1 == D ? 0 : cstg + 1;
+            typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+            v4i afx[MATH ? TM : 1][4], bfx[MATH ? TN : 1][4];
+            if constexpr (MATH == 1) {
+                auto convert = [](const v8i &raw, v4i (&dst)[4]) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        const int w = raw[c >> 1];
+                        dst[c >> 2][c & 3] = (c & 1) ? __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true))
+                                                     : __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false));
+                    }
+                };
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) convert(af[mt], afx[mt]);
+#pragma unroll
+                for (int t = 0; t < TN; ++t) convert(bf[t], bfx[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                if (t < cnt) {
+                    const float sb = second_block[t] ? sfb1 : sfb0;
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt) {
+                        v4f pr;
+                        if constexpr (MATH == 1) {
+                            pr = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                pr = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, bfx[t][q]),
+                                                                             __builtin_bit_cast(v8bf, afx[mt][q]), pr, 0, 0, 0);
+                        } else
+                        pr = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[t], af[mt], v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
+                        const float s = sfa_r[mt] * sb;
+                        acc[mt][t].x = __builtin_fmaf(pr.x, s, acc[mt][t].x);
+                        acc[mt][t].y = __builtin_fmaf(pr.y, s, acc[mt][t].y);
+                        acc[mt][t].z = __builtin_fmaf(pr.z, s, acc[mt][t].z);
+                        acc[mt][t].w = __builtin_fmaf(pr.w, s, acc[mt][t].w);
+                    }
+                }
+            }
+        }
+        // ---- the pass's partial tiles meet in the slab behind the rings (the rings keep streaming the next pass)
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+            for (int t = 0; t < TN; ++t) *(v4f *)(slab + (size_t)wave * BM * BNW + (mt * 16 + li) * BNW + t * 16 + 4 * kg) = acc[mt][t];
+        __syncthreads();
+        const bool vec_ok = ((p.ldc & 3) == 0) && ((((uintptr_t)p.out) & 7) == 0);
+        for (int g = tid; g < BM * (BNW / 4); g += NT) {
+            const int m = g / (BNW / 4), nl = (g % (BNW / 4)) * 4;
+            if (m >= M || nl >= cnt * 16) continue;
+            v4f v = *(const v4f *)(slab + m * BNW + nl);
+            for (int s = 1; s < s_eff; ++s) v += *(const v4f *)(slab + (size_t)s * BM * BNW + m * BNW + nl);
+            const v2bf h0 = __builtin_convertvector(v2f{v.x, v.y}, v2bf), h1 = __builtin_convertvector(v2f{v.z, v.w}, v2bf);
+            uint16_t *dst = p.out + (int64_t)m * p.ldc + n0 + nl;
+            if (vec_ok && n0 + nl + 4 <= p.n) {
+                typedef int v2i __attribute__((ext_vector_type(2)));
+                *(v2i *)dst = v2i{__builtin_bit_cast(int, h0), __builtin_bit_cast(int, h1)};
+            } else {
+                const uint32_t w0 = __builtin_bit_cast(uint32_t, h0), w1 = __builtin_bit_cast(uint32_t, h1);
+                const uint16_t e[4] = {(uint16_t)(w0 & 0xFFFFu), (uint16_t)(w0 >> 16), (uint16_t)(w1 & 0xFFFFu), (uint16_t)(w1 >> 16)};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (n0 + nl + q < p.n) dst[q] = e[q];
+            }
+        }
+        if (pass + 1 < npass) __syncthreads();   // everyone has read the slab before the next pass's partial tiles go there
+    }
+    wait_vmcnt<0>();   // the refills past the sequence (zeros) have landed
+}
+
 }  // namespace dga

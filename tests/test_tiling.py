@@ -83,7 +83,8 @@ def test_mi355x_selection_is_launchable(dga):
     assert dga.select_kernel(0, 128, 128).blockDim == 0
     # decode rows: the one-launch workgroup split-K where it won its cold sweep (M <= 16, N <= 10240, 2048 <= K <= 18432)
     assert dga.select_kernel(8, 7168, 18432).kernelSerial == 6 and dga.select_kernel(16, 4096, 7168).kernelSerial == 6
-    assert dga.select_kernel(32, 4096, 7168).kernelSerial != 6 and dga.select_kernel(8, 18432, 7168).kernelSerial != 6
+    assert dga.select_kernel(32, 4096, 7168).kernelSerial != 6 and dga.select_kernel(8, 18432, 7168).kernelSerial == 6
+    assert dga.select_kernel(8, 57344, 8192).kernelSerial != 6 and dga.select_kernel(8, 24576, 1536).kernelSerial != 6
     assert dga.select_kernel(8, 7168, 1536).kernelSerial != 6
 
 
