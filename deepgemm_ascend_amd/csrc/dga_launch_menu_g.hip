@@ -1,6 +1,6 @@
 // fp8 kernel menu, part G: the one-launch workgroup split-K builds for short-M problems (gemm_fp8_wsk_kernel.hpp,
-// kernelSerial DGA_KERNEL_SPLITK_WORKGROUP): 8 waves = 8 K slices of one output tile, fragments streamed global -> registers,
-// partial tiles combined in LDS.
+// kernelSerial DGA_KERNEL_SPLITK_WORKGROUP): 8 waves = 8 K slices of one output tile, partial tiles combined in LDS -- operands
+// staged through per-wave LDS-DMA rings (M <= 32; pass-by-pass and continuous-ring builds) or streamed global -> registers (M <= 64).
 #include "dga_fp8_menu_impl.hpp"
 #include "gemm_fp8_wsk_kernel.hpp"
 namespace dga {

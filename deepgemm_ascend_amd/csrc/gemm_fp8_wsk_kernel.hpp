@@ -19,8 +19,13 @@
 // arithmetic (one v_mfma_scale_f32_16x16x128_f8f6f4 per scale block, fp32 promotion) and the same combine order (s ascending) as
 // the two-launch split-K with splitkFactor 8 (gemm_fp8_kernel.hpp + splitk_reduce_bf16_kernel): the outputs are bit-identical
 // to it, which is what tests/test_wsk_gpu.py asserts.
-// A is re-read by every workgroup (from L2: it is M x K bytes in all); the selector (dga_tiling.cpp) takes this kernel only
-// where that stays below the B stream.
+// A is re-read by every workgroup (from L2: it is M x K bytes in all).
+//
+// Three builds in this file.  gemm_fp8_wsk_kernel (below): fragments global -> registers, M <= 64 -- never the fastest kernel of its
+// cold sweep (a fragment load takes half a cache line per request and its loads are ones the compiler counts), kept selectable
+// (tiling.stages = 1).  gemm_fp8_wskd_kernel: the operands staged through per-wave LDS-DMA rings, M <= 32 -- what kernelSerial 6 runs
+// and what the tuned table and the selector pick for decode rows (profiles/r04_sweep_wskd/).  gemm_fp8_wskc_kernel: the same with a
+// ring that runs on across the passes of a workgroup that walks more n-tiles than one pass holds (wide matrices).
 #pragma once
 #include "gemm_fp8_kernel.hpp"
 
