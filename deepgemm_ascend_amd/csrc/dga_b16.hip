@@ -21,6 +21,7 @@
 #include "dga_hip.h"
 #include "dga_internal.hpp"
 #include "gemm_b16_kernel.hpp"
+#include "gemm_b16_wsk_kernel.hpp"
 
 namespace dga {
 
@@ -307,6 +308,43 @@ static int launch_b16(const void *x, const void *y, float *z, int batch, int m, 
     return record_hip(hipGetLastError());
 }
 
+// ---- decode rows of the operator: the one-launch workgroup split-K (gemm_b16_wsk_kernel.hpp) ------------------------------
+template <bool BF16, int TN, int D>
+static int launch_b16_wsk_one(const B16Params &p, unsigned grid, hipStream_t stream)
+{
+    auto kfn = gemm_b16_wsk_kernel<BF16, TN, D>;
+    constexpr int kLds = 8 * (D * (16 + TN * 16) * 128 + 16 * TN * 16 * 4);
+    static_assert(kLds <= 160 * 1024, "LDS of one CU");
+    static std::once_flag once[64];
+    static hipError_t attr_err[64];
+    int dev = 0;
+    if (int rc = record_hip(hipGetDevice(&dev))) return rc;
+    if (dev < 0 || dev >= 64) return DGA_E_HIP;
+    std::call_once(once[dev], [&] {
+        attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    });
+    if (int rc = record_hip(attr_err[dev])) return rc;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), kLds, stream, p);
+    return record_hip(hipGetLastError());
+}
+
+// M <= 16, operands 16-byte aligned with rows of whole 128-byte k steps (in place or padded); DGA_E_TILING: not a launch it takes
+template <bool BF16>
+static int launch_b16_wsk(const B16Params &p, hipStream_t stream)
+{
+    if (p.m > 16 || p.m <= 0 || p.batch != 1 || (p.k % 64) || !p.z16 || ((p.ldx * 2) & 15) || ((p.ldy * 2) & 15) ||
+        (reinterpret_cast<uintptr_t>(p.x) & 15) || (reinterpret_cast<uintptr_t>(p.yt) & 15) ||
+        static_cast<int64_t>(p.m) * p.ldx * 2 >= 0x7FFFFFFFll)
+        return DGA_E_TILING;
+    const int nt = (p.n + 15) / 16;
+    const int64_t cus = device_cus();
+    const unsigned g = static_cast<unsigned>(nt < cus ? nt : cus);
+    const int per = static_cast<int>((nt + g - 1) / g), p2 = (per + 1) / 2, p3 = (per + 2) / 3;
+    if (per <= 1) return launch_b16_wsk_one<BF16, 1, 4>(p, g, stream);
+    if (per == 3 || (per >= 5 && p3 < p2 && per % 3 != 1)) return launch_b16_wsk_one<BF16, 3, 2>(p, g, stream);
+    return launch_b16_wsk_one<BF16, 2, 3>(p, g, stream);
+}
+
 // ---- the aclnn operator in its own dtypes: out[M,N] (16-bit) = self[M,K] . mat2, mat2 stored [N,K] (NT) -----------------
 static size_t b16_nt_workspace_bytes(int m, int n, int k, const void *a, const void *b)
 {
@@ -360,6 +398,17 @@ static int launch_b16_nt(const void *a, const void *b, void *out, int m, int n, 
     p.y_bs = static_cast<int64_t>(n) * p.ldy;
     p.z_bs = static_cast<int64_t>(m) * n;
     p.batch = 1;
+    // decode rows (M <= 16): one launch, the K slices are the waves of a workgroup.  Cold, bf16, against the planned tile kernel
+    // (+ combine): ahead on 51 of 57 (M, N, K) of the decode grid, by 15-35 % on most -- 129280 x 7168 432 -> 316 us, 57344 x 8192
+    // 238 -> 166, 28672 x 4096 70 -> 45, 4096 x 7168 18.8 -> 13.3 (profiles/r04_op16_wsk_cold.txt).  Not where the rows are a
+    // multiple of 32 KB apart (7168 x 16384: 2-15 % behind -- every row of a stage starts in the same memory channel).
+    // $DGA_B16_WSK = 0 / 1 overrides the rule.
+    const char *wsk_e = std::getenv("DGA_B16_WSK");   // (read per call, like $DGA_B16_PLAN: the tests flip it inside one process)
+    const int wsk_env = wsk_e ? std::atoi(wsk_e) : -1;
+    if (wsk_env >= 0 ? wsk_env != 0 : (m <= 16 && kp >= 512 && (kp % 16384) != 0)) {
+        const int rc = bf ? launch_b16_wsk<true>(p, stream) : launch_b16_wsk<false>(p, stream);
+        if (rc != DGA_E_TILING) return rc;
+    }
     B16Plan pl = b16_plan(1, m, n, k);
     if (!workspace) { pl.splitk = 1; pl.ks_per_split = static_cast<int>(kp / 64); }
     p.splitk = pl.splitk;

@@ -23,7 +23,7 @@ CSRC = ROOT / "deepgemm_ascend_amd" / "csrc"
     ("dga_launch_menu_f.hip", 6, "gemm_fp8_bf16x_"),            # bf16-exact image builds (8 / 4 waves, A-image) x k-tail
     ("dga_launch_menu_g.hip", 6, "gemm_fp8_wsk_kernel"),         # workgroup split-K (3 row counts x k-tail)
     ("dga_launch_menu_h.hip", 2, "gemm_fp8_bf16x_persistent_kernel"),   # persistent bf16-exact 128x256 build x k-tail
-    ("dga_b16.hip", 20, "gemm_b16_nt_f32_kernel")])
+    ("dga_b16.hip", 26, "gemm_b16_")])                           # 16-bit tile builds + the workgroup split-K (3 builds x bf16 / fp16)
 def test_no_kernel_spills_or_scratch(unit, min_kernels, tile_kernel):
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT / 'include'}", f"-I{CSRC}",
            "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1",   # the Makefile's flags: the build that ships
