@@ -129,20 +129,58 @@ static int b16_raster(int tiles_m)
 }
 
 struct B16Plan { int bm, bn, splitk, ks_per_split; };
-static B16Plan b16_plan(int batch, int m, int n, int k)
+
+// Swept plans of the operator's decode rows (the 16-bit counterpart of tuned/mi355x.csv; the reference keeps such winners in its
+// CSV tiling cache, op_host/op_tiling/cache.cpp:22-101): for the (N, K) of the cold decode sweep (scripts/op16_plan_cold.py ->
+// profiles/r04_op16_plan_cold.txt) the plan that won in each row bucket (0,8] (8,16] (16,32] (32,64] (64,128], where it beat the
+// rule below by more than 6 % (the sweep times the rule first, which costs it ~3 %).  bm = 0: the one-launch workgroup split-K.  Generated by scripts/build_b16_plan_table.py.
+struct B16Swept { int m_hi, n, k; short bm, bn, s; };
+static const B16Swept kB16Swept[] = {     // the operator: y stored [N, K]
+#include "b16_plans_mi355x.inc"
+    {0, 0, 0, 0, 0, 0}};
+static const B16Swept kB16SweptNN[] = {   // run_mmad_rtc / run_mmad_bench: y [K, N] read where it lies (profiles/r04_mmad_plan_cold.txt)
+#include "b16_plans_mi355x_nn.inc"
+    {0, 0, 0, 0, 0, 0}};
+static const B16Swept *b16_swept(int batch, int m, int n, int k, bool nn)
+{
+    if (batch != 1 || m > 128) return nullptr;
+    if (const char *e = std::getenv("DGA_B16_NO_TABLE"); e && *e == '1') return nullptr;   // (per call: the sweep flips it)
+    const int m_hi = m <= 8 ? 8 : (m <= 16 ? 16 : (m <= 32 ? 32 : (m <= 64 ? 64 : 128)));
+    for (const B16Swept *r = nn ? kB16SweptNN : kB16Swept; r->m_hi; ++r)
+        if (r->m_hi == m_hi && r->n == n && r->k == k) return r;
+    return nullptr;
+}
+
+static B16Plan b16_plan(int batch, int m, int n, int k, bool nn)
 {
     const int ks_n = (k + 63) / 64;
     auto tiles_of = [&](int bm, int bn) { return static_cast<int64_t>(batch) * ((m + bm - 1) / bm) * ((n + bn - 1) / bn); };
     B16Plan pl{128, 128, 1, ks_n};
+    auto split = [&](int s) {
+        if (s > 1) { pl.ks_per_split = (ks_n + s - 1) / s; pl.splitk = (ks_n + pl.ks_per_split - 1) / pl.ks_per_split; }
+    };
     if (const char *e = std::getenv("DGA_B16_PLAN")) {   // development: "bm,bn,splitk" (scripts/op16_plan_ab.py)
         int bm = 0, bn = 0, s = 1;
         if (std::sscanf(e, "%d,%d,%d", &bm, &bn, &s) >= 2 && bm > 0 && bn > 0) {
             pl.bm = bm; pl.bn = bn;
-            if (s > 1) { pl.ks_per_split = (ks_n + s - 1) / s; pl.splitk = (ks_n + pl.ks_per_split - 1) / pl.ks_per_split; }
+            split(s);
             return pl;
         }
     }
+    if (const B16Swept *r = b16_swept(batch, m, n, k, nn); r && r->bm) { pl.bm = r->bm; pl.bn = r->bn; split(r->s); return pl; }
     const int64_t cus = device_cus();            // 256 on a whole MI355X; fewer under a compute-partition mode
+    // At most 128 rows over a long weight stream: the matmul is a read of y, and what reads fastest is the 128 x 256 tile with its
+    // three 48 KB stages in flight per CU -- one workgroup per CU, split-K filling the CUs once with at least 8 k steps a slice
+    // (cold sweep, profiles/r04_op16_plan_cold.txt: 129280 x 7168 at 32 / 64 rows 430 / 440 -> 310 us against the 128 x 128 tile
+    // the fill rule below picks, 57344 x 8192 237 -> 171, 7168 x 18432 62 / 68 -> 54 / 56, 18432 x 7168 at 64 rows 63 -> 58).
+    // Shorter streams stay with the rules below (within 2-8 % of the best plan there).
+    const int64_t nk = static_cast<int64_t>(n) * k;
+    if (batch == 1 && m <= 128 && (nk >= (48ll << 20) || (m <= 64 && n >= 16384))) {
+        const int64_t t = tiles_of(128, 256);
+        pl.bm = 128; pl.bn = 256;
+        split(static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({t <= cus ? cus / t : 1, ks_n / 8, 12}))));
+        return pl;
+    }
     // More than one short tile row: (tile, split-K) by rounds x k steps x the tile's measured time per 64-wide k step, + the
     // combine of a split (device-timed A/B of the plans on nine mid-size shapes, scripts/op16_plan_ab.py ->
     // profiles/r03_op16_plan_ab.txt: 1024x4096x7168 84 -> 64 us, 1536x6144x4096 101 -> 78, 512x7168x4096 49 -> 41,
@@ -188,7 +226,7 @@ static size_t b16_workspace_bytes(int batch, int m, int n, int k, const void *x)
     size_t bytes = ((static_cast<size_t>(batch) * n * kp * 2 + 255) & ~size_t(255));       // yT
     const bool x_in_place = (k % 64 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     if (!x_in_place) bytes += ((static_cast<size_t>(batch) * m * kp * 2 + 255) & ~size_t(255));  // padded x
-    const B16Plan pl = b16_plan(batch, m, n, k);
+    const B16Plan pl = b16_plan(batch, m, n, k, true);
     if (pl.splitk > 1) bytes += ((static_cast<size_t>(pl.splitk) * batch * m * n * 4 + 255) & ~size_t(255));  // fp32 slabs
     return bytes + 256;
 }
@@ -258,7 +296,7 @@ static int launch_b16(const void *x, const void *y, float *z, int batch, int m, 
         p.z_bs = static_cast<int64_t>(m) * n;
         static const int plain = [] { const char *e = std::getenv("DGA_B16_PLAIN"); return e ? std::atoi(e) : 0; }();
         const bool bf = dtype == DGA_DT_BF16;
-        B16Plan pl = b16_plan(batch, m, n, k);
+        B16Plan pl = b16_plan(batch, m, n, k, true);
         if (!workspace) { pl.splitk = 1; pl.ks_per_split = static_cast<int>(kp / 64); }  // no room for the slabs
         p.batch = batch;
         p.splitk = pl.splitk;
@@ -330,8 +368,11 @@ static int launch_b16_wsk_one(const B16Params &p, unsigned grid, hipStream_t str
 
 // M <= 16, operands 16-byte aligned with rows of whole 128-byte k steps (in place or padded); DGA_E_TILING: not a launch it takes
 template <bool BF16>
-static int launch_b16_wsk(const B16Params &p, hipStream_t stream)
+static int launch_b16_wsk(const B16Params &p_in, hipStream_t stream)
 {
+    B16Params p = p_in;
+    p.ks_per_split = (p.k / 64 + 7) / 8;
+    if (const char *e = std::getenv("DGA_B16_WSK_ODD"); e && *e == '1' && p.ks_per_split % 2 == 0) ++p.ks_per_split;
     if (p.m > 16 || p.m <= 0 || p.batch != 1 || (p.k % 64) || !p.z16 || ((p.ldx * 2) & 15) || ((p.ldy * 2) & 15) ||
         (reinterpret_cast<uintptr_t>(p.x) & 15) || (reinterpret_cast<uintptr_t>(p.yt) & 15) ||
         static_cast<int64_t>(p.m) * p.ldx * 2 >= 0x7FFFFFFFll)
@@ -353,7 +394,7 @@ static size_t b16_nt_workspace_bytes(int m, int n, int k, const void *a, const v
     const bool in_place = (k % 64 == 0) && (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0);
     size_t bytes = 0;
     if (!in_place) bytes += ((static_cast<size_t>(m) * kp * 2 + 255) & ~size_t(255)) + ((static_cast<size_t>(n) * kp * 2 + 255) & ~size_t(255));
-    const B16Plan pl = b16_plan(1, m, n, k);
+    const B16Plan pl = b16_plan(1, m, n, k, false);
     if (pl.splitk > 1) bytes += (static_cast<size_t>(pl.splitk) * m * n * 4 + 255) & ~size_t(255);
     return bytes ? bytes + 256 : 0;
 }
@@ -405,11 +446,12 @@ static int launch_b16_nt(const void *a, const void *b, void *out, int m, int n, 
     // $DGA_B16_WSK = 0 / 1 overrides the rule.
     const char *wsk_e = std::getenv("DGA_B16_WSK");   // (read per call, like $DGA_B16_PLAN: the tests flip it inside one process)
     const int wsk_env = wsk_e ? std::atoi(wsk_e) : -1;
-    if (wsk_env >= 0 ? wsk_env != 0 : (m <= 16 && kp >= 512 && (kp % 16384) != 0)) {
+    const B16Swept *swept = m <= 16 ? b16_swept(1, m, n, k, false) : nullptr;
+    if (wsk_env >= 0 ? wsk_env != 0 : (swept ? swept->bm == 0 : (m <= 16 && kp >= 512 && (kp % 16384) != 0))) {
         const int rc = bf ? launch_b16_wsk<true>(p, stream) : launch_b16_wsk<false>(p, stream);
         if (rc != DGA_E_TILING) return rc;
     }
-    B16Plan pl = b16_plan(1, m, n, k);
+    B16Plan pl = b16_plan(1, m, n, k, false);
     if (!workspace) { pl.splitk = 1; pl.ks_per_split = static_cast<int>(kp / 64); }
     p.splitk = pl.splitk;
     p.ks_per_split = pl.ks_per_split;

@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(512) gemm_b16_wsk_kernel(const B16Params p)
     const int nt0 = (int)(((int64_t)blockIdx.x * nt_total) / G), nt1 = (int)(((int64_t)(blockIdx.x + 1) * nt_total) / G);
     if (nt1 <= nt0) return;
     const int npass = (nt1 - nt0 + TN - 1) / TN;
-    const int ksps = (KS + WAVES - 1) / WAVES;
+    const int ksps = p.ks_per_split;                            // the host's slice length: ceil(KS / 8), see launch_b16_wsk
     const int c0 = wave * ksps, c1 = min(KS, c0 + ksps);
     const int len = max(0, c1 - c0);                            // k steps of this wave's slice
     const int s_eff = (KS + ksps - 1) / ksps;                   // waves that own at least one k step
