@@ -8,8 +8,9 @@ import deepgemm_ascend_amd as dga
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 150):
-    m = int(rng.choice([1, 5, 16, 40, 64, 100, 128, 257, 512, 1000, 2048, 4096])); n = int(rng.choice([8, 16, 72, 128, 200, 512, 1024, 2048, 4100]))
-    k = int(rng.choice([3, 16, 64, 72, 128, 192, 1000, 1024, 4096])); dt = [torch.bfloat16, torch.float16][it & 1]
+    m = int(rng.choice([1, 5, 9, 16, 17, 40, 64, 100, 128, 257, 512, 1000, 2048, 4096])); n = int(rng.choice([1, 7, 8, 16, 72, 128, 200, 512, 1024, 2048, 4100, 8200, 20000]))
+    k = int(rng.choice([3, 16, 64, 72, 128, 192, 512, 576, 1000, 1024, 4096, 8192, 16384])); dt = [torch.bfloat16, torch.float16][it & 1]
+    if m * n * k > (1 << 34): continue
     a = (torch.randn((m, k), device="cuda") * 0.5).to(dt); b = (torch.randn((n, k), device="cuda") * 0.5).to(dt)
     gold = a.float() @ b.float().T
     out = torch.full((m, n), float("nan"), dtype=dt, device="cuda")
