@@ -549,7 +549,38 @@ def widen_leg():
                              "kernel_us": round(us, 1), "algorithmic_bytes": byt,
                              "roofline": {"bound": "hbm", "achieved": round(byt / us / 1e3, 1), "peak": PEAK_HBM_GBPS,
                                           "unit": "GB/s", "frac": round(byt / us / 1e3 / PEAK_HBM_GBPS, 4)}}
+    del x
+    res["reference_benchmark_fp16"] = reference_benchmark_rows()
     return res
+
+
+def reference_benchmark_rows():
+    """The reference's own benchmark as it runs it (framework/benchmark/benchmark.py:24-44, :364-377): run_mmad_bench's launch --
+    x[M,K] fp16, y[K,N] fp16 read where it lies, z[M,N] f32 -- over the 18-shape list; device time by graph replay (warm)."""
+    import torch
+    from deepgemm_ascend_amd import _lib, api
+    from deepgemm_ascend_amd.harness import sweep
+    lib = _lib.lib()
+    rows = []
+    for (m, n, k) in sweep.SHAPE_GROUP:
+        g = torch.Generator(device="cuda").manual_seed(m + n + k)
+        x = (torch.randn((m, k), device="cuda", generator=g) * 0.5).to(torch.float16)
+        y = (torch.randn((k, n), device="cuda", generator=g) * 0.5).to(torch.float16)
+        z = torch.empty((m, n), dtype=torch.float32, device="cuda")
+
+        def fn():
+            ws_ptr, ws_bytes = api._mmad_workspace(1, m, n, k, x)
+            rc = lib.dga_run_mmad_rtc_ws(x.data_ptr(), y.data_ptr(), z.data_ptr(), 1, m, n, k, api._dt16(x), ws_ptr, ws_bytes,
+                                         api._stream_ptr(z))
+            if rc != 0:
+                raise RuntimeError(f"dga_run_mmad_rtc_ws: {rc}")
+        us = _graph_us(fn, 10, replays=3, prewarm_ms=30.0)
+        flops, byt = 2.0 * m * n * k, 2.0 * (m * k + n * k) + 4.0 * m * n
+        t_m, t_h = flops / (PEAK_BF16_TFLOPS * 1e6), byt / (PEAK_HBM_GBPS * 1e3)
+        rows.append({"shape": [m, n, k], "us": round(us, 2), "tflops": round(flops / us / 1e6, 1), "gbps": round(byt / us / 1e3, 1),
+                     "bound": "mfma" if t_m >= t_h else "hbm", "frac": round(max(t_m, t_h) / us, 3)})
+        del x, y, z
+    return rows
 
 
 class _HostStagedCollectives:
