@@ -347,11 +347,11 @@ static int launch_b16(const void *x, const void *y, float *z, int batch, int m, 
 }
 
 // ---- decode rows of the operator: the one-launch workgroup split-K (gemm_b16_wsk_kernel.hpp) ------------------------------
-template <bool BF16, int TN, int D>
+template <bool BF16, int TN, int D, int TM = 1>
 static int launch_b16_wsk_one(const B16Params &p, unsigned grid, hipStream_t stream)
 {
-    auto kfn = gemm_b16_wsk_kernel<BF16, TN, D>;
-    constexpr int kLds = 8 * (D * (16 + TN * 16) * 128 + 16 * TN * 16 * 4);
+    auto kfn = gemm_b16_wsk_kernel<BF16, TN, D, TM>;
+    constexpr int kLds = 8 * (D * (16 * TM + TN * 16) * 128 + 16 * TM * TN * 16 * 4);
     static_assert(kLds <= 160 * 1024, "LDS of one CU");
     static std::once_flag once[64];
     static hipError_t attr_err[64];
@@ -366,14 +366,14 @@ static int launch_b16_wsk_one(const B16Params &p, unsigned grid, hipStream_t str
     return record_hip(hipGetLastError());
 }
 
-// M <= 16, operands 16-byte aligned with rows of whole 128-byte k steps (in place or padded); DGA_E_TILING: not a launch it takes
+// M <= 32, operands 16-byte aligned with rows of whole 128-byte k steps (in place or padded); DGA_E_TILING: not a launch it takes
 template <bool BF16>
 static int launch_b16_wsk(const B16Params &p_in, hipStream_t stream)
 {
     B16Params p = p_in;
     p.ks_per_split = (p.k / 64 + 7) / 8;
     if (const char *e = std::getenv("DGA_B16_WSK_ODD"); e && *e == '1' && p.ks_per_split % 2 == 0) ++p.ks_per_split;
-    if (p.m > 16 || p.m <= 0 || p.batch != 1 || (p.k % 64) || !p.z16 || ((p.ldx * 2) & 15) || ((p.ldy * 2) & 15) ||
+    if (p.m > 32 || p.m <= 0 || p.batch != 1 || (p.k % 64) || !p.z16 || ((p.ldx * 2) & 15) || ((p.ldy * 2) & 15) ||
         (reinterpret_cast<uintptr_t>(p.x) & 15) || (reinterpret_cast<uintptr_t>(p.yt) & 15) ||
         static_cast<int64_t>(p.m) * p.ldx * 2 >= 0x7FFFFFFFll)
         return DGA_E_TILING;
@@ -381,6 +381,8 @@ static int launch_b16_wsk(const B16Params &p_in, hipStream_t stream)
     const int64_t cus = device_cus();
     const unsigned g = static_cast<unsigned>(nt < cus ? nt : cus);
     const int per = static_cast<int>((nt + g - 1) / g), p2 = (per + 1) / 2, p3 = (per + 2) / 3;
+    if (p.m > 16)   // two 16-row tiles of x: the LDS holds 2 n-tiles x 2 stages or 1 x 3 (160 KB with the slab either way)
+        return per <= 1 ? launch_b16_wsk_one<BF16, 1, 3, 2>(p, g, stream) : launch_b16_wsk_one<BF16, 2, 2, 2>(p, g, stream);
     if (per <= 1) return launch_b16_wsk_one<BF16, 1, 4>(p, g, stream);
     if (per == 3 || (per >= 5 && p3 < p2 && per % 3 != 1)) return launch_b16_wsk_one<BF16, 3, 2>(p, g, stream);
     return launch_b16_wsk_one<BF16, 2, 3>(p, g, stream);
@@ -446,8 +448,14 @@ static int launch_b16_nt(const void *a, const void *b, void *out, int m, int n, 
     // $DGA_B16_WSK = 0 / 1 overrides the rule.
     const char *wsk_e = std::getenv("DGA_B16_WSK");   // (read per call, like $DGA_B16_PLAN: the tests flip it inside one process)
     const int wsk_env = wsk_e ? std::atoi(wsk_e) : -1;
-    const B16Swept *swept = m <= 16 ? b16_swept(1, m, n, k, false) : nullptr;
-    if (wsk_env >= 0 ? wsk_env != 0 : (swept ? swept->bm == 0 : (m <= 16 && kp >= 512 && (kp % 16384) != 0))) {
+    // 17..32 rows (two 16-row tiles of x, a shallower ring, x read once per workgroup): ahead where the stream is short -- N K <= 32 M
+    // elements (4096 x 4096 16.2 -> 13.0 us, 7168 x 2048 14.1 -> 11.6, 576 x 7168 12.3 -> 10.9) -- or where the workgroups' reads of x
+    // stay below the read of y (N >= 8192) and N K <= 72 M (8192 x 8192 34.2 -> 30.6, 24576 x 1536 23.8 -> 21.9); behind on longer ones.
+    const B16Swept *swept = m <= 32 ? b16_swept(1, m, n, k, false) : nullptr;
+    const int64_t nk = static_cast<int64_t>(n) * kp;
+    const bool wsk_rule = kp >= 512 && (kp % 16384) != 0 &&
+                          (m <= 16 || (m <= 32 && kp >= 1024 && (nk <= (32ll << 20) || (n >= 8192 && nk <= (72ll << 20)))));
+    if (wsk_env >= 0 ? wsk_env != 0 : (swept ? swept->bm == 0 : wsk_rule)) {
         const int rc = bf ? launch_b16_wsk<true>(p, stream) : launch_b16_wsk<false>(p, stream);
         if (rc != DGA_E_TILING) return rc;
     }

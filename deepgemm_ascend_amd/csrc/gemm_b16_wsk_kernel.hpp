@@ -1,6 +1,6 @@
 // One-launch split-K inside a workgroup for the decode rows of the 16-bit operator (catlass_dynamic_matmul, NT, bf16 / fp16 in and
 // out): the 16-bit form of gemm_fp8_wskc_kernel (gemm_fp8_wsk_kernel.hpp).  The 8 waves of a workgroup take the 8 K slices of the
-// workgroup's n-tiles (16 columns each, all M <= 16 rows); every wave stages its k steps (64 elements = 128 bytes per row) through
+// workgroup's n-tiles (16 columns each, all M <= 16 or 32 rows); every wave stages its k steps (64 elements = 128 bytes per row) through
 // a private ring of D stages in LDS by LDS-DMA -- whole 128-byte lines, the tile kernels' XOR image -- and reads fragments back with
 // ds_read_b128; no barrier while streaming, hand-counted vmcnt (every vector-memory instruction of the loop is inline-asm DMA); the
 // ring runs on across the passes of a workgroup that walks more n-tiles than one pass holds; the eight fp32 partial tiles meet in a
@@ -17,10 +17,10 @@
 
 namespace dga {
 
-template <bool BF16, int TN, int D>
+template <bool BF16, int TN, int D, int TM = 1>   // TM: 16-row tiles of x (M <= 16 TM)
 __global__ void __launch_bounds__(512) gemm_b16_wsk_kernel(const B16Params p)
 {
-    constexpr int WAVES = 8, BM = 16, BNW = TN * 16, ROWS = BM + BNW, NT = WAVES * 64;
+    constexpr int WAVES = 8, BM = 16 * TM, BNW = TN * 16, ROWS = BM + BNW, NT = WAVES * 64;
     constexpr int L = ROWS / 8;                                  // DMA instructions per stage: 8 rows each
     constexpr int STAGE = ROWS * 128, RING = D * STAGE, SLAB = BM * BNW * 4;
     static_assert(WAVES * (RING + SLAB) <= 160 * 1024, "LDS of one CU");
@@ -97,18 +97,24 @@ __global__ void __launch_bounds__(512) gemm_b16_wsk_kernel(const B16Params p)
     int cstg = 0;
     for (int pass = 0; pass < npass; ++pass) {
         const int ntc = nt0 + pass * TN, cnt = min(TN, nt1 - ntc), n0 = ntc * 16;
-        v4f acc[TN];
+        v4f acc[TM][TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = v4f{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < TM; ++u)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[u][j] = v4f{0.f, 0.f, 0.f, 0.f};
         for (int i = 0; i < len; ++i) {
             wait_vmcnt<(D - 1) * L>();   // the oldest stage has landed; the D - 1 younger ones stay in flight
             const uint8_t *st = ring + cstg * STAGE;
-            const v4i a0 = *(const v4i *)(st + f_off0), a1 = *(const v4i *)(st + f_off1);
-            v4i b0[TN], b1[TN];
+            v4i a0[TM], a1[TM], b0[TN], b1[TN];
+#pragma unroll
+            for (int u = 0; u < TM; ++u) {
+                a0[u] = *(const v4i *)(st + u * 2048 + f_off0);
+                a1[u] = *(const v4i *)(st + u * 2048 + f_off1);
+            }
 #pragma unroll
             for (int t = 0; t < TN; ++t) {
-                b0[t] = *(const v4i *)(st + (1 + t) * 2048 + f_off0);
-                b1[t] = *(const v4i *)(st + (1 + t) * 2048 + f_off1);
+                b0[t] = *(const v4i *)(st + (TM + t) * 2048 + f_off0);
+                b1[t] = *(const v4i *)(st + (TM + t) * 2048 + f_off1);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage is in registers: refill it
             issue_next();
@@ -116,15 +122,20 @@ __global__ void __launch_bounds__(512) gemm_b16_wsk_kernel(const B16Params p)
 #pragma unroll
             for (int t = 0; t < TN; ++t) {
                 if (t < cnt) {
-                    acc[t] = mfma_b16<BF16>(b0[t], a0, acc[t]);
-                    acc[t] = mfma_b16<BF16>(b1[t], a1, acc[t]);
+#pragma unroll
+                    for (int u = 0; u < TM; ++u) {
+                        acc[u][t] = mfma_b16<BF16>(b0[t], a0[u], acc[u][t]);
+                        acc[u][t] = mfma_b16<BF16>(b1[t], a1[u], acc[u][t]);
+                    }
                 }
             }
         }
         // ---- the pass's partial tiles meet in the slab behind the rings (the rings keep streaming the next pass): lane (li, kg)
-        //      owns row m = li, columns 16 t + 4 kg + [0, 4)
+        //      owns rows m = 16 u + li, columns 16 t + 4 kg + [0, 4)
 #pragma unroll
-        for (int t = 0; t < TN; ++t) *(v4f *)(slab + (size_t)wave * BM * BNW + li * BNW + t * 16 + 4 * kg) = acc[t];
+        for (int u = 0; u < TM; ++u)
+#pragma unroll
+            for (int t = 0; t < TN; ++t) *(v4f *)(slab + (size_t)wave * BM * BNW + (16 * u + li) * BNW + t * 16 + 4 * kg) = acc[u][t];
         __syncthreads();
         for (int g = tid; g < BM * BNW; g += NT) {
             const int m = g / BNW, nl = g % BNW;

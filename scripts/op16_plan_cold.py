@@ -60,7 +60,7 @@ def main():
             row = {"shape": [m, n, k], "auto_us": round(timed(), 2), "plans": {}}
             os.environ["DGA_B16_NO_TABLE"] = "1"
             row["rule_us"] = round(timed(), 2)
-            if m <= 16 and not mmad:
+            if m <= 32 and not mmad:
                 os.environ["DGA_B16_WSK"] = "1"
                 row["plans"]["wsk"] = round(timed(), 2)
             os.environ["DGA_B16_WSK"] = "0"

@@ -18,8 +18,8 @@ def _run(dga, x, w, wsk):
     old = {k: os.environ.get(k) for k in ("DGA_B16_WSK", "DGA_B16_PLAN")}
     try:
         os.environ["DGA_B16_WSK"] = "1" if wsk else "0"
-        if not wsk:
-            os.environ["DGA_B16_PLAN"] = "16,128,8"     # the tile kernel with K cut eight ways + the combine kernel
+        if not wsk:   # the tile kernel with K cut eight ways + the combine kernel
+            os.environ["DGA_B16_PLAN"] = "16,128,8" if m <= 16 else "32,128,8"
         dga.catlass_dynamic_matmul(x, w.t(), out, sync=True)
     finally:
         for k, v in old.items():
@@ -35,6 +35,7 @@ def _run(dga, x, w, wsk):
     (1, 80, 1024), (8, 512, 2048), (16, 1000, 4096 + 64), (5, 48, 64), (16, 16 * 256 + 16, 2048), (9, 16 * 700 + 5, 1024 + 64),
     (16, 16 * 1300, 1152), (3, 24, 128 * 9), (16, 4096, 7168),
     (7, 333, 1000),       # K % 64 != 0: the operands go through the padding pass first
+    (17, 80, 1024), (32, 512, 2048), (24, 16 * 300 + 7, 1152), (32, 16 * 1300, 1088), (31, 4096, 7168), (20, 333, 1000),   # two row tiles
 ])
 def test_bit_identical_to_the_two_launch_split_k(dga, dtype, m, n, k):
     g = torch.Generator(device="cuda").manual_seed(m + n + k)
@@ -49,8 +50,8 @@ def test_bit_identical_to_the_two_launch_split_k(dga, dtype, m, n, k):
     assert bool((err <= tol * want.abs() + tol * (x.float().abs() @ w.float().abs().t()) * 2.0 ** -6).all())
 
 
-def test_rows_beyond_sixteen_keep_the_tile_kernels(dga):
-    x = torch.randn((17, 2048), device="cuda").to(torch.bfloat16)
+def test_rows_beyond_thirty_two_keep_the_tile_kernels(dga):
+    x = torch.randn((33, 2048), device="cuda").to(torch.bfloat16)
     w = torch.randn((256, 2048), device="cuda").to(torch.bfloat16)
     a = _run(dga, x, w, True)      # the request falls through (DGA_E_TILING) to the planned tile kernel
     os.environ.pop("DGA_B16_PLAN", None)
