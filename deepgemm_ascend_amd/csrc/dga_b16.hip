@@ -128,7 +128,8 @@ static int b16_raster(int tiles_m)
     return tiles_m >= 4 ? 4 : (tiles_m >= 2 ? 2 : 1);
 }
 
-struct B16Plan { int bm, bn, splitk, ks_per_split; };
+struct B16Plan { int bm, bn, splitk, ks_per_split, tail; };   // tail: the last partial round of a 256 x 256 / 128 x 256 raster in
+                                                               // sub-tiles of `tail` x 128 (0: none)
 
 // Swept plans of the operator's decode rows (the 16-bit counterpart of tuned/mi355x.csv; the reference keeps such winners in its
 // CSV tiling cache, op_host/op_tiling/cache.cpp:22-101): for the (N, K) of the cold decode sweep (scripts/op16_plan_cold.py ->
@@ -155,15 +156,18 @@ static B16Plan b16_plan(int batch, int m, int n, int k, bool nn)
 {
     const int ks_n = (k + 63) / 64;
     auto tiles_of = [&](int bm, int bn) { return static_cast<int64_t>(batch) * ((m + bm - 1) / bm) * ((n + bn - 1) / bn); };
-    B16Plan pl{128, 128, 1, ks_n};
+    B16Plan pl{128, 128, 1, ks_n, 0};
     auto split = [&](int s) {
         if (s > 1) { pl.ks_per_split = (ks_n + s - 1) / s; pl.splitk = (ks_n + pl.ks_per_split - 1) / pl.ks_per_split; }
     };
     if (const char *e = std::getenv("DGA_B16_PLAN")) {   // development: "bm,bn,splitk" (scripts/op16_plan_ab.py)
-        int bm = 0, bn = 0, s = 1;
-        if (std::sscanf(e, "%d,%d,%d", &bm, &bn, &s) >= 2 && bm > 0 && bn > 0) {
+        int bm = 0, bn = 0, s = 1, tail = 0;
+        if (std::sscanf(e, "%d,%d,%d,%d", &bm, &bn, &s, &tail) >= 2 && bm > 0 && bn > 0) {
             pl.bm = bm; pl.bn = bn;
             split(s);
+            if (tail == 1) tail = bm / 2;   // quarter tiles
+            pl.tail = (pl.splitk == 1 && batch == 1 && bn == 256 && (bm == 256 || bm == 128) && tail < bm &&
+                       (tail == 128 || tail == 64 || tail == 32)) ? tail : 0;
             return pl;
         }
     }
@@ -198,8 +202,30 @@ static B16Plan b16_plan(int batch, int m, int n, int k, bool nn)
                 const double share = static_cast<double>(std::min<int64_t>(c.wpc, (items + cus - 1) / cus));
                 double t = 3.0 + rounds * per * c.us_per_step * std::pow(share, 0.6);
                 if (s_eff > 1) t += 4.0 + static_cast<double>(s_eff) * batch * m * n * 8.0 / 5.0e6;
-                if (t < best) { best = t; pl.bm = c.bm; pl.bn = c.bn; pl.splitk = s_eff; pl.ks_per_split = per; }
+                if (t < best) { best = t; pl.bm = c.bm; pl.bn = c.bn; pl.splitk = s_eff; pl.ks_per_split = per; pl.tail = 0; }
             }
+        // the whole rounds of a 256 x 256 / 128 x 256 raster as they are, the last partial round in sub-tiles (128 / 64 / 32 rows x
+        // 128 columns, a second launch): 4-16 times as many CUs busy for a fraction of a round -- what the reference's Stream-K
+        // handler is for (select_kernel.cpp:303-331) without partial sums: every output is one accumulation in k order, the bytes
+        // are the single launch's (tests/test_op16_tail_gpu.py).  bf16, warm (scripts/op16_tail_ab.py -> profiles/r04_op16_tail_ab.txt):
+        // 1024 x 18432 x 7168 289 -> 265 us, 5119 x 6997 x 9901 762 -> 705, 4608 x 4096 x 7168 260 -> 227, 2304 x 8192 x 4096 153 -> 137
+        if (batch == 1) {
+            static const Cand kSub[] = {{128, 128, 0.73, 2}, {64, 128, 0.58, 2}, {32, 128, 0.50, 2}};
+            for (int ci = 0; ci < 2; ++ci) {
+                const Cand &c = kCands[ci];
+                const int64_t tiles = tiles_of(c.bm, c.bn), tail = tiles % cus;
+                if (tiles <= cus || tail == 0) continue;
+                for (const Cand &q : kSub) {
+                    if (q.bm >= c.bm || q.bm * 8 < c.bm) continue;
+                    const int64_t items = tail * (c.bm / q.bm) * (c.bn / q.bn);
+                    const double rounds = std::ceil(static_cast<double>(items) / static_cast<double>(cus * q.wpc));
+                    const double share = static_cast<double>(std::min<int64_t>(q.wpc, (items + cus - 1) / cus));
+                    const double t = 3.0 + static_cast<double>(tiles / cus) * ks_n * c.us_per_step + 2.0 +
+                                     rounds * ks_n * q.us_per_step * std::pow(share, 0.6);
+                    if (t < best) { best = t; pl.bm = c.bm; pl.bn = c.bn; pl.splitk = 1; pl.ks_per_split = ks_n; pl.tail = q.bm; }
+                }
+            }
+        }
         return pl;
     }
     const int64_t fill = cus * 3 / 4;            // "the big tile fills the chip": three quarters of the CUs
@@ -244,8 +270,9 @@ static int launch_tiled(const B16Params &p, int batch, hipStream_t stream)
         attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     });
     if (record_hip(attr_err[dev]) != DGA_OK) return DGA_E_HIP;
-    hipLaunchKernelGGL(kfn, dim3(static_cast<unsigned>(batch) * p.tiles_m * p.tiles_n * (p.splitk > 1 ? p.splitk : 1)),
-                       dim3(Cfg::NT), lds, stream, p);
+    const unsigned grid = p.launch_tiles > 0 ? static_cast<unsigned>(p.launch_tiles)
+                                             : static_cast<unsigned>(batch) * p.tiles_m * p.tiles_n * (p.splitk > 1 ? p.splitk : 1);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), lds, stream, p);
     return record_hip(hipGetLastError());
 }
 
@@ -307,18 +334,34 @@ static int launch_b16(const void *x, const void *y, float *z, int batch, int m, 
         auto go = [&](auto cfg, auto pp) -> int {
             using Cfg = decltype(cfg);
             constexpr int PPv = decltype(pp)::value;
-            p.tiles_m = (m + Cfg::kBM - 1) / Cfg::kBM;
-            p.tiles_n = (n + Cfg::kBN - 1) / Cfg::kBN;
-            p.raster_group = b16_raster(p.tiles_m);
+            if (!p.tail_sub) {
+                p.tiles_m = (m + Cfg::kBM - 1) / Cfg::kBM;
+                p.tiles_n = (n + Cfg::kBN - 1) / Cfg::kBN;
+                p.raster_group = b16_raster(p.tiles_m);
+            }
             if (direct)
                 return bf ? launch_tiled<Cfg, true, PPv, true>(p, batch, stream) : launch_tiled<Cfg, false, PPv, true>(p, batch, stream);
             return bf ? launch_tiled<Cfg, true, PPv>(p, batch, stream) : launch_tiled<Cfg, false, PPv>(p, batch, stream);
         };
         using P0 = std::integral_constant<int, 0>;
         using P2 = std::integral_constant<int, 2>;
+        // main launch over the whole rounds, then the parent raster's remaining tiles as quarter tiles (pl.tail)
+        auto go_tail = [&](auto cfg, auto pp) -> int {
+            using Cfg = decltype(cfg);
+            const int tiles = ((m + Cfg::kBM - 1) / Cfg::kBM) * ((n + Cfg::kBN - 1) / Cfg::kBN), cus = static_cast<int>(device_cus());
+            const int tail = tiles % cus, main_tiles = tiles - tail;
+            if (!pl.tail || tail == 0 || main_tiles == 0) return go(cfg, pp);
+            p.launch_tiles = main_tiles;
+            if (int rc = go(cfg, pp)) return rc;
+            const int sm = Cfg::kBM / pl.tail, sn = Cfg::kBN / 128;
+            p.launch_tiles = tail * sm * sn; p.tail_begin = main_tiles; p.tail_sub = sm | (sn << 8);
+            if (pl.tail == 128) return go(GemmCfg<128, 128, 2, 2>{}, P0{});
+            if (pl.tail == 64) return go(GemmCfg<64, 128, 1, 4>{}, P0{});
+            return go(GemmCfg<32, 128, 1, 4>{}, P0{});
+        };
         int rc;
-        if (pl.bm == 256) rc = plain ? go(GemmCfg<256, 256, 4, 2>{}, P0{}) : go(GemmCfg<256, 256, 4, 2>{}, P2{});
-        else if (pl.bm == 128 && pl.bn == 256) rc = go(GemmCfg<128, 256, 2, 4, 3>{}, P0{});
+        if (pl.bm == 256) rc = plain ? go(GemmCfg<256, 256, 4, 2>{}, P0{}) : go_tail(GemmCfg<256, 256, 4, 2>{}, P2{});
+        else if (pl.bm == 128 && pl.bn == 256) rc = go_tail(GemmCfg<128, 256, 2, 4, 3>{}, P0{});
         else if (pl.bm == 128) rc = go(GemmCfg<128, 128, 2, 2>{}, P0{});
         else if (pl.bm == 64) rc = go(GemmCfg<64, 128, 1, 4>{}, P0{});
         else if (pl.bm == 32) rc = go(GemmCfg<32, 128, 1, 4>{}, P0{});
@@ -467,16 +510,31 @@ static int launch_b16_nt(const void *a, const void *b, void *out, int m, int n, 
     auto go = [&](auto cfg, auto pp) -> int {
         using Cfg = decltype(cfg);
         constexpr int PPv = decltype(pp)::value;
-        p.tiles_m = (m + Cfg::kBM - 1) / Cfg::kBM;
-        p.tiles_n = (n + Cfg::kBN - 1) / Cfg::kBN;
-        p.raster_group = b16_raster(p.tiles_m);
+        if (!p.tail_sub) {
+            p.tiles_m = (m + Cfg::kBM - 1) / Cfg::kBM;
+            p.tiles_n = (n + Cfg::kBN - 1) / Cfg::kBN;
+            p.raster_group = b16_raster(p.tiles_m);
+        }
         return bf ? launch_tiled<Cfg, true, PPv, false, true>(p, 1, stream) : launch_tiled<Cfg, false, PPv, false, true>(p, 1, stream);
     };
     using P0 = std::integral_constant<int, 0>;
     using P2 = std::integral_constant<int, 2>;
+    auto go_tail = [&](auto cfg, auto pp) -> int {
+        using Cfg = decltype(cfg);
+        const int tiles = ((m + Cfg::kBM - 1) / Cfg::kBM) * ((n + Cfg::kBN - 1) / Cfg::kBN), cus = static_cast<int>(device_cus());
+        const int tail = tiles % cus, main_tiles = tiles - tail;
+        if (!pl.tail || tail == 0 || main_tiles == 0) return go(cfg, pp);
+        p.launch_tiles = main_tiles;
+        if (int rc = go(cfg, pp)) return rc;
+        const int sm = Cfg::kBM / pl.tail, sn = Cfg::kBN / 128;
+        p.launch_tiles = tail * sm * sn; p.tail_begin = main_tiles; p.tail_sub = sm | (sn << 8);
+        if (pl.tail == 128) return go(GemmCfg<128, 128, 2, 2>{}, P0{});
+        if (pl.tail == 64) return go(GemmCfg<64, 128, 1, 4>{}, P0{});
+        return go(GemmCfg<32, 128, 1, 4>{}, P0{});
+    };
     int rc;
-    if (pl.bm == 256) rc = go(GemmCfg<256, 256, 4, 2>{}, P2{});
-    else if (pl.bm == 128 && pl.bn == 256) rc = go(GemmCfg<128, 256, 2, 4, 3>{}, P0{});
+    if (pl.bm == 256) rc = go_tail(GemmCfg<256, 256, 4, 2>{}, P2{});
+    else if (pl.bm == 128 && pl.bn == 256) rc = go_tail(GemmCfg<128, 256, 2, 4, 3>{}, P0{});
     else if (pl.bm == 128) rc = go(GemmCfg<128, 128, 2, 2>{}, P0{});
     else if (pl.bm == 64) rc = go(GemmCfg<64, 128, 1, 4>{}, P0{});
     else if (pl.bm == 32) rc = go(GemmCfg<32, 128, 1, 4>{}, P0{});

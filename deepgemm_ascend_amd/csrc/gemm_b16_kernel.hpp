@@ -31,6 +31,9 @@ struct B16Params {
     int ks_per_split;    //      and writes its fp32 partial tile to slab s of `partial` ([splitk][batch][m][n])
     float *partial;
     uint16_t *z16;       // OUT16 builds: the output in the inputs' 16-bit type ([batch][m][n]); z is unused then
+    int launch_tiles;    // > 0: the grid holds this many tiles (batch 1, no split-K), not the whole raster
+    int tail_begin, tail_sub;   // tail_sub = sm | sn << 8 != 0: this launch's tiles are SUB-tiles (sm x sn per parent) of the parent
+                                // raster's tiles [tail_begin, ...); tiles_m / tiles_n / raster_group then describe the PARENT raster
 };
 
 template <bool BF16>
@@ -80,8 +83,10 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
     const int per_batch = p.tiles_m * p.tiles_n;
     const int split = p.splitk > 1 ? tile / (per_batch * p.batch) : 0;
     tile -= split * per_batch * p.batch;
-    const int bi = tile / per_batch;
-    const int t_in = tile - bi * per_batch;
+    const int bi = p.tail_sub ? 0 : tile / per_batch;
+    const int sm = p.tail_sub & 255, sn = p.tail_sub >> 8, nsub = max(1, sm * sn);
+    const int sub = p.tail_sub ? tile % nsub : 0;
+    const int t_in = p.tail_sub ? p.tail_begin + tile / nsub : tile - bi * per_batch;
     int tm, tn;
     {
         const int gm = p.raster_group, per = gm * p.tiles_n, band = t_in / per, first = band * gm;
@@ -89,7 +94,8 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
         tm = first + loc % rows;
         tn = loc / rows;
     }
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = p.tail_sub ? (sm * tm + sub % sm) * BM : tm * BM, n0 = p.tail_sub ? (sn * tn + sub / sm) * BN : tn * BN;
+    if (p.tail_sub && (m0 >= p.m || n0 >= p.n)) return;   // a quarter tile beyond the matrix edge
     const uint8_t *X = (const uint8_t *)(p.x + (int64_t)bi * p.x_bs);
     const uint8_t *Y = (const uint8_t *)(p.yt + (int64_t)bi * p.y_bs);
     float *Z = (p.splitk > 1 ? p.partial + (int64_t)split * p.batch * p.z_bs : p.z) + (int64_t)bi * p.z_bs;
@@ -157,9 +163,11 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
         for (int j = 0; j < TN; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
 
     const int KS = p.k / 64;
+    const int ks_begin = p.splitk > 1 ? split * p.ks_per_split : 0;   // this workgroup's k steps (split-K: one slice)
+    const int ks_end = p.splitk > 1 ? min(KS, ks_begin + p.ks_per_split) : KS;
     if constexpr (PP == 2) {
         // ---- continuous pipeline.  One k step = STEPS single MFMAs, ordered (n-tile, k half, m-tile) so that the two
-        // MFMAs that chain through one accumulator are TM steps apart.  Stage s = ks & 1.
+        // MFMAs that chain through one accumulator are TM steps apart.  Stage s = parity of the step inside the slice.
         //   * B fragments rotate through two register sets (next n-tile read at the n-tile's first step); the rotation
         //     continues into the next k step;
         //   * step SB = first step of the last n-tile: vmcnt(0) + the ONE barrier.  Passing it means stage s^1 has landed
@@ -178,9 +186,9 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
         };
         v4i af[TM][2], bf[2][2];
 #pragma unroll
-        for (int idx = 0; idx < NL; ++idx) issue_one(idx, 0, 0);
+        for (int idx = 0; idx < NL; ++idx) issue_one(idx, 0, ks_begin);
 #pragma unroll
-        for (int idx = 0; idx < TAIL_DMA; ++idx) issue_one(idx, 1, 1);
+        for (int idx = 0; idx < TAIL_DMA; ++idx) issue_one(idx, 1, ks_begin + 1);
         wait_vmcnt<TAIL_DMA>();
         barrier();
         bf[0][0] = load_b(smem, 0, 0);
@@ -190,9 +198,10 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
             af[mt][0] = *(const v4i *)(smem + a_off0 + mt * 2048);
             af[mt][1] = *(const v4i *)(smem + a_off1 + mt * 2048);
         }
-        for (int ks = 0; ks < KS; ++ks) {
-            const uint8_t *st = smem + (ks & 1) * STAGE;
-            const uint8_t *sn = smem + ((ks & 1) ^ 1) * STAGE;
+        for (int ks = ks_begin; ks < ks_end; ++ks) {
+            const int par = (ks - ks_begin) & 1;   // stage of this k step
+            const uint8_t *st = smem + par * STAGE;
+            const uint8_t *sn = smem + (par ^ 1) * STAGE;
 #pragma unroll
             for (int i = 0; i < STEPS; ++i) {
                 const int nt = i / (2 * TM), h = (i / TM) & 1, mt = i % TM;
@@ -205,9 +214,9 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
                 if (i < HEAD_STEPS) {   // head part of k step ks + 1's refill (stage s^1 is free since the previous barrier)
 #pragma unroll
                     for (int j = (i * (NL - TAIL_DMA)) / HEAD_STEPS; j < ((i + 1) * (NL - TAIL_DMA)) / HEAD_STEPS; ++j)
-                        issue_one(TAIL_DMA + j, (ks & 1) ^ 1, ks + 1);
+                        issue_one(TAIL_DMA + j, par ^ 1, ks + 1);
                 }
-                if (i > SB && i <= SB + TAIL_DMA) issue_one(i - SB - 1, ks & 1, ks + 2);  // tail part of ks + 2 into this stage
+                if (i > SB && i <= SB + TAIL_DMA) issue_one(i - SB - 1, par, ks + 2);  // tail part of ks + 2 into this stage
                 if (h == 0 && mt == 0) {  // next n-tile's B fragment (wraps into the next k step)
                     const uint8_t *src = nt + 1 < TN ? st : sn;
                     const int nn = nt + 1 < TN ? nt + 1 : 0;
@@ -220,8 +229,6 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
         }
         wait_vmcnt<0>();
     } else {
-    const int ks_begin = p.splitk > 1 ? split * p.ks_per_split : 0;
-    const int ks_end = p.splitk > 1 ? min(KS, ks_begin + p.ks_per_split) : KS;
     // STG LDS stages (Cfg::STAGES; 3 for the 128x256 8-wave build: two refills in flight)
     constexpr int STG = Cfg::STAGES;
 #pragma unroll
