@@ -152,6 +152,19 @@ static const B16Swept *b16_swept(int batch, int m, int n, int k, bool nn)
     return nullptr;
 }
 
+// Tiles of at most 64 rows exist with two LDS stages (48 KB at most: up to three workgroups share a CU) and with FOUR (one workgroup per
+// CU, three stages in flight): where the launch gives every CU at most one workgroup the deep build keeps three times the bytes in
+// flight -- cold, bf16: 64 x 24576 x 1536 28.3 -> 22.1 us, 64 x 4096 x 7168 split 4 32.2 -> 22.3, 48 x 7168 x 4608 split 4 24.4 -> 18.8,
+// 64 x 32768 x 512 13.1 -> 10.9; with more workgroups than CUs the shared CU wins (64 x 24576 x 1536 split 4: 32.4 against 34.4).
+// $DGA_B16_DEEP = 0 / 1 overrides (development).
+static bool b16_deep(const B16Plan &pl, int batch, int m, int n)
+{
+    if (pl.bm > 64) return false;
+    if (const char *e = std::getenv("DGA_B16_DEEP")) return std::atoi(e) != 0;
+    const int64_t items = static_cast<int64_t>(batch) * ((m + pl.bm - 1) / pl.bm) * ((n + pl.bn - 1) / pl.bn) * pl.splitk;
+    return items <= device_cus();
+}
+
 static B16Plan b16_plan(int batch, int m, int n, int k, bool nn)
 {
     const int ks_n = (k + 63) / 64;
@@ -178,6 +191,24 @@ static B16Plan b16_plan(int batch, int m, int n, int k, bool nn)
     // (cold sweep, profiles/r04_op16_plan_cold.txt: 129280 x 7168 at 32 / 64 rows 430 / 440 -> 310 us against the 128 x 128 tile
     // the fill rule below picks, 57344 x 8192 237 -> 171, 7168 x 18432 62 / 68 -> 54 / 56, 18432 x 7168 at 64 rows 63 -> 58).
     // Shorter streams stay with the rules below (within 2-8 % of the best plan there).
+    // At most 128 rows and a raster of small tiles that fits the CUs once: the deep (four-stage) build of the smallest tile that covers
+    // the rows (or half of them), split-K filling the CUs once with at least 12 k steps a slice -- every CU streams with three
+    // stages in flight.  Taken where it fills at least three quarters of the CUs; fitted to the cold sweeps of both paths
+    // (profiles/r04_op16_plan_cold.txt, r04_mmad_plan_cold.txt: mean distance from the best plan 10.3 % / 7.8 % -> 5.1 % / 2.9 %).
+    if (batch == 1 && m <= 128) {
+        const int bm0 = m <= 16 ? 16 : (m <= 32 ? 32 : 64);
+        int best_bm = 0, best_s = 1, best_fill = -1;
+        for (int bm = bm0; bm >= 16 && bm >= bm0 / 2; bm /= 2) {
+            const int64_t t = tiles_of(bm, 128);
+            if (t > cus) continue;
+            const int smax = static_cast<int>(std::min<int64_t>({cus / t, std::max(1, ks_n / 12), 12}));
+            int s = 1;
+            for (int c : {2, 3, 4, 6, 8, 12}) if (c <= smax) s = c;
+            const int fill = static_cast<int>(100 * t * s / cus);   // per cent of the CUs
+            if (fill > best_fill) { best_fill = fill; best_bm = bm; best_s = s; }
+        }
+        if (best_fill >= 75) { pl.bm = best_bm; pl.bn = 128; split(best_s); return pl; }
+    }
     const int64_t nk = static_cast<int64_t>(n) * k;
     if (batch == 1 && m <= 128 && (nk >= (48ll << 20) || (m <= 64 && n >= 16384))) {
         const int64_t t = tiles_of(128, 256);
@@ -345,7 +376,8 @@ static int launch_b16(const void *x, const void *y, float *z, int batch, int m, 
         };
         using P0 = std::integral_constant<int, 0>;
         using P2 = std::integral_constant<int, 2>;
-        // main launch over the whole rounds, then the parent raster's remaining tiles as quarter tiles (pl.tail)
+        const bool deep = b16_deep(pl, batch, m, n);
+        // main launch over the whole rounds, then the parent raster's remaining tiles as sub-tiles (pl.tail)
         auto go_tail = [&](auto cfg, auto pp) -> int {
             using Cfg = decltype(cfg);
             const int tiles = ((m + Cfg::kBM - 1) / Cfg::kBM) * ((n + Cfg::kBN - 1) / Cfg::kBN), cus = static_cast<int>(device_cus());
@@ -363,9 +395,9 @@ static int launch_b16(const void *x, const void *y, float *z, int batch, int m, 
         if (pl.bm == 256) rc = plain ? go(GemmCfg<256, 256, 4, 2>{}, P0{}) : go_tail(GemmCfg<256, 256, 4, 2>{}, P2{});
         else if (pl.bm == 128 && pl.bn == 256) rc = go_tail(GemmCfg<128, 256, 2, 4, 3>{}, P0{});
         else if (pl.bm == 128) rc = go(GemmCfg<128, 128, 2, 2>{}, P0{});
-        else if (pl.bm == 64) rc = go(GemmCfg<64, 128, 1, 4>{}, P0{});
-        else if (pl.bm == 32) rc = go(GemmCfg<32, 128, 1, 4>{}, P0{});
-        else rc = go(GemmCfg<16, 128, 1, 4>{}, P0{});
+        else if (pl.bm == 64) rc = deep ? go(GemmCfg<64, 128, 1, 4, 4>{}, P0{}) : go(GemmCfg<64, 128, 1, 4>{}, P0{});
+        else if (pl.bm == 32) rc = deep ? go(GemmCfg<32, 128, 1, 4, 4>{}, P0{}) : go(GemmCfg<32, 128, 1, 4>{}, P0{});
+        else rc = deep ? go(GemmCfg<16, 128, 1, 4, 4>{}, P0{}) : go(GemmCfg<16, 128, 1, 4>{}, P0{});
         if (rc != DGA_OK || pl.splitk <= 1) return rc;
         const int64_t total = static_cast<int64_t>(batch) * m * n;
         hipLaunchKernelGGL(splitk_reduce_f32_kernel, dim3(static_cast<unsigned>((total / 4 + 255) / 256 + 1)), dim3(256), 0,
@@ -519,6 +551,7 @@ static int launch_b16_nt(const void *a, const void *b, void *out, int m, int n, 
     };
     using P0 = std::integral_constant<int, 0>;
     using P2 = std::integral_constant<int, 2>;
+    const bool deep = b16_deep(pl, 1, m, n);
     auto go_tail = [&](auto cfg, auto pp) -> int {
         using Cfg = decltype(cfg);
         const int tiles = ((m + Cfg::kBM - 1) / Cfg::kBM) * ((n + Cfg::kBN - 1) / Cfg::kBN), cus = static_cast<int>(device_cus());
@@ -536,9 +569,9 @@ static int launch_b16_nt(const void *a, const void *b, void *out, int m, int n, 
     if (pl.bm == 256) rc = go_tail(GemmCfg<256, 256, 4, 2>{}, P2{});
     else if (pl.bm == 128 && pl.bn == 256) rc = go_tail(GemmCfg<128, 256, 2, 4, 3>{}, P0{});
     else if (pl.bm == 128) rc = go(GemmCfg<128, 128, 2, 2>{}, P0{});
-    else if (pl.bm == 64) rc = go(GemmCfg<64, 128, 1, 4>{}, P0{});
-    else if (pl.bm == 32) rc = go(GemmCfg<32, 128, 1, 4>{}, P0{});
-    else rc = go(GemmCfg<16, 128, 1, 4>{}, P0{});
+    else if (pl.bm == 64) rc = deep ? go(GemmCfg<64, 128, 1, 4, 4>{}, P0{}) : go(GemmCfg<64, 128, 1, 4>{}, P0{});
+    else if (pl.bm == 32) rc = deep ? go(GemmCfg<32, 128, 1, 4, 4>{}, P0{}) : go(GemmCfg<32, 128, 1, 4>{}, P0{});
+    else rc = deep ? go(GemmCfg<16, 128, 1, 4, 4>{}, P0{}) : go(GemmCfg<16, 128, 1, 4>{}, P0{});
     if (rc != DGA_OK || pl.splitk <= 1) return rc;
     const int64_t total = static_cast<int64_t>(m) * n;
     if (bf) hipLaunchKernelGGL(splitk_reduce_16_kernel<true>, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, stream,

@@ -14,22 +14,27 @@ TILES = ["16,128", "32,128", "64,128", "128,128", "128,256", "256,256"]
 SPLITS = [1, 2, 3, 5]
 
 
-def _with_plan(plan, fn):
-    old = os.environ.get("DGA_B16_PLAN")
+def _with_plan(plan, fn, deep=None):
+    """deep: $DGA_B16_DEEP -- the four-stage build of a tile of at most 64 rows forced on ("1") or off ("0")."""
+    old = {k: os.environ.get(k) for k in ("DGA_B16_PLAN", "DGA_B16_DEEP")}
     try:
         os.environ["DGA_B16_PLAN"] = plan
+        if deep is not None:
+            os.environ["DGA_B16_DEEP"] = deep
         return fn()
     finally:
-        if old is None:
-            os.environ.pop("DGA_B16_PLAN", None)
-        else:
-            os.environ["DGA_B16_PLAN"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("tile", TILES)
 @pytest.mark.parametrize("split", SPLITS)
-def test_operator_every_plan(dga, dtype, tile, split):
+@pytest.mark.parametrize("deep", ["0", "1"])
+def test_operator_every_plan(dga, dtype, tile, split, deep):
     m, n, k = 300, 520, 1344     # ragged in every dimension of every tile; 21 k steps: uneven slices
     g = torch.Generator(device="cuda").manual_seed(split)
     x = (torch.randn((m, k), device="cuda", generator=g) * 0.5).to(dtype)
@@ -39,7 +44,7 @@ def test_operator_every_plan(dga, dtype, tile, split):
         out = torch.full((m, n), float("nan"), dtype=dtype, device="cuda")
         dga.catlass_dynamic_matmul(x, w.t(), out, sync=True)
         return out
-    got = _with_plan(f"{tile},{split}", run)
+    got = _with_plan(f"{tile},{split}", run, deep)
     want = x.float() @ w.float().t()
     tol = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
     assert bool(((got.float() - want).abs() <= tol * want.abs() + 2.0 ** -12 * (x.float().abs() @ w.float().abs().t())).all())
@@ -48,13 +53,14 @@ def test_operator_every_plan(dga, dtype, tile, split):
 @pytest.mark.parametrize("tile", TILES)
 @pytest.mark.parametrize("split", SPLITS)
 @pytest.mark.parametrize("n", [520, 523])       # y read where it lies / through the transposing pre-pass
-def test_run_mmad_rtc_every_plan(dga, tile, split, n):
+@pytest.mark.parametrize("deep", ["0", "1"])
+def test_run_mmad_rtc_every_plan(dga, tile, split, n, deep):
     m, k = 300, 1344
     g = torch.Generator(device="cuda").manual_seed(split + n)
     x = (torch.randn((2, m, k), device="cuda", generator=g) * 0.5).to(torch.float16)
     y = (torch.randn((2, k, n), device="cuda", generator=g) * 0.5).to(torch.float16)
     z = torch.full((2, m, n), float("nan"), dtype=torch.float32, device="cuda")
-    _with_plan(f"{tile},{split}", lambda: dga.run_mmad_rtc(x, y, z))
+    _with_plan(f"{tile},{split}", lambda: dga.run_mmad_rtc(x, y, z), deep)
     for b in range(2):
         want = x[b].float() @ y[b].float()
         assert bool(((z[b] - want).abs() <= 2.0 ** -16 * (x[b].float().abs() @ y[b].float().abs())).all())
