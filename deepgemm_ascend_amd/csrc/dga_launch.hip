@@ -82,7 +82,10 @@ static const Variant kVariants[] = {
     DGA_VARIANT(32, 256, 1, 4),  DGA_VARIANT(32, 128, 1, 4),  DGA_VARIANT(16, 256, 1, 4),
     DGA_VARIANT(16, 128, 1, 4),
     // three stages for the short tiles too: decode shapes stream their weights cold, and a second refill in flight per
-    // workgroup is what the HBM round trip needs (profiles/r02_steady_table.json: warm 5.5 TB/s, cold 3.8 with two stages)
+    // workgroup is what the HBM round trip needs (profiles/r02_steady_table.json: warm 5.5 TB/s, cold 3.8 with two stages).
+    // (Five stages -- one workgroup per CU, four refills in flight -- were tried in round 4 after the 16-bit tiles gained 15-25 %
+    //  from going 2 -> 4: here they change nothing or lose 3-10 % on eight cold decode shapes at 48-128 rows; two workgroups of three
+    //  stages already keep enough in flight.  Not in the menu.)
     Variant{64, 128, 1, 4, &launch_cfg<GemmCfg<64, 128, 1, 4, 3>, 0>, GemmCfg<64, 128, 1, 4, 3>::LDS_BYTES, nullptr, nullptr, 3,
             &launch_cfg<GemmCfg<64, 128, 1, 4, 3, 4>, 0>, &launch_persistent<GemmCfg<64, 128, 1, 4, 3, 4>>},
     Variant{32, 256, 1, 4, &launch_cfg<GemmCfg<32, 256, 1, 4, 3>, 0>, GemmCfg<32, 256, 1, 4, 3>::LDS_BYTES, nullptr, nullptr, 3},
