@@ -128,8 +128,9 @@ static int b16_raster(int tiles_m)
     return tiles_m >= 4 ? 4 : (tiles_m >= 2 ? 2 : 1);
 }
 
-struct B16Plan { int bm, bn, splitk, ks_per_split, tail; };   // tail: the last partial round of a 256 x 256 / 128 x 256 raster in
-                                                               // sub-tiles of `tail` x 128 (0: none)
+struct B16Plan { int bm, bn, splitk, ks_per_split, tail, w8; };   // tail: the last partial round of a 256 x 256 / 128 x 256 raster in
+                                                                   // sub-tiles of `tail` x 128 (0: none); w8: the 128 x 128 tile's
+                                                                   // 8-wave three-stage build (one workgroup per CU)
 
 // Swept plans of the operator's decode rows (the 16-bit counterpart of tuned/mi355x.csv; the reference keeps such winners in its
 // CSV tiling cache, op_host/op_tiling/cache.cpp:22-101): for the (N, K) of the cold decode sweep (scripts/op16_plan_cold.py ->
@@ -169,14 +170,14 @@ static B16Plan b16_plan(int batch, int m, int n, int k, bool nn)
 {
     const int ks_n = (k + 63) / 64;
     auto tiles_of = [&](int bm, int bn) { return static_cast<int64_t>(batch) * ((m + bm - 1) / bm) * ((n + bn - 1) / bn); };
-    B16Plan pl{128, 128, 1, ks_n, 0};
+    B16Plan pl{128, 128, 1, ks_n, 0, 0};
     auto split = [&](int s) {
         if (s > 1) { pl.ks_per_split = (ks_n + s - 1) / s; pl.splitk = (ks_n + pl.ks_per_split - 1) / pl.ks_per_split; }
     };
     if (const char *e = std::getenv("DGA_B16_PLAN")) {   // development: "bm,bn,splitk" (scripts/op16_plan_ab.py)
-        int bm = 0, bn = 0, s = 1, tail = 0;
-        if (std::sscanf(e, "%d,%d,%d,%d", &bm, &bn, &s, &tail) >= 2 && bm > 0 && bn > 0) {
-            pl.bm = bm; pl.bn = bn;
+        int bm = 0, bn = 0, s = 1, tail = 0, w8 = 0;
+        if (std::sscanf(e, "%d,%d,%d,%d,%d", &bm, &bn, &s, &tail, &w8) >= 2 && bm > 0 && bn > 0) {
+            pl.bm = bm; pl.bn = bn; pl.w8 = (w8 && bm == 128 && bn == 128) ? 1 : 0;
             split(s);
             if (tail == 1) tail = bm / 2;   // quarter tiles
             pl.tail = (pl.splitk == 1 && batch == 1 && bn == 256 && (bm == 256 || bm == 128) && tail < bm &&
@@ -221,8 +222,12 @@ static B16Plan b16_plan(int batch, int m, int n, int k, bool nn)
     // profiles/r03_op16_plan_ab.txt: 1024x4096x7168 84 -> 64 us, 1536x6144x4096 101 -> 78, 512x7168x4096 49 -> 41,
     // 1024x18432x7168 326 -> 287 against the fill-the-chip-with-the-biggest-tile rule below, which stays for M <= 64).
     if (m > 64) {
-        struct Cand { int bm, bn; double us_per_step; int wpc; };
-        static const Cand kCands[] = {{256, 256, 1.45, 1}, {128, 256, 0.87, 1}, {128, 128, 0.73, 2}, {64, 128, 0.58, 2}};
+        // (the 128 x 128 tile twice: 4 waves and two LDS stages -- two workgroups share a CU -- and 8 waves with three stages, one
+        //  workgroup per CU, 0.48 us a step where the 4-wave build alone on a CU takes 0.73: 1024 x 4096 x 7168 63.0 -> 57.2 us,
+        //  512 x 7168 x 4096 41.1 -> 32.6, level with the vendor library's 58.2 / 34.0; scripts/op16_tail_ab.py)
+        struct Cand { int bm, bn; double us_per_step; int wpc, w8; };
+        static const Cand kCands[] = {{256, 256, 1.45, 1, 0}, {128, 256, 0.87, 1, 0}, {128, 128, 0.73, 2, 0}, {64, 128, 0.58, 2, 0},
+                                      {128, 128, 0.48, 1, 1}};
         double best = 1e300;
         for (const Cand &c : kCands)
             for (int s : {1, 2, 3, 4, 6, 8, 12, 16}) {
@@ -233,7 +238,7 @@ static B16Plan b16_plan(int batch, int m, int n, int k, bool nn)
                 const double share = static_cast<double>(std::min<int64_t>(c.wpc, (items + cus - 1) / cus));
                 double t = 3.0 + rounds * per * c.us_per_step * std::pow(share, 0.6);
                 if (s_eff > 1) t += 4.0 + static_cast<double>(s_eff) * batch * m * n * 8.0 / 5.0e6;
-                if (t < best) { best = t; pl.bm = c.bm; pl.bn = c.bn; pl.splitk = s_eff; pl.ks_per_split = per; pl.tail = 0; }
+                if (t < best) { best = t; pl.bm = c.bm; pl.bn = c.bn; pl.splitk = s_eff; pl.ks_per_split = per; pl.tail = 0; pl.w8 = c.w8; }
             }
         // the whole rounds of a 256 x 256 / 128 x 256 raster as they are, the last partial round in sub-tiles (128 / 64 / 32 rows x
         // 128 columns, a second launch): 4-16 times as many CUs busy for a fraction of a round -- what the reference's Stream-K
@@ -241,7 +246,7 @@ static B16Plan b16_plan(int batch, int m, int n, int k, bool nn)
         // are the single launch's (tests/test_op16_tail_gpu.py).  bf16, warm (scripts/op16_tail_ab.py -> profiles/r04_op16_tail_ab.txt):
         // 1024 x 18432 x 7168 289 -> 265 us, 5119 x 6997 x 9901 762 -> 705, 4608 x 4096 x 7168 260 -> 227, 2304 x 8192 x 4096 153 -> 137
         if (batch == 1) {
-            static const Cand kSub[] = {{128, 128, 0.73, 2}, {64, 128, 0.58, 2}, {32, 128, 0.50, 2}};
+            static const Cand kSub[] = {{128, 128, 0.73, 2, 0}, {64, 128, 0.58, 2, 0}, {32, 128, 0.50, 2, 0}};
             for (int ci = 0; ci < 2; ++ci) {
                 const Cand &c = kCands[ci];
                 const int64_t tiles = tiles_of(c.bm, c.bn), tail = tiles % cus;
@@ -251,9 +256,10 @@ static B16Plan b16_plan(int batch, int m, int n, int k, bool nn)
                     const int64_t items = tail * (c.bm / q.bm) * (c.bn / q.bn);
                     const double rounds = std::ceil(static_cast<double>(items) / static_cast<double>(cus * q.wpc));
                     const double share = static_cast<double>(std::min<int64_t>(q.wpc, (items + cus - 1) / cus));
+                    const bool q8 = q.bm == 128 && items <= cus;   // (the sub-launch takes the 8-wave 128 x 128 build then)
                     const double t = 3.0 + static_cast<double>(tiles / cus) * ks_n * c.us_per_step + 2.0 +
-                                     rounds * ks_n * q.us_per_step * std::pow(share, 0.6);
-                    if (t < best) { best = t; pl.bm = c.bm; pl.bn = c.bn; pl.splitk = 1; pl.ks_per_split = ks_n; pl.tail = q.bm; }
+                                     (q8 ? ks_n * 0.48 : rounds * ks_n * q.us_per_step * std::pow(share, 0.6));
+                    if (t < best) { best = t; pl.bm = c.bm; pl.bn = c.bn; pl.splitk = 1; pl.ks_per_split = ks_n; pl.tail = q.bm; pl.w8 = 0; }
                 }
             }
         }
@@ -387,14 +393,14 @@ static int launch_b16(const void *x, const void *y, float *z, int batch, int m, 
             if (int rc = go(cfg, pp)) return rc;
             const int sm = Cfg::kBM / pl.tail, sn = Cfg::kBN / 128;
             p.launch_tiles = tail * sm * sn; p.tail_begin = main_tiles; p.tail_sub = sm | (sn << 8);
-            if (pl.tail == 128) return go(GemmCfg<128, 128, 2, 2>{}, P0{});
+            if (pl.tail == 128) return p.launch_tiles <= cus ? go(GemmCfg<128, 128, 2, 4, 3>{}, P0{}) : go(GemmCfg<128, 128, 2, 2>{}, P0{});
             if (pl.tail == 64) return go(GemmCfg<64, 128, 1, 4>{}, P0{});
             return go(GemmCfg<32, 128, 1, 4>{}, P0{});
         };
         int rc;
         if (pl.bm == 256) rc = plain ? go(GemmCfg<256, 256, 4, 2>{}, P0{}) : go_tail(GemmCfg<256, 256, 4, 2>{}, P2{});
         else if (pl.bm == 128 && pl.bn == 256) rc = go_tail(GemmCfg<128, 256, 2, 4, 3>{}, P0{});
-        else if (pl.bm == 128) rc = go(GemmCfg<128, 128, 2, 2>{}, P0{});
+        else if (pl.bm == 128) rc = pl.w8 ? go(GemmCfg<128, 128, 2, 4, 3>{}, P0{}) : go(GemmCfg<128, 128, 2, 2>{}, P0{});
         else if (pl.bm == 64) rc = deep ? go(GemmCfg<64, 128, 1, 4, 4>{}, P0{}) : go(GemmCfg<64, 128, 1, 4>{}, P0{});
         else if (pl.bm == 32) rc = deep ? go(GemmCfg<32, 128, 1, 4, 4>{}, P0{}) : go(GemmCfg<32, 128, 1, 4>{}, P0{});
         else rc = deep ? go(GemmCfg<16, 128, 1, 4, 4>{}, P0{}) : go(GemmCfg<16, 128, 1, 4>{}, P0{});
@@ -561,14 +567,14 @@ static int launch_b16_nt(const void *a, const void *b, void *out, int m, int n, 
         if (int rc = go(cfg, pp)) return rc;
         const int sm = Cfg::kBM / pl.tail, sn = Cfg::kBN / 128;
         p.launch_tiles = tail * sm * sn; p.tail_begin = main_tiles; p.tail_sub = sm | (sn << 8);
-        if (pl.tail == 128) return go(GemmCfg<128, 128, 2, 2>{}, P0{});
+        if (pl.tail == 128) return p.launch_tiles <= cus ? go(GemmCfg<128, 128, 2, 4, 3>{}, P0{}) : go(GemmCfg<128, 128, 2, 2>{}, P0{});
         if (pl.tail == 64) return go(GemmCfg<64, 128, 1, 4>{}, P0{});
         return go(GemmCfg<32, 128, 1, 4>{}, P0{});
     };
     int rc;
     if (pl.bm == 256) rc = go_tail(GemmCfg<256, 256, 4, 2>{}, P2{});
     else if (pl.bm == 128 && pl.bn == 256) rc = go_tail(GemmCfg<128, 256, 2, 4, 3>{}, P0{});
-    else if (pl.bm == 128) rc = go(GemmCfg<128, 128, 2, 2>{}, P0{});
+    else if (pl.bm == 128) rc = pl.w8 ? go(GemmCfg<128, 128, 2, 4, 3>{}, P0{}) : go(GemmCfg<128, 128, 2, 2>{}, P0{});
     else if (pl.bm == 64) rc = deep ? go(GemmCfg<64, 128, 1, 4, 4>{}, P0{}) : go(GemmCfg<64, 128, 1, 4>{}, P0{});
     else if (pl.bm == 32) rc = deep ? go(GemmCfg<32, 128, 1, 4, 4>{}, P0{}) : go(GemmCfg<32, 128, 1, 4>{}, P0{});
     else rc = deep ? go(GemmCfg<16, 128, 1, 4, 4>{}, P0{}) : go(GemmCfg<16, 128, 1, 4>{}, P0{});

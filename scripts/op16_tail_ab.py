@@ -1,5 +1,6 @@
-"""16-bit operator (bf16): the planned launch against forced plans with / without the quarter-tile tail, warm, device time by graph
-replay.  Usage: python scripts/op16_tail_ab.py"""
+"""16-bit operator (bf16) at more than 128 rows: the planned launch against forced plans -- with / without the sub-tile tail, the 4- and
+8-wave builds of the 128 x 128 tile -- and the vendor GEMM library (yardstick), warm, device time by graph replay.
+Usage: python scripts/op16_tail_ab.py"""
 import json
 import os
 import sys
@@ -13,8 +14,10 @@ import deepgemm_ascend_amd as dga  # noqa: E402
 from deepgemm_ascend_amd.harness import sweep  # noqa: E402
 
 SHAPES = [(1024, 18432, 7168), (5119, 6997, 9901), (1024, 4096, 7168), (2048, 4096, 7168), (4096, 4096, 4096), (3511, 6151, 8191),
-          (1279, 5003, 7681), (2304, 8192, 4096), (1536, 12288, 5120), (4608, 4096, 7168), (3072, 6144, 4096), (8192, 4608, 4096)]
-PLANS = [None, "256,256,1,0", "256,256,1,128", "256,256,1,64", "256,256,1,32", "128,256,1,0", "128,256,1,64", "128,256,1,32", "128,128,1,0"]
+          (1279, 5003, 7681), (2304, 8192, 4096), (1536, 12288, 5120), (4608, 4096, 7168), (3072, 6144, 4096), (8192, 4608, 4096),
+          (512, 7168, 4096), (768, 8192, 8192), (1024, 2048, 7168), (256, 7168, 7168), (384, 16384, 4096), (640, 5120, 5120)]
+PLANS = [None, "256,256,1,0", "256,256,1,128", "256,256,1,64", "256,256,1,32", "128,256,1,0", "128,256,2,0", "128,256,1,64", "128,128,1,0",
+         "128,128,1,0,1", "128,128,2,0,1"]   # (fifth field 1: the 8-wave three-stage build of the 128 x 128 tile)
 
 
 def main():

@@ -10,7 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-TILES = ["16,128", "32,128", "64,128", "128,128", "128,256", "256,256"]
+TILES = ["16,128", "32,128", "64,128", "128,128", "128,256", "256,256", "128,128;w8"]   # ;w8 = the 8-wave build of the 128 x 128 tile
 SPLITS = [1, 2, 3, 5]
 
 
@@ -44,7 +44,7 @@ def test_operator_every_plan(dga, dtype, tile, split, deep):
         out = torch.full((m, n), float("nan"), dtype=dtype, device="cuda")
         dga.catlass_dynamic_matmul(x, w.t(), out, sync=True)
         return out
-    got = _with_plan(f"{tile},{split}", run, deep)
+    got = _with_plan(f"{tile.split(';')[0]},{split}" + (",0,1" if ";" in tile else ""), run, deep)
     want = x.float() @ w.float().t()
     tol = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
     assert bool(((got.float() - want).abs() <= tol * want.abs() + 2.0 ** -12 * (x.float().abs() @ w.float().abs().t())).all())
@@ -60,7 +60,7 @@ def test_run_mmad_rtc_every_plan(dga, tile, split, n, deep):
     x = (torch.randn((2, m, k), device="cuda", generator=g) * 0.5).to(torch.float16)
     y = (torch.randn((2, k, n), device="cuda", generator=g) * 0.5).to(torch.float16)
     z = torch.full((2, m, n), float("nan"), dtype=torch.float32, device="cuda")
-    _with_plan(f"{tile},{split}", lambda: dga.run_mmad_rtc(x, y, z), deep)
+    _with_plan(f"{tile.split(';')[0]},{split}" + (",0,1" if ";" in tile else ""), lambda: dga.run_mmad_rtc(x, y, z), deep)
     for b in range(2):
         want = x[b].float() @ y[b].float()
         assert bool(((z[b] - want).abs() <= 2.0 ** -16 * (x[b].float().abs() @ y[b].float().abs())).all())
