@@ -232,6 +232,7 @@ static B16Plan b16_plan(int batch, int m, int n, int k, bool nn)
         for (const Cand &c : kCands)
             for (int s : {1, 2, 3, 4, 6, 8, 12, 16}) {
                 if (s > 1 && ks_n / s < 8) continue;
+                if (s > 1 && static_cast<int64_t>(s) * batch * m * n * 4 > (256ll << 20)) continue;   // fp32 slabs <= 256 MiB (as the fp8 selector)
                 const int per = (ks_n + s - 1) / s, s_eff = (ks_n + per - 1) / per;
                 const int64_t items = tiles_of(c.bm, c.bn) * s_eff;
                 const double rounds = std::ceil(static_cast<double>(items) / static_cast<double>(cus * c.wpc));
