@@ -73,3 +73,46 @@ def test_every_entry_point_in_one_hip_graph(dga):
     assert torch.equal(q, want_q)
     for k, v in outs.items():
         assert torch.equal(v.view(torch.int16), want[k].view(torch.int16)), k
+
+
+def test_the_16_bit_operators_plans_in_one_hip_graph(dga):
+    """The 16-bit operator's round-4 kernels under capture: the one-launch workgroup split-K (one and two row tiles), a deep small
+    tile with split-K (tile kernel + combine), the 128x128 8-wave build and a raster whose last partial round runs in sub-tiles
+    (two launches, forced by $DGA_B16_PLAN, which is read per call); replay == eager, bit for bit."""
+    import os
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(5)
+    cases = {"wsk8": (8, 2048, 1024, None), "wsk24": (24, 1536, 2048, None), "deep": (64, 4096, 1024, "64,128,4"),
+             "w8": (512, 1024, 512, "128,128,1,0,1"), "tail": (2100, 8000, 128, "256,256,1,64")}
+    data = {}
+    for name, (m, n, k, plan) in cases.items():
+        x = (torch.randn((m, k), device=dev, generator=g) * 0.5).to(torch.bfloat16)
+        w = (torch.randn((n, k), device=dev, generator=g) * 0.5).to(torch.bfloat16)
+        data[name] = (x, w, torch.zeros((m, n), dtype=torch.bfloat16, device=dev), plan)
+
+    def layer():
+        for name, (x, w, o, plan) in data.items():
+            if plan:
+                os.environ["DGA_B16_PLAN"] = plan
+            try:
+                dga.catlass_dynamic_matmul(x, w.t(), o)
+            finally:
+                os.environ.pop("DGA_B16_PLAN", None)
+
+    layer(); torch.cuda.synchronize()
+    want = {k: v[2].clone() for k, v in data.items()}
+    for name, (x, w, o, _) in data.items():
+        ref = x.float() @ w.float().t()
+        assert bool(((o.float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 2.0 ** -12 * (x.float().abs() @ w.float().abs().t())).all()), name
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        layer()
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        layer()
+    for v in data.values():
+        v[2].zero_()
+    graph.replay(); torch.cuda.synchronize()
+    for name, v in data.items():
+        assert torch.equal(v[2].view(torch.int16), want[name].view(torch.int16)), name
