@@ -551,7 +551,29 @@ def widen_leg():
                              "roofline": {"bound": "hbm", "achieved": round(byt / us / 1e3, 1), "peak": PEAK_HBM_GBPS,
                                           "unit": "GB/s", "frac": round(byt / us / 1e3 / PEAK_HBM_GBPS, 4)}}
     del x
+    res["operator_bf16"] = operator_16bit_rows()
     return res
+
+
+def operator_16bit_rows():
+    """The reference's operator in its own dtypes -- catlass_dynamic_matmul, bf16 in and out, mat2 stored [N,K] (op_host/
+    catlass_dynamic_matmul.cpp:50-80) -- over the 18-shape list; device time by graph replay (warm)."""
+    import torch
+    import deepgemm_ascend_amd as dga
+    from deepgemm_ascend_amd.harness import sweep
+    rows = []
+    for (m, n, k) in sweep.SHAPE_GROUP:
+        g = torch.Generator(device="cuda").manual_seed(m + n + k)
+        x = (torch.randn((m, k), device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+        w = (torch.randn((n, k), device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+        o = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+        us = _graph_us(lambda: dga.catlass_dynamic_matmul(x, w.t(), o), 10, replays=3, prewarm_ms=30.0)
+        flops, byt = 2.0 * m * n * k, 2.0 * (m * k + n * k + m * n)
+        t_m, t_h = flops / (PEAK_BF16_TFLOPS * 1e6), byt / (PEAK_HBM_GBPS * 1e3)
+        rows.append({"shape": [m, n, k], "us": round(us, 2), "tflops": round(flops / us / 1e6, 1), "gbps": round(byt / us / 1e3, 1),
+                     "bound": "mfma" if t_m >= t_h else "hbm", "frac": round(max(t_m, t_h) / us, 3)})
+        del x, w, o
+    return rows
 
 
 def reference_benchmark_rows():
