@@ -196,7 +196,9 @@ static B16Plan b16_plan(int batch, int m, int n, int k, bool nn)
     // the rows (or half of them), split-K filling the CUs once with at least 12 k steps a slice -- every CU streams with three
     // stages in flight.  Taken where it fills at least three quarters of the CUs; fitted to the cold sweeps of both paths
     // (profiles/r04_op16_plan_cold.txt, r04_mmad_plan_cold.txt: mean distance from the best plan 10.3 % / 7.8 % -> 5.1 % / 2.9 %).
-    if (batch == 1 && m <= 128) {
+    // (two tile rows -- more than 64 rows -- read y twice through the L2: only where the stream is short; longer ones take the
+    //  128 x 256 rule below: 128 x 8192 x 28672 149 -> 101 us)
+    if (batch == 1 && (m <= 64 || (m <= 128 && static_cast<int64_t>(n) * k < (48ll << 20)))) {
         const int bm0 = m <= 16 ? 16 : (m <= 32 ? 32 : 64);
         int best_bm = 0, best_s = 1, best_fill = -1;
         for (int bm = bm0; bm >= 16 && bm >= bm0 / 2; bm /= 2) {
@@ -523,20 +525,21 @@ static int launch_b16_nt(const void *a, const void *b, void *out, int m, int n, 
     p.y_bs = static_cast<int64_t>(n) * p.ldy;
     p.z_bs = static_cast<int64_t>(m) * n;
     p.batch = 1;
-    // decode rows (M <= 16): one launch, the K slices are the waves of a workgroup.  Cold, bf16, against the planned tile kernel
-    // (+ combine): ahead on 51 of 57 (M, N, K) of the decode grid, by 15-35 % on most -- 129280 x 7168 432 -> 316 us, 57344 x 8192
-    // 238 -> 166, 28672 x 4096 70 -> 45, 4096 x 7168 18.8 -> 13.3 (profiles/r04_op16_wsk_cold.txt).  Not where the rows are a
-    // multiple of 32 KB apart (7168 x 16384: 2-15 % behind -- every row of a stage starts in the same memory channel).
-    // $DGA_B16_WSK = 0 / 1 overrides the rule.
+    // decode rows: one launch, the K slices are the waves of a workgroup (gemm_b16_wsk_kernel.hpp).  When it was built the tile path
+    // was two-stage tiles by the fill rule and it won on 51 of 57 cold decode shapes by 15-35 % (profiles/r04_op16_wsk_cold.txt);
+    // the deep small tiles took most of that back.  $DGA_B16_WSK = 0 / 1 overrides the rule.
     const char *wsk_e = std::getenv("DGA_B16_WSK");   // (read per call, like $DGA_B16_PLAN: the tests flip it inside one process)
     const int wsk_env = wsk_e ? std::atoi(wsk_e) : -1;
-    // 17..32 rows (two 16-row tiles of x, a shallower ring, x read once per workgroup): ahead where the stream is short -- N K <= 32 M
-    // elements (4096 x 4096 16.2 -> 13.0 us, 7168 x 2048 14.1 -> 11.6, 576 x 7168 12.3 -> 10.9) -- or where the workgroups' reads of x
-    // stay below the read of y (N >= 8192) and N K <= 72 M (8192 x 8192 34.2 -> 30.6, 24576 x 1536 23.8 -> 21.9); behind on longer ones.
+    // The rule, against the best tile plan of the cold sweep (profiles/r04_op16_plan_cold.txt; since the small tiles have their deep
+    // builds): at <= 16 rows the one launch is ahead by 5-25 % on streams of N K <= 32 M elements and level (+-5 %) on longer ones
+    // unless the workgroups' reads of x weigh in (N < 8192: 5120 x 13824 +12..22 %, 7168 x 18432 +10 %); K = 512 gives a wave one k
+    // step (+28..39 %); rows a multiple of 32 KB apart collide in the memory channels.  17..32 rows (two 16-row tiles of x, a
+    // shallower ring): ahead only on short streams of short rows -- K <= 4096 and N K <= 16 M (4096 x 4096 0.97 of the best tile
+    // plan, 7168 x 2048 0.95, 7168 x 1536 0.86, 1024 x 4096 0.90) -- and 5-40 % behind elsewhere.
     const B16Swept *swept = m <= 32 ? b16_swept(1, m, n, k, false) : nullptr;
     const int64_t nk = static_cast<int64_t>(n) * kp;
-    const bool wsk_rule = kp >= 512 && (kp % 16384) != 0 &&
-                          (m <= 16 || (m <= 32 && kp >= 1024 && (nk <= (32ll << 20) || (n >= 8192 && nk <= (72ll << 20)))));
+    const bool wsk_rule = kp >= 1024 && (kp % 16384) != 0 &&
+                          (m <= 16 ? (nk <= (32ll << 20) || n >= 8192) : (m <= 32 && kp <= 4096 && nk <= (16ll << 20)));
     if (wsk_env >= 0 ? wsk_env != 0 : (swept ? swept->bm == 0 : wsk_rule)) {
         const int rc = bf ? launch_b16_wsk<true>(p, stream) : launch_b16_wsk<false>(p, stream);
         if (rc != DGA_E_TILING) return rc;
