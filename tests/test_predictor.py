@@ -50,10 +50,14 @@ def test_cxx_forward_equals_numpy(predictor):
             assert math.isclose(got, want, rel_tol=2e-4), (m, n, k, p, got, want)
 
 
+DEPARTURES = [(5248, 1152, 512), (624, 1408, 9344), (1152, 896, 8448), (1707, 1152, 15744)]
+
+
 def test_pick_is_native_or_a_candidate_with_the_promised_gain(predictor):
     from deepgemm_ascend_amd.harness import sweep
     changed = 0
-    for (m, n, k) in SHAPES + [(m, n, k) for m, n, k in sweep.grid_shapes(40, seed=5)]:
+    # (since the selector's round-4 refit the model departs from it on ~1 % of random shapes: three that it does change are named)
+    for (m, n, k) in SHAPES + DEPARTURES + [(m, n, k) for m, n, k in sweep.grid_shapes(40, seed=5)]:
         native = predictor.select_kernel(m, n, k)
         t, pred_us, native_us = predictor.select_kernel_with_predictor(m, n, k)
         # dispatchPolicyTag 4 (loader waves) is the plain loop's build with extra DMA waves: every 3-stage pick is upgraded to
@@ -89,7 +93,7 @@ def test_picks_resolve_to_the_build_the_sweep_timed(predictor, tmp_path):
     from deepgemm_ascend_amd.harness import sweep
     seen = set()
     try:
-        for i, (m, n, k) in enumerate(SHAPES + [(512, 4096, 7168)] + list(sweep.grid_shapes(60, seed=11))):
+        for i, (m, n, k) in enumerate(SHAPES + DEPARTURES + [(512, 4096, 7168)] + list(sweep.grid_shapes(60, seed=11))):
             t, _, _ = predictor.select_kernel_with_predictor(m, n, k)
             native = predictor.select_kernel(m, n, k)
             if (t.m1, t.n1, t.stages, t.splitkFactor) == (native.m1, native.n1, native.stages, native.splitkFactor):
@@ -158,6 +162,17 @@ def test_tiling_consults_the_predictor_on_a_cache_miss(predictor):
            (t_pred.m1, t_pred.n1, t_pred.stages, t_pred.splitkFactor, t_pred.dispatchPolicyTag)
     if t.stages == 3 and (t.m1, t.n1) in ((128, 256), (128, 128), (64, 256), (64, 128), (16, 128)):   # the tiles that have a loader-wave build
         assert t.dispatchPolicyTag == 4
+
+
+@pytest.mark.parametrize("m,n,k", [(8, 1000, 4096), (16, 6000, 6144), (4, 9000, 3072), (8, 20000, 8192), (1, 2000, 8192)])
+def test_the_predictor_leaves_the_workgroup_split_k_alone(predictor, m, n, k):
+    """kernelSerial 6 is outside the model's candidate space (as the quarter-tile tail is): seen as "16 x 128, no split" it was
+    replaced by a two-launch split-K on every decode shape off the tuned table (8 x 1024 x 4096 cold: 5.7 -> 8.6 us) until round 4."""
+    heur = predictor.select_kernel(m, n, k)
+    assert heur.kernelSerial == 6      # (shapes the selector's decode rule takes; none of them is in the tuned table)
+    t, _, _ = predictor.select_kernel_with_predictor(m, n, k)
+    assert (t.kernelSerial, t.m1, t.n1, t.splitkFactor, t.stages) == (6, 16, 128, 1, 3)
+    assert predictor.tiling(m, n, k).kernelSerial == 6
 
 
 def test_training_export_round_trips_into_the_cxx_loader(predictor, tmp_path):
