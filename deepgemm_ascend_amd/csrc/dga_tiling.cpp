@@ -546,6 +546,18 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
     // is long, K is cut so that every CU streams a share of the operands; the fp32 partial tiles are combined by a
     // second kernel.  Worth it only while the partial slabs stay small next to the operand stream.
     t.kernelSerial = (blocks <= pf.coreNum && t.k <= t.k1) ? DGA_KERNEL_SMALL : DGA_KERNEL_COMMON;
+    // Decode rows whose raster fills at most half of the CUs with the split the model chose: the model's form misses the 100-128
+    // tile range (N ~ 12-16 K at 128 columns a tile), where it sees no reason to split and a split of 2 is 15-20 % faster cold
+    // (32 x 14336 x 4096 23.3 -> 18.7 us, 32 x 13824 x 5120 27.9 -> 22.7: profiles/r04_sweep_decode3/).  Double it while the launch
+    // still fits the CUs once and a slice keeps >= 16 k blocks -- on 30 unseen (N, K) x 3 row counts it changes 12 picks, all
+    // for the better (0.75-0.89 of the time, profiles/r04_sweep_decode3/fill_bump_ab.txt); with 8 k blocks a slice (K = 2048) the
+    // same doubling costs 2-10 %.  $DGA_NO_FILL_BUMP = 1: the model's own split (A/B).
+    static const bool no_bump = [] { const char *e = std::getenv("DGA_NO_FILL_BUMP"); return e && std::atoi(e) != 0; }();
+    if (!no_bump && dense_splitk >= 1 && groups == 1 && !contiguous && t.m <= 128) {
+        while (blocks * dense_splitk * 2 <= pf.coreNum && kb / (2 * dense_splitk) >= 16 &&
+               static_cast<uint64_t>(2 * dense_splitk) * t.m * t.n * 4 <= kMaxSlabBytes)
+            dense_splitk *= 2;
+    }
     if (dense_splitk > 1) {
         t.splitkFactor = static_cast<uint16_t>(dense_splitk);
         t.kernelSerial = DGA_KERNEL_STREAMK;
