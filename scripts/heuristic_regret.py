@@ -10,6 +10,8 @@ import deepgemm_ascend_amd as dga
 shapes = {}
 for d in sys.argv[1:]:
     for f in glob.glob(str(Path(d) / "shape_*_rank_*.jsonl")):
+        if f.endswith("_checkpoint.jsonl"):
+            continue
         for line in open(f):
             r = json.loads(line)
             if r["negative"] or r["time"] <= 0:
