@@ -347,7 +347,11 @@ void prefer_loader_waves(dga_tiling_t &t, bool upgrade_plain)
         // boundary of theirs does) -- the same device-timed sweep; round 2's rule (every tile) came from launch intervals timed
         // through Python, which could not tell kernels under ~12 us apart
         const bool tall = (t.m1 == 128 && (t.n1 == 256 || t.n1 == 128)) || (t.m1 == 64 && t.n1 == 256);
-        if ((tiles > device_cus() && tall) || weight_stream) t.dispatchPolicyTag = DGA_POLICY_PERSISTENT;
+        // (... unless the whole problem is a few tiles of a few k blocks: 16 groups x 64 rows x (1536, 4096) -- 192 tiles of 32 k
+        //  blocks, 20 us of work -- takes 31 us on the persistent build and 20-22 on the one-tile ones; at 192 tiles of 64 k
+        //  blocks the persistent build is ahead again, 93.6 against 100)
+        const uint64_t kb = (static_cast<uint64_t>(t.k) + 127) / 128;
+        if ((tiles > device_cus() && tall) || (weight_stream && tiles * kb >= 8192)) t.dispatchPolicyTag = DGA_POLICY_PERSISTENT;
     }
     // ... and the continuous 256x256 kernel has its own persistent form (dispatchPolicyTag 6,
     // gemm_fp8_cont_persistent_kernel.hpp) for dense rasters of full tiles: the next tile's first stages are fetched from
@@ -467,7 +471,12 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
         // Long groups (>= 512 rows on average) take the 256x256 tile all the same: it runs a second pass on the tiles
         // that straddle two groups (about every second group boundary) and still wins by 15-25 % (scripts/contig_ab.py).
         if (contiguous) {
-            const bool tall = t.m / std::max(1u, t.groups) >= 512 && t.n >= 256;
+            // (... where its raster fills the CUs' rounds: 4 groups x 1024 rows x (2048, 4096) is 128 such tiles -- half the CUs --
+            //  and takes 49 us against the 128 x 256 tile's 38; x (5120, 5120), 320 tiles = 1.25 rounds, 129 against 112;
+            //  scripts/grouped_selector_regret.py)
+            const uint64_t tiles256 = static_cast<uint64_t>(ceil_div(t.m, 256)) * ceil_div(t.n, 256);
+            const double fill256 = static_cast<double>(tiles256) / (std::ceil(static_cast<double>(tiles256) / pf.coreNum) * pf.coreNum);
+            const bool tall = t.m / std::max(1u, t.groups) >= 512 && t.n >= 256 && fill256 >= 0.8;
             if (tall ? !(e.bm == 2 * DGA_CONTIGUOUS_M_ALIGNMENT && e.bn == 256)
                      : (e.bm > DGA_CONTIGUOUS_M_ALIGNMENT || DGA_CONTIGUOUS_M_ALIGNMENT % e.bm))
                 continue;
@@ -528,6 +537,19 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
     // dense: the same sweep has the three-stage build (with its loader waves where it has them) ahead on every tile, cold by
     // 13-32 % and warm by 3-26 % (except the 256-wide short tiles on warm operands, which tall problems do not get)
     if (dense_splitk && tile_has_three_stages(pick.bm, pick.bn)) t.stages = 3;
+    // The masked grouped stream on short tiles (at most 64 rows a group), off the tuned table: the three-stage build -- with its
+    // loader waves in the persistent form where the tile has them (16 / 64 x 128: prefer_loader_waves below) -- instead of the
+    // two-stage plain loop this function used to leave them with: 64 groups x 16 rows x (3072, 8192) 291 -> 260 us, x (1536, 4096)
+    // 99 -> 85, 16 x 64 x (1536, 4096) 29 -> 20-22 (every legal build timed on 12 unseen grouped problems:
+    // scripts/grouped_selector_regret.py -> profiles/r04_grouped_selector_regret.txt).  A 16-row group takes the 128-wide tile (the
+    // one with loader waves: 272 against the 256-wide tile's 300-315 us at 64 x 16 x (5120, 5120)); the 32-row tiles have no such
+    // build and are level at two and three stages: left alone.
+    if (groups > 1 && !contiguous && pick.bm <= 64 && pick.bm != 32) {
+        if (pick.bm == 16 && pick.bn == 256)
+            for (const MenuEntry &e : seen)
+                if (e.bm == 16 && e.bn == 128) { pick = e; t.n1 = 128; t.wavesM = static_cast<uint8_t>(e.wm); t.wavesN = static_cast<uint8_t>(e.wn); t.ldsBytes = e.lds; }
+        if (tile_has_three_stages(pick.bm, pick.bn)) t.stages = 3;
+    }
     // 128x256 with three stages has two builds: 4 waves (2x2) and 8 waves (2x4, two per SIMD).  The masked grouped
     // stream (HBM-bound) is 3 % faster on 4 waves, everything compute-bound 3-14 % faster on 8 (4096x2048x7168: 66.8 ->
     // 61.8 us; scripts/steady_ab.py, scripts/contig_ab.py).
