@@ -239,7 +239,13 @@ static B16Plan b16_plan(int batch, int m, int n, int k, bool nn)
                 const int64_t items = tiles_of(c.bm, c.bn) * s_eff;
                 const double rounds = std::ceil(static_cast<double>(items) / static_cast<double>(cus * c.wpc));
                 const double share = static_cast<double>(std::min<int64_t>(c.wpc, (items + cus - 1) / cus));
-                double t = 3.0 + rounds * per * c.us_per_step * std::pow(share, 0.6);
+                // a SINGLE round that leaves CUs idle runs its k steps faster than the full chip's figure (clock and memory headroom:
+                // 168 tiles of 256 x 256 take 1.20 us a step, 140 take 1.11, 256 take 1.45 -- scripts/op16_plan_mid.py; the partial
+                // last round of a longer raster does not: 350 tiles take two full rounds); the 64-row tile's figure is its
+                // two-stage build's -- a launch of at most one workgroup per CU runs the deep build (b16_deep): 0.36
+                const double busy = rounds > 1.0 ? 1.0 : std::max(0.5, std::min(1.0, static_cast<double>(items) / static_cast<double>(cus)));
+                const double us_step = (c.bm == 64 && items <= cus) ? 0.36 : c.us_per_step;
+                double t = 3.0 + rounds * per * us_step * std::pow(share, 0.6) * (0.55 + 0.45 * busy);
                 if (s_eff > 1) t += 4.0 + static_cast<double>(s_eff) * batch * m * n * 8.0 / 5.0e6;
                 if (t < best) { best = t; pl.bm = c.bm; pl.bn = c.bn; pl.splitk = s_eff; pl.ks_per_split = per; pl.tail = 0; pl.w8 = c.w8; }
             }
