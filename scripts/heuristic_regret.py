@@ -21,9 +21,12 @@ for d in sys.argv[1:]:
             key = (p["m1"], p["n1"], p["stages"], p["splitk"], pol, bool(p.get("tail")))
             cur = shapes.setdefault((r["M"], r["N"], r["K"]), {})
             cur[key] = min(cur.get(key, 1e30), r["time"])
-rows, missing = [], 0
+rows, missing, wsk = [], 0, 0
 for (m, n, k), cs in shapes.items():
     t = dga.select_kernel(m, n, k)
+    if t.kernelSerial == 6:   # the one-launch workgroup split-K: not a candidate of these records
+        wsk += 1
+        continue
     pol = {5: 4, 6: 2}.get(t.dispatchPolicyTag, t.dispatchPolicyTag)
     key = (t.m1, t.n1, 3 if t.stages == 3 else 2, max(1, t.splitkFactor), pol, t.kernelSerial == 5)
     best = min(cs.values())
