@@ -60,3 +60,20 @@ def test_without_workspace_and_errors(dga, oracle):
         dga.catlass_dynamic_matmul(ac, bc.half().t(), out)
     empty = torch.empty((0, 90), dtype=torch.bfloat16, device="cuda")
     dga.catlass_dynamic_matmul(torch.empty((0, 72), dtype=torch.bfloat16, device="cuda"), bc.t(), empty)
+
+
+@pytest.mark.parametrize("m,n,k", [(8, 512, 1000), (8, 2048, 2048), (24, 640, 4096), (64, 4096, 1024), (300, 8000, 128), (2100, 8000, 128)])
+def test_without_workspace_on_the_round_4_plans(dga, m, n, k):
+    """No workspace (a legal call of the C entry): decode rows with odd K (no room for the padded copies: element-wise kernel) and with
+    whole k steps (the one-launch workgroup split-K needs none), a plan that would split K (runs unsplit), a raster with a sub-tile
+    tail (two launches, no slab): every one against the fp32 matmul of the same bf16 values."""
+    from deepgemm_ascend_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(m + n + k)
+    x = (torch.randn((m, k), device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn((n, k), device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+    out = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device="cuda")
+    rc = _lib.lib().dga_catlass_dynamic_matmul(x.data_ptr(), w.data_ptr(), out.data_ptr(), m, n, k, _lib.DT_BF16, None, 0, None)
+    torch.cuda.synchronize()
+    assert rc == 0
+    want = x.float() @ w.float().t()
+    assert bool(((out.float() - want).abs() <= 2.0 ** -7 * want.abs() + 2.0 ** -12 * (x.float().abs() @ w.float().abs().t())).all())
