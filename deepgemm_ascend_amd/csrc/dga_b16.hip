@@ -25,6 +25,8 @@
 
 namespace dga {
 
+int launch_b16_w4(const B16Params &p, bool bf16, hipStream_t stream);   // dga_b16_w4.hip
+
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef uint16_t v8u __attribute__((ext_vector_type(8)));
@@ -582,7 +584,12 @@ static int launch_b16_nt(const void *a, const void *b, void *out, int m, int n, 
         return go(GemmCfg<32, 128, 1, 4>{}, P0{});
     };
     int rc;
-    if (pl.bm == 256) rc = go_tail(GemmCfg<256, 256, 4, 2>{}, P2{});
+    static const int w4_env = [] { const char *e = std::getenv("DGA_B16_W4"); return e ? std::atoi(e) : 0; }();
+    if (pl.bm == 256 && w4_env && !pl.tail && pl.splitk == 1) {
+        p.tiles_m = (m + 255) / 256; p.tiles_n = (n + 255) / 256; p.raster_group = b16_raster(p.tiles_m);
+        rc = launch_b16_w4(p, bf, stream);
+    }
+    else if (pl.bm == 256) rc = go_tail(GemmCfg<256, 256, 4, 2>{}, P2{});
     else if (pl.bm == 128 && pl.bn == 256) rc = go_tail(GemmCfg<128, 256, 2, 4, 3>{}, P0{});
     else if (pl.bm == 128) rc = pl.w8 ? go(GemmCfg<128, 128, 2, 4, 3>{}, P0{}) : go(GemmCfg<128, 128, 2, 2>{}, P0{});
     else if (pl.bm == 64) rc = deep ? go(GemmCfg<64, 128, 1, 4, 4>{}, P0{}) : go(GemmCfg<64, 128, 1, 4>{}, P0{});

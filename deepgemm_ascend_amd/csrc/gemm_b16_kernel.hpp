@@ -334,6 +334,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_b16_nt_f32_kernel(const B16Param
     }
 }
 
+#ifndef DGA_B16_TILE_KERNEL_ONLY   // (a second translation unit that includes this header for the tile kernel and its types only: dga_b16_w4.hip)
 // y [K][N] (16-bit) -> yT [N][kp], kp = K rounded up to 64, zero filled: 64 x 64 tiles through LDS.  Both global
 // sides move 16 bytes per lane on full 128-byte row segments (8 lanes per row); the transposition happens in the LDS
 // reads (eight 16-bit reads of one column, conflict-free on the 66-element pitch).  `vec` = N % 8 == 0 and both bases
@@ -396,6 +397,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_f32_kernel(const float *par
     }
 }
 
+#endif  // DGA_B16_TILE_KERNEL_ONLY
 // split-K combine with 16-bit output (the operator's dtype contract): out = round16( sum_s slab[s] ), s ascending
 template <bool BF16>
 __global__ void __launch_bounds__(256) splitk_reduce_16_kernel(const float *partial, uint16_t *z, int64_t total, int splitk)

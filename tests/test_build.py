@@ -23,10 +23,11 @@ CSRC = ROOT / "deepgemm_ascend_amd" / "csrc"
     ("dga_launch_menu_f.hip", 6, "gemm_fp8_bf16x_"),            # bf16-exact image builds (8 / 4 waves, A-image) x k-tail
     ("dga_launch_menu_g.hip", 6, "gemm_fp8_wsk_kernel"),         # workgroup split-K (3 row counts x k-tail)
     ("dga_launch_menu_h.hip", 2, "gemm_fp8_bf16x_persistent_kernel"),   # persistent bf16-exact 128x256 build x k-tail
-    ("dga_b16.hip", 26, "gemm_b16_")])                           # 16-bit tile builds + the workgroup split-K (3 builds x bf16 / fp16)
+    ("dga_b16.hip", 26, "gemm_b16_"),                            # 16-bit tile builds + the workgroup split-K (3 builds x bf16 / fp16)
+    ("dga_b16_w4.hip", 2, "gemm_b16_w4_kernel")])                # the four-wave 32x32x16 build (bf16 / fp16): accumulators in AGPRs on purpose
 def test_no_kernel_spills_or_scratch(unit, min_kernels, tile_kernel):
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT / 'include'}", f"-I{CSRC}",
-           "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1",   # the Makefile's flags: the build that ships
+           "-fno-slp-vectorize", *([] if unit == "dga_b16_w4.hip" else ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),   # the Makefile's flags: the build that ships
            *(["-mllvm", "-pragma-unroll-threshold=1000000"] if unit == "dga_launch_menu_f.hip" else []),
            "-x", "hip", "--cuda-device-only", "-S", "-o", "/dev/null",
            "-Rpass-analysis=kernel-resource-usage", str(CSRC / unit)]
@@ -53,6 +54,6 @@ def test_no_kernel_spills_or_scratch(unit, min_kernels, tile_kernel):
             assert int(m.group(1)) <= 256, name
         m = re.search(r"AGPRs: (\d+)", line)
         # (the both-operand image builds read their fragments straight into AGPRs on purpose: MFMA operands, never promoted values)
-        if m and "gemm_" in (name or "") and "bf16x_image_kernel" not in (name or ""):
+        if m and "gemm_" in (name or "") and "bf16x_image_kernel" not in (name or "") and "gemm_b16_w4_kernel" not in (name or ""):
             assert int(m.group(1)) == 0, f"{name}: MFMA results in AGPRs (a v_accvgpr_read per promoted value in the main loop)"
     assert seen >= min_kernels, seen
