@@ -123,6 +123,10 @@ __global__ void __launch_bounds__(256) gemm_b16_w4_kernel(const B16Params p)
     for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) af[mt][kc] = *(const v4i *)(smem + a_off[kc] + mt * 4096);
+#ifdef DGA_W4_STAMPS
+    const uint64_t t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t wait_cycles = 0;
+#endif
     for (int ks = 0; ks < KS; ++ks) {
         const int par = ks & 1;
         const uint8_t *st = smem + par * STAGE;
@@ -131,8 +135,14 @@ __global__ void __launch_bounds__(256) gemm_b16_w4_kernel(const B16Params p)
         for (int i = 0; i < STEPS; ++i) {
             const int nt = i / (KC * TM), kc = (i / TM) % KC, mt = i % TM;
             if (i == SB) {
+#ifdef DGA_W4_STAMPS
+                const uint64_t w0 = __builtin_readcyclecounter();
+#endif
                 wait_vmcnt<0>();
                 barrier();
+#ifdef DGA_W4_STAMPS
+                wait_cycles += __builtin_readcyclecounter() - w0;
+#endif
             }
             acc[mt][nt] = mfma32_b16<BF16>(bfr[nt & 1][kc], af[mt][kc], acc[mt][nt]);
             __builtin_amdgcn_sched_barrier(0);
@@ -153,6 +163,13 @@ __global__ void __launch_bounds__(256) gemm_b16_w4_kernel(const B16Params p)
         }
     }
     wait_vmcnt<0>();
+#ifdef DGA_W4_STAMPS
+    if (p.partial && lane == 0) {
+        const uint64_t t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+        uint64_t *o = (uint64_t *)p.partial + ((size_t)blockIdx.x * 4 + wave) * 3;
+        o[0] = t1 - t0; o[1] = r1 - r0; o[2] = wait_cycles;
+    }
+#endif
 
     // epilogue: lane (l32, h) owns row m = 32 mt + l32 of its wave's rows; of n-tile nt the columns 8 h + [0, 8) (registers 0-3, 8-11)
     // and 16 + 8 h + [0, 8) (registers 4-7, 12-15)
