@@ -472,9 +472,10 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
         const int tiles = p.tiles_m * p.tiles_n, cus = static_cast<int>(device_cus());
         const int tail = tiles % cus, main_tiles = tiles - tail;
         const Variant *vq = find_variant(128, 128, 0, 0, 3);
-        // (the selector asks for this only when the tail is at most a quarter of the CUs -- apply_tail_split; a caller's tiling that
-        //  names it on a longer tail runs the single launch)
-        if (tail > 0 && tail * 4 <= cus && main_tiles > 0 && vq) {
+        // (up to half of the CUs' worth of parent tiles: two quarter tiles per CU.  A tail longer than a quarter of the RASTER used to
+        //  fault -- the kernel read a quarter-tile index beyond the parent tile count as a group index; fixed there, tested in
+        //  tests/test_gemm_gpu.py)
+        if (tail > 0 && tail * 2 <= cus && main_tiles > 0 && vq) {
             GemmParams pm = p;
             pm.launch_tiles = main_tiles;
             int rc = launch_main(pm);
@@ -483,10 +484,9 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
             pt.tail_begin = main_tiles;
             pt.tail_sub = 2;
             pt.launch_tiles = tail * 4;
-            // (the 4 + 4 loader-wave build of the quarter tile is 1-2 % faster on the whole call -- 1024 x 18432 x 7168 139.8 -> 136.9 us --
-            //  and ran clean through the tests; it was withdrawn the same day after a forced tiling with a 94-tile tail on an
-            //  odd-shaped problem (3511 x 6151 x 8191) ended in a GPU memory fault that was not run a second time to tell the two
-            //  changes apart: the plain build below is the one every sweep and test of rounds 2-4 has run)
+            // (the quarter tiles give a CU at most two workgroups: the 4 + 4 loader-wave build of the tile, -1..-2 % on the whole call:
+            //  1024 x 18432 x 7168 139.8 -> 136.9 us, 4608 x 4096 x 7168 139.2 -> 136.2; same arithmetic, same bytes)
+            if (vq->launch_lc) return vq->launch_lc(pt, stream);
             return vq->launch(pt, stream);
         }
     }

@@ -184,7 +184,9 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
     // split-K (dense only, groups == 1): the grid is splitk x tiles, split-major, so the splits of one tile run on
     // different XCDs/CUs at the same time; grouped: group-major
     const int split = p.splitk > 1 ? tile / tiles_per_group : 0;
-    const int g = p.splitk > 1 ? 0 : tile / tiles_per_group;
+    // (a tail launch is dense: its grid counts QUARTER tiles, which outnumber the parent raster's tiles once the tail is longer than a
+    //  quarter of it -- read as a group index that sent the stores of such a launch past the output, a GPU memory fault)
+    const int g = (p.splitk > 1 || p.tail_sub) ? 0 : tile / tiles_per_group;
     int t_in = tile - (p.splitk > 1 ? split : g) * tiles_per_group;
     int tm, tn;
     const int sub = p.tail_sub ? (t_in & 3) : 0;

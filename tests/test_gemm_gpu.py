@@ -354,3 +354,23 @@ def test_persistent_continuous_with_the_quarter_tile_tail(dga):
     o2 = torch.full((m, n), -1.0, dtype=torch.bfloat16, device="cuda")
     dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), o2, tiling_=t2, sync=True)
     assert torch.equal(o6.view(torch.int16), o2.view(torch.int16))
+
+
+@pytest.mark.parametrize("m,n,k", [(3584, 6400, 256), (3511, 6151, 272), (2816, 8192, 128)])
+def test_quarter_tile_tail_longer_than_a_quarter_of_the_raster(dga, oracle, m, n, k):
+    """A caller's tiling may name kernelSerial 5 on a raster whose partial last round is long (the selector stops at a quarter of the
+    CUs): 350 parent tiles, 94 of them in the tail = 376 quarter tiles, MORE than the parent raster holds -- the kernel once read such
+    an index as a group index and stored past the output (a GPU memory fault).  Same bytes as the single launch."""
+    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=k)
+    ta, tsfa, tb, tsfb = [torch.from_numpy(x).cuda() for x in (a, sfa, b, sfb)]
+    outs = []
+    for ks in (5, 0):
+        t = dga.select_kernel(m, n, k)
+        t.m1, t.n1, t.wavesM, t.wavesN, t.stages, t.dispatchPolicyTag, t.splitkFactor, t.kernelSerial = 256, 256, 0, 0, 2, 2, 1, ks
+        out = torch.zeros((m, n), dtype=torch.bfloat16, device="cuda")
+        dga.gemm_fp8_fp8_bf16_nt((ta, tsfa), (tb, tsfb), out, tiling_=t, sync=True)
+        outs.append(out)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    rows = np.r_[0:32, m - 200:m]
+    want = oracle.gemm_fp8_fp8_bf16_nt(a[rows], sfa[rows], b, sfb, threads=8)
+    oracle.assert_parity(outs[0][torch.from_numpy(rows).cuda()].view(torch.int16).cpu().numpy().view(np.uint16), want, a[rows], sfa[rows], b, sfb)
