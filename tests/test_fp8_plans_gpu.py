@@ -50,3 +50,33 @@ def test_the_net_is_not_empty():
         pytest.skip("run together with the cases above")
     print("fp8 plans:", TALLY)
     assert TALLY["ran"] >= 100, TALLY
+
+
+KS_CASES = [(m, n, k, bm, bn, st, ks) for (m, n, k) in ((300, 520, 1344), (40, 1000, 2048), (70, 333, 1001))
+            for (bm, bn, st) in ((256, 256, 2), (128, 256, 3), (64, 128, 3), (16, 128, 3), (16, 128, 1))
+            for ks in (0, 1, 2, 4, 5, 6)]
+
+
+@pytest.mark.parametrize("m,n,k,bm,bn,st,ks", KS_CASES)
+def test_any_kernel_serial_a_caller_names(dga, oracle, m, n, k, bm, bn, st, ks):
+    """kernelSerial is the caller's too (the reference's TilingParams carries it, tiling_params.h:19-66): every value of the menu named
+    on every kind of problem -- ragged, decode-sized, odd K -- with tiles that do and do not have the kernel in question.  The launcher
+    runs the kernel where it applies and the tiling's tile kernel where it does not; the bytes are the product's either way."""
+    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=m + k)
+    dev = tuple(torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in (a, sfa, b, sfb))
+    want = oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, threads=8)
+    t = dga.tiling(m, n, k)
+    t.m1, t.n1, t.wavesM, t.wavesN, t.stages, t.dispatchPolicyTag = bm, bn, 0, 0, st, 0
+    t.splitkFactor, t.kernelSerial = (2 if ks == 4 else 1), ks
+    out = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device="cuda")
+    try:
+        dga.gemm_fp8_fp8_bf16_nt((dev[0], dev[1]), (dev[2], dev[3]), out, tiling_=t, sync=True)
+    except RuntimeError as e:
+        assert "tiling" in str(e).lower(), e
+        return
+    got = out.view(torch.int16).cpu().numpy().view(np.uint16)
+    if m * n >= 2048 * 8:
+        oracle.assert_parity(got, want, a, sfa, b, sfb)
+    else:
+        rep = oracle.parity_report(got, want, a, sfa, b, sfb)
+        assert rep["nan_positions_equal"] and rep["worst_excess_over_S"] <= oracle.eps_for_k(k), rep
