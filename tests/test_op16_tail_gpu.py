@@ -24,7 +24,7 @@ def _with_plan(plan, fn):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("tile,sub", [("256,256", 128), ("256,256", 64), ("256,256", 32), ("128,256", 64), ("128,256", 32)])
-@pytest.mark.parametrize("m,n,k", [(2100, 8000, 512), (4096, 4608, 256), (1100, 16500, 320), (2048, 9000, 200)])
+@pytest.mark.parametrize("m,n,k", [(2100, 8000, 512), (4096, 4608, 256), (1100, 16500, 320), (2048, 9000, 200), (2101, 8001, 130), (3511, 6151, 72)])
 def test_operator_tail_matches_the_single_launch(dga, dtype, tile, sub, m, n, k):
     if tile == "128,256" and m * n < 257 * 128 * 256:
         m = 2 * m
