@@ -624,8 +624,11 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
     static const bool no_wsk = [] { const char *e = std::getenv("DGA_NO_WSK_PICK"); return e && std::atoi(e) != 0; }();
     // (wider matrices, up to 32768 rows with K >= 4096, take its continuous-ring build: 3-7 % ahead on 16384 / 18432 x 7168 and
     //  28672 x 4096, profiles/r04_sweep_wskd/table_wide.txt)
-    if (!no_wsk && groups == 1 && !contiguous && t.m <= 16 && (t.k % 16) == 0 && kb >= 16 && kb <= 144 &&
-        (t.n <= 10240 || (t.n <= 32768 && kb >= 32))) {
+    // (round 4's fourth decode grid, eight more (N, K) of common models: ahead too at K = 18944 -- 148 k blocks, 3584 x 18944 0.85-0.90
+    //  of the best tile plan up to 8 rows -- and on 37888 x 3584 (0.89-0.95); level on 53248 x 16384; behind once a slice is very
+    //  long on a narrow matrix, 5120 x 27648 1.03-1.34: profiles/r04_sweep_decode4/)
+    if (!no_wsk && groups == 1 && !contiguous && t.m <= 16 && (t.k % 16) == 0 && kb >= 16 && kb <= 160 &&
+        (t.n <= 10240 || (t.n <= 65536 && kb >= 24))) {
         t.kernelSerial = DGA_KERNEL_SPLITK_WORKGROUP;
         t.m1 = 16; t.n1 = 128; t.k1 = 128;
         t.splitkFactor = 1; t.stages = 3; t.wavesM = 1; t.wavesN = 4; t.dispatchPolicyTag = DGA_POLICY_PLAIN; t.swizzleOffset = 1;

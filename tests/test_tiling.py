@@ -84,7 +84,9 @@ def test_mi355x_selection_is_launchable(dga):
     # decode rows: the one-launch workgroup split-K where it won its cold sweep (M <= 16, N <= 10240, 2048 <= K <= 18432)
     assert dga.select_kernel(8, 7168, 18432).kernelSerial == 6 and dga.select_kernel(16, 4096, 7168).kernelSerial == 6
     assert dga.select_kernel(32, 4096, 7168).kernelSerial != 6 and dga.select_kernel(8, 18432, 7168).kernelSerial == 6
-    assert dga.select_kernel(8, 57344, 8192).kernelSerial != 6 and dga.select_kernel(8, 24576, 1536).kernelSerial != 6
+    assert dga.select_kernel(8, 129280, 7168).kernelSerial != 6 and dga.select_kernel(8, 24576, 1536).kernelSerial != 6
+    assert dga.select_kernel(8, 57344, 8192).kernelSerial == 6 and dga.select_kernel(4, 3584, 18944).kernelSerial == 6   # (round 4's fourth grid)
+    assert dga.select_kernel(8, 5120, 27648).kernelSerial != 6                                                            # (216 k blocks: a slice too long)
     assert dga.select_kernel(8, 7168, 1536).kernelSerial != 6
 
 
