@@ -19,7 +19,8 @@ from deepgemm_ascend_amd.harness import sweep  # noqa: E402
 NK = [(4096, 16384), (2048, 32768), (576, 7168), (1536, 7168), (2048, 7168), (4096, 4096), (4096, 7168), (4096, 14336), (7168, 2048), (7168, 4608), (7168, 16384),
       (7168, 18432), (8192, 8192), (10240, 8192), (16384, 7168), (18432, 7168), (24576, 1536), (28672, 4096), (32768, 512), (57344, 8192),
       (129280, 7168), (2112, 7168), (4608, 7168), (6144, 4096), (7168, 1536), (8192, 28672), (14336, 4096), (5120, 5120), (13824, 5120),
-      (5120, 13824), (3072, 8192), (1024, 4096)]
+      (5120, 13824), (3072, 8192), (1024, 4096), (16384, 16384), (53248, 16384), (16384, 53248), (27648, 5120), (5120, 27648), (3584, 3584),
+      (37888, 3584), (3584, 18944)]
 TILES = [(16, 128), (32, 128), (64, 128), (128, 128), (128, 256)]
 SPLITS = [1, 2, 3, 4, 6, 8, 12, 16]
 
