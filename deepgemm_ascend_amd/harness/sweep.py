@@ -451,12 +451,17 @@ def main(argv=None):
                     help=f"shapes with M <= {COLD_MAX_M}: rotate operand sets past the Infinity Cache (decode weights are never warm)")
     ap.add_argument("--grouped", action="store_true",
                     help="sweep the masked / contiguous grouped shapes (GROUPED_SHAPES) instead of the dense list")
+    ap.add_argument("--grouped-shapes", nargs="*", default=None,
+                    help="with --grouped: layout,groups,rows,n,k ... instead of GROUPED_SHAPES (layout: masked | contiguous)")
     a = ap.parse_args(argv)
     torch.cuda.set_device(a.rank % max(1, torch.cuda.device_count()))
     out_dir = Path(a.out); out_dir.mkdir(parents=True, exist_ok=True)
     if a.grouped:
         rows_out = []
-        for shape in GROUPED_SHAPES[a.rank::a.num_processes]:
+        gshapes = GROUPED_SHAPES
+        if a.grouped_shapes:
+            gshapes = [(s.split(",")[0],) + tuple(int(x) for x in s.split(",")[1:]) for s in a.grouped_shapes]
+        for shape in gshapes[a.rank::a.num_processes]:
             prob, best = benchmark_grouped(shape, out_dir, a.iters, a.prewarm_ms / 1e3)
             if best:
                 us, c = best

@@ -1,6 +1,6 @@
 """The grouped selector on shapes it was never tuned on: every legal build of the menu timed on a masked / contiguous grouped
 problem (harness/sweep.py benchmark_grouped: full mask, correctness-gated) against the tiling dga_tiling() names for it.
-Usage: python scripts/grouped_selector_regret.py"""
+Usage: python scripts/grouped_selector_regret.py [layout,groups,rows,n,k ...]"""
 import json
 import math
 import sys
@@ -19,6 +19,9 @@ SHAPES = ([("masked", g, mm, n, k) for (n, k) in ((5120, 5120), (3072, 8192), (1
 
 
 def main():
+    global SHAPES
+    if len(sys.argv) > 1:   # layout,groups,rows,n,k ...
+        SHAPES = [(s.split(",")[0],) + tuple(int(x) for x in s.split(",")[1:]) for s in sys.argv[1:]]
     ratios = []
     out_dir = Path(tempfile.mkdtemp())
     for shape in SHAPES:
