@@ -44,3 +44,41 @@ def test_two_threads_two_streams(dga):
     for t in ts:
         t.join()
     assert not errors, errors[:5]
+
+
+def test_two_threads_two_streams_16_bit_operator(dga):
+    """The 16-bit operator from two host threads on their own streams: the one-launch workgroup split-K, a deep small tile with split-K
+    (per-stream workspace), the 8-wave 128x128 tile and a raster with a sub-tile tail (two launches) at the same time; every result
+    equals the one the same call gives alone."""
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(11)
+    cases = []
+    for (m, n, k) in [(8, 2048, 2048), (64, 4096, 1024), (512, 1024, 512), (2100, 8000, 128), (24, 1536, 2048)]:
+        x = (torch.randn((m, k), device=dev, generator=g) * 0.5).to(torch.bfloat16)
+        w = (torch.randn((n, k), device=dev, generator=g) * 0.5).to(torch.bfloat16)
+        want = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+        dga.catlass_dynamic_matmul(x, w.t(), want, sync=True)
+        cases.append((x, w, want))
+    errors = []
+
+    def worker(seed):
+        try:
+            torch.cuda.set_device(0)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for it in range(40):
+                    x, w, want = cases[(it + seed) % len(cases)]
+                    out = torch.empty_like(want)
+                    dga.catlass_dynamic_matmul(x, w.t(), out)
+                    s.synchronize()
+                    if not torch.equal(out.view(torch.int16), want.view(torch.int16)):
+                        errors.append((seed, it))
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:5]
