@@ -61,6 +61,13 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="dense_4096", choices=sorted(WORKLOADS))
+    ap.add_argument("--policy", default="bf16_exact", choices=["bf16_exact", "fast"],
+                    help="arithmetic policy of the timed steps = of `value`.  bf16_exact (default, also the operator's default): the "
+                         "fastest policy inside north_star's tolerance (<= 1e-5 of the outputs beyond 2 bf16 ULP of the fp32-accumulate "
+                         "result).  fast: the fp8 matrix instruction (6.7e-4 beyond 2 ULP) -- reported in the `fast` object either way")
+    ap.add_argument("--detail-out", default=None,
+                    help="file for the full record (every leg, every column); default gpurun_out/bench_detail.json, /tmp if that "
+                         "is not writable.  stdout carries ONE compact line (< 4 KB) -- the record the driver parses")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grouped", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -116,18 +123,20 @@ def _rand_fp8(shape, gen):
     return torch.where((x & 0x7F) == 0x7F, x & 0x80, x)  # no NaN encodings
 
 
-def make_dense_inputs(m, n, k, seed):
+def make_dense_inputs(m, n, k, seed, ue8m0=False):
     """Synthetic data of the SURVEY.md 8(d) shape: fp32 ~ N(0,1), amax-scaled per 1x128 / 128x128, cast to
-    e4m3fn.  Generated on the device (torch casts saturate identically to the oracle for |x| <= 448)."""
+    e4m3fn.  Generated on the device (torch casts saturate identically to the oracle for |x| <= 448).
+    ue8m0: the scales rounded UP to powers of two (2^ceil(log2(amax / 448)): upstream DeepGEMM's use_ue8m0 quantisation)."""
     import torch
     g = torch.Generator(device="cuda").manual_seed(seed)
     xa = torch.randn((m, k), device="cuda", generator=g)
     xb = torch.randn((n, k), device="cuda", generator=g)
     kb = k // 128
-    sa = xa.view(m, kb, 128).abs().amax(dim=2).clamp_min(1e-30) / 448.0
+    pow2 = (lambda s: torch.exp2(torch.ceil(torch.log2(s)))) if ue8m0 else (lambda s: s)
+    sa = pow2(xa.view(m, kb, 128).abs().amax(dim=2).clamp_min(1e-30) / 448.0)
     qa = (xa.view(m, kb, 128) / sa[..., None]).reshape(m, k).to(torch.float8_e4m3fn).view(torch.uint8)
     nb = n // 128
-    sb = xb.view(nb, 128, kb, 128).abs().amax(dim=(1, 3)).clamp_min(1e-30) / 448.0
+    sb = pow2(xb.view(nb, 128, kb, 128).abs().amax(dim=(1, 3)).clamp_min(1e-30) / 448.0)
     qb = (xb.view(nb, 128, kb, 128) / sb[:, None, :, None]).reshape(n, k).to(torch.float8_e4m3fn).view(torch.uint8)
     return qa.contiguous(), sa.contiguous().float(), qb.contiguous(), sb.contiguous().float()
 
@@ -155,7 +164,7 @@ def pmc_traffic(workload: str):
     return None
 
 
-def live_pmc_traffic(m, n, k, launches=260, skip=200, timeout_s=90):
+def live_pmc_traffic(m, n, k, launches=260, skip=200, timeout_s=90, policy="bf16_exact"):
     """HBM-side bytes per launch of the dense tile kernel measured BY THIS RUN: two child processes (scripts/prof_dense.py, the
     same kernel on the same recipe) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... WRITE_SIZE` -- separate passes,
     the counters' units and the gfx950 correction as MI355X_MICROARCH.md prescribes (FETCH_SIZE counts 64 B per 128-B request of
@@ -175,7 +184,7 @@ def live_pmc_traffic(m, n, k, launches=260, skip=200, timeout_s=90):
         d = tempfile.mkdtemp(prefix="dga_pmc_", dir="/tmp")
         try:
             cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
-                   str(ROOT / "scripts" / "prof_dense.py"), str(m), str(n), str(k), str(launches)]
+                   str(ROOT / "scripts" / "prof_dense.py"), str(m), str(n), str(k), str(launches), "--policy", policy]
             # its own session: on a timeout the whole group goes (rocprofv3 AND the python child it started -- killing the
             # wrapper alone would leave 260 launches of the kernel running beside the legs timed next)
             proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
@@ -197,7 +206,7 @@ def live_pmc_traffic(m, n, k, launches=260, skip=200, timeout_s=90):
             per = {}
             with open(files[0]) as f:
                 for row in _csv.DictReader(f):
-                    if "gemm_fp8_blockscaled" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    if "gemm_fp8" in row["Kernel_Name"] and row["Counter_Name"] == counter:
                         per[int(row["Dispatch_Id"])] = per.get(int(row["Dispatch_Id"]), 0.0) + float(row["Counter_Value"])
             vals = [v for _, v in sorted(per.items())][skip:]
             if not vals:
@@ -315,7 +324,7 @@ def grouped_leg(args, rank, world, dist):
     return parallel.bench_grouped(rank, world, dist, steps=max(3, min(args.steps, 20)), warmup=3,
                                   groups_total=args.groups, m_max=128, n=2048, k=7168,
                                   mask=args.grouped_mask, capacity_factor=args.capacity_factor,
-                                  indexed=True if args.sharded_indexed else None, parity=not args.no_parity)
+                                  indexed=True if args.sharded_indexed else None, parity=not args.no_parity, policy=args.policy)
 
 
 def _time_us(fn, iters, warm):
@@ -332,17 +341,34 @@ def _time_us(fn, iters, warm):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
-def roofline_mfma(dga, a, sfa, b, sfb, out, t, m, n, k, kernel_us, cus):
-    """`roofline` object of a dense launch: achieved = 2MNK / average launch time; peak = the vendor dense fp8 figure;
-    clock_mhz = the shader clock measured inside the kernel's main loop right after the timed region (loop-clock build
-    of the same kernel); frac_at_measured_clock prices the same launch against CUs x clk x 8192."""
+def kernel_name(t, policy):
+    """Name under which the rocprofv3 kernel trace lists the launch a tiling resolves to (csrc/dga_launch.hip)."""
+    if policy == "bf16_exact":
+        if int(t.kernelSerial) == 6:
+            return "gemm_fp8_wsk_dma_kernel (MATH = 1)"
+        return "gemm_fp8_blockscaled_nt_kernel<..., MATH = 1> (bf16-exact build; persistent form where every CU gets the same tile count)"
+    if policy == "strict":
+        return "gemm_fp8_strict_nt_kernel"
+    tag = int(t.dispatchPolicyTag)
+    return {5: "gemm_fp8_blockscaled_nt_persistent_kernel", 6: "gemm_fp8_cont_persistent_kernel"}.get(tag, "gemm_fp8_blockscaled_nt_kernel")
+
+
+def roofline_mfma(dga, a, sfa, b, sfb, out, t, m, n, k, kernel_us, cus, policy="fast"):
+    """`roofline` object of a dense launch: achieved = 2MNK / average launch time; peak = the vendor dense fp8 figure (the
+    metric's own denominator, whatever instruction the policy computes on; `instruction_peak` prices it against that one);
+    clock_mhz = the shader clock measured inside the kernel's main loop right after the timed region (loop-clock build of the
+    same kernel, fast policy only); frac_at_measured_clock prices the same launch against CUs x clk x 8192."""
     flops = 2.0 * m * n * k
     achieved = flops / (kernel_us * 1e-6) / 1e12
+    ipeak, instr, _ = POLICY_SPEC[policy]
     r = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s",
          "frac": round(achieved / PEAK_FP8_TFLOPS, 4), "traffic": None, "kernel_us": round(kernel_us, 3),
          "algorithmic_bytes": m * k + n * k + 2 * m * n + 4 * (sfa.numel() + sfb.numel()),
-         "kernel": "gemm_fp8_blockscaled_nt_kernel", "tile": f"{t.m1}x{t.n1}x{t.k1}", "clock_mhz": None,
-         "frac_at_measured_clock": None}
+         "kernel": kernel_name(t, policy), "tile": f"{t.m1}x{t.n1}x{t.k1}", "policy": policy, "instruction": instr,
+         "instruction_peak": ipeak, "frac_of_instruction_peak": round(achieved / ipeak, 4),
+         "clock_mhz": None, "frac_at_measured_clock": None}
+    if policy != "fast":
+        return r
     try:
         # 1000 launches: the stamps of the last one are read, and after the gap behind the timed region the chip needs a few
         # hundred launches to be back at the clocks of a busy stream (with 100 the probe read 1.42 GHz where the stream
@@ -379,39 +405,51 @@ def _graph_us(fn, iters, replays=5, prewarm_ms=30.0):
     return us
 
 
-def policy_legs(dga, a, sfa, b, sfb, m, n, k, args, fast, ceilings):
+POLICY_SPEC = {
+    # policy: (peak of the instruction it computes on, instruction, dispatchPolicyTag)
+    "fast": (PEAK_FP8_TFLOPS, "v_mfma_f32_16x16x128_f8f6f4 per scale block + fp32 promotion", "0-2, 4-6 (the tiling's schedule)"),
+    "bf16_exact": (PEAK_BF16_TFLOPS, "v_mfma_f32_16x16x32_bf16 x4 per scale block on e4m3 bytes up-converted in registers", 7),
+    "strict": (PEAK_FP32_MATRIX_TFLOPS, "v_mfma_f32_16x16x4_f32 x32 per scale block, the oracle's own order", 3),
+}
+
+
+def policy_legs(dga, a, sfa, b, sfb, m, n, k, args, headline_policy, headline, ceilings):
     """The three arithmetic policies side by side on one workload: value, roofline and parity of each.
-      fast        the headline kernel (fp8 matrix instruction; `fast` = its already measured {"kernel_us", "roofline", "parity"})
-      bf16_exact  e4m3 -> bf16 in registers, bf16 matrix instruction (dispatchPolicyTag 7), priced against the bf16 peak
-      strict      fp32-input matrix instruction in the oracle's order (dispatchPolicyTag 3), priced against the fp32 matrix peak
-    Each roofline also carries `ceiling_tflops`: what this box's matrix pipe sustains on the policy's inner step with the
-    operands already in registers (dga_mfma_ceiling), and the kernel's fraction of it."""
+      fast        the fp8 matrix instruction (whatever schedule the tiling names)
+      bf16_exact  e4m3 -> bf16 in registers, bf16 matrix instruction (dispatchPolicyTag 7) -- the operator's default
+      strict      fp32-input matrix instruction in the oracle's order (dispatchPolicyTag 3)
+    `headline` = the already measured {"kernel_us", "roofline", "parity"} of `headline_policy` (the timed steps); the other two
+    are timed here.  Every roofline prices the launch against the fp8 peak (the metric's denominator) AND against the peak of
+    the instruction the policy computes on (`instruction_peak`), and carries `ceiling_tflops`: what this box's matrix pipe
+    sustains on the policy's inner step with the operands already in registers (dga_mfma_ceiling)."""
     import torch
     flops = 2.0 * m * n * k
     out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
     legs = {}
-    spec = {"bf16_exact": (PEAK_BF16_TFLOPS, "v_mfma_f32_16x16x32_bf16 x4 per scale block on e4m3 bytes up-converted in registers",
-                           max(20, min(args.steps, 200)), args.prewarm_ms),
-            "strict": (PEAK_FP32_MATRIX_TFLOPS, "v_mfma_f32_16x16x4_f32 x32 per scale block, the oracle's own order",
-                       max(5, min(args.steps, 20)), min(args.prewarm_ms, 50.0))}
-    fr = dict(fast["roofline"])
-    if ceilings.get("fast"):
-        fr["ceiling_tflops"] = round(ceilings["fast"], 1)
-        fr["frac_of_ceiling"] = round(fr["achieved"] / ceilings["fast"], 4)
-    legs["fast"] = {"dispatchPolicyTag": "0-2, 4-6 (the tiling's schedule)", "value": fr["achieved"], "unit": "TFLOP/s",
-                    "kernel_us": fast["kernel_us"], "roofline": fr, "parity": fast.get("parity")}
-    for pol, (peak, instr, iters, prewarm) in spec.items():
+
+    def with_ceiling(roof, pol):
+        if ceilings.get(pol):
+            roof["ceiling_tflops"] = round(ceilings[pol], 1)
+            roof["frac_of_ceiling"] = round(roof["achieved"] / ceilings[pol], 4)
+        return roof
+    peak, instr, tag = POLICY_SPEC[headline_policy]
+    legs[headline_policy] = {"dispatchPolicyTag": tag, "value": headline["roofline"]["achieved"], "unit": "TFLOP/s",
+                             "kernel_us": headline["kernel_us"], "roofline": with_ceiling(dict(headline["roofline"]), headline_policy),
+                             "parity": headline.get("parity"), "timed_as": "the headline steps"}
+    iters = {"fast": (max(20, min(args.steps, 200)), args.prewarm_ms), "bf16_exact": (max(20, min(args.steps, 200)), args.prewarm_ms),
+             "strict": (max(5, min(args.steps, 20)), min(args.prewarm_ms, 50.0))}
+    for pol in ("fast", "bf16_exact", "strict"):   # strict last: its output stays in `out` for the CPU oracle's rows
+        if pol == headline_policy:
+            continue
+        peak, instr, tag = POLICY_SPEC[pol]
         try:
             fn = lambda: dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, policy=pol)
-            us = _prewarmed_us(fn, iters, prewarm)
+            us = _prewarmed_us(fn, *iters[pol])
             tf = flops / us / 1e6
-            roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                    "kernel_us": round(us, 3), "instruction": instr}
-            if ceilings.get(pol):
-                roof["ceiling_tflops"] = round(ceilings[pol], 1)
-                roof["frac_of_ceiling"] = round(tf / ceilings[pol], 4)
-            leg = {"dispatchPolicyTag": 7 if pol == "bf16_exact" else 3, "value": round(tf, 2), "unit": "TFLOP/s",
-                   "kernel_us": round(us, 3), "roofline": roof}
+            roof = with_ceiling({"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round(tf / PEAK_FP8_TFLOPS, 4), "instruction_peak": peak,
+                                 "frac_of_instruction_peak": round(tf / peak, 4), "kernel_us": round(us, 3), "instruction": instr}, pol)
+            leg = {"dispatchPolicyTag": tag, "value": round(tf, 2), "unit": "TFLOP/s", "kernel_us": round(us, 3), "roofline": roof}
             if not args.no_parity:
                 fn(); torch.cuda.synchronize()
                 leg["parity"] = parity_vs_strict(dga, a, sfa, b, sfb, out, policy=pol)
@@ -477,9 +515,10 @@ def shape_list_leg(dga, iters=20):
                          "policy": int(t.dispatchPolicyTag), "us": round(us, 2), "us_eager": round(us_eager, 2), "timing": timing, "tflops": round(flops / us / 1e6, 1),
                          "gbps": round(byt / us / 1e3, 1), "bound": bound, "frac": round(max(t_mfma, t_hbm) / us, 4),
                          "parity_ok": bool(ok), "frac_gt_2ulp": frac})
-            if m <= 128 and k % 16 == 0:
-                # the short-M rows under the in-contract policy (bf16-exact arithmetic, its own tiling): decode rows stream their weights,
-                # so the exact arithmetic costs them little -- up to 16-32 rows it runs on the same one-launch kernel as the fast policy
+            try:
+                # every row under the in-contract policy (bf16-exact arithmetic, its own tiling = what a call without a policy runs):
+                # decode rows stream their weights, so the exact arithmetic costs them little -- up to 16-32 rows it runs on the same
+                # one-launch kernel as the fast policy; MFMA-bound rows run at the bf16 matrix rate
                 tb = dga.tiling(m, n, k, policy="bf16_exact")
                 fb = lambda: dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, tiling_=tb, policy="bf16_exact")
                 fb(); torch.cuda.synchronize()
@@ -488,8 +527,11 @@ def shape_list_leg(dga, iters=20):
                     usb = _graph_us(fb, n_it)
                 except Exception:
                     usb = _prewarmed_us(fb, n_it, 30.0)
-                rows[-1].update({"us_in_contract": round(usb, 2), "in_contract_kernel": int(tb.kernelSerial), "in_contract_parity_ok": bool(okb),
-                                 "in_contract_frac_gt_2ulp": fracb})
+                rows[-1].update({"us_in_contract": round(usb, 2), "in_contract_tile": f"{tb.m1}x{tb.n1}", "in_contract_kernel": int(tb.kernelSerial),
+                                 "in_contract_parity_ok": bool(okb), "in_contract_frac_gt_2ulp": fracb,
+                                 "in_contract_frac": round(max(t_mfma, t_hbm) / usb, 4)})
+            except Exception as e:
+                rows[-1]["in_contract_error"] = repr(e)
             if k % 16:
                 # the same bytes in rows round_up(K, 16) apart with zero tails (what the quantisers' aligned_rows forms write):
                 # read in place, no padding pass -- both operands, and the weights alone (padded once at load time)
@@ -513,7 +555,8 @@ def shape_list_leg(dga, iters=20):
             del a, b, out, golden, s_abs
         except Exception as e:
             rows.append({"m": m, "n": n, "k": k, "error": repr(e)})
-    return {"source": "framework/benchmark/benchmark.py:24-44 (the reference's sweep shape list)", "protocol": "warm, auto tiling, fast policy; us = device time per call (the calls captured into a HIP graph and replayed), "
+    return {"source": "framework/benchmark/benchmark.py:24-44 (the reference's sweep shape list)", "protocol": "warm, auto tiling; us / frac / parity_ok = the fast policy (fp8 matrix instruction), us_in_contract / in_contract_* = the operator's default "
+                        "(bf16-exact) under its own tiling; us = device time per call (the calls captured into a HIP graph and replayed), "
                         "us_eager = launch interval of the same calls issued one by one from Python (host-bound below ~6 us); M <= 128 rows: us_in_contract = the "
                         "bf16-exact policy with its own tiling (in_contract_kernel 6 = the one-launch workgroup split-K); K % 16 != 0 rows: "
                         "us = contiguous operands (padding pass + tile kernel), us_rows_aligned = both operands in 16-byte aligned zero-tailed rows "
@@ -697,6 +740,7 @@ def main():
 
     m, n, k = WORKLOADS[args.workload]
     dga = None
+    pol = args.policy
     if args.stub:
         import numpy as np
         xs = np.ones((64, 64), np.float32)
@@ -710,10 +754,10 @@ def main():
         dga.lib()  # fails loudly if libdga_hip.so is missing
         a, sfa, b, sfb = make_dense_inputs(m, n, k, seed=rank)
         out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
-        t = dga.tiling(m, n, k)
+        t = dga.tiling(m, n, k, policy=pol if pol == "bf16_exact" else None)
 
-        def step():   # the operator call as a caller makes it: the tiling comes from the (m,n,k) cache on every call
-            dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out)
+        def step():   # the operator call as a caller makes it: the plan comes from the (m,n,k) cache on every call
+            dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, policy=pol)
 
     t_pre = time.perf_counter()
     while not args.stub and (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:   # untimed: sustained clocks
@@ -765,9 +809,11 @@ def main():
         "metric": "fp8 TFLOPS + % MFMA peak, 4096^3 block-scaled GEMM; grouped-GEMM tok/s at 1/2/4/8 GPU",
         "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": dist.get_world_size() if dist else 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "fp8_e4m3fn", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: gemm_fp8_fp8_bf16_nt M={m} N={n} K={k}, per-1x128 / per-128x128 f32 scales, bf16 out",
-                   "tile": f"{t.m1}x{t.n1}x{t.k1}" if t is not None else None,
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if pol == "bf16_exact" else "fp8_e4m3fn",   # the arithmetic type the timed path multiplies in (operands are e4m3fn bytes either way)
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: gemm_fp8_fp8_bf16_nt M={m} N={n} K={k}, e4m3fn operands, per-1x128 / per-128x128 f32 scales, bf16 out",
+                   "policy": pol, "tile": f"{t.m1}x{t.n1}x{t.k1}" if t is not None else None,
                    "parallelism": "replicas" if world > 1 else "single", "prewarm_ms": args.prewarm_ms,
                    "backend": backend, "stub": bool(args.stub)},
         "per_rank_kernel_us": per_rank_us,
@@ -780,19 +826,19 @@ def main():
         res["distributed"] = {"backend": backend, "rccl_version": ver, "world_size": world, "ranks": ranks_seen}
     if args.stub:
         if rank == 0:
-            print(json.dumps(res), flush=True)
+            emit(res, args)
         if dist:
             dist.barrier()
             dist.destroy_process_group()
         return
 
     cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    res["roofline"] = roofline_mfma(dga, a, sfa, b, sfb, out, t, m, n, k, kernel_us, cus)
+    res["roofline"] = roofline_mfma(dga, a, sfa, b, sfb, out, t, m, n, k, kernel_us, cus, policy=pol)
     if args.workload == "dense_4096":
-        res["roofline"]["traffic"] = pmc_traffic("dense")
-        res["roofline"]["traffic_source"] = pmc_traffic_source()
+        res["roofline"]["traffic"] = pmc_traffic("dense" if pol == "fast" else "dense_bf16_exact")
+        res["roofline"]["traffic_source"] = "committed: " + str(pmc_traffic_source())
         if rank == 0 and world == 1 and not args.no_live_traffic:   # the counters of THIS run where rocprofv3 is there to take them
-            live, how = live_pmc_traffic(m, n, k)
+            live, how = live_pmc_traffic(m, n, k, policy=pol)
             if live is not None:
                 res["roofline"]["traffic_committed"] = res["roofline"]["traffic"]
                 res["roofline"]["traffic"], res["roofline"]["traffic_source"] = live, how
@@ -801,33 +847,33 @@ def main():
 
     if rank == 0 and not args.no_parity:
         try:
-            dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, sync=True)
-            res["parity"] = parity_vs_strict(dga, a, sfa, b, sfb, out)
+            dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, policy=pol, sync=True)
+            res["parity"] = parity_vs_strict(dga, a, sfa, b, sfb, out, policy=pol)
         except Exception as e:
             res["parity"] = {"error": repr(e)}
 
-    # the three arithmetic policies side by side (rank 0; the headline above is the "fast" column)
+    # the three arithmetic policies side by side (rank 0; the headline above is the `pol` column)
     ceilings = {}
     strict_out = None
     if rank == 0 and not args.no_policies:
-        for pol in ("fast", "bf16_exact"):
+        for cp in ("fast", "bf16_exact"):
             try:
-                ceilings[pol] = dga.mfma_ceiling(pol, launches=300)
+                ceilings[cp] = dga.mfma_ceiling(cp, launches=300)
             except Exception as e:
-                ceilings[pol] = None
-                res.setdefault("ceiling_errors", {})[pol] = repr(e)
-        if ceilings.get("fast"):
-            res["roofline"]["ceiling_tflops"] = round(ceilings["fast"], 1)
-            res["roofline"]["frac_of_ceiling"] = round(res["roofline"]["achieved"] / ceilings["fast"], 4)
-        res["policies"], strict_out = policy_legs(dga, a, sfa, b, sfb, m, n, k, args,
+                ceilings[cp] = None
+                res.setdefault("ceiling_errors", {})[cp] = repr(e)
+        if ceilings.get(pol):
+            res["roofline"]["ceiling_tflops"] = round(ceilings[pol], 1)
+            res["roofline"]["frac_of_ceiling"] = round(res["roofline"]["achieved"] / ceilings[pol], 4)
+        res["policies"], strict_out = policy_legs(dga, a, sfa, b, sfb, m, n, k, args, pol,
                                                   {"kernel_us": round(kernel_us, 3), "roofline": res["roofline"],
                                                    "parity": res.get("parity")}, ceilings)
         res["in_contract"] = in_contract(res["policies"])
-        bx = res["policies"].get("bf16_exact", {}).get("roofline")
-        if isinstance(bx, dict) and args.workload == "dense_4096":
-            bx["traffic"] = pmc_traffic("dense_bf16_exact")
-            bx["traffic_source"] = "committed: " + str(pmc_traffic_source())
-            bx["algorithmic_bytes"] = res["roofline"]["algorithmic_bytes"]
+        fx = res["policies"].get("fast", {}).get("roofline")
+        if isinstance(fx, dict) and args.workload == "dense_4096" and pol != "fast":
+            fx["traffic"] = pmc_traffic("dense")
+            fx["traffic_source"] = "committed: " + str(pmc_traffic_source())
+            fx["algorithmic_bytes"] = res["roofline"]["algorithmic_bytes"]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(m, n, k, a, sfa, b, sfb, gpu_out=out, budget_s=args.cpu_budget,
@@ -846,8 +892,8 @@ def main():
             del a, b, out
             pa, psfa, pb, psfb = make_dense_inputs(pm, pn, pk, seed=100 + rank)
             pout = torch.empty((pm, pn), dtype=torch.bfloat16, device="cuda")
-            pt = dga.tiling(pm, pn, pk)
-            pstep = lambda: dga.gemm_fp8_fp8_bf16_nt((pa, psfa), (pb, psfb), pout)
+            pt = dga.tiling(pm, pn, pk, policy=pol if pol == "bf16_exact" else None)
+            pstep = lambda: dga.gemm_fp8_fp8_bf16_nt((pa, psfa), (pb, psfb), pout, policy=pol)
             # the same untimed clock pre-warm as in front of the headline's steps: this leg follows the CPU baseline, i.e.
             # seconds of an idle GPU, and 200 warm launches (12 ms) alone leave it inside the clock ramp (59 us instead of 55)
             t_pre = time.perf_counter()
@@ -856,21 +902,22 @@ def main():
                     pstep()
                 torch.cuda.synchronize()
             us = _time_us(pstep, max(50, min(args.steps, 400)), 200)
-            res["dsv3_prefill"] = {"workload": f"gemm_fp8_fp8_bf16_nt M={pm} N={pn} K={pk} (BASELINE configs[2])",
+            res["dsv3_prefill"] = {"workload": f"gemm_fp8_fp8_bf16_nt M={pm} N={pn} K={pk} (BASELINE configs[2])", "policy": pol,
                                    "value": round(2.0 * pm * pn * pk / us / 1e6, 2), "unit": "TFLOP/s",
-                                   "roofline": roofline_mfma(dga, pa, psfa, pb, psfb, pout, pt, pm, pn, pk, us, cus)}
-            res["dsv3_prefill"]["roofline"]["traffic"] = pmc_traffic("dsv3_prefill")
-            res["dsv3_prefill"]["roofline"]["traffic_source"] = "committed: " + str(pmc_traffic_source())
+                                   "roofline": roofline_mfma(dga, pa, psfa, pb, psfb, pout, pt, pm, pn, pk, us, cus, policy=pol)}
+            if pol == "fast":
+                res["dsv3_prefill"]["roofline"]["traffic"] = pmc_traffic("dsv3_prefill")
+                res["dsv3_prefill"]["roofline"]["traffic_source"] = "committed: " + str(pmc_traffic_source())
             if rank == 0 and not args.no_parity:
-                dga.gemm_fp8_fp8_bf16_nt((pa, psfa), (pb, psfb), pout, sync=True)
-                res["dsv3_prefill"]["parity"] = parity_vs_strict(dga, pa, psfa, pb, psfb, pout)
+                dga.gemm_fp8_fp8_bf16_nt((pa, psfa), (pb, psfb), pout, policy=pol, sync=True)
+                res["dsv3_prefill"]["parity"] = parity_vs_strict(dga, pa, psfa, pb, psfb, pout, policy=pol)
             if rank == 0 and not args.no_policies:
-                if ceilings.get("fast"):
+                if ceilings.get(pol):
                     pr = res["dsv3_prefill"]["roofline"]
-                    pr["ceiling_tflops"] = round(ceilings["fast"], 1)
-                    pr["frac_of_ceiling"] = round(pr["achieved"] / ceilings["fast"], 4)
+                    pr["ceiling_tflops"] = round(ceilings[pol], 1)
+                    pr["frac_of_ceiling"] = round(pr["achieved"] / ceilings[pol], 4)
                 res["dsv3_prefill"]["policies"], _ = policy_legs(
-                    dga, pa, psfa, pb, psfb, pm, pn, pk, args,
+                    dga, pa, psfa, pb, psfb, pm, pn, pk, args, pol,
                     {"kernel_us": round(us, 3), "roofline": res["dsv3_prefill"]["roofline"],
                      "parity": res["dsv3_prefill"].get("parity")}, ceilings)
             del pa, pb, pout
@@ -880,7 +927,7 @@ def main():
     if not args.no_grouped:
         try:
             grouped = grouped_leg(args, rank, world, dist)
-            if isinstance(grouped.get("roofline"), dict) and world == 1 and args.groups == 256 and args.grouped_mask == "full":
+            if isinstance(grouped.get("roofline"), dict) and world == 1 and args.groups == 256 and args.grouped_mask == "full" and pol == "fast":
                 grouped["roofline"]["traffic"] = pmc_traffic("grouped")
                 grouped["roofline"]["traffic_source"] = "committed: " + str(pmc_traffic_source())
             res["grouped"] = grouped
@@ -904,10 +951,132 @@ def main():
         except Exception as e:
             res["widen"] = {"error": repr(e)}
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        emit(res, args)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------------------------------------- output
+
+COMPACT_LIMIT = 4096   # bytes: the driver reads the LAST stdout line; a 21 KB line went unparsed in round 4
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact(res: dict) -> dict:
+    """The record the driver parses: the contract's keys + `roofline` + `cpu_baseline` in full meaning but few columns, and one
+    short object per side leg.  Everything else (every policy's roofline, the 18-shape list, the reference's own benchmark
+    list, per-phase times ...) is in the detail file named by `detail`.  Counterpart of the reference harness's one short
+    Result record per run (framework/benchmark/benchmark.py:195-225, 420-428)."""
+    c = _pick(res, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data"))
+    c["vs_baseline"] = res.get("vs_baseline")
+    cfg = res.get("config") or {}
+    c["config"] = _pick(cfg, ("workload", "policy", "tile", "parallelism", "backend"))
+    if cfg.get("stub"):
+        c["config"]["stub"] = True
+    if "roofline" in res:
+        r = res["roofline"]
+        c["roofline"] = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "kernel_us", "algorithmic_bytes", "kernel", "policy",
+                                  "instruction_peak", "frac_of_instruction_peak", "clock_mhz", "frac_at_measured_clock",
+                                  "ceiling_tflops", "frac_of_ceiling"))
+        c["roofline"]["traffic"] = r.get("traffic")
+        if r.get("traffic_source"):
+            c["roofline"]["traffic_source"] = "this run (rocprofv3 --pmc child passes)" if str(r["traffic_source"]).startswith("this run") else "committed profiles/ pass"
+        if isinstance(r.get("kernel"), str) and len(r["kernel"]) > 64:
+            c["roofline"]["kernel"] = r["kernel"][:61] + "..."
+    if "cpu_baseline" in res:
+        cb = res["cpu_baseline"]
+        c["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "blas_value"))
+        if cb.get("sample"):
+            c["cpu_baseline"]["sample"] = str(cb["sample"])[:120]
+        if isinstance(cb.get("gpu_rows_vs_oracle"), dict):
+            c["cpu_baseline"]["gpu_rows_vs_oracle"] = _pick(cb["gpu_rows_vs_oracle"], ("rows", "max_ulp", "frac_gt_2ulp"))
+    if isinstance(res.get("parity"), dict):
+        c["parity"] = _pick(res["parity"], ("elements", "max_ulp", "frac_gt_2ulp", "elements_gt_2ulp", "worst_excess_over_S", "within_bar", "error"))
+    if isinstance(res.get("in_contract"), dict):
+        c["in_contract"] = _pick(res["in_contract"], ("policy", "value", "unit", "kernel_us", "frac_of_fp8_peak", "frac_gt_2ulp", "max_ulp"))
+    pols = res.get("policies") or {}
+    for name in ("fast", "bf16_exact", "strict"):
+        leg = pols.get(name)
+        if isinstance(leg, dict) and name != (res.get("config") or {}).get("policy"):
+            o = _pick(leg, ("value", "kernel_us", "error"))
+            if isinstance(leg.get("roofline"), dict):
+                o["frac_of_fp8_peak"] = leg["roofline"].get("frac")
+            if isinstance(leg.get("parity"), dict):
+                o.update(_pick(leg["parity"], ("max_ulp", "frac_gt_2ulp")))
+            if isinstance(leg.get("parity_vs_oracle"), dict):
+                o["bit_identical_to_cpu_oracle"] = leg["parity_vs_oracle"].get("bit_identical")
+            c[name] = o
+    if isinstance(res.get("dsv3_prefill"), dict):
+        dp = res["dsv3_prefill"]
+        o = _pick(dp, ("policy", "value", "unit", "error"))
+        if isinstance(dp.get("roofline"), dict):
+            o.update(_pick(dp["roofline"], ("frac", "kernel_us")))
+        if isinstance(dp.get("parity"), dict):
+            o.update(_pick(dp["parity"], ("max_ulp", "frac_gt_2ulp")))
+        fl = (dp.get("policies") or {}).get("fast")
+        if isinstance(fl, dict) and dp.get("policy") != "fast":
+            o["fast"] = _pick(fl, ("value", "kernel_us"))
+        c["dsv3_prefill"] = o
+    if isinstance(res.get("grouped"), dict):
+        g = res["grouped"]
+        o = _pick(g, ("policy", "n_gpus", "tokens", "tok_per_s_gemm_only", "tok_per_s_with_alltoall", "ms_gemm", "ms_end_to_end", "error"))
+        if isinstance(g.get("roofline"), dict):
+            o["roofline"] = _pick(g["roofline"], ("bound", "achieved", "peak", "unit", "frac", "kernel_us", "algorithmic_bytes", "traffic"))
+        for side in ("fast", "in_contract"):
+            if isinstance(g.get(side), dict):
+                o[side] = _pick(g[side], ("policy", "tok_per_s_gemm_only", "ms_gemm", "frac_of_8TBps"))
+        if isinstance(g.get("parity"), dict):
+            o["parity"] = {kk: _pick(vv, ("max_ulp", "frac_gt_2ulp")) for kk, vv in g["parity"].items() if isinstance(vv, dict)}
+        if isinstance(g.get("dropped_tokens"), dict):
+            o["dropped_tokens"] = g["dropped_tokens"].get("timed_steps")
+        c["grouped"] = o
+    if isinstance(res.get("shape_list"), dict) and isinstance(res["shape_list"].get("shapes"), list):
+        rows = [r for r in res["shape_list"]["shapes"] if "frac" in r]
+        if rows:
+            fr = sorted(r["frac"] for r in rows)
+            fi = sorted(r["in_contract_frac"] for r in rows if "in_contract_frac" in r) or [None]
+            c["shape_list"] = {"shapes": len(res["shape_list"]["shapes"]),
+                               "in_contract": {"parity_ok": sum(1 for r in rows if r.get("in_contract_parity_ok")), "frac_of_bound_min": fi[0],
+                                               "frac_of_bound_median": fi[len(fi) // 2], "frac_of_bound_max": fi[-1]},
+                               "fast": {"parity_ok": sum(1 for r in rows if r.get("parity_ok")), "frac_of_bound_min": fr[0],
+                                        "frac_of_bound_median": fr[len(fr) // 2], "frac_of_bound_max": fr[-1]}}
+    if "detail" in res:
+        c["detail"] = res["detail"]
+    if "per_rank_kernel_us" in res and (res.get("n_gpus") or 1) > 1:
+        c["per_rank_kernel_us"] = res["per_rank_kernel_us"]
+    line = json.dumps(c)
+    for drop in ("shape_list", "dsv3_prefill", "strict", "parity", "cpu_baseline.sample"):   # never expected: a guard, not a plan
+        if len(line) < COMPACT_LIMIT:
+            break
+        if "." in drop:
+            a_, b_ = drop.split(".")
+            (c.get(a_) or {}).pop(b_, None)
+        else:
+            c.pop(drop, None)
+        line = json.dumps(c)
+    return c
+
+
+def emit(res: dict, args) -> None:
+    """Full record -> the detail file (and stderr); ONE compact line -> stdout, last."""
+    path = None
+    for cand in ([args.detail_out] if args.detail_out else [str(ROOT / "gpurun_out" / "bench_detail.json"), "/tmp/dga_bench_detail.json"]):
+        try:
+            Path(cand).parent.mkdir(parents=True, exist_ok=True)
+            Path(cand).write_text(json.dumps(res, indent=1))
+            path = cand
+            break
+        except OSError:
+            continue
+    res = dict(res)
+    res["detail"] = path
+    print("bench.py: full record (every leg and column) in " + str(path), file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    print(json.dumps(compact(res)), flush=True)
 
 
 if __name__ == "__main__":

@@ -42,6 +42,7 @@ from .api import (  # noqa: F401
     run_mmad_rtc,
     select_kernel,
     tiling,
+    tiling_check,
     tiling_cache_clear,
     tiling_cache_open,
     tiling_cache_size,

@@ -170,6 +170,7 @@ SIGNATURES = {
     "dga_sharded_events_create": (c_int, [c_int, POINTER(c_void_p)]),
     "dga_sharded_events_destroy": (c_int, [c_int, POINTER(c_void_p)]),
     "dga_mfma_ceiling": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, POINTER(c_float)]),
+    "dga_tiling_check": (c_int, [POINTER(Tiling)]),
     "dga_status_string": (c_char_p, [c_int]),
     "dga_last_hip_error": (c_int, []),
     "dga_abi_version": (c_int, []),
@@ -206,7 +207,7 @@ def lib() -> ctypes.CDLL:
                 raise DGALibraryError(f"{LIB_PATH} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
-        if L.dga_abi_version() != 5:
+        if L.dga_abi_version() != 6:
             raise DGALibraryError("ABI version mismatch")
         _lib = L
     return _lib

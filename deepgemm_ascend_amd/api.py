@@ -130,9 +130,19 @@ POLICY_BF16_EXACT = 7
 #   "strict"      fp32-input matrix instruction in the oracle's own order: bit-identical to the reference CPU path
 #   "auto"        "bf16_exact" where it is nearly free -- the decode rows the one-launch workgroup split-K takes (the weights are
 #                 streamed, the exact arithmetic rides along: +2..+15 %) -- and "fast" everywhere else; dense calls without an
-#                 explicit tiling only.  $DGA_DEFAULT_POLICY names the policy of calls that pass none (default: "fast").
-ARITHMETIC_POLICIES = {"fast": None, "bf16_exact": POLICY_BF16_EXACT, "strict": POLICY_STRICT, "auto": None}
-_DEFAULT_POLICY = os.environ.get("DGA_DEFAULT_POLICY") or None
+#                 explicit tiling only.
+# A call that names neither a policy nor a tiling runs $DGA_DEFAULT_POLICY, default "bf16_exact": the fastest policy whose outputs
+# stay inside the operator's contract (within 2 bf16 ULP of the fp32-accumulate CPU path; <= 1e-5 of the outputs of a 4096^3
+# problem differ by more, each a sum that cancels to the level of the fp32 reference's own rounding).  "fast" is an opt-in: the
+# fp8 matrix instruction drops product bits ~13 below each octet's largest (6.7e-4 of the same outputs beyond 2 ULP).  An explicit
+# tiling_ keeps the arithmetic its dispatchPolicyTag names.
+#   "fast_ue8m0"  "fast" for scale tensors whose values are exact powers of two (UE8M0 scales: per_token_cast_to_fp8(...,
+#                 use_ue8m0=True), upstream DeepGEMM's convention for hardware-scaled MFMAs): the scales ride in the matrix
+#                 instruction's E8M0 operands and the MFMA accumulates in place -- no promotion on the vector pipe.  Same outputs
+#                 as "fast" up to fp32 rounding order; a scale that is not a power of two is read as its exponent alone.
+ARITHMETIC_POLICIES = {"fast": None, "bf16_exact": POLICY_BF16_EXACT, "strict": POLICY_STRICT, "auto": None, "fast_ue8m0": None}
+POLICY_UE8M0_SCALES = 16      # DGA_POLICY_UE8M0_SCALES: a flag beside the fast-path schedules
+_DEFAULT_POLICY = os.environ.get("DGA_DEFAULT_POLICY") or "bf16_exact"
 
 
 def _with_policy(t: Tiling, strict: bool, policy: Optional[str] = None) -> Tiling:
@@ -140,6 +150,9 @@ def _with_policy(t: Tiling, strict: bool, policy: Optional[str] = None) -> Tilin
     _require(policy is None or policy in ARITHMETIC_POLICIES, f"policy must be one of {sorted(ARITHMETIC_POLICIES)}")
     _require(not (strict and policy not in (None, "strict")), "strict=True contradicts policy=%r" % (policy,))
     tag = POLICY_STRICT if strict else ARITHMETIC_POLICIES.get(policy)
+    if policy == "fast_ue8m0" and not strict:
+        _require((t.dispatchPolicyTag & 15) not in (POLICY_STRICT, POLICY_BF16_EXACT), "policy='fast_ue8m0' needs a fast-path tiling")
+        tag = (t.dispatchPolicyTag & 15) | POLICY_UE8M0_SCALES
     if tag is None or t.dispatchPolicyTag == tag:
         return t
     c = Tiling()
@@ -188,7 +201,9 @@ def _planned(index: int, m: int, n: int, k: int, groups: int, expected_m: int, c
     if t is None:
         if len(_PLANS) > 4096:
             _PLANS.clear()
+        _require(policy is None or policy in ARITHMETIC_POLICIES, f"policy (or $DGA_DEFAULT_POLICY) must be one of {sorted(ARITHMETIC_POLICIES)}")
         if policy == "auto":   # the exact arithmetic where the decode kernel carries it, the fast path elsewhere
+            _require(not strict, "strict=True contradicts policy='auto'")
             tb = tiling(m, n, k, policy="bf16_exact") if groups == 1 and not contiguous else None
             if tb is not None and tb.kernelSerial == 6:   # DGA_KERNEL_SPLITK_WORKGROUP
                 t = tb
@@ -236,6 +251,12 @@ def tiling(m: int, n: int, k: int, groups: int = 1, expected_m: int = 0, contigu
         return t
     _lib.check(_lib.lib().dga_tiling(ctypes.byref(p), ctypes.byref(t)), "tiling")
     return _with_policy(t, False, policy) if policy else t
+
+
+def tiling_check(t: Tiling) -> int:
+    """dga_tiling_check: 0 if the compiled menu holds this tiling, else the (negative) status every fp8 GEMM entry returns for
+    it before any launch (the TilingFunc's GRAPH_FAILED, catlass_dynamic_matmul_tiling.cpp:86-100)."""
+    return int(_lib.lib().dga_tiling_check(ctypes.byref(t)))
 
 
 def select_kernel(m: int, n: int, k: int, platform: Optional[Platform] = None, groups: int = 1,
@@ -620,7 +641,11 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(lhs, rhs, out: torch.Tensor, m_ind
         _require(t.is_contiguous(), "operands must be contiguous")
     with _device_guard(a, b, sfa, sfb, out, m_indices):
         if tiling_ is None:   # (the C side buckets Msum in its cache key and re-derives the workgroup count per call: not memoised here)
-            tiling_ = tiling(msum, n, k, groups=g, contiguous=True)
+            if policy is None and not strict:
+                policy = _DEFAULT_POLICY       # no tiling, no policy: the operator's default arithmetic, as in the other entries
+            _require(policy != "auto" or not strict, "strict=True contradicts policy='auto'")
+            policy = "fast" if policy == "auto" else policy
+            tiling_ = tiling(msum, n, k, groups=g, contiguous=True, policy="bf16_exact" if policy == "bf16_exact" else None)
         tiling_ = _with_policy(tiling_, strict, policy)
         ws_ptr, ws_bytes = _workspace(tiling_, out.device)
         rc = _lib.lib().dga_m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(

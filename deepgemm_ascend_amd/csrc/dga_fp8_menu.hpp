@@ -81,6 +81,10 @@ int launch_wsk_dma(const GemmParams &p, hipStream_t stream, int math = 0);
 int wsk_rows(int m);
 int wsk_max_ntiles(int m);
 
+// hardware-scale builds (gemm_fp8_kernel.hpp MATH = 2; dga_launch_menu_i.hip): block scales that are exact powers of two ride in
+// the matrix instruction's E8M0 operands, the MFMA accumulates in place.  DGA_E_TILING: no such build of that tile
+int launch_ue8m0(int bm, int bn, bool loaders, bool cont, const GemmParams &p, hipStream_t stream);
+
 // persistent continuous-pipeline build of the 256x256 tile (gemm_fp8_cont_persistent_kernel.hpp, dispatchPolicyTag 6): dense
 // rasters of full tiles only -- launch_cont_persistent returns DGA_E_TILING for anything else
 int launch_cont_persistent(const GemmParams &p, hipStream_t stream);

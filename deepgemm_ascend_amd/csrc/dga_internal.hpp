@@ -9,6 +9,9 @@ namespace dga {
 int record_hip(hipError_t e);
 // CUs of the current device (cached); the MI355X constant 256 when no device is visible (host-only tiling calls)
 uint32_t device_cus();
+// $DGA_DEFAULT_POLICY, read once: the arithmetic of a GEMM call that names no tiling.  1 = bf16-exact (the default: inside the
+// operator's 2-ULP contract), 0 = "fast" (fp8 matrix instruction), 2 = "strict".
+int default_policy();
 // indexed masked-grouped form: flat row buffers + slot -> row table (dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed)
 struct Fp8Indexed {
     const int64_t *row_index;   // device int64[groups * m_max]

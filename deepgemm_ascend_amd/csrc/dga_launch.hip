@@ -119,6 +119,17 @@ static const Bf16xVariant *find_bf16x_variant(int m1, int n1)
     return nullptr;
 }
 
+int default_policy()
+{
+    static const int v = [] {
+        const char *e = std::getenv("DGA_DEFAULT_POLICY");
+        if (e && !std::strcmp(e, "fast")) return 0;
+        if (e && !std::strcmp(e, "strict")) return 2;
+        return 1;
+    }();
+    return v;
+}
+
 int variant_count() { return kNumVariants; }
 int variant_stages(int i) { return kVariants[i].stages; }
 bool variant_has_loader_waves(int i) { return kVariants[i].launch_lc != nullptr; }
@@ -137,6 +148,48 @@ static const Variant *find_variant(int bm, int bn, int wm, int wn, int stages)
             return &kVariants[i];
     if (stages == 3) return find_variant(bm, bn, wm, wn, 2);
     return wm ? find_variant(bm, bn, 0, 0, 2) : nullptr;
+}
+
+// Every (kernelSerial, dispatchPolicyTag, tile, wave grid, stage count, split factor) the compiled menu holds -- anything else is
+// refused BEFORE any launch (dga_tiling_check; run_fp8 calls it first).  A caller's dga_tiling_t is data from outside: the
+// counterpart of CatlassDynamicMatmulTilingFunc returning GRAPH_FAILED on what it cannot tile
+// (/root/reference/aclnn_catlass_dynamic_matmul/op_host/catlass_dynamic_matmul_tiling.cpp:86-100).
+//   tiling.stages also names a BUILD where no tile build has that many stages (the magic values of include/dga_hip.h):
+//     fast path      0 / 2 / 3 = LDS stages (0: the tile's default); 1 only with kernelSerial 6 (the register workgroup split-K)
+//     bf16-exact     0 / 2 / 3 = the in-register build; 4 / 5 / 6 = the A-image / 8-wave image / 4-wave image builds (128 x 256 tile);
+//                    7 / 8 = persistent / one-tile build; 1 only with kernelSerial 6
+static int check_tiling(const dga_tiling_t &t)
+{
+    if (t.dispatchPolicyTag & ~(DGA_POLICY_UE8M0_SCALES | 7)) return DGA_E_TILING;      // bits nobody defined
+    const int tag = t.dispatchPolicyTag & 7;
+    switch (t.kernelSerial) {
+        case DGA_KERNEL_COMMON: case DGA_KERNEL_SMALL: case DGA_KERNEL_PADDING_COMMON: case DGA_KERNEL_STREAMK:
+        case DGA_KERNEL_STREAMK_TAIL: case DGA_KERNEL_SPLITK_WORKGROUP: break;
+        default: return DGA_E_TILING;
+    }
+    if (t.k1 != 0 && t.k1 != 128) return DGA_E_TILING;                                  // one scale block per k step
+    if (t.splitkFactor > 1024) return DGA_E_RANGE;
+    if (tag == DGA_POLICY_STRICT) return DGA_OK;                                        // takes every shape as it is
+    if (t.m1 == 0 || t.n1 == 0) return DGA_E_TILING;
+    const bool wsk = t.kernelSerial == DGA_KERNEL_SPLITK_WORKGROUP;
+    if (tag == DGA_POLICY_BF16_EXACT) {
+        if (!find_bf16x_variant(t.m1, t.n1)) return DGA_E_TILING;
+        const int st = t.stages;
+        if (!(st == 0 || st == 2 || st == 3 || (st >= 4 && st <= 8) || (st == 1 && wsk))) return DGA_E_TILING;
+        return DGA_OK;
+    }
+    bool tile = false, grid = false;
+    for (int i = 0; i < kNumVariants; ++i)
+        if (kVariants[i].bm == t.m1 && kVariants[i].bn == t.n1) {
+            tile = true;
+            if (kVariants[i].wm == t.wavesM && kVariants[i].wn == t.wavesN) grid = true;
+        }
+    if (!tile) return DGA_E_TILING;
+    if ((t.wavesM || t.wavesN) && !grid) return DGA_E_TILING;                           // a wave grid no build of this tile has
+    if (!(t.stages == 0 || t.stages == 2 || t.stages == 3 || (t.stages == 1 && wsk))) return DGA_E_TILING;
+    if (tag == DGA_POLICY_PINGPONG && !(t.m1 == 256 && t.n1 == 256)) return DGA_E_TILING;
+    if (t.kernelSerial == DGA_KERNEL_STREAMK_TAIL && !(t.m1 == 256 && t.n1 == 256)) return DGA_E_TILING;
+    return DGA_OK;
 }
 
 // the loop-clock build of a variant (dga_gemm_fp8_loop_clock), where one is compiled (DGA_MENU_CLK)
@@ -170,10 +223,29 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
         pr.layoutTagA = DGA_LAYOUT_ROW_MAJOR; pr.layoutTagB = DGA_LAYOUT_COLUMN_MAJOR;
         pr.layoutTagC = DGA_LAYOUT_ROW_MAJOR; pr.dtype = DGA_DT_FP8_E4M3FN;
         pr.flags = m_indices ? DGA_PROBLEM_CONTIGUOUS_M : 0;
+        // A call that names no tiling runs the policy whose outputs stay inside the operator's contract (within 2 bf16 ULP of the
+        // fp32-accumulate result: bf16-exact, dispatchPolicyTag 7) unless $DGA_DEFAULT_POLICY says "fast" (the fp8 matrix
+        // instruction: twice the rate, product bits ~13 below each octet's largest dropped) or "strict".  $DGA_BF16_EXACT=1
+        // (older switch) still forces the bf16-exact pick.
+        const int default_policy = dga::default_policy();
         static const int bf16x_auto = [] { const char *e = std::getenv("DGA_BF16_EXACT"); return e ? std::atoi(e) : 0; }();
-        int rc = bf16x_auto ? dga_tiling_bf16_exact(&pr, &local) : dga_tiling(&pr, &local);
+        int rc = (bf16x_auto || default_policy == 1) ? dga_tiling_bf16_exact(&pr, &local) : dga_tiling(&pr, &local);
+        if (rc == DGA_OK && default_policy == 2) local.dispatchPolicyTag = DGA_POLICY_STRICT;
         if (rc != DGA_OK) return rc;
         tiling = &local;
+    }
+    if (int rc = check_tiling(*tiling)) return rc;
+    // DGA_POLICY_UE8M0_SCALES: a flag beside the schedule -- the caller promises power-of-two scales; the tile builds that carry
+    // the scales in the matrix instruction's E8M0 operands run where they exist (launch_ue8m0), everything else reads the tag
+    // without the flag
+    dga_tiling_t unflagged;
+    bool ue8m0 = false;
+    if (tiling->dispatchPolicyTag & DGA_POLICY_UE8M0_SCALES) {
+        unflagged = *tiling;
+        unflagged.dispatchPolicyTag &= static_cast<uint8_t>(~DGA_POLICY_UE8M0_SCALES);
+        ue8m0 = unflagged.dispatchPolicyTag != DGA_POLICY_STRICT && unflagged.dispatchPolicyTag != DGA_POLICY_BF16_EXACT &&
+                unflagged.dispatchPolicyTag != DGA_POLICY_PINGPONG;
+        tiling = &unflagged;
     }
     // workspace == NULL is allowed (split-K and the odd-K padding pass are then skipped: single-pass / element-wise
     // kernels, same results); a workspace that is passed must be as large as dga_workspace_bytes() says
@@ -447,6 +519,12 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
         return vx->launch(p, stream);
     }
     auto launch_main = [&](const GemmParams &q) -> int {
+        if (ue8m0 && !q.stamps) {   // power-of-two scales: the build that accumulates in the MFMA, where the tile has one
+            const bool cont = (policy == DGA_POLICY_CONTINUOUS || policy == DGA_POLICY_CONTINUOUS_PERSISTENT) && v->launch_cont;
+            const bool loaders = (policy == DGA_POLICY_LOADER_WAVES || policy == DGA_POLICY_PERSISTENT) && v->launch_lc;
+            const int rc = launch_ue8m0(v->bm, v->bn, loaders, cont, q, stream);
+            if (rc != DGA_E_TILING) return rc;
+        }
         if (q.stamps) {
             auto clk = find_clock_build(v, (policy == 2 || policy == DGA_POLICY_CONTINUOUS_PERSISTENT) && v->launch_cont ? 2 : (policy == DGA_POLICY_LOADER_WAVES && v->launch_lc ? policy : 0));
             return clk ? clk(q, stream) : DGA_E_TILING;
@@ -486,6 +564,10 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
             pt.launch_tiles = tail * 4;
             // (the quarter tiles give a CU at most two workgroups: the 4 + 4 loader-wave build of the tile, -1..-2 % on the whole call:
             //  1024 x 18432 x 7168 139.8 -> 136.9 us, 4608 x 4096 x 7168 139.2 -> 136.2; same arithmetic, same bytes)
+            if (ue8m0) {
+                const int rq = launch_ue8m0(128, 128, vq->launch_lc != nullptr, false, pt, stream);
+                if (rq != DGA_E_TILING) return rq;
+            }
             if (vq->launch_lc) return vq->launch_lc(pt, stream);
             return vq->launch(pt, stream);
         }
@@ -496,6 +578,12 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
 }  // namespace dga
 
 extern "C" {
+
+int dga_tiling_check(const dga_tiling_t *tiling)
+{
+    if (!tiling) return DGA_E_NULL;
+    return dga::check_tiling(*tiling);
+}
 
 int dga_gemm_fp8_fp8_bf16_nt(const void *a, const float *sfa, const void *b, const float *sfb, void *out, int m,
                              int n, int k, const dga_tiling_t *tiling, void *workspace, size_t workspace_bytes,

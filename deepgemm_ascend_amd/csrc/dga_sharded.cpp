@@ -227,8 +227,12 @@ int dga_sharded_forward(const dga_sharded_shape_t *shape, const dga_sharded_buff
         pr.m = m_max; pr.n = n; pr.k = k; pr.groups = d.glc; pr.expected_m = em;
         pr.layoutTagA = DGA_LAYOUT_ROW_MAJOR; pr.layoutTagB = DGA_LAYOUT_COLUMN_MAJOR; pr.layoutTagC = DGA_LAYOUT_ROW_MAJOR;
         pr.dtype = DGA_DT_FP8_E4M3FN;
-        if (int rc = dga_tiling(&pr, &tiling)) return rc;
-        if (shape->policy >= 0) tiling.dispatchPolicyTag = static_cast<uint8_t>(shape->policy);
+        // policy -1 = the library's default arithmetic ($DGA_DEFAULT_POLICY: bf16-exact unless told otherwise), -2 = the fast
+        // policy's own tiling as it is; the bf16-exact policy picks its own tile (height from expected_m)
+        const int dp = dga::default_policy();
+        const int pol = shape->policy == -1 ? (dp == 1 ? DGA_POLICY_BF16_EXACT : (dp == 2 ? DGA_POLICY_STRICT : -2)) : shape->policy;
+        if (int rc = pol == DGA_POLICY_BF16_EXACT ? dga_tiling_bf16_exact(&pr, &tiling) : dga_tiling(&pr, &tiling)) return rc;
+        if (pol >= 0) tiling.dispatchPolicyTag = static_cast<uint8_t>(pol);
     }
     uint8_t *send = static_cast<uint8_t *>(buf->send), *recv = static_cast<uint8_t *>(buf->recv);
     uint8_t *osend = static_cast<uint8_t *>(buf->osend), *oback = static_cast<uint8_t *>(buf->oback);

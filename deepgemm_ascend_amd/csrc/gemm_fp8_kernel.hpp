@@ -140,6 +140,13 @@ struct LoopClock {
 // MATH = 0: the fp8 matrix instruction (one v_mfma_scale_f32_16x16x128_f8f6f4 per 128-wide scale block).
 // MATH = 1 (PP = 0, three LDS stages): the bf16-exact policy -- the e4m3 bytes are up-converted to bf16 in registers (exact)
 //         and a scale block is four chained v_mfma_f32_16x16x32_bf16, whose sums are fp32-class (see the loop below).
+// MATH = 2 (PP = 0 or 2): the fp8 matrix instruction with the block scales in its E8M0 operands -- for scale tensors whose values
+//         are exact powers of two ("UE8M0" scales, what upstream DeepGEMM's per_token_cast_to_fp8(..., use_ue8m0=True) writes):
+//         acc = v_mfma_scale_f32_16x16x128_f8f6f4(b, a, acc, e8m0(sfb), e8m0(sfa)) -- the MFMA accumulates in place exactly as
+//         the reference's Mmad(c1Local, ..., init on first) does (generate_code.hpp:320-335); no partial-sum ring, no promotion
+//         FMAs: the vector pipe carries nothing but the matrix instruction.  C-in keeps fp32 (scripts/ubench/probe_mfma_scale_acc.hip
+//         -> profiles/r05_probe_scale_acc.txt: 13 directed cases = fp32(C + p); K = 4096 / 7168 chains give the SAME bf16 output as the
+//         promotion form on all 76 800 outputs, max fp32 difference 2^-27 S).
 // UNAL (loader-wave builds, plain loop, dense): the operands' rows start at ANY byte (K % 16 != 0, no padded copy): the loader waves
 //         fetch them to registers with dword-aligned loads, realign (v_alignbyte), zero the bytes beyond K and ds_write the same
 //         swizzled image the LDS-DMA would have written -- the computing waves are unchanged.  The counterpart of the reference's
@@ -149,6 +156,7 @@ template <class Cfg, int PP, bool KTAIL, bool CLK = false, int MATH = 0, bool UN
 __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const GemmParams p)
 {
     static_assert(!UNAL || (Cfg::kLC && PP == 0 && MATH == 0 && KTAIL), "unaligned rows: loader waves, plain loop, fp8 matrix instruction");
+    static_assert(MATH != 2 || PP != 1, "hardware-scale builds: plain or continuous loop");
     LoopClock<CLK> loop_clock;
     constexpr int BM = Cfg::kBM, BN = Cfg::kBN, WN = Cfg::kWN;
     constexpr int NT = Cfg::NT, TM = Cfg::TM, TN = Cfg::TN;
@@ -628,6 +636,10 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         for (int i = 0; i < RING; ++i) part[i] = v4f{0.f, 0.f, 0.f, 0.f};
         v8i bf[2], af[TM];
         float s[TM], s_prev[TM], s_next[TM], sfb_next = 0.f;
+        // MATH = 2: the block's scales as E8M0 bytes (the fp32 exponent field) in byte 0 of a register: sae[mt] for this lane's
+        // row of m-tile mt (the MFMA's second operand), sbe for the wave's 128-column block (first operand)
+        int sae[TM], sbe = 0;
+        auto e8m0 = [](float v) { return (int)((uint32_t)__builtin_bit_cast(int, v) >> 23); };
         const int KB = p.kb_n;
         DGA_STAMP_DECL
         DGA_STAMP_ABS(0);        // (diagnostic builds: wave entry, a few set-up instructions late)
@@ -665,9 +677,11 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
                 s[mt] = *(const float *)(smem + sa_off + mt * 64) * sfb0;
+                if constexpr (MATH == 2) sae[mt] = e8m0(*(const float *)(smem + sa_off + mt * 64));
                 s_prev[mt] = 0.f;   // the first LAG "previous block" promotions add part (= 0) * 0
                 s_next[mt] = 0.f;
             }
+            if constexpr (MATH == 2) sbe = e8m0(sfb0);
         }
         DGA_STAMP_ABS(1);        // first fragments in registers: the k loop starts
         for (int kb = 0; kb < KB; ++kb) {
@@ -683,6 +697,9 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
 #endif
                     barrier();
                 }
+                if constexpr (MATH == 2)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[nt & 1], af[mt], acc[mt][nt], 0, 0, 0, sbe, 0, sae[mt]);
+                else
                 part[i % RING] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
                     bf[nt & 1], af[mt], v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -722,6 +739,9 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
                     s_next[mt] = *(const float *)(sn + sa_off + mt * 64);
                 }
                 // promotion of step i - LAG
+                if constexpr (MATH == 2) {
+                    // (nothing: the MFMA accumulated in place)
+                } else
                 if (i >= LAG) {
                     const int j = i - LAG, jn = j / TM, jm = j % TM;
                     const v4f pr = part[j % RING];
@@ -745,13 +765,18 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
             }
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
-                s_prev[mt] = s[mt];
-                s[mt] = s_next[mt] * sfb_next;
+                if constexpr (MATH == 2) {
+                    sae[mt] = e8m0(s_next[mt]);
+                } else {
+                    s_prev[mt] = s[mt];
+                    s[mt] = s_next[mt] * sfb_next;
+                }
             }
+            if constexpr (MATH == 2) sbe = e8m0(sfb_next);
         }
         // drain: the last LAG results of the last k block
 #pragma unroll
-        for (int i = 0; i < LAG; ++i) {
+        for (int i = 0; i < (MATH == 2 ? 0 : LAG); ++i) {
             const int j = STEPS - LAG + i, jn = j / TM, jm = j % TM;
             const v4f pr = part[j % RING];
             acc[jm][jn].x = __builtin_fmaf(pr.x, s_prev[jm], acc[jm][jn].x);
@@ -1124,6 +1149,13 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
             const float sfb_v = *(const float *)(st + sb_off);
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) s[mt] = *(const float *)(st + sa_off + mt * 64);
+            // MATH = 2: the scales as E8M0 bytes (the fp32 exponent field) in byte 0 of a register
+            int sae[TM], sbe = 0;
+            if constexpr (MATH == 2) {
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) sae[mt] = (int)((uint32_t)__builtin_bit_cast(int, s[mt]) >> 23);
+                sbe = (int)((uint32_t)__builtin_bit_cast(int, sfb_v) >> 23);
+            }
             DGA_STAMP(3);                            // segment 3: first fragments + scales out of LDS
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1134,6 +1166,9 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
                     part[i % RING] = v4f{0.f, 0.f, 0.f, 0.f};   // diagnostic: the stream without the matrix work
                     asm volatile("" : "+v"(part[i % RING]) : "v"(bf[nt & 1]), "v"(af[mt]));
 #else
+                    if constexpr (MATH == 2)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[nt & 1], af[mt], acc[mt][nt], 0, 0, 0, sbe, 0, sae[mt]);
+                    else
                     part[i % RING] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
                         bf[nt & 1], af[mt], v4f{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
 #endif
@@ -1159,11 +1194,11 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
                     if (mt == 0 && nt + 1 < TN) { bf[(nt + 1) & 1] = bf[nt & 1]; asm volatile("" : "+v"(bf[(nt + 1) & 1])); }
 #endif
                 }
-                if (i == LAG) {
+                if (MATH != 2 && i == LAG) {
 #pragma unroll
                     for (int mt = 0; mt < TM; ++mt) s[mt] *= sfb_v;  // two-level scale: sfa[m,kb] * sfb[n/128,kb]
                 }
-                if (i >= LAG) {
+                if (MATH != 2 && i >= LAG) {
                     const int j = i - LAG, nt = j / TM, mt = j % TM;
                     const v4f pr = part[j % RING];
                     // scalar FMAs on purpose: v_pk_fma_f32 beside MFMAs is slower than two v_fma_f32

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define DGA_ABI_VERSION 5
+#define DGA_ABI_VERSION 6
 
 /* ---- status codes (reference: DGA_HOST_ASSERT throws DGAException,
  *      deep_gemm_ascend/framework/csrc/utils/exception.hpp:9-33; op hooks return
@@ -78,10 +78,18 @@ enum { DGA_KERNEL_COMMON = 0, DGA_KERNEL_SMALL = 1, DGA_KERNEL_PADDING_COMMON = 
  *     outputs of BASELINE configs[1] (every one a sum that cancels to < 2^-21 of its terms), at the bf16 matrix rate.  Takes
  *     every layout the tile kernels take (dense, masked, contiguous, indexed, split-K); the tile comes from the tiling's
  *     (m1, n1) mapped onto the policy's own menu (wave tiles of at most 64 x 64).  $DGA_BF16_EXACT=1 forces it for every fp8
- *     call of the process. */
+ *     call of the process.
+ *   | 16 (DGA_POLICY_UE8M0_SCALES, a FLAG on the fast-path schedules 0, 2, 4, 5, 6): the caller's promise that every value of sfa
+ *     and sfb is an exact power of two in the normal fp32 range ("UE8M0" scales: 2^ceil(log2(amax / 448)), what upstream DeepGEMM's
+ *     per_token_cast_to_fp8(..., use_ue8m0=True) writes).  The scales then ride in the E8M0 operands of
+ *     v_mfma_scale_f32_16x16x128_f8f6f4 and the MFMA accumulates in place, as the reference's Mmad(c1Local, ..., init on first)
+ *     does (framework/csrc/jit/generate_code.hpp:320-335): no promotion on the vector pipe.  Outputs equal the promotion form's up
+ *     to fp32 rounding order (profiles/r05_probe_scale_acc.txt: identical bf16 on 76 800 of 76 800 outputs); a tile without such a
+ *     build runs the promotion form.  A scale that is NOT a power of two is read as its exponent alone (mantissa dropped); zero
+ *     reads as 2^-127.  Ignored by policies 3 and 7. */
 enum { DGA_POLICY_PLAIN = 0, DGA_POLICY_PINGPONG = 1, DGA_POLICY_CONTINUOUS = 2, DGA_POLICY_STRICT = 3,
        DGA_POLICY_LOADER_WAVES = 4, DGA_POLICY_PERSISTENT = 5, DGA_POLICY_CONTINUOUS_PERSISTENT = 6,
-       DGA_POLICY_BF16_EXACT = 7 };
+       DGA_POLICY_BF16_EXACT = 7, DGA_POLICY_UE8M0_SCALES = 16 };
 
 /* Platform description: the CDNA4 retarget of PlatformInfo
  * (op_tiling/platform_info.h:16-41; Python mirror get_best_config/tiling_calculator.py:25-30).
@@ -153,6 +161,18 @@ int dga_tiling(const dga_problem_t *problem, dga_tiling_t *out);
  * split-K factor picked from that policy's own menu by its own cost model (wave tiles <= 64 x 64, one 8-wave build; the fast path's
  * tuned tile is 10-40 % off there on mid-M shapes).  out->dispatchPolicyTag = DGA_POLICY_BF16_EXACT.  No reference counterpart. */
 int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out);
+
+/* Does the compiled kernel menu hold this tiling?  DGA_OK, or the error every fp8 GEMM entry returns for it BEFORE any launch
+ * (they call the same check first): DGA_E_TILING for a (kernelSerial, dispatchPolicyTag, m1 x n1, wavesM x wavesN, stages) no build
+ * answers to, DGA_E_RANGE for a split factor beyond 1024.  A caller-written dga_tiling_t is data from outside; the counterpart of
+ * CatlassDynamicMatmulTilingFunc returning GRAPH_FAILED (op_host/catlass_dynamic_matmul_tiling.cpp:86-100).  What the fields may
+ * hold:  kernelSerial 0, 1, 2, 4, 5, 6;  k1 0 or 128;  dispatchPolicyTag 0..7, optionally | DGA_POLICY_UE8M0_SCALES;
+ *   policy 3 (strict): any tile (the kernel picks its own);
+ *   policy 7 (bf16-exact): any m1, n1 > 0 (mapped onto that policy's menu); stages 0 / 2 / 3 = the in-register build, 4 = A-image,
+ *     5 / 6 = 8- / 4-wave image builds, 7 / 8 = persistent / one-tile build, 1 only with kernelSerial 6;
+ *   fast path: m1 x n1 a tile of the menu, wavesM x wavesN either 0 x 0 or a wave grid that tile is built with, stages 0 / 2 / 3
+ *     (1 only with kernelSerial 6: the register build of the workgroup split-K); policy 1 and kernelSerial 5: 256 x 256 only. */
+int dga_tiling_check(const dga_tiling_t *tiling);
 
 /* SelectKernel without the cache, on an explicit platform (select_kernel.cpp:333-369).
  * platform == NULL -> MI355X.  With dga_platform_ascend910b() it replays the reference's
@@ -375,7 +395,9 @@ typedef struct dga_sharded_shape_t {
                                  <= 0: the provable bound min(max_tokens, experts per chunk x m_max) */
     int32_t indexed;          /* 1: the GEMM gathers its rows from the receive buffer and scatters results into the buffer that
                                  travels back (no unpack / gather copy); 0: packed masked layout */
-    int32_t policy;           /* dispatchPolicyTag of the GEMM (DGA_POLICY_STRICT, DGA_POLICY_BF16_EXACT, ...) or -1 = the tiling's */
+    int32_t policy;           /* dispatchPolicyTag of the GEMM (DGA_POLICY_STRICT, DGA_POLICY_BF16_EXACT, ...); -1 = the library's default
+                                 arithmetic ($DGA_DEFAULT_POLICY: bf16-exact unless it says "fast" / "strict"); -2 = the fast policy's
+                                 own tiling, schedule included */
 } dga_sharded_shape_t;
 
 /* Payload row of the dispatch exchange: [K fp8 bytes][ceil(K/128) fp32 scales][int32 header = expert index on its owner, -1 =

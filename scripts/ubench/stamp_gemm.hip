@@ -31,7 +31,11 @@ int main(int argc, char **argv)
     hipMalloc(&st, (size_t)grid * 8 * 8 * 8); hipMemset(st, 0, (size_t)grid * 8 * 8 * 8);
     p.stamps = st;
     const int pp = argc > 4 ? atoi(argv[4]) : 0;
-    auto kfn = pp == 2 ? gemm_fp8_blockscaled_nt_kernel<Cfg, 2, false> : pp ? gemm_fp8_blockscaled_nt_kernel<Cfg, 1, false> : gemm_fp8_blockscaled_nt_kernel<Cfg, 0, false>;
+#ifndef CFG_MATH
+#define CFG_MATH 0     // 2: the hardware-scale build (block scales in the MFMA's E8M0 operands; the scales below are powers of two)
+#endif
+    auto kfn = pp == 2 ? gemm_fp8_blockscaled_nt_kernel<Cfg, 2, false, false, CFG_MATH>
+             : pp ? gemm_fp8_blockscaled_nt_kernel<Cfg, 1, false> : gemm_fp8_blockscaled_nt_kernel<Cfg, 0, false, false, CFG_MATH>;
     hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int warm = argc > 5 ? atoi(argv[5]) : 5;   // 4000+ = sustained clocks (the default 5 is inside the ramp after idle)

@@ -50,3 +50,53 @@ def test_world_size_mismatch_is_an_error_not_a_mislabelled_run():
 def test_a_failing_rank_fails_the_launcher():
     r = _run(["--gpus", "2", "--stub", "--steps", "2", "--workload", "no_such_workload"])
     assert r.returncode != 0
+
+
+# ---- the line the driver parses: ONE stdout line, compact (round 4's 21 KB line went unparsed: BENCH_r04.json parsed = null)
+
+def test_stdout_is_one_compact_line_and_the_detail_file_holds_the_rest(tmp_path):
+    detail = tmp_path / "detail.json"
+    r = _run(["--stub", "--steps", "3", "--warmup", "1", "--detail-out", str(detail)])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout            # nothing else on stdout: the driver may read the first or the last line
+    assert len(lines[0]) < 4096
+    d = json.loads(lines[0])
+    assert d["detail"] == str(detail) and d["config"]["policy"] == "bf16_exact"
+    full = json.loads(detail.read_text())
+    assert full["value"] == d["value"] and full["steps"] == 3
+
+
+def _full_record():
+    """A record as large as a real default run's: round 4's committed 21 KB line re-labelled to this round's keys."""
+    sys.path.insert(0, str(ROOT))
+    d = json.loads((ROOT / "profiles" / "r04_bench.json").read_text())
+    d["config"]["policy"] = "bf16_exact"
+    d["roofline"].update({"policy": "bf16_exact", "instruction_peak": 2500.0, "frac_of_instruction_peak": 0.47,
+                          "traffic_source": "this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE " + "x" * 300,
+                          "kernel": "gemm_fp8_blockscaled_nt_kernel<..., MATH = 1> (bf16-exact build; persistent form where every CU gets the same tile count)"})
+    d["grouped"]["policy"] = "bf16_exact"
+    d["grouped"]["fast"] = {"policy": "fast", "ms_gemm": 0.7, "tok_per_s_gemm_only": 4.6e7, "frac_of_8TBps": 0.74, "note": "y" * 200}
+    for row in d["shape_list"]["shapes"]:
+        row.setdefault("in_contract_frac", 0.2); row.setdefault("in_contract_parity_ok", True)
+    return d
+
+
+def test_compact_of_a_full_size_record_is_under_4_kb_and_keeps_the_contract():
+    sys.path.insert(0, str(ROOT))
+    import bench
+    full = _full_record()
+    assert len(json.dumps(full)) > 15000          # the premise: the full record is what went unparsed
+    c = bench.compact(dict(full, detail="gpurun_out/bench_detail.json"))
+    line = json.dumps(c)
+    assert len(line) < bench.COMPACT_LIMIT == 4096, len(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in c, key
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in c["roofline"], key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c["cpu_baseline"], key
+    assert c["config"]["workload"].startswith("dense_4096") and "model" not in c["config"]
+    assert c["in_contract"]["policy"] == "bf16_exact" and c["grouped"]["roofline"]["bound"] == "hbm"
+    assert c["value"] == full["value"] and c["roofline"]["frac"] == full["roofline"]["frac"]   # numbers copied, never recomputed

@@ -1,0 +1,105 @@
+"""CPU: dga_tiling_check -- a caller-written dga_tiling_t is data from outside; what the compiled menu does not hold is refused
+before any launch (every fp8 GEMM entry calls the same check first; the GPU half is tests/test_tiling_check_gpu.py).
+Counterpart of CatlassDynamicMatmulTilingFunc returning GRAPH_FAILED on what it cannot tile
+(/root/reference/aclnn_catlass_dynamic_matmul/op_host/catlass_dynamic_matmul_tiling.cpp:86-100)."""
+import ctypes
+import itertools
+import random
+
+import pytest
+
+import deepgemm_ascend_amd as dga
+from deepgemm_ascend_amd import _lib
+
+OK, E_TILING, E_RANGE = 0, -6, -9
+FAST_TILES = {(256, 256), (128, 256), (256, 128), (128, 128), (64, 256), (64, 128), (32, 256), (32, 128), (16, 256), (16, 128)}
+
+
+def _copy(t):
+    c = _lib.Tiling()
+    ctypes.memmove(ctypes.byref(c), ctypes.byref(t), ctypes.sizeof(_lib.Tiling))
+    return c
+
+
+def test_every_tiling_the_selectors_write_passes():
+    n = 0
+    for m, nn, k in itertools.product((1, 16, 64, 100, 128, 512, 1279, 4096), (128, 2048, 4096, 5003, 18432), (128, 2048, 7168, 7681)):
+        for pol in (None, "bf16_exact", "strict"):
+            assert dga.tiling_check(dga.tiling(m, nn, k, policy=pol)) == OK, (m, nn, k, pol)
+            n += 1
+    for g, em in ((256, 128), (256, 16), (32, 64), (8, 4)):
+        for pol in (None, "bf16_exact"):
+            assert dga.tiling_check(dga.tiling(128, 2048, 7168, groups=g, expected_m=em, policy=pol)) == OK
+    assert dga.tiling_check(dga.tiling(8192, 4096, 7168, groups=8, contiguous=True)) == OK
+    assert n > 400
+
+
+def test_fields_outside_the_menu_are_refused():
+    base = dga.tiling(4096, 4096, 4096)
+    assert (base.m1, base.n1) == (256, 256) and dga.tiling_check(base) == OK
+    for field, bad in (("kernelSerial", 3), ("kernelSerial", 7), ("kernelSerial", 255), ("dispatchPolicyTag", 8), ("dispatchPolicyTag", 32),
+                       ("dispatchPolicyTag", 0x80 | 2), ("k1", 64), ("k1", 256), ("m1", 0), ("n1", 0), ("m1", 512), ("m1", 48), ("n1", 64),
+                       ("stages", 1), ("stages", 4), ("stages", 9), ("wavesM", 3), ("wavesN", 7)):
+        t = _copy(base)
+        setattr(t, field, bad)
+        assert dga.tiling_check(t) == E_TILING, (field, bad)
+    t = _copy(base); t.splitkFactor = 1025
+    assert dga.tiling_check(t) == E_RANGE
+    t = _copy(base); t.splitkFactor = 1024
+    assert dga.tiling_check(t) == OK
+    # what a field MAY hold beside the selector's pick
+    for field, good in (("stages", 0), ("stages", 3), ("wavesM", 0), ("dispatchPolicyTag", 0), ("dispatchPolicyTag", 1), ("dispatchPolicyTag", 2 | 16),
+                        ("dispatchPolicyTag", 6), ("kernelSerial", 5), ("k1", 0)):
+        t = _copy(base)
+        setattr(t, field, good)
+        if field == "wavesM":
+            t.wavesN = 0
+        assert dga.tiling_check(t) == OK, (field, good)
+    # ping-pong and the quarter-tile tail exist for the 256 x 256 tile only
+    small = dga.tiling(1024, 2048, 7168)
+    for field, v in (("dispatchPolicyTag", 1), ("kernelSerial", 5)):
+        t = _copy(small)
+        if (t.m1, t.n1) != (256, 256):
+            setattr(t, field, v)
+            assert dga.tiling_check(t) == E_TILING
+    # stages = 1 names the register build of the workgroup split-K and nothing else
+    t = _copy(base); t.stages = 1; t.kernelSerial = 6
+    assert dga.tiling_check(t) == OK
+    # the bf16-exact policy's build names: 4 .. 8; strict takes anything
+    bx = dga.tiling(4096, 4096, 4096, policy="bf16_exact")
+    for st, want in ((0, OK), (2, OK), (3, OK), (4, OK), (5, OK), (6, OK), (7, OK), (8, OK), (1, E_TILING), (9, E_TILING), (200, E_TILING)):
+        t = _copy(bx); t.stages = st
+        assert dga.tiling_check(t) == want, st
+    t = _copy(base); t.dispatchPolicyTag = 3; t.m1 = 7; t.n1 = 9; t.stages = 77; t.wavesM = 5
+    assert dga.tiling_check(t) == OK
+
+
+def test_fuzzed_structs_are_either_in_the_menu_or_refused():
+    """Random field values: the check never crashes, is deterministic, and what it accepts on the fast path is a tile, a wave grid
+    and a stage count the menu holds."""
+    rng = random.Random(5)
+    base = dga.tiling(2048, 4096, 7168)
+    accepted = 0
+    for _ in range(20000):
+        t = _copy(base)
+        t.kernelSerial = rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 9, 255])
+        t.dispatchPolicyTag = rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 15, 16, 18, 20, 22, 23, 24, 31, 64, 255])
+        t.m1 = rng.choice([0, 8, 16, 32, 48, 64, 96, 128, 256, 512, 65535])
+        t.n1 = rng.choice([0, 64, 128, 192, 256, 512])
+        t.k1 = rng.choice([0, 128, 128, 128, 64, 256])
+        t.wavesM = rng.choice([0, 0, 1, 2, 3, 4, 8]); t.wavesN = rng.choice([0, 0, 1, 2, 4, 8])
+        t.stages = rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 255])
+        t.splitkFactor = rng.choice([0, 1, 2, 4, 8, 56, 1024, 1025, 65535])
+        rc = dga.tiling_check(t)
+        assert rc in (OK, E_TILING, E_RANGE) and rc == dga.tiling_check(t)
+        if rc == OK:
+            accepted += 1
+            tag = t.dispatchPolicyTag & 7
+            assert t.kernelSerial in (0, 1, 2, 4, 5, 6) and t.k1 in (0, 128) and t.splitkFactor <= 1024 and not (t.dispatchPolicyTag & ~23)
+            if tag not in (3, 7):
+                assert (t.m1, t.n1) in FAST_TILES and t.stages in (0, 2, 3) or (t.stages == 1 and t.kernelSerial == 6)
+    assert 0 < accepted < 20000
+
+
+def test_null_is_an_error_not_a_crash():
+    assert _lib.lib().dga_tiling_check(None) == -1
