@@ -58,6 +58,7 @@ class Problem(ctypes.Structure):
 
 PROBLEM_CONTIGUOUS_M = 1
 ROWS_A_ZERO_PADDED, ROWS_B_ZERO_PADDED = 1, 2   # dga_gemm_fp8_fp8_bf16_nt_strided flags
+CAST_UE8M0 = 1                                  # dga_cast_to_fp8_*_ex flag: block scales rounded up to powers of two
 CONTIGUOUS_M_ALIGNMENT = 128
 
 
@@ -136,6 +137,8 @@ SIGNATURES = {
     "dga_cast_to_fp8_128x128": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "dga_cast_to_fp8_1x128_ld": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "dga_cast_to_fp8_128x128_ld": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
+    "dga_cast_to_fp8_1x128_ex": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p]),
+    "dga_cast_to_fp8_128x128_ex": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p]),
     "dga_catlass_dynamic_matmul_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_void_p, c_void_p]),
     "dga_catlass_dynamic_matmul": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                                            c_void_p]),

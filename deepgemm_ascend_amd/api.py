@@ -659,7 +659,7 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(lhs, rhs, out: torch.Tensor, m_ind
 _CAST_DT = {torch.float32: _lib.DT_FP32, torch.bfloat16: _lib.DT_BF16, torch.float16: _lib.DT_FP16}
 
 
-def _cast(fn_name: str, x: torch.Tensor, block_rows: int, aligned_rows: bool = False):
+def _cast(fn_name: str, x: torch.Tensor, block_rows: int, aligned_rows: bool = False, use_ue8m0: bool = False):
     _require(x.dim() == 2 and x.is_contiguous(), "x must be a contiguous [rows, k] tensor")
     _require(x.dtype in _CAST_DT, "x must be float32, bfloat16 or float16")
     rows, k = x.shape
@@ -667,7 +667,10 @@ def _cast(fn_name: str, x: torch.Tensor, block_rows: int, aligned_rows: bool = F
     q = torch.empty((rows, ldq), dtype=torch.uint8, device=x.device)
     sf = torch.empty(((rows + block_rows - 1) // block_rows, (k + 127) // 128), dtype=torch.float32, device=x.device)
     with _device_guard(x):
-        if ldq != k:
+        if use_ue8m0:     # block scales rounded up to powers of two (dga_cast_to_fp8_*_ex, DGA_CAST_UE8M0)
+            rc = getattr(_lib.lib(), fn_name + "_ex")(x.data_ptr(), _CAST_DT[x.dtype], rows, k, q.data_ptr(), ldq, sf.data_ptr(),
+                                                      _lib.CAST_UE8M0, _stream_ptr(x))
+        elif ldq != k:
             rc = getattr(_lib.lib(), fn_name + "_ld")(x.data_ptr(), _CAST_DT[x.dtype], rows, k, q.data_ptr(), ldq, sf.data_ptr(),
                                                       _stream_ptr(x))
         else:
@@ -681,20 +684,22 @@ def _cast(fn_name: str, x: torch.Tensor, block_rows: int, aligned_rows: bool = F
     return q, sf
 
 
-def per_token_cast_to_fp8(x: torch.Tensor, aligned_rows: bool = False):
+def per_token_cast_to_fp8(x: torch.Tensor, aligned_rows: bool = False, use_ue8m0: bool = False):
     """Activation quantiser: x [rows,k] -> (e4m3fn [rows,k], fp32 scales [rows, ceil(k/128)]), one scale per 1x128
     block: scale = amax/448, q = RNE-satfinite(x/scale) (the A-operand format of gemm_fp8_fp8_bf16_nt).
     aligned_rows=True: the result is a [rows, k] view of rows round_up(k, 128) bytes apart with zero tails, which
     gemm_fp8_fp8_bf16_nt reads in place whatever k is (no padding pass for k % 16 != 0; 1279 x 5003 x 7681: 80.6 -> 65.8 us.
     Rows only 16-byte aligned are read in place too but gain nothing: a 128-byte row piece that straddles two cache lines
-    costs two requests on every re-read, profiles/r04_odd_k_rows.txt)."""
-    return _cast("dga_cast_to_fp8_1x128", x, 1, aligned_rows)
+    costs two requests on every re-read, profiles/r04_odd_k_rows.txt).
+    use_ue8m0=True (upstream DeepGEMM's keyword): scale = 2^ceil(log2(amax / 448)), a power of two -- operands quantised this way
+    on BOTH sides may be multiplied under policy="fast_ue8m0" (the scales ride in the matrix instruction's E8M0 operands)."""
+    return _cast("dga_cast_to_fp8_1x128", x, 1, aligned_rows, use_ue8m0)
 
 
-def per_block_cast_to_fp8(x: torch.Tensor, aligned_rows: bool = False):
+def per_block_cast_to_fp8(x: torch.Tensor, aligned_rows: bool = False, use_ue8m0: bool = False):
     """Weight quantiser: x [rows,k] -> (e4m3fn [rows,k], fp32 scales [ceil(rows/128), ceil(k/128)]), one scale per
-    128x128 block (the B-operand format).  aligned_rows: as per_token_cast_to_fp8."""
-    return _cast("dga_cast_to_fp8_128x128", x, 128, aligned_rows)
+    128x128 block (the B-operand format).  aligned_rows, use_ue8m0: as per_token_cast_to_fp8."""
+    return _cast("dga_cast_to_fp8_128x128", x, 128, aligned_rows, use_ue8m0)
 
 
 def route_tokens(expert_ids: torch.Tensor, groups: int):

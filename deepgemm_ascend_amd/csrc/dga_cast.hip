@@ -49,6 +49,19 @@ __device__ __forceinline__ float row16_max(float x)
     return x;
 }
 
+// DGA_CAST_UE8M0: the block scale rounded UP to a power of two, 2^ceil(log2(amax / 448)) -- upstream DeepGEMM's use_ue8m0
+// quantisation; such scales ride in the matrix instruction's E8M0 operands (DGA_POLICY_UE8M0_SCALES).  Exact on the bits: a
+// scale with a non-zero mantissa moves to the next exponent.
+__device__ __forceinline__ float block_scale(float amax, bool ue8m0)
+{
+    float s = amax > 0.f ? amax / 448.f : 1.f;
+    if (ue8m0) {
+        const uint32_t b = __float_as_uint(s);
+        if (b & 0x007FFFFFu) s = __uint_as_float((b & 0x7F800000u) + 0x00800000u);
+    }
+    return s;
+}
+
 __device__ __forceinline__ bool has_ff_byte(uint32_t w) { return (((~w) - 0x01010101u) & w & 0x80808080u) != 0; }
 
 // 8 values of one scale block -> 8 codes.  Fast path: the IEEE quotient x / s by the compiler's own fp32 division
@@ -123,7 +136,7 @@ template <> struct Elem<F16Tag> {
 // are contiguous per 16-lane group (256 / 512 bytes in, 128 bytes out).
 template <typename T>
 __global__ void __launch_bounds__(256) cast_1x128_kernel(const void *x, uint8_t *q, float *sf, int64_t rows, int64_t k,
-                                                         int64_t kb_n, bool vec_in, bool vec_out, int64_t ldq)
+                                                         int64_t kb_n, bool vec_in, bool vec_out, int64_t ldq, bool ue8m0)
 {
     const int64_t blk = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
     if (blk >= rows * kb_n) return;  // whole 16-lane groups leave together
@@ -141,7 +154,7 @@ __global__ void __launch_bounds__(256) cast_1x128_kernel(const void *x, uint8_t 
 #pragma unroll
     for (int j = 0; j < 8; ++j) amax = __builtin_fmaxf(amax, __builtin_fabsf(v[j]));
     amax = row16_max(amax);
-    const float s = amax > 0.f ? amax / 448.f : 1.f;
+    const float s = block_scale(amax, ue8m0);
     if (sub == 0) sf[blk] = s;
     uint32_t w0, w1;
     quant8(v, s, w0, w1);
@@ -160,7 +173,7 @@ __global__ void __launch_bounds__(256) cast_1x128_kernel(const void *x, uint8_t 
 // instead of one load.  Block j of a group is blk + j * stride (stride = a U-th of the blocks), so that each of the U passes of
 // the grid is the contiguous stream the one-block kernel reads.  Whole rows only on the fast path (vec_in, vec_out, K % 128 == 0).
 template <typename T, int U>
-__global__ void __launch_bounds__(256) cast_1x128_unrolled_kernel(const void *x, uint8_t *q, float *sf, int64_t blocks, int64_t stride)
+__global__ void __launch_bounds__(256) cast_1x128_unrolled_kernel(const void *x, uint8_t *q, float *sf, int64_t blocks, int64_t stride, bool ue8m0)
 {
     const int64_t blk0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
     if (blk0 >= stride) return;
@@ -181,7 +194,7 @@ __global__ void __launch_bounds__(256) cast_1x128_unrolled_kernel(const void *x,
 #pragma unroll
         for (int e = 0; e < 8; ++e) amax = __builtin_fmaxf(amax, __builtin_fabsf(v[j][e]));
         amax = row16_max(amax);
-        const float s = amax > 0.f ? amax / 448.f : 1.f;
+        const float s = block_scale(amax, ue8m0);
         if (sub == 0) sf[blk] = s;
         uint32_t w0, w1;
         quant8(v[j], s, w0, w1);
@@ -193,7 +206,7 @@ __global__ void __launch_bounds__(256) cast_1x128_unrolled_kernel(const void *x,
 // through LDS, nothing is read twice.
 template <typename T>
 __global__ void __launch_bounds__(256) cast_128x128_kernel(const void *x, uint8_t *q, float *sf, int64_t rows, int64_t k,
-                                                           int64_t kb_n, bool vec_in, bool vec_out, int64_t ldq)
+                                                           int64_t kb_n, bool vec_in, bool vec_out, int64_t ldq, bool ue8m0)
 {
     __shared__ float red[4];
     const int64_t rb = blockIdx.x / kb_n, kb = blockIdx.x - rb * kb_n;
@@ -224,7 +237,7 @@ __global__ void __launch_bounds__(256) cast_128x128_kernel(const void *x, uint8_
     if ((t & 63) == 0) red[t >> 6] = amax;
     __syncthreads();
     amax = __builtin_fmaxf(__builtin_fmaxf(red[0], red[1]), __builtin_fmaxf(red[2], red[3]));
-    const float s = amax > 0.f ? amax / 448.f : 1.f;
+    const float s = block_scale(amax, ue8m0);
     if (t == 0) sf[blockIdx.x] = s;
     if (!row_ok) return;
 #pragma unroll
@@ -247,7 +260,7 @@ __global__ void __launch_bounds__(256) cast_128x128_kernel(const void *x, uint8_
 }
 
 template <typename T>
-static int launch_cast(int mode, const void *x, void *q, float *sf, int64_t rows, int64_t k, int64_t ldq, hipStream_t stream)
+static int launch_cast(int mode, const void *x, void *q, float *sf, int64_t rows, int64_t k, int64_t ldq, bool ue8m0, hipStream_t stream)
 {
     const int64_t kb_n = (k + 127) / 128;
     // a lane's 8 elements start at element row*k + 8*j: 16-byte aligned for every row iff k % 8 == 0
@@ -264,10 +277,10 @@ static int launch_cast(int mode, const void *x, void *q, float *sf, int64_t rows
         if (grid > 0x7FFFFFFFll) return DGA_E_RANGE;
         if (unroll >= 4)
             hipLaunchKernelGGL((cast_1x128_unrolled_kernel<T, 4>), dim3(static_cast<unsigned>(((blocks + 3) / 4 * 16 + 255) / 256)), dim3(256), 0,
-                               stream, x, static_cast<uint8_t *>(q), sf, blocks, (blocks + 3) / 4);
+                               stream, x, static_cast<uint8_t *>(q), sf, blocks, (blocks + 3) / 4, ue8m0);
         else
             hipLaunchKernelGGL((cast_1x128_unrolled_kernel<T, 2>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream, x,
-                               static_cast<uint8_t *>(q), sf, blocks, stride);
+                               static_cast<uint8_t *>(q), sf, blocks, stride, ue8m0);
         return record_hip(hipGetLastError());
     }
     if (mode == 0) {
@@ -275,26 +288,28 @@ static int launch_cast(int mode, const void *x, void *q, float *sf, int64_t rows
         const int64_t grid = (blocks * 16 + 255) / 256;
         if (grid > 0x7FFFFFFFll) return DGA_E_RANGE;
         hipLaunchKernelGGL(cast_1x128_kernel<T>, dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream, x,
-                           static_cast<uint8_t *>(q), sf, rows, k, kb_n, vec_in, vec_out, ldq);
+                           static_cast<uint8_t *>(q), sf, rows, k, kb_n, vec_in, vec_out, ldq, ue8m0);
     } else {
         const int64_t grid = ((rows + 127) / 128) * kb_n;
         if (grid > 0x7FFFFFFFll) return DGA_E_RANGE;
         hipLaunchKernelGGL(cast_128x128_kernel<T>, dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream, x,
-                           static_cast<uint8_t *>(q), sf, rows, k, kb_n, vec_in, vec_out, ldq);
+                           static_cast<uint8_t *>(q), sf, rows, k, kb_n, vec_in, vec_out, ldq, ue8m0);
     }
     return record_hip(hipGetLastError());
 }
 
-static int run_cast(int mode, const void *x, int x_dtype, int64_t rows, int64_t k, void *q, int64_t ldq, float *sf, void *stream)
+static int run_cast(int mode, const void *x, int x_dtype, int64_t rows, int64_t k, void *q, int64_t ldq, float *sf, void *stream, int flags = 0)
 {
+    if (flags & ~DGA_CAST_UE8M0) return DGA_E_RANGE;
+    const bool ue8m0 = (flags & DGA_CAST_UE8M0) != 0;
     if (rows < 0 || k < 0 || ldq < k || ldq > (k + 127) / 128 * 128) return DGA_E_SHAPE;
     if (rows == 0 || k == 0) return DGA_OK;
     if (!x || !q || !sf) return DGA_E_NULL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (x_dtype) {
-        case DGA_DT_FP32: return launch_cast<float>(mode, x, q, sf, rows, k, ldq, st);
-        case DGA_DT_BF16: return launch_cast<Bf16Tag>(mode, x, q, sf, rows, k, ldq, st);
-        case DGA_DT_FP16: return launch_cast<F16Tag>(mode, x, q, sf, rows, k, ldq, st);
+        case DGA_DT_FP32: return launch_cast<float>(mode, x, q, sf, rows, k, ldq, ue8m0, st);
+        case DGA_DT_BF16: return launch_cast<Bf16Tag>(mode, x, q, sf, rows, k, ldq, ue8m0, st);
+        case DGA_DT_FP16: return launch_cast<F16Tag>(mode, x, q, sf, rows, k, ldq, ue8m0, st);
         default: return DGA_E_DTYPE;
     }
 }
@@ -321,6 +336,16 @@ int dga_cast_to_fp8_1x128_ld(const void *x, int x_dtype, int64_t rows, int64_t k
 int dga_cast_to_fp8_128x128_ld(const void *x, int x_dtype, int64_t rows, int64_t k, void *q, int64_t ldq, float *sf, void *stream)
 {
     return dga::run_cast(1, x, x_dtype, rows, k, q, ldq, sf, stream);
+}
+
+int dga_cast_to_fp8_1x128_ex(const void *x, int x_dtype, int64_t rows, int64_t k, void *q, int64_t ldq, float *sf, int flags, void *stream)
+{
+    return dga::run_cast(0, x, x_dtype, rows, k, q, ldq, sf, stream, flags);
+}
+
+int dga_cast_to_fp8_128x128_ex(const void *x, int x_dtype, int64_t rows, int64_t k, void *q, int64_t ldq, float *sf, int flags, void *stream)
+{
+    return dga::run_cast(1, x, x_dtype, rows, k, q, ldq, sf, stream, flags);
 }
 
 }  // extern "C"

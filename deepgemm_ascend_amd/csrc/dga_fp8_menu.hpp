@@ -84,6 +84,8 @@ int wsk_max_ntiles(int m);
 // hardware-scale builds (gemm_fp8_kernel.hpp MATH = 2; dga_launch_menu_i.hip): block scales that are exact powers of two ride in
 // the matrix instruction's E8M0 operands, the MFMA accumulates in place.  DGA_E_TILING: no such build of that tile
 int launch_ue8m0(int bm, int bn, bool loaders, bool cont, const GemmParams &p, hipStream_t stream);
+// ... and the 256 x 256 tile on FOUR waves (wave tile 128 x 128, accumulators in AGPRs; dga_launch_menu_j.hip), continuous loop
+int launch_ue8m0_w4(const GemmParams &p, hipStream_t stream);
 
 // persistent continuous-pipeline build of the 256x256 tile (gemm_fp8_cont_persistent_kernel.hpp, dispatchPolicyTag 6): dense
 // rasters of full tiles only -- launch_cont_persistent returns DGA_E_TILING for anything else

@@ -320,7 +320,10 @@ gemm_fp8_bf16x_persistent_kernel(const GemmParams p)
                     const v4i pk = v4i{__builtin_bit_cast(int, h0), __builtin_bit_cast(int, h1),
                                        __builtin_bit_cast(int, h2), __builtin_bit_cast(int, h3)};
                     if (vec_ok && n + 8 <= p.n) {
-                        *(v4i *)(crow + n) = pk;
+                        if (p.out_nt == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(crow + n), "v"(pk) : "memory");
+                        else if (p.out_nt == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(crow + n), "v"(pk) : "memory");
+                        else if (p.out_nt == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(crow + n), "v"(pk) : "memory");
+                        else *(v4i *)(crow + n) = pk;
                     } else {
                         const uint16_t *e = (const uint16_t *)&pk;
 #pragma unroll

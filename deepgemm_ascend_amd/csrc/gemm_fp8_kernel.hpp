@@ -411,7 +411,14 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
 #ifdef DGA_ABL_NOSTORE
                     if (lo.x == 12345.678f) *(v4i *)(crow + n) = pk;  // diagnostic: keep the math, drop the write stream
 #else
-                    *(v4i *)(crow + n) = pk;
+                    // out_nt (dense one-tile-per-CU rasters): the tile's rows leave with a cache policy that does not park them in
+                    // the XCD's L2 -- every CU stores its 128 KB at the same moment and the kernel-end write-back of what the L2
+                    // still holds dirty would otherwise follow the store burst instead of running under it
+                    // (inline asm: written as a builtin beside a plain store the branches are merged and the hint is lost)
+                    if (p.out_nt == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(crow + n), "v"(pk) : "memory");
+                    else if (p.out_nt == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(crow + n), "v"(pk) : "memory");
+                    else if (p.out_nt == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(crow + n), "v"(pk) : "memory");
+                    else *(v4i *)(crow + n) = pk;
 #endif
                 } else {
                     const uint16_t *e = (const uint16_t *)&pk;

@@ -354,7 +354,9 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_persistent_ke
                         // not take L2 lines from the A rows the expert's other tiles re-read (-3.5 % on 256 x (128, 7168, 2048))
                         // (inline asm: written as __builtin_nontemporal_store beside a plain store, the two branches are merged
                         //  by the compiler and the hint is lost)
-                        if (p.out_nt) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(crow + n), "v"(pk) : "memory");
+                        if (p.out_nt == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(crow + n), "v"(pk) : "memory");
+                        else if (p.out_nt == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(crow + n), "v"(pk) : "memory");
+                        else if (p.out_nt == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(crow + n), "v"(pk) : "memory");
                         else *(v4i *)(crow + n) = pk;
                     } else {
                         const uint16_t *e = (const uint16_t *)&pk;

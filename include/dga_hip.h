@@ -306,6 +306,13 @@ int dga_cast_to_fp8_128x128(const void *x, int x_dtype, int64_t rows, int64_t k,
  * dga_gemm_fp8_fp8_bf16_nt_strided reads in place (DGA_ROWS_*_ZERO_PADDED). */
 int dga_cast_to_fp8_1x128_ld(const void *x, int x_dtype, int64_t rows, int64_t k, void *q, int64_t ldq, float *sf, void *stream);
 int dga_cast_to_fp8_128x128_ld(const void *x, int x_dtype, int64_t rows, int64_t k, void *q, int64_t ldq, float *sf, void *stream);
+/* The same with flags (ABI 6).  DGA_CAST_UE8M0: every block scale is rounded UP to a power of two, 2^ceil(log2(amax / 448)) -- the
+ * "UE8M0" scales of upstream DeepGEMM's per_token_cast_to_fp8(..., use_ue8m0=True); still written as fp32.  GEMM calls on such
+ * operands may set DGA_POLICY_UE8M0_SCALES (the scales then ride in the matrix instruction's E8M0 operands).  ldq as in the _ld forms
+ * (ldq = k: contiguous rows).  DGA_E_RANGE: an unknown flag. */
+#define DGA_CAST_UE8M0 1
+int dga_cast_to_fp8_1x128_ex(const void *x, int x_dtype, int64_t rows, int64_t k, void *q, int64_t ldq, float *sf, int flags, void *stream);
+int dga_cast_to_fp8_128x128_ex(const void *x, int x_dtype, int64_t rows, int64_t k, void *q, int64_t ldq, float *sf, int flags, void *stream);
 
 /* ---- the framework's 28-int Config (deep_gemm_ascend/framework/csrc/jit/get_best_config.hpp) ---- */
 

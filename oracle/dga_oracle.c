@@ -244,6 +244,53 @@ DGA_ORACLE_API int dga_oracle_m_grouped_gemm_fp8_fp8_bf16_nt_masked(
 /* ---- quantiser used to make synthetic inputs (per-1x128 rows / per-128x128 blocks):
  *      scale = amax/448 (1.0 if amax==0), q = e4m3fn(x/scale).  Input-generation
  *      helper, not part of the GEMM definition. ---- */
+/* ue8m0 != 0: the scale rounded UP to a power of two, 2^ceil(log2(amax / 448)) -- upstream DeepGEMM's use_ue8m0 quantisation
+ * (ceil_to_ue8m0: 2^ceil(log2 x)); stated on the bits so that there is no libm in it: a scale with a non-zero mantissa moves to
+ * the next exponent.  No reference counterpart (the reference has no quantiser at all). */
+static float dga_oracle_block_scale(float amax, int ue8m0)
+{
+    float s = amax > 0.0f ? amax / 448.0f : 1.0f;
+    if (ue8m0) {
+        uint32_t b;
+        memcpy(&b, &s, 4);
+        if (b & 0x007FFFFFu) { b = (b & 0x7F800000u) + 0x00800000u; memcpy(&s, &b, 4); }
+    }
+    return s;
+}
+
+DGA_ORACLE_API void dga_oracle_quant_1x128_ex(const float *x, uint8_t *q, float *sf, int64_t rows, int64_t k, int ue8m0)
+{
+    const int64_t kb_n = (k + 127) / 128;
+    for (int64_t i = 0; i < rows; ++i) {
+        for (int64_t kb = 0; kb < kb_n; ++kb) {
+            const int64_t k0 = kb * 128, k1 = (k0 + 128 < k) ? k0 + 128 : k;
+            float amax = 0.0f;
+            for (int64_t p = k0; p < k1; ++p) amax = fmaxf(amax, fabsf(x[i * k + p]));
+            const float s = dga_oracle_block_scale(amax, ue8m0);
+            sf[i * kb_n + kb] = s;
+            for (int64_t p = k0; p < k1; ++p) q[i * k + p] = dga_oracle_f32_to_e4m3fn(x[i * k + p] / s);
+        }
+    }
+}
+
+DGA_ORACLE_API void dga_oracle_quant_128x128_ex(const float *x, uint8_t *q, float *sf, int64_t rows, int64_t k, int ue8m0)
+{
+    const int64_t kb_n = (k + 127) / 128, rb_n = (rows + 127) / 128;
+    for (int64_t rb = 0; rb < rb_n; ++rb) {
+        const int64_t r0 = rb * 128, r1 = (r0 + 128 < rows) ? r0 + 128 : rows;
+        for (int64_t kb = 0; kb < kb_n; ++kb) {
+            const int64_t k0 = kb * 128, k1 = (k0 + 128 < k) ? k0 + 128 : k;
+            float amax = 0.0f;
+            for (int64_t i = r0; i < r1; ++i)
+                for (int64_t p = k0; p < k1; ++p) amax = fmaxf(amax, fabsf(x[i * k + p]));
+            const float s = dga_oracle_block_scale(amax, ue8m0);
+            sf[rb * kb_n + kb] = s;
+            for (int64_t i = r0; i < r1; ++i)
+                for (int64_t p = k0; p < k1; ++p) q[i * k + p] = dga_oracle_f32_to_e4m3fn(x[i * k + p] / s);
+        }
+    }
+}
+
 DGA_ORACLE_API void dga_oracle_quant_1x128(const float *x, uint8_t *q, float *sf, int64_t rows, int64_t k)
 {
     const int64_t kb_n = (k + 127) / 128;

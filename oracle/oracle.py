@@ -73,6 +73,8 @@ def lib():
                 c_u8p, c_f32p, c_u8p, c_f32p, c_u16p, c_i32p, i64, i64, i64, i64, i64, i64]
             L.dga_oracle_quant_1x128.argtypes = [c_f32p, c_u8p, c_f32p, i64, i64]
             L.dga_oracle_quant_128x128.argtypes = [c_f32p, c_u8p, c_f32p, i64, i64]
+            L.dga_oracle_quant_1x128_ex.argtypes = [c_f32p, c_u8p, c_f32p, i64, i64, ctypes.c_int]
+            L.dga_oracle_quant_128x128_ex.argtypes = [c_f32p, c_u8p, c_f32p, i64, i64, ctypes.c_int]
             L.dga_oracle_verify_isclose.restype = i64
             L.dga_oracle_verify_isclose.argtypes = [c_f32p, c_f32p, i64, ctypes.c_double, ctypes.c_double, c_f64p]
             _lib = L
@@ -246,24 +248,26 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(a, sfa, b, sfb, out_init, m_indice
 
 # --------------------------------------------------------------------------- inputs
 
-def quant_1x128(x: np.ndarray):
+def quant_1x128(x: np.ndarray, ue8m0: bool = False):
+    """ue8m0: scales rounded up to powers of two (2^ceil(log2(amax / 448)))."""
     x = _c(x, np.float32)
     rows, k = x.shape
     q = np.empty((rows, k), np.uint8); sf = np.empty((rows, (k + 127) // 128), np.float32)
-    lib().dga_oracle_quant_1x128(_p(x, c_f32p), _p(q, c_u8p), _p(sf, c_f32p), rows, k)
+    lib().dga_oracle_quant_1x128_ex(_p(x, c_f32p), _p(q, c_u8p), _p(sf, c_f32p), rows, k, 1 if ue8m0 else 0)
     return q, sf
 
 
-def quant_128x128(x: np.ndarray):
+def quant_128x128(x: np.ndarray, ue8m0: bool = False):
     x = _c(x, np.float32)
     rows, k = x.shape
     q = np.empty((rows, k), np.uint8); sf = np.empty(((rows + 127) // 128, (k + 127) // 128), np.float32)
-    lib().dga_oracle_quant_128x128(_p(x, c_f32p), _p(q, c_u8p), _p(sf, c_f32p), rows, k)
+    lib().dga_oracle_quant_128x128_ex(_p(x, c_f32p), _p(q, c_u8p), _p(sf, c_f32p), rows, k, 1 if ue8m0 else 0)
     return q, sf
 
 
-def make_inputs(m: int, n: int, k: int, seed: int = 0, unit_scales: bool = False):
-    """SURVEY.md 8(d) recipe: fp32 ~ N(0,1), per-1x128 (A) / per-128x128 (B) amax scaling, cast e4m3fn."""
+def make_inputs(m: int, n: int, k: int, seed: int = 0, unit_scales: bool = False, ue8m0: bool = False):
+    """SURVEY.md 8(d) recipe: fp32 ~ N(0,1), per-1x128 (A) / per-128x128 (B) amax scaling, cast e4m3fn.
+    ue8m0: the scales rounded up to powers of two."""
     rng = np.random.default_rng(seed)
     xa = rng.standard_normal((m, k), dtype=np.float32)
     xb = rng.standard_normal((n, k), dtype=np.float32)
@@ -274,8 +278,8 @@ def make_inputs(m: int, n: int, k: int, seed: int = 0, unit_scales: bool = False
         sfa = np.ones((m, (k + 127) // 128), np.float32)
         sfb = np.ones(((n + 127) // 128, (k + 127) // 128), np.float32)
         return a, sfa, b, sfb
-    a, sfa = quant_1x128(xa)
-    b, sfb = quant_128x128(xb)
+    a, sfa = quant_1x128(xa, ue8m0)
+    b, sfb = quant_128x128(xb, ue8m0)
     return a, sfa, b, sfb
 
 

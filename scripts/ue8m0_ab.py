@@ -23,7 +23,7 @@ def timed(fn, prewarm_ms=300.0):
 
 print(f"{'shape':>20} {'tile':>9} {'pol':>3} | {'fast us':>8} {'ue8m0 us':>8} {'ratio':>6} | {'TF fast':>8} {'TF ue8m0':>8} | same bf16 | ue8m0 vs strict: max_ulp frac>2ulp")
 for (m, n, k) in [(4096, 4096, 4096), (4096, 2048, 7168), (8192, 8192, 8192), (2048, 4096, 7168), (1024, 4096, 7168), (4096, 7168, 2048),
-                  (4096, 4096, 4224), (4000, 4100, 4096 + 64)]:
+                  (4096, 4096, 4224), (8192, 4096, 4096), (2048, 5120, 13824)]:
     a, sfa, b, sfb = bench.make_dense_inputs(m, n, (k // 128) * 128, seed=3, ue8m0=True)
     kk = a.shape[1]
     o_f = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
@@ -37,8 +37,19 @@ for (m, n, k) in [(4096, 4096, 4096), (4096, 2048, 7168), (8192, 8192, 8192), (2
     ul = (key(o_u) - key(o_s)).abs()
     us_f, us_u = timed(f_fast), timed(f_ue)
     fl = 2.0 * m * n * kk
+    w4 = ""
+    if (t.m1, t.n1) == (256, 256):     # the same tile on FOUR waves (wave tile 128 x 128, accumulators in AGPRs)
+        t4 = dga.tiling(m, n, kk)
+        t4.wavesM, t4.wavesN, t4.dispatchPolicyTag = 2, 2, 2 | 16
+        o_4 = torch.empty_like(o_u)
+        f_4 = lambda: dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), o_4, tiling_=t4)
+        f_4(); torch.cuda.synchronize()
+        same4 = float((o_4.view(torch.int16) == o_u.view(torch.int16)).double().mean())
+        us_4 = timed(f_4)
+        w4 = f" | w4: {us_4:8.2f} us {fl / us_4 / 1e6:8.1f} TF same {same4:.7f}"
+        del o_4
     print(f"{m:>6}x{n:>6}x{kk:>6} {t.m1:>4}x{t.n1:<4} {t.dispatchPolicyTag:>3} | {us_f:8.2f} {us_u:8.2f} {us_u / us_f:6.3f} | {fl / us_f / 1e6:8.1f} {fl / us_u / 1e6:8.1f} | "
-          f"{same:9.7f} | {int(ul.max())} {float((ul > 2).double().mean()):.3e}", flush=True)
+          f"{same:9.7f} | {int(ul.max())} {float((ul > 2).double().mean()):.3e}{w4}", flush=True)
     del a, b, o_f, o_u, o_s
 
 # grouped masked stream (BASELINE configs[3])
