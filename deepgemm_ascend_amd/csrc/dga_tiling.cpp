@@ -603,8 +603,11 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
     const uint32_t wpc = std::max<uint32_t>(1, std::min<uint32_t>(pf.l1Size / std::max(1u, lds_pick), 2048 / (pick.wm * pick.wn * 64)));
     const uint32_t per_xcd = std::max<uint32_t>(1, static_cast<uint32_t>(static_cast<uint64_t>(t.blockDim) / std::max(1u, pf.xcdNum)));
     const uint32_t conc = std::min<uint32_t>(per_xcd, pf.coreNum / std::max(1u, pf.xcdNum) * wpc);
+    // (a patch of gm x (conc / gm) tiles fetches gm * BM + (conc / gm) * BN operand rows into the XCD's L2: the minimum is at
+    //  gm^2 = conc * BN / BM -- square in ROWS, not in tiles.  128 x 256 tiles, one per CU: gm 4 -> 8 takes 29 MB off the 170 MB
+    //  configs[2] moves per launch at the same time, profiles/r05_raster_traffic.txt; 8 XCDs x (1024 + 1024) rows x K is the floor)
     uint32_t gm = 1;
-    while ((gm * 2) * (gm * 2) <= conc && gm * 2 <= tiles_m) gm *= 2;
+    while (static_cast<uint64_t>(gm * 2) * (gm * 2) * t.m1 <= static_cast<uint64_t>(conc) * t.n1 && gm * 2 <= tiles_m) gm *= 2;
     // contiguous-grouped layout: tile rows of different groups share no B panel, so a band should not be taller than a
     // group (one 128-row block per group: walk along N, the group's tiles then share its A panel and stream its B once:
     // 933 -> 826 us at 256 groups x 128 rows; scripts/contig_stream.py)
@@ -1065,9 +1068,17 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out)
     out->splitkFactor = static_cast<uint16_t>(sk);
     out->kernelSerial = sk > 1 ? DGA_KERNEL_STREAMK : DGA_KERNEL_COMMON;
     out->stages = 3; out->wavesM = 0; out->wavesN = 0;
-    out->swizzleOffset = 4;
     const uint64_t tiles = static_cast<uint64_t>((out->m + bm - 1) / bm) * ((out->n + bn - 1) / bn);
     out->blockDim = static_cast<uint32_t>(tiles * sk);
+    {   // raster group: the XCD's concurrent patch square in operand ROWS (see select_mi355x); 4096^3 on 128 x 256 tiles:
+        // 202 -> 169 MB of fabric traffic per launch at the same time (profiles/r05_raster_traffic.txt)
+        const uint32_t tiles_m = (out->m + bm - 1) / bm;
+        const uint32_t wpc = (bm * bn <= 64 * 128) ? 2 : 1;
+        const uint32_t conc = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint64_t>(1, tiles / 8), static_cast<uint64_t>(cus / 8) * wpc));
+        uint32_t gm = 1;
+        while (static_cast<uint64_t>(gm * 2) * (gm * 2) * bm <= static_cast<uint64_t>(conc) * bn && gm * 2 <= tiles_m) gm *= 2;
+        out->swizzleOffset = static_cast<uint8_t>(gm);
+    }
     // Decode rows: the workgroup split-K on LDS-DMA rings runs this policy's arithmetic too (gemm_fp8_wskd_kernel<..., MATH = 1>), and
     // since the stream pays for neither the conversions nor the bf16 matrix rate it takes the fast policy's time: cold, 20-44 % ahead
     // of this policy's tile kernels on 103 of 120 decode shapes (profiles/r04_wskd_cold_bf16x.txt) -- up to 16 rows wherever a wave
