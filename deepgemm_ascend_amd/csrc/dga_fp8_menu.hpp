@@ -87,6 +87,11 @@ int launch_ue8m0(int bm, int bn, bool loaders, bool cont, const GemmParams &p, h
 // ... and the 256 x 256 tile on FOUR waves (wave tile 128 x 128, accumulators in AGPRs; dga_launch_menu_j.hip), continuous loop
 int launch_ue8m0_w4(const GemmParams &p, hipStream_t stream);
 
+// one-launch Stream-K build of the 256 x 256 continuous kernel (gemm_fp8_streamk_kernel.hpp; dga_launch_menu_k.hip): dense rasters of
+// full tiles, fp32 partial tiles through the caller's workspace.  DGA_E_TILING: not a problem it takes
+int launch_streamk(const GemmParams &p, void *ws, size_t ws_bytes, bool ue8m0, hipStream_t stream);
+size_t streamk_workspace_bytes();
+
 // persistent continuous-pipeline build of the 256x256 tile (gemm_fp8_cont_persistent_kernel.hpp, dispatchPolicyTag 6): dense
 // rasters of full tiles only -- launch_cont_persistent returns DGA_E_TILING for anything else
 int launch_cont_persistent(const GemmParams &p, hipStream_t stream);

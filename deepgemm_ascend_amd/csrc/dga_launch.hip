@@ -164,7 +164,7 @@ static int check_tiling(const dga_tiling_t &t)
     const int tag = t.dispatchPolicyTag & 7;
     switch (t.kernelSerial) {
         case DGA_KERNEL_COMMON: case DGA_KERNEL_SMALL: case DGA_KERNEL_PADDING_COMMON: case DGA_KERNEL_STREAMK:
-        case DGA_KERNEL_STREAMK_TAIL: case DGA_KERNEL_SPLITK_WORKGROUP: break;
+        case DGA_KERNEL_STREAMK_TAIL: case DGA_KERNEL_SPLITK_WORKGROUP: case DGA_KERNEL_STREAMK_ONE_LAUNCH: break;
         default: return DGA_E_TILING;
     }
     if (t.k1 != 0 && t.k1 != 128) return DGA_E_TILING;                                  // one scale block per k step
@@ -192,7 +192,8 @@ static int check_tiling(const dga_tiling_t &t)
     if ((t.wavesM || t.wavesN) && !grid) return DGA_E_TILING;                           // a wave grid no build of this tile has
     if (!(t.stages == 0 || t.stages == 2 || t.stages == 3 || (t.stages == 1 && wsk))) return DGA_E_TILING;
     if (tag == DGA_POLICY_PINGPONG && !(t.m1 == 256 && t.n1 == 256)) return DGA_E_TILING;
-    if (t.kernelSerial == DGA_KERNEL_STREAMK_TAIL && !(t.m1 == 256 && t.n1 == 256)) return DGA_E_TILING;
+    if ((t.kernelSerial == DGA_KERNEL_STREAMK_TAIL || t.kernelSerial == DGA_KERNEL_STREAMK_ONE_LAUNCH) && !(t.m1 == 256 && t.n1 == 256))
+        return DGA_E_TILING;
     return DGA_OK;
 }
 
@@ -557,6 +558,17 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
         if ((policy == 2 || policy == DGA_POLICY_CONTINUOUS_PERSISTENT) && v->launch_cont) return v->launch_cont(q, stream);
         return v->launch(q, stream);
     };
+
+    // ---- Stream-K proper (kernelSerial 7): one launch, the raster's k blocks cut evenly over the CUs, fp32 partial tiles through the
+    //      workspace (gemm_fp8_streamk_kernel.hpp).  What it does not take (ragged shapes, no workspace) runs the tile kernel below.
+    if (tiling->kernelSerial == DGA_KERNEL_STREAMK_ONE_LAUNCH && !vx && !clock_stamps && groups == 1 && !masked_m && !m_indices && !ix &&
+        v->bm == 256 && v->bn == 256) {
+        const size_t need = streamk_workspace_bytes();
+        if (uint8_t *sk_ws = carve(need)) {
+            const int rc = launch_streamk(p, sk_ws, need, ue8m0, stream);
+            if (rc != DGA_E_TILING) return rc;
+        }
+    }
 
     // ---- tail in quarter tiles (kernelSerial 5): the whole waves of 256x256 tiles run as they are; the last partial wave
     //      is covered by 128x128 tiles (four per parent tile) in a second launch, so that it occupies four times as many

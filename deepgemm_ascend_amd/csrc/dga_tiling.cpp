@@ -1109,6 +1109,8 @@ size_t dga_workspace_bytes(const dga_tiling_t *tiling)
         add(groups * tiling->n * kp);
     }
     if (tiling->splitkFactor > 1) add(static_cast<size_t>(tiling->splitkFactor) * tiling->m * tiling->n * 4);
+    // Stream-K proper: one fp32 partial tile (256 x 256) per CU + the flags
+    if (tiling->kernelSerial == DGA_KERNEL_STREAMK_ONE_LAUNCH) add(static_cast<size_t>(dga::device_cus()) * (256 * 256 * 4) + 4096);
     return bytes ? bytes + 256 : 0;
 }
 

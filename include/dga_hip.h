@@ -53,7 +53,13 @@ enum { DGA_KERNEL_COMMON = 0, DGA_KERNEL_SMALL = 1, DGA_KERNEL_PADDING_COMMON = 
                                           combined in LDS -- one launch, no slab (the reference's single-core split-K kernel types,
                                           op_kernel/catlass_dynamic_matmul_tiling_key.h:30-36); the bits of split-K with factor 8.
                                           M <= 32: operands staged through per-wave LDS-DMA rings (tiling.stages = 1 names the
-                                          older build that streams fragments global -> registers instead) */ };
+                                          older build that streams fragments global -> registers instead) */,
+       DGA_KERNEL_STREAMK_ONE_LAUNCH = 7 /* Stream-K proper (the reference's kernel type 4, padding_streamk_matmul_kernel.h:94-98): ONE
+                                          launch of one workgroup per CU; the raster's (tile, k block) units are cut evenly over the
+                                          workgroups, a run that ends inside a tile leaves an fp32 partial tile in the workspace and the
+                                          workgroup holding the tile's first k blocks adds the partials in k order.  256 x 256 tile, dense,
+                                          M and N multiples of 256, K of 128; anything else runs the tiling's tile kernel.  Needs
+                                          dga_workspace_bytes() of workspace (256 KB per CU) */ };
 
 /* dispatchPolicyTag of the fp8 tile kernels (the reference's field selects a catlass dispatch policy,
  * op_tiling/tiling_params.h:19-66; here it selects the main-loop schedule or the exact-arithmetic kernel):
@@ -166,12 +172,12 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out);
  * (they call the same check first): DGA_E_TILING for a (kernelSerial, dispatchPolicyTag, m1 x n1, wavesM x wavesN, stages) no build
  * answers to, DGA_E_RANGE for a split factor beyond 1024.  A caller-written dga_tiling_t is data from outside; the counterpart of
  * CatlassDynamicMatmulTilingFunc returning GRAPH_FAILED (op_host/catlass_dynamic_matmul_tiling.cpp:86-100).  What the fields may
- * hold:  kernelSerial 0, 1, 2, 4, 5, 6;  k1 0 or 128;  dispatchPolicyTag 0..7, optionally | DGA_POLICY_UE8M0_SCALES;
+ * hold:  kernelSerial 0, 1, 2, 4, 5, 6, 7;  k1 0 or 128;  dispatchPolicyTag 0..7, optionally | DGA_POLICY_UE8M0_SCALES;
  *   policy 3 (strict): any tile (the kernel picks its own);
  *   policy 7 (bf16-exact): any m1, n1 > 0 (mapped onto that policy's menu); stages 0 / 2 / 3 = the in-register build, 4 = A-image,
  *     5 / 6 = 8- / 4-wave image builds, 7 / 8 = persistent / one-tile build, 1 only with kernelSerial 6;
  *   fast path: m1 x n1 a tile of the menu, wavesM x wavesN either 0 x 0 or a wave grid that tile is built with, stages 0 / 2 / 3
- *     (1 only with kernelSerial 6: the register build of the workgroup split-K); policy 1 and kernelSerial 5: 256 x 256 only. */
+ *     (1 only with kernelSerial 6: the register build of the workgroup split-K); policy 1 and kernelSerial 5 / 7: 256 x 256 only. */
 int dga_tiling_check(const dga_tiling_t *tiling);
 
 /* SelectKernel without the cache, on an explicit platform (select_kernel.cpp:333-369).
