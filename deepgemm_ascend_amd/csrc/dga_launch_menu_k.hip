@@ -33,23 +33,31 @@ static int launch_streamk_one(const GemmParams &p, const StreamKArgs &sk, unsign
 int launch_streamk(const GemmParams &p, void *ws, size_t ws_bytes, bool ue8m0, hipStream_t stream)
 {
     if (p.groups != 1 || p.masked_m || p.m_indices || p.row_index || p.splitk > 1 || p.tail_sub || p.stamps || p.launch_tiles) return DGA_E_TILING;
-    if ((p.m % 256) || (p.n % 256) || (p.k % 128) || p.kb_n < 4) return DGA_E_TILING;
+    if ((p.m % 256) || (p.n % 256) || (p.k % 128) || p.kb_n < 2) return DGA_E_TILING;
     const int64_t cus = device_cus();
-    const int64_t units = static_cast<int64_t>(p.tiles_m) * p.tiles_n * p.kb_n;
-    // one workgroup per CU (they wait for one another's partial tiles: all of them must fit the device at once), each with a run
-    // of at least two k blocks
-    const int64_t grid = std::min<int64_t>(cus, units / 2);
-    if (grid < 1 || units * grid >= 0x7FFFFFFFll) return DGA_E_TILING;
+    // one workgroup per CU (they wait for one another's partial tiles: all of them must fit the device at once)
+    const int64_t grid = cus;
     if (!ws || ws_bytes < static_cast<size_t>(grid) * (256 * 256 * 4) + static_cast<size_t>(grid) * 8) return DGA_E_WORKSPACE;
     if (reinterpret_cast<uintptr_t>(ws) & 15) return DGA_E_ALIGN;
     StreamKArgs sk;
     sk.partials = static_cast<float *>(ws);
     sk.flags = reinterpret_cast<unsigned long long *>(sk.partials + static_cast<size_t>(grid) * (256 * 256));
-    static std::atomic<unsigned long long> launches{0};
-    const unsigned long long e = launches.fetch_add(1) + 1;
     static const int debug = [] { const char *d = std::getenv("DGA_SK_DEBUG"); return d ? std::atoi(d) : 0; }();
     sk.debug = debug;
-    sk.epoch = (e * 0x9E3779B97F4A7C15ull) | 1ull;     // odd, never 0, 64 mixed bits: what stale workspace bytes will not hold
+    // A flag is raised when it holds this launch's epoch: 64 mixed bits no earlier launch used and stale workspace bytes will not
+    // hold -- nothing to zero.  A launch that is being CAPTURED into a graph is replayed with the same arguments, so there the flags
+    // are zeroed by a memset node in front of the kernel and the epoch is a constant.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+    if (cap != hipStreamCaptureStatusNone) {
+        if (int rc = record_hip(hipMemsetAsync(sk.flags, 0, static_cast<size_t>(grid) * 8, stream))) return rc;
+        sk.epoch = 1ull;
+    } else {
+        static std::atomic<unsigned long long> launches{0};
+        const unsigned long long e = launches.fetch_add(1) + 1;
+        sk.epoch = (e * 0x9E3779B97F4A7C15ull) | 1ull;     // odd, never 0 (and never 1: e >= 1 gives at least 2^63-ish mixed bits)
+        if (sk.epoch == 1ull) sk.epoch = 3ull;
+    }
     return ue8m0 ? launch_streamk_one<2>(p, sk, static_cast<unsigned>(grid), stream)
                  : launch_streamk_one<0>(p, sk, static_cast<unsigned>(grid), stream);
 }

@@ -1,25 +1,24 @@
-// Stream-K form of the continuous-pipeline 256x256 kernel: ONE launch, one workgroup per CU, and the unit of work is the k block,
-// not the tile.  The raster's tiles x k blocks are laid end to end and cut into gridDim.x equal runs; a workgroup walks its run
-// with the LDS ring running straight through (as gemm_fp8_cont_persistent_kernel.hpp does across whole tiles).  A run may start in
-// the middle of a tile and may end in the middle of another:
-//   * a segment that does NOT start at k block 0 leaves its fp32 partial tile in the workspace (256 KB per workgroup, one slot
-//     each) and raises the workgroup's flag -- it is the FIRST thing its workgroup does, so the partial is there long before it is
-//     wanted;
-//   * a segment that starts at k block 0 but stops short of the tile's end is the LAST thing its workgroup does: it then adds the
-//     partials of the workgroups that hold the rest of the tile, in k order (a fixed order: the result does not depend on timing),
-//     and stores the bf16 rows;
-//   * whole tiles in between are stored as they are.
-// So a raster of 1.125 rounds of tiles costs 1.125 rounds of k blocks on every CU instead of two rounds on some, and a raster of
-// 0.6 rounds keeps every CU busy.  Counterpart in the reference: kernel type 4, PaddingStreamkMatmulKernel -- Stream-K split of the
-// k loop over all cores + StreamkReduceAdd over fp32 partials
-// (/root/reference/aclnn_catlass_dynamic_matmul/op_kernel/kernel/padding_streamk_matmul_kernel.h:94-98; selection rule
-// op_host/op_tiling/select_kernel.cpp:303-331).
+// Stream-K form of the continuous-pipeline 256x256 kernel: ONE launch, one workgroup per CU.  Whole rounds of the raster run as in
+// gemm_fp8_cont_persistent_kernel.hpp (a workgroup walks its tiles, the LDS ring running straight through); the LAST, partial round
+// -- R tiles for P workgroups -- is split along K into s = 2^floor(log2(P / R)) parts per tile, so that it costs a 1/s of a round
+// instead of a whole one:
+//   * part j of every remainder tile goes to the SAME group of workgroups of an XCD (logical index q -> part q / R, tile q % R):
+//     the workgroups of an XCD then read the same k slice of the operand panels they share at the same time, as in a whole round.
+//     (A first form cut the raster's k blocks into P contiguous runs: every workgroup at its own k offset -- the L2 stopped serving
+//     them, 2.3 us per k block instead of 1.25: profiles/r05_streamk_skewed_ab.txt.)
+//   * every part leaves its fp32 partial tile in the workspace (256 KB per workgroup, one slot each), raises its flag, waits for the
+//     flags of the tile's other parts, and then reduces ITS 1/s of the tile's accumulator registers over the s partials, in k order
+//     (a fixed order: the result does not depend on timing), and stores those bf16 rows: per workgroup 256 KB written and 256 KB
+//     read whatever s is.
+// So a raster of 1.125 rounds costs 1.125 rounds of k blocks on every CU instead of two rounds on some.  Counterpart in the
+// reference: kernel type 4, PaddingStreamkMatmulKernel -- Stream-K split of the k loop over all cores + StreamkReduceAdd over fp32
+// partials (/root/reference/aclnn_catlass_dynamic_matmul/op_kernel/kernel/padding_streamk_matmul_kernel.h:94-98; selection rule
+// op_host/op_tiling/select_kernel.cpp:303-331: more blocks than cores, a remainder below 0.8 of the cores, k > 3072).
 //
-// No workgroup ever waits for a workgroup that waits: a flag is raised by a FIRST segment, which waits for nothing.  (So the launch
-// makes progress whatever subset of its workgroups is resident.)  A flag is "raised" when it holds this launch's 64-bit epoch value:
-// nothing has to be zeroed in front of the launch (a memset costs a 5 us launch of its own), whatever the workspace held.
-// Cuts are snapped so that no segment is shorter than two k blocks (the refill slots look two blocks ahead).
-// Restrictions (launcher): dense, M and N multiples of 256, K of 128, at least 4 k blocks.
+// Waiting is safe whatever subset of the workgroups is resident: a flag is raised before its workgroup waits for anything.
+// A flag is "raised" when it holds this launch's 64-bit epoch value, so nothing has to be zeroed in front of an ordinary launch; a
+// launch that is being captured into a graph (replays repeat the epoch) has its flags zeroed by a memset node instead (launcher).
+// Restrictions (launcher): dense, M and N multiples of 256, K of 128, at least 2 k blocks per part.
 // MATH = 0: the promotion form; MATH = 2: block scales in the MFMA's E8M0 operands (power-of-two scales), accumulate in place.
 #pragma once
 #include "gemm_fp8_kernel.hpp"
@@ -57,21 +56,41 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_streamk_kerne
     const int wm = wave / WN, wn = wave % WN;
     const int KB = p.kb_n;
 
-    // ---- this workgroup's run of (tile, k block) units.  Logical index: workgroups of one XCD (blockIdx & 7) take neighbouring
-    //      runs, so that the tiles an XCD works on at one time share operand panels in its L2
+    // ---- this workgroup's segments: its whole tiles (the XCD's contiguous chunk of the raster's whole rounds, strided by the XCD's
+    //      workgroups, as in the persistent kernel), then at most one part of a tile of the last, partial round
     const int P = gridDim.x;
-    const int w = (p.xcd_remap && (P & 7) == 0) ? (int)(blockIdx.x & 7) * (P >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const uint32_t U = (uint32_t)p.tiles_m * (uint32_t)p.tiles_n * (uint32_t)KB;     // (the launcher keeps U * P below 2^31)
-    auto cut = [&](int i) -> int {
-        const uint32_t c = (uint32_t)i * U / (uint32_t)P;
-        const uint32_t r = c % (uint32_t)KB;
-        if (r == 0) return (int)c;
-        if (r < (uint32_t)MINSEG) return (int)(c - r);
-        if ((uint32_t)KB - r < (uint32_t)MINSEG) return (int)(c + ((uint32_t)KB - r));
-        return (int)c;
-    };
-    const int u0 = cut(w), u1 = cut(w + 1);
-    if (u0 >= u1) return;
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int n_dp = __builtin_amdgcn_readfirstlane(tiles / P);   // whole tiles of this workgroup
+    const int full = n_dp * P;                     // tiles of the whole rounds
+    const int R = tiles - full;                    // tiles of the partial round (< P)
+    int first = 0, step = P, local = blockIdx.x, q = blockIdx.x;
+    if (p.xcd_remap && (P & 7) == 0) {
+        const int xcd = blockIdx.x & 7;
+        first = xcd * (full >> 3);
+        step = P >> 3;
+        local = blockIdx.x >> 3;
+        q = xcd * (P >> 3) + local;                // logical index: the workgroups of an XCD are neighbours
+    }
+    // the split of the partial round: s parts per tile (a power of two, at most 16, at least 2 k blocks each); 1 = no split (the
+    // first R workgroups take a whole tile each)
+    int lg = 0;                                    // log2 of the parts per tile
+    while (R > 0 && (2 << lg) * R <= P && (2 << lg) <= 16 && (KB >> (lg + 1)) >= MINSEG) ++lg;
+    const int sp = 1 << lg;
+    // (integer divisions run on the vector pipe: their results are uniform but sit in vector registers -- read them back, the DMA
+    //  statements below want scalars)
+    // the R * sp parts are spread evenly over the XCDs (R * sp / 8 each, rounded up): when they are fewer than the workgroups, the
+    // idle ones are a few CUs of every XCD, not whole XCDs (160 whole tiles on five of the eight XCDs ran 27 % slower than on eight)
+    int qt = q;                                    // index of this workgroup's part in (part-major, tile-minor) order; >= R * sp: none
+    if (p.xcd_remap && (P & 7) == 0) {
+        const int per_xcd = (R * sp + 7) >> 3;
+        qt = local < per_xcd ? (int)(blockIdx.x & 7) * per_xcd + local : P;
+    }
+    const int kpart = R > 0 ? __builtin_amdgcn_readfirstlane(qt / R) : 0;
+    const int rt = R > 0 ? __builtin_amdgcn_readfirstlane(qt % R) : 0;
+    const bool has_tail = R > 0 && kpart < sp;
+    const int tail_b = has_tail ? (kpart * KB) >> lg : 0, tail_e = has_tail ? ((kpart + 1) * KB) >> lg : 0;
+    const int n_seg = n_dp + (has_tail ? 1 : 0);
+    if (n_seg == 0) return;
     auto tile_origin = [&](int t_in, int &m0, int &n0) {
         const int gm = p.raster_group;
         const int per = gm * p.tiles_n;
@@ -82,6 +101,8 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_streamk_kerne
         m0 = (row0 + loc % rows) * BM;
         n0 = (loc / rows) * BN;
     };
+    // segment i: tile and k range
+    auto seg_tile = [&](int i) { return i < n_dp ? first + local + i * step : full + rt; };
 
     constexpr int DNT = Cfg::DNT;
     const int dtid = tid & (DNT - 1);
@@ -101,14 +122,15 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_streamk_kerne
     };
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
 
-    // current segment: tile t, k blocks [kb_b, kb_e); the next one (always a tile start) is set up a segment ahead
-    int t = u0 / KB;
-    int kb_b = u0 - t * KB;
-    int kb_e = min(KB, u1 - t * KB);
+    // current segment: tile t, k blocks [kb_b, kb_e); the next one is set up a segment ahead
+    int seg = 0;
+    int t = seg_tile(0);
+    int kb_b = n_dp > 0 ? 0 : tail_b, kb_e = n_dp > 0 ? KB : tail_e;
+    int kb_b_n = 0;                               // first k block of the next segment
     int m0, n0, m0n, n0n;
     tile_origin(t, m0, n0);
-    bool have_next = t * KB + kb_e < u1;
-    if (have_next) tile_origin(t + 1, m0n, n0n);
+    bool have_next = n_seg > 1;
+    if (have_next) { tile_origin(seg_tile(1), m0n, n0n); kb_b_n = 1 < n_dp ? 0 : tail_b; }
     else { m0n = m0; n0n = n0; }
     v4i a_rsrc = make_rsrc(p.a + (int64_t)m0 * p.lda, (int64_t)(p.m - m0) * p.lda);
     v4i b_rsrc = make_rsrc(p.b + (int64_t)n0 * p.ldb, (int64_t)(p.n - n0) * p.ldb);
@@ -222,15 +244,16 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_streamk_kerne
     int gb = 0;   // k blocks done by this workgroup: the stage of a block is its parity
     for (;;) {
         for (int kb = kb_b; kb < kb_e; ++kb, ++gb) {
-            const uint8_t *st = smem + (gb & 1) * Cfg::STAGE_BYTES;
-            const uint8_t *sn = smem + ((gb & 1) ^ 1) * Cfg::STAGE_BYTES;
+            const int stg = __builtin_amdgcn_readfirstlane(gb & 1);   // (uniform; said so, or the DMA's LDS address is built on the vector pipe)
+            const uint8_t *st = smem + stg * Cfg::STAGE_BYTES;
+            const uint8_t *sn = smem + (stg ^ 1) * Cfg::STAGE_BYTES;
             // whose blocks the refill slots of this k block fetch: blocks kb+1 (head part) and kb+2 (tail part) of this segment, or
             // blocks 0 / 1 of the next one (which starts its tile)
             const bool hn = kb + 1 >= kb_e, tn = kb + 2 >= kb_e;
             const v4i ha = hn ? a_rsrc_n : a_rsrc, hb = hn ? b_rsrc_n : b_rsrc;
             const v4i ta = tn ? a_rsrc_n : a_rsrc, tb = tn ? b_rsrc_n : b_rsrc;
             const float *hs = hn ? sc_src_n : sc_src, *ts = tn ? sc_src_n : sc_src;
-            const int hk = hn ? kb + 1 - kb_e : kb + 1, tk = tn ? kb + 2 - kb_e : kb + 2;
+            const int hk = hn ? kb_b_n + kb + 1 - kb_e : kb + 1, tk = tn ? kb_b_n + kb + 2 - kb_e : kb + 2;
 #pragma unroll
             for (int i = 0; i < STEPS; ++i) {
                 const int nt = i / TM, mt = i % TM;
@@ -247,12 +270,12 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_streamk_kerne
                 if (i < HEAD_STEPS) {
 #pragma unroll
                     for (int j = (i * (NL - TAIL_DMA)) / HEAD_STEPS; j < ((i + 1) * (NL - TAIL_DMA)) / HEAD_STEPS; ++j)
-                        issue_one(TAIL_DMA + j, (gb & 1) ^ 1, ha, hb, hs, hk);
+                        issue_one(TAIL_DMA + j, stg ^ 1, ha, hb, hs, hk);
                 }
                 if (i > SB) {
 #pragma unroll
                     for (int j = ((i - SB - 1) * TAIL_DMA) / TM; j < ((i - SB) * TAIL_DMA) / TM; ++j)
-                        issue_one(j, gb & 1, ta, tb, ts, tk);
+                        issue_one(j, stg, ta, tb, ts, tk);
                 }
                 if (mt == 0) {
                     if (nt + 1 < TN) bf[(nt + 1) & 1] = read_b(st, nt + 1);
@@ -305,40 +328,20 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_streamk_kerne
                 acc[jm][jn].w = __builtin_fmaf(pr.w, s_prev[jm], acc[jm][jn].w);
             }
         }
-        if (kb_b > 0) {
-            // ---- a segment that does not start its tile (the first of this workgroup's run): the fp32 partial goes to this
-            //      workgroup's slot, lane-linear (16 bytes per lane per accumulator tile), then the flag.  Every access to a slot or
-            //      a flag carries sc1: it is served at the device-coherent level (a partial is read by a workgroup of another XCD),
-            //      so neither side needs an L2 write-back or invalidate -- an acquire loop that invalidates the XCD's L2 on every
-            //      poll took the operand panels of every workgroup of that XCD with it (first version: 2.3 x the run time)
-            float *slot = sk.partials + (int64_t)w * SLOT + tid * 4;     // (one running pointer: an asm operand takes no immediate offset)
-            if (!(sk.debug & 1))
-#pragma unroll
-            for (int mt = 0; mt < TM; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < TN; ++nt) {
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(slot), "v"(acc[mt][nt]) : "memory");
-                    slot += NT * 4;
-                    asm volatile("" : "+v"(slot));
-                }
-            wait_vmcnt<0>();                                        // this wave's rows have reached the coherent level ...
-            barrier();                                              // ... every wave's have
-            if (tid == 0) __hip_atomic_store(sk.flags + w, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (kb_e < KB) {
-            break;      // a segment that starts its tile but does not end it is the LAST of the run: finished below, outside the loop
-        } else {
-            store_tile(acc, m0, n0);
-        }
+        if (seg >= n_dp) break;     // the part of a partial-round tile is the LAST segment: finished below, outside the loop
+        store_tile(acc, m0, n0);
         if (!have_next) break;
-        // ---- on to the next segment (a tile start): its descriptors become the current ones, the one after it is set up
-        t += 1;
-        kb_b = 0;
-        kb_e = min(KB, u1 - t * KB);
+        // ---- on to the next segment: its descriptors become the current ones, the one after it is set up
+        seg += 1;
+        t = seg_tile(seg);
+        kb_b = kb_b_n;
+        kb_e = seg < n_dp ? KB : tail_e;
         m0 = m0n; n0 = n0n;
         a_rsrc = a_rsrc_n; b_rsrc = b_rsrc_n; sc_src = sc_src_n;
-        have_next = t * KB + kb_e < u1;
+        have_next = seg + 1 < n_seg;
         if (have_next) {
-            tile_origin(t + 1, m0n, n0n);
+            tile_origin(seg_tile(seg + 1), m0n, n0n);
+            kb_b_n = seg + 1 < n_dp ? 0 : tail_b;
             a_rsrc_n = make_rsrc(p.a + (int64_t)m0n * p.lda, (int64_t)(p.m - m0n) * p.lda);
             b_rsrc_n = make_rsrc(p.b + (int64_t)n0n * p.ldb, (int64_t)(p.n - n0n) * p.ldb);
             sc_src_n = scale_src(m0n, n0n);
@@ -353,45 +356,76 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_streamk_kerne
         for (int mt = 0; mt < TM; ++mt) s_prev[mt] = 0.f;
     }
     wait_vmcnt<0>();   // the run-ahead refills behind the last segment land in LDS nobody reads: drain them before exit
-    if (kb_b == 0 && kb_e < KB) {
-        // ---- the run ended inside a tile it started: add the partials of the workgroups that hold the rest of that tile, in k order
-        //      (they were written at the START of those workgroups' runs), then store.  Out here the fragment and scale registers
-        //      of the main loop are dead, so a whole row of accumulator tiles travels per round trip.
-        int done = t * KB + kb_e;
-        const int tile_end = (t + 1) * KB;
-        int wq = w + 1;
-        while (done < tile_end && wq < P) {
-            const int c0 = cut(wq), c1 = cut(wq + 1);
-            if (c1 > c0) {     // (a workgroup with an empty run holds nothing)
-                if (!(sk.debug & 4))
-                while (__hip_atomic_load(sk.flags + wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) __builtin_amdgcn_s_sleep(8);
-                const float *slot = sk.partials + (int64_t)wq * SLOT + tid * 4;
-                if (!(sk.debug & 2))
-#pragma unroll
-                for (int mt = 0; mt < TM; ++mt) {
-                    v4f q[TN];
-#pragma unroll
-                    for (int nt = 0; nt < TN; ++nt) {
-                        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(q[nt]) : "v"(slot) : "memory");
-                        slot += NT * 4;
-                        asm volatile("" : "+v"(slot));
-                    }
-                    wait_vmcnt<0>();
-#pragma unroll
-                    for (int nt = 0; nt < TN; ++nt) {
-                        asm volatile("" : "+v"(q[nt]));     // (the load's result is valid from here on)
-                        acc[mt][nt].x += q[nt].x; acc[mt][nt].y += q[nt].y; acc[mt][nt].z += q[nt].z; acc[mt][nt].w += q[nt].w;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // the flag goes back to "not raised": a graph replay launches with the same epoch
-                barrier();
-                if (tid == 0) __hip_atomic_store(sk.flags + wq, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                done = min(tile_end, c1);
-            }
-            ++wq;
+    if (has_tail) {
+        if (sp == 1) {          // the partial round is not split: a whole tile
+            store_tile(acc, m0, n0);
+            return;
         }
-        store_tile(acc, m0, n0);
+        // ---- part `kpart` of remainder tile `rt`: the fp32 partial goes to this workgroup's slot, lane-linear (16 bytes per lane per
+        //      accumulator tile), then the flag.  Every access to a slot or a flag carries sc1: it is served at the device-coherent
+        //      level (a partial is read by workgroups of other XCDs), so neither side needs an L2 write-back or invalidate -- an
+        //      acquire loop that invalidates the XCD's L2 on every poll took the operand panels of its neighbours with it.
+        {
+            float *slot = sk.partials + (int64_t)(kpart * R + rt) * SLOT + tid * 4;     // (one running pointer: an asm operand takes no immediate offset)
+            if (!(sk.debug & 1))
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt) {
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(slot), "v"(acc[mt][nt]) : "memory");
+                    slot += NT * 4;
+                    asm volatile("" : "+v"(slot));
+                }
+            wait_vmcnt<0>();                                        // this wave's rows have reached the coherent level ...
+            barrier();                                              // ... every wave's have
+            if (tid == 0) __hip_atomic_store(sk.flags + kpart * R + rt, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ---- this part's share of the reduction: accumulator tiles [kpart * 32 / sp, +32 / sp) of every lane (pairs of n-tiles: one
+        //      16-byte bf16 store each), summed over the sp partials in k order
+        const int per = (TM * TN) / sp;                  // 16, 8, 4 or 2
+        if (!(sk.debug & 4))
+            for (int j = 0; j < sp; ++j)
+                while (__hip_atomic_load(sk.flags + j * R + rt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) __builtin_amdgcn_s_sleep(8);
+        const bool vec_ok = ((p.ldc & 7) == 0) && ((((uintptr_t)p.out) & 15) == 0);
+        if (!(sk.debug & 2))
+        for (int pi = 0; pi < per; pi += 2) {
+            const int idx = kpart * per + pi, mt = idx / TN, nt = idx % TN;      // (nt is even)
+            v4f lo = v4f{0.f, 0.f, 0.f, 0.f}, hi = v4f{0.f, 0.f, 0.f, 0.f};
+            for (int j0 = 0; j0 < sp; j0 += 4) {           // four partials per round trip
+                v4f ql[4], qh[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = min(j0 + u, sp - 1);
+                    const float *src = sk.partials + (int64_t)(j * R + rt) * SLOT + (idx * NT + tid) * 4;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(ql[u]) : "v"(src) : "memory");
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(qh[u]) : "v"(src + NT * 4) : "memory");
+                }
+                wait_vmcnt<0>();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    asm volatile("" : "+v"(ql[u]), "+v"(qh[u]));     // (the loads' results are valid from here on)
+                    if (j0 + u < sp) {
+                        lo.x += ql[u].x; lo.y += ql[u].y; lo.z += ql[u].z; lo.w += ql[u].w;
+                        hi.x += qh[u].x; hi.y += qh[u].y; hi.z += qh[u].z; hi.w += qh[u].w;
+                    }
+                }
+            }
+            const int m = m0 + wm * (BM / Cfg::kWM) + li + mt * 16;
+            const int n = n0 + wn * (BN / WN) + 8 * kg + 32 * (nt >> 1);
+            uint16_t *crow = p.out + (int64_t)m * p.ldc;
+            const v2bf h0 = __builtin_convertvector(v2f{lo.x, lo.y}, v2bf);
+            const v2bf h1 = __builtin_convertvector(v2f{lo.z, lo.w}, v2bf);
+            const v2bf h2 = __builtin_convertvector(v2f{hi.x, hi.y}, v2bf);
+            const v2bf h3 = __builtin_convertvector(v2f{hi.z, hi.w}, v2bf);
+            const v4i pk = v4i{__builtin_bit_cast(int, h0), __builtin_bit_cast(int, h1), __builtin_bit_cast(int, h2), __builtin_bit_cast(int, h3)};
+            if (vec_ok) {
+                *(v4i *)(crow + n) = pk;
+            } else {
+                const uint16_t *e = (const uint16_t *)&pk;
+#pragma unroll
+                for (int qq = 0; qq < 8; ++qq) crow[n + qq] = e[qq];
+            }
+        }
     }
 }
 
