@@ -37,7 +37,7 @@ def test_every_tiling_the_selectors_write_passes():
 def test_fields_outside_the_menu_are_refused():
     base = dga.tiling(4096, 4096, 4096)
     assert (base.m1, base.n1) == (256, 256) and dga.tiling_check(base) == OK
-    for field, bad in (("kernelSerial", 3), ("kernelSerial", 7), ("kernelSerial", 255), ("dispatchPolicyTag", 8), ("dispatchPolicyTag", 32),
+    for field, bad in (("kernelSerial", 3), ("kernelSerial", 8), ("kernelSerial", 255), ("dispatchPolicyTag", 8), ("dispatchPolicyTag", 32),
                        ("dispatchPolicyTag", 0x80 | 2), ("k1", 64), ("k1", 256), ("m1", 0), ("n1", 0), ("m1", 512), ("m1", 48), ("n1", 64),
                        ("stages", 1), ("stages", 4), ("stages", 9), ("wavesM", 3), ("wavesN", 7)):
         t = _copy(base)
@@ -49,15 +49,15 @@ def test_fields_outside_the_menu_are_refused():
     assert dga.tiling_check(t) == OK
     # what a field MAY hold beside the selector's pick
     for field, good in (("stages", 0), ("stages", 3), ("wavesM", 0), ("dispatchPolicyTag", 0), ("dispatchPolicyTag", 1), ("dispatchPolicyTag", 2 | 16),
-                        ("dispatchPolicyTag", 6), ("kernelSerial", 5), ("k1", 0)):
+                        ("dispatchPolicyTag", 6), ("kernelSerial", 5), ("kernelSerial", 7), ("k1", 0)):
         t = _copy(base)
         setattr(t, field, good)
         if field == "wavesM":
             t.wavesN = 0
         assert dga.tiling_check(t) == OK, (field, good)
-    # ping-pong and the quarter-tile tail exist for the 256 x 256 tile only
+    # ping-pong, the quarter-tile tail and the one-launch Stream-K exist for the 256 x 256 tile only
     small = dga.tiling(1024, 2048, 7168)
-    for field, v in (("dispatchPolicyTag", 1), ("kernelSerial", 5)):
+    for field, v in (("dispatchPolicyTag", 1), ("kernelSerial", 5), ("kernelSerial", 7)):
         t = _copy(small)
         if (t.m1, t.n1) != (256, 256):
             setattr(t, field, v)
@@ -82,7 +82,7 @@ def test_fuzzed_structs_are_either_in_the_menu_or_refused():
     accepted = 0
     for _ in range(20000):
         t = _copy(base)
-        t.kernelSerial = rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 9, 255])
+        t.kernelSerial = rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 255])
         t.dispatchPolicyTag = rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 15, 16, 18, 20, 22, 23, 24, 31, 64, 255])
         t.m1 = rng.choice([0, 8, 16, 32, 48, 64, 96, 128, 256, 512, 65535])
         t.n1 = rng.choice([0, 64, 128, 192, 256, 512])
@@ -95,7 +95,7 @@ def test_fuzzed_structs_are_either_in_the_menu_or_refused():
         if rc == OK:
             accepted += 1
             tag = t.dispatchPolicyTag & 7
-            assert t.kernelSerial in (0, 1, 2, 4, 5, 6) and t.k1 in (0, 128) and t.splitkFactor <= 1024 and not (t.dispatchPolicyTag & ~23)
+            assert t.kernelSerial in (0, 1, 2, 4, 5, 6, 7) and t.k1 in (0, 128) and t.splitkFactor <= 1024 and not (t.dispatchPolicyTag & ~23)
             if tag not in (3, 7):
                 assert (t.m1, t.n1) in FAST_TILES and t.stages in (0, 2, 3) or (t.stages == 1 and t.kernelSerial == 6)
     assert 0 < accepted < 20000
