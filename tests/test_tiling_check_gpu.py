@@ -17,7 +17,8 @@ def _bits(t):
 @pytest.mark.parametrize("m,n,k", [(300, 520, 1024), (48, 1030, 2048)])
 def test_fuzzed_tilings_run_correctly_or_are_refused(dga, oracle, m, n, k):
     from deepgemm_ascend_amd import _lib
-    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=m + k)
+    # power-of-two block scales: a tiling may carry DGA_POLICY_UE8M0_SCALES (16), the caller's promise that they are
+    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=m + k, ue8m0=True)
     want = oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, threads=8)
     ta, tsa, tb, tsb = (torch.from_numpy(x).cuda() for x in (a, sfa, b, sfb))
     rng = random.Random(m)
@@ -45,9 +46,14 @@ def test_fuzzed_tilings_run_correctly_or_are_refused(dga, oracle, m, n, k):
             continue
         dga.gemm_fp8_fp8_bf16_nt((ta, tsa), (tb, tsb), out, tiling_=t, sync=True)
         got = _bits(out)
-        if (t.dispatchPolicyTag & 7) == 3:
-            assert np.array_equal(got, want)
-        else:
-            oracle.assert_parity(got, want, a, sfa, b, sfb)
+        what = (f"kernelSerial {t.kernelSerial} policy {t.dispatchPolicyTag} tile {t.m1}x{t.n1} waves {t.wavesM}x{t.wavesN} "
+                f"stages {t.stages} splitk {t.splitkFactor}")
+        try:
+            if (t.dispatchPolicyTag & 7) == 3:
+                assert np.array_equal(got, want)
+            else:
+                oracle.assert_parity(got, want, a, sfa, b, sfb)
+        except AssertionError as e:
+            raise AssertionError(f"{what}: {e}") from None
         ran += 1
     assert ran >= 20 and refused >= 20, (ran, refused)
