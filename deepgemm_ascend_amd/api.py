@@ -140,7 +140,10 @@ POLICY_BF16_EXACT = 7
 #                 use_ue8m0=True), upstream DeepGEMM's convention for hardware-scaled MFMAs): the scales ride in the matrix
 #                 instruction's E8M0 operands and the MFMA accumulates in place -- no promotion on the vector pipe.  Same outputs
 #                 as "fast" up to fp32 rounding order; a scale that is not a power of two is read as its exponent alone.
-ARITHMETIC_POLICIES = {"fast": None, "bf16_exact": POLICY_BF16_EXACT, "strict": POLICY_STRICT, "auto": None, "fast_ue8m0": None}
+#   "bf16_exact_ue8m0"  "bf16_exact" for power-of-two scales: the scales are folded into the exact e4m3 -> bf16 conversions and the
+#                 bf16 matrix instruction accumulates in place -- the in-contract arithmetic without its promotion.
+ARITHMETIC_POLICIES = {"fast": None, "bf16_exact": POLICY_BF16_EXACT, "strict": POLICY_STRICT, "auto": None, "fast_ue8m0": None,
+                       "bf16_exact_ue8m0": POLICY_BF16_EXACT | 16}
 POLICY_UE8M0_SCALES = 16      # DGA_POLICY_UE8M0_SCALES: a flag beside the fast-path schedules
 _DEFAULT_POLICY = os.environ.get("DGA_DEFAULT_POLICY") or "bf16_exact"
 
@@ -211,7 +214,8 @@ def _planned(index: int, m: int, n: int, k: int, groups: int, expected_m: int, c
                 t = tiling(m, n, k, groups=groups, expected_m=expected_m, contiguous=contiguous)
             _PLANS[key] = t
             return t
-        t = tiling(m, n, k, groups=groups, expected_m=expected_m, contiguous=contiguous, policy=policy if policy == "bf16_exact" else None)
+        t = tiling(m, n, k, groups=groups, expected_m=expected_m, contiguous=contiguous,
+                   policy="bf16_exact" if policy in ("bf16_exact", "bf16_exact_ue8m0") else None)
         t = _PLANS[key] = _with_policy(t, strict, policy)
     return t
 
@@ -645,7 +649,7 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(lhs, rhs, out: torch.Tensor, m_ind
                 policy = _DEFAULT_POLICY       # no tiling, no policy: the operator's default arithmetic, as in the other entries
             _require(policy != "auto" or not strict, "strict=True contradicts policy='auto'")
             policy = "fast" if policy == "auto" else policy
-            tiling_ = tiling(msum, n, k, groups=g, contiguous=True, policy="bf16_exact" if policy == "bf16_exact" else None)
+            tiling_ = tiling(msum, n, k, groups=g, contiguous=True, policy="bf16_exact" if policy in ("bf16_exact", "bf16_exact_ue8m0") else None)
         tiling_ = _with_policy(tiling_, strict, policy)
         ws_ptr, ws_bytes = _workspace(tiling_, out.device)
         rc = _lib.lib().dga_m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(

@@ -86,6 +86,9 @@ int wsk_max_ntiles(int m);
 int launch_ue8m0(int bm, int bn, bool loaders, bool cont, const GemmParams &p, hipStream_t stream);
 // ... and the 256 x 256 tile on FOUR waves (wave tile 128 x 128, accumulators in AGPRs; dga_launch_menu_j.hip), continuous loop
 int launch_ue8m0_w4(const GemmParams &p, hipStream_t stream);
+// bf16-exact arithmetic for power-of-two scales (MATH = 3: scales folded into the A conversions, the bf16 MFMA accumulates in place, AGPR
+// accumulators; dga_launch_menu_j.hip).  DGA_E_TILING: no such build of that tile
+int launch_bf16u(int bm, int bn, const GemmParams &p, hipStream_t stream);
 
 // one-launch Stream-K build of the 256 x 256 continuous kernel (gemm_fp8_streamk_kernel.hpp; dga_launch_menu_k.hip): dense rasters of
 // full tiles, fp32 partial tiles through the caller's workspace.  DGA_E_TILING: not a problem it takes

@@ -244,12 +244,13 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     // the scales in the matrix instruction's E8M0 operands run where they exist (launch_ue8m0), everything else reads the tag
     // without the flag
     dga_tiling_t unflagged;
-    bool ue8m0 = false;
+    bool ue8m0 = false, bx_ue8m0 = false;   // the flag beside a fast-path schedule / beside the bf16-exact policy
     if (tiling->dispatchPolicyTag & DGA_POLICY_UE8M0_SCALES) {
         unflagged = *tiling;
         unflagged.dispatchPolicyTag &= static_cast<uint8_t>(~DGA_POLICY_UE8M0_SCALES);
         ue8m0 = unflagged.dispatchPolicyTag != DGA_POLICY_STRICT && unflagged.dispatchPolicyTag != DGA_POLICY_BF16_EXACT &&
                 unflagged.dispatchPolicyTag != DGA_POLICY_PINGPONG;
+        bx_ue8m0 = unflagged.dispatchPolicyTag == DGA_POLICY_BF16_EXACT;
         tiling = &unflagged;
     }
     // workspace == NULL is allowed (split-K and the odd-K padding pass are then skipped: single-pass / element-wise
@@ -500,7 +501,10 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
             p.partial = slabs;
             GemmParams pk = p;
             pk.groups = s;  // grid = splitk x tiles
-            int rc = vx ? (bx_image ? launch_bf16x_image(pk, bx_image, stream) : vx->launch(pk, stream)) : v->launch(pk, stream);
+            int rc = DGA_E_TILING;
+            if (vx && bx_ue8m0 && !bx_image) rc = launch_bf16u(vx->bm, vx->bn, pk, stream);
+            if (rc == DGA_E_TILING)
+                rc = vx ? (bx_image ? launch_bf16x_image(pk, bx_image, stream) : vx->launch(pk, stream)) : v->launch(pk, stream);
             if (rc != DGA_OK) return rc;
             const int64_t mn = static_cast<int64_t>(m) * n;
             hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3(static_cast<unsigned>((mn / 8 + 255) / 256 + 1)), dim3(256),
@@ -513,6 +517,10 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     static const int pp_env = [] { const char *e = std::getenv("DGA_PINGPONG"); return e ? std::atoi(e) : -1; }();
     const int policy = pp_env >= 0 ? pp_env : tiling->dispatchPolicyTag;
     if (vx) {   // bf16-exact: one launch over the whole raster
+        if (bx_ue8m0 && !bx_image && !clock_stamps) {   // power-of-two scales: folded into the conversions, the MFMA accumulates in place
+            const int rc = launch_bf16u(vx->bm, vx->bn, p, stream);
+            if (rc != DGA_E_TILING) return rc;
+        }
         if (bx_image) return launch_bf16x_image(p, bx_image, stream);
         // the 128 x 256 tile's persistent form (gemm_fp8_bf16x_persistent_kernel.hpp; same bits).  The dispatcher hides most of a tile
         // boundary already, so it pays little -- masked grouped 256 x (128, 7168, 2048): full mask 1010 -> 998 us, random masks

@@ -147,6 +147,12 @@ struct LoopClock {
 //         FMAs: the vector pipe carries nothing but the matrix instruction.  C-in keeps fp32 (scripts/ubench/probe_mfma_scale_acc.hip
 //         -> profiles/r05_probe_scale_acc.txt: 13 directed cases = fp32(C + p); K = 4096 / 7168 chains give the SAME bf16 output as the
 //         promotion form on all 76 800 outputs, max fp32 difference 2^-27 S).
+// MATH = 3 (PP = 0, three LDS stages): the bf16-exact arithmetic for power-of-two scales.  v_cvt_scalef32_pk_bf16_fp8 multiplies by a
+//         power of two for free, so the A fragments are converted with sfa[m, kb] * sfb[n / 128, kb] folded in (exact: an e4m3 value
+//         times a power of two is a bf16 value) and the bf16 MFMA chain simply runs on through every k block with C-in -- exact
+//         products, fp32-class sums, NO promotion: per MFMA the vector pipe carries conversions only, and since no vector instruction
+//         touches an accumulator they may live in AGPRs: four waves with 64 x 128 wave tiles (1.5 conversions per MFMA instead of
+//         2 + a promotion FMA).  Same LDS image, DMA and fragment reads as MATH = 1.
 // UNAL (loader-wave builds, plain loop, dense): the operands' rows start at ANY byte (K % 16 != 0, no padded copy): the loader waves
 //         fetch them to registers with dword-aligned loads, realign (v_alignbyte), zero the bytes beyond K and ds_write the same
 //         swizzled image the LDS-DMA would have written -- the computing waves are unchanged.  The counterpart of the reference's
@@ -157,6 +163,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
 {
     static_assert(!UNAL || (Cfg::kLC && PP == 0 && MATH == 0 && KTAIL), "unaligned rows: loader waves, plain loop, fp8 matrix instruction");
     static_assert(MATH != 2 || PP != 1, "hardware-scale builds: plain or continuous loop");
+    static_assert(MATH != 3 || PP == 0, "bf16-exact builds: plain loop");
     LoopClock<CLK> loop_clock;
     constexpr int BM = Cfg::kBM, BN = Cfg::kBN, WN = Cfg::kWN;
     constexpr int NT = Cfg::NT, TM = Cfg::TM, TN = Cfg::TN;
@@ -799,7 +806,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         epilogue(acc);
         DGA_STAMP_ABS(3);        // stores issued (not yet complete)
         DGA_STAMP_FLUSH();
-    } else if constexpr (MATH == 1) {
+    } else if constexpr (MATH == 1 || MATH == 3) {
         // ---- bf16-exact main loop (dispatchPolicyTag 7) ---------------------------------------------------------------
         // Numerics: every e4m3 value is a bf16 value, so v_cvt_scalef32_pk_bf16_fp8 (scale 1) converts exactly; the products
         // are exact in fp32 and v_mfma_f32_16x16x32_bf16 sums them with fp32-class error (profiles/r02_mfma_forms.txt: 2^-25 S
@@ -828,7 +835,8 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         // partner; a priority that falls as a wave advances -- s_setprio 3..0 per quarter block -- evens the two out, 2699 / 3119,
         // and changes the total by 0.8 %: the sum of the two waves' issue slots is what counts, not who takes them).
         static_assert(PP == 0 && Cfg::STAGES == 3 && !LC, "bf16-exact: plain loop, three stages, no loader waves");
-        static_assert((TM == 2 || TM == 4) && (TN == 2 || TN == 4), "bf16-exact: wave tiles of 32..64 x 32..64");
+        static_assert((TM == 2 || TM == 4) && (TN == 2 || TN == 4 || (MATH == 3 && TN == 8)), "bf16-exact: wave tiles of 32..64 x 32..64 (x 128 for MATH = 3)");
+        constexpr bool UE = MATH == 3;    // power-of-two scales folded into the A conversions, the MFMA chain accumulates in place
         constexpr int STG = 3, NL = Cfg::LOADS_PER_STAGE, TILES = TM * TN, G = 4 * TM, LAGT = 2, RING = 4;
         static_assert(TILES % RING == 0 && TILES > LAGT && 4 * TILES >= 4 + NL && 16 % G == 0, "ring positions / DMA slots line up");
         typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
@@ -845,10 +853,10 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         float s_cur[TM], s_old[TM], s_nxt[TM];
         // conversion c (0..15) of a fragment: dword c >> 1 of the 32 raw bytes, half c & 1 -> dword c & 3 of MFMA (c >> 2).
         // (c is a constant after unrolling; the builtin's half selector must be an immediate)
-        auto convert = [](const v4i (&raw)[2], v4i (&dst)[4], int c) {
+        auto convert = [](const v4i (&raw)[2], v4i (&dst)[4], int c, float scale = 1.0f) {
             const int w = raw[(c >> 1) >> 2][(c >> 1) & 3];
-            dst[c >> 2][c & 3] = (c & 1) ? __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true))
-                                         : __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false));
+            dst[c >> 2][c & 3] = (c & 1) ? __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, scale, true))
+                                         : __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, scale, false));
         };
         auto b_frag_off = [](int nt) { return (nt >> 1) * 4096 + (nt & 1) * 512; };
         // prologue: blocks 0 and 1 on their way, block 0 landed; its fragments converted in one burst (once per tile)
@@ -866,9 +874,9 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
                 // (buffer mt & 1: block 0's first tile converts A[TM - 1] once more from the buffer it was read into)
                 araw[mt & 1][0] = *(const v4i *)(smem + a_off0 + mt * 2048);
                 araw[mt & 1][1] = *(const v4i *)(smem + a_off1 + mt * 2048);
-#pragma unroll
-                for (int c = 0; c < 16; ++c) convert(araw[mt & 1], afx[mt], c);
                 s_cur[mt] = *(const float *)(smem + sa_off + mt * 64) * sfb0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) convert(araw[mt & 1], afx[mt], c, UE ? s_cur[mt] : 1.0f);
                 s_old[mt] = 0.f;    // the first LAGT tiles "promote the previous block": part (= 0) * 0
                 s_nxt[mt] = 0.f;
             }
@@ -912,6 +920,10 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
 #pragma unroll
             for (int u = 0; u < 4 * TILES; ++u) {
                 const int t = u >> 2, q = u & 3, nt = t / TM, mt = t % TM, g = u % G;
+                if constexpr (UE)    // the scales are inside the A fragments: the chain runs on through every block
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(v8bf, bfx[nt & 1][q]), __builtin_bit_cast(v8bf, afx[mt][q]), acc[mt][nt], 0, 0, 0);
+                else
                 part[t % RING] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     __builtin_bit_cast(v8bf, bfx[nt & 1][q]), __builtin_bit_cast(v8bf, afx[mt][q]),
                     q == 0 ? v4f{0.f, 0.f, 0.f, 0.f} : part[t % RING], 0, 0, 0);
@@ -937,20 +949,21 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
                 }
                 if (nt == TN - 1 && mt >= 1) {     // the tile behind (mt - 1, TN - 1): A[mt - 1] of the next block
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) convert(araw[(mt - 1) & 1], afx[mt - 1], 4 * q + c);
+                    for (int c = 0; c < 4; ++c) convert(araw[(mt - 1) & 1], afx[mt - 1], 4 * q + c, UE ? s_nxt[mt - 1] : 1.0f);
                 }
                 if (t == 0) {                      // the tile behind the previous block's (TM - 1, TN - 1): A[TM - 1] of THIS block
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) convert(araw[(TM - 1) & 1], afx[TM - 1], 4 * q + c);
+                    for (int c = 0; c < 4; ++c) convert(araw[(TM - 1) & 1], afx[TM - 1], 4 * q + c, UE ? s_cur[TM - 1] : 1.0f);
                 }
-                // the next block's scales (needed from its first promotions, LAGT tiles into it)
-                if (u == 4 * TILES - 8) {
+                // the next block's scales: needed from its first promotions, LAGT tiles into it -- or (UE) by the conversions of its A
+                // fragments, which start in this block's last n-tile: read at the block's first gap (the stage has landed)
+                if (u == (UE ? 0 : 4 * TILES - 8)) {
                     const float sfbn = *(const float *)(sn + sb_off);
 #pragma unroll
                     for (int i = 0; i < TM; ++i) s_nxt[i] = *(const float *)(sn + sa_off + i * 64) * sfbn;
                 }
                 // promotion of tile t - LAGT, one accumulator element per gap
-                {
+                if constexpr (!UE) {
                     const int j = t >= LAGT ? t - LAGT : TILES + t - LAGT, jn = j / TM, jm = j % TM;
                     const float sv = t >= LAGT ? s_cur[jm] : s_old[jm];
                     acc[jm][jn][q] = __builtin_fmaf(part[j % RING][q], sv, acc[jm][jn][q]);
@@ -967,11 +980,13 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
             cur = nxt; nxt = fill; fill = f;
         }
         // drain: the last LAGT tiles of the last block
+        if constexpr (!UE) {
 #pragma unroll
         for (int t = 0; t < LAGT; ++t) {
             const int j = TILES + t - LAGT, jn = j / TM, jm = j % TM;
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[jm][jn][q] = __builtin_fmaf(part[j % RING][q], s_old[jm], acc[jm][jn][q]);
+        }
         }
         wait_vmcnt<0>();   // the refills past the last k block land in LDS nobody reads: drain them before the stores / exit
         DGA_STAMP_CLOCK(6, 7);

@@ -92,7 +92,10 @@ enum { DGA_KERNEL_COMMON = 0, DGA_KERNEL_SMALL = 1, DGA_KERNEL_PADDING_COMMON = 
  *     does (framework/csrc/jit/generate_code.hpp:320-335): no promotion on the vector pipe.  Outputs equal the promotion form's up
  *     to fp32 rounding order (profiles/r05_probe_scale_acc.txt: identical bf16 on 76 800 of 76 800 outputs); a tile without such a
  *     build runs the promotion form.  A scale that is NOT a power of two is read as its exponent alone (mantissa dropped); zero
- *     reads as 2^-127.  Ignored by policies 3 and 7. */
+ *     reads as 2^-127.  Ignored by policy 3.
+ *     On policy 7 (7 | 16): the bf16-exact arithmetic with the scales folded into the e4m3 -> bf16 conversions of the A fragments (a
+ *     power of two times an e4m3 value is a bf16 value: exact) -- the bf16 MFMA chain then accumulates through every k block in
+ *     place, no promotion; 128 x 256 and 64 x 256 tiles, every layout; other tiles run policy 7 as it is. */
 enum { DGA_POLICY_PLAIN = 0, DGA_POLICY_PINGPONG = 1, DGA_POLICY_CONTINUOUS = 2, DGA_POLICY_STRICT = 3,
        DGA_POLICY_LOADER_WAVES = 4, DGA_POLICY_PERSISTENT = 5, DGA_POLICY_CONTINUOUS_PERSISTENT = 6,
        DGA_POLICY_BF16_EXACT = 7, DGA_POLICY_UE8M0_SCALES = 16 };

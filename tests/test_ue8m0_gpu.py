@@ -152,3 +152,56 @@ def test_policy_name_rules(dga):
         dga.gemm_fp8_fp8_bf16_nt((a, s), (a, sb), out, policy="fast_ue8m0", tiling_=t)       # a bf16-exact tiling is not a fast-path tiling
     with pytest.raises(Exception):
         dga.gemm_fp8_fp8_bf16_nt((a, s), (a, sb), out, policy="fast_ue8m0", strict=True)
+
+
+# ---- policy "bf16_exact_ue8m0" (7 | 16): the in-contract arithmetic with the power-of-two scales folded into the exact e4m3 -> bf16
+#      conversions, the bf16 MFMA chain accumulating in place (gemm_fp8_kernel.hpp MATH = 3).  Held to the bf16-exact policy's bar.
+
+def _assert_in_contract(oracle, got, want, a, sfa, b, sfb):
+    rep = oracle.parity_report(got, want, a, sfa, b, sfb)
+    size = int(np.asarray(got).size)
+    assert rep["nan_positions_equal"]
+    assert int(round(rep["frac_gt_max_ulp"] * size)) <= max(1e-5 * size, 2), rep
+    assert rep["worst_excess_over_S"] <= 2.0 ** -22, rep
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 256, 512), (300, 520, 1040), (512, 768, 1024), (129, 257, 4096), (64, 512, 2048), (200, 392, 1921),
+                                   (1024, 2048, 896)])
+def test_bf16_exact_ue8m0_meets_the_contract(dga, oracle, m, n, k):
+    a, sfa, b, sfb = _inputs(m, n, k, seed=m + 3 * n + k)
+    got = _run(dga, a, sfa, b, sfb, "bf16_exact_ue8m0")
+    want = oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, threads=8)
+    _assert_in_contract(oracle, got, want, a, sfa, b, sfb)
+
+
+@pytest.mark.parametrize("tile", [(128, 256), (64, 256), (128, 128), (32, 128)])
+def test_bf16_exact_ue8m0_builds_by_name(dga, oracle, tile):
+    """128 x 256 and 64 x 256 have a build with the scales folded in; the other tiles run the bf16-exact policy as it is."""
+    m, n, k = 520, 1030, 1152
+    a, sfa, b, sfb = _inputs(m, n, k, seed=tile[0] + tile[1])
+    t = dga.tiling(m, n, k, policy="bf16_exact")
+    t.m1, t.n1 = tile; t.wavesM = t.wavesN = 0; t.stages = 3; t.splitkFactor = 1; t.kernelSerial = 0; t.dispatchPolicyTag = 7 | 16
+    assert dga.tiling_check(t) == 0
+    got = _run(dga, a, sfa, b, sfb, None, tiling_=t)
+    _assert_in_contract(oracle, got, oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, threads=8), a, sfa, b, sfb)
+    t.splitkFactor = 3; t.kernelSerial = 4           # split-K slabs of the same builds
+    got = _run(dga, a, sfa, b, sfb, None, tiling_=t)
+    _assert_in_contract(oracle, got, oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, threads=8), a, sfa, b, sfb)
+
+
+def test_bf16_exact_ue8m0_masked_grouped(dga, oracle):
+    g, mmax, n, k = 6, 128, 512, 1024
+    parts = [_inputs(mmax, n, k, seed=70 + i) for i in range(g)]
+    A, SFA, B, SFB = (np.stack([p[j] for p in parts]) for j in range(4))
+    masked = np.array([0, 1, 77, 128, 64, 127], np.int32)
+    dev = lambda x: torch.from_numpy(x).cuda()
+    out = torch.zeros((g, mmax, n), dtype=torch.bfloat16, device="cuda")
+    dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((dev(A), dev(SFA)), (dev(B), dev(SFB)), out, dev(masked), expected_m=96,
+                                              policy="bf16_exact_ue8m0", sync=True)
+    got = _bits(out)
+    want = oracle.m_grouped_gemm_fp8_fp8_bf16_nt_masked(A, SFA, B, SFB, np.zeros((g, mmax, n), np.uint16), masked)
+    for i in range(g):
+        mm = int(masked[i])
+        assert (got[i, mm:] == 0).all(), "rows >= masked_m were written"
+        if mm:
+            _assert_in_contract(oracle, got[i, :mm], want[i, :mm], A[i, :mm], SFA[i, :mm], B[i], SFB[i])
