@@ -461,6 +461,27 @@ def policy_legs(dga, a, sfa, b, sfb, m, n, k, args, headline_policy, headline, c
     return legs, out
 
 
+def ue8m0_leg(dga, m, n, k, args):
+    """configs[1] with the block scales rounded up to powers of two (2^ceil(log2(amax / 448))): policy "fast_ue8m0" (fp8 MFMA with
+    the scales in its E8M0 operands, accumulate in place) and "bf16_exact_ue8m0" (in contract: scales folded into the exact
+    conversions, bf16 MFMA accumulates in place), each with its parity against the strict kernel on the same inputs."""
+    import torch
+    a, sfa, b, sfb = make_dense_inputs(m, n, k, seed=7, ue8m0=True)
+    out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    flops = 2.0 * m * n * k
+    leg = {"recipe": "SURVEY.md 8(d) with scale = 2^ceil(log2(amax / 448)) (per_token_cast_to_fp8(..., use_ue8m0=True))"}
+    for pol in ("fast_ue8m0", "bf16_exact_ue8m0"):
+        fn = lambda: dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, policy=pol)
+        us = _prewarmed_us(fn, max(20, min(args.steps, 200)), args.prewarm_ms)
+        o = {"value": round(flops / us / 1e6, 2), "unit": "TFLOP/s", "kernel_us": round(us, 3), "frac_of_fp8_peak": round(flops / us / 1e6 / PEAK_FP8_TFLOPS, 4)}
+        if not args.no_parity:
+            fn(); torch.cuda.synchronize()
+            par = parity_vs_strict(dga, a, sfa, b, sfb, out, policy="fast" if pol == "fast_ue8m0" else "bf16_exact")
+            o.update({"max_ulp": par["max_ulp"], "frac_gt_2ulp": par["frac_gt_2ulp"], "within_bar": par["within_bar"]})
+        leg[pol] = o
+    return leg
+
+
 IN_CONTRACT_FRAC = 1e-5   # at most this fraction of the outputs beyond 2 bf16 ULP of the fp32-accumulate result
 
 
@@ -875,6 +896,14 @@ def main():
             fx["traffic_source"] = "committed: " + str(pmc_traffic_source())
             fx["algorithmic_bytes"] = res["roofline"]["algorithmic_bytes"]
 
+    # the same problem quantised with power-of-two ("UE8M0") scales -- upstream DeepGEMM's use_ue8m0 recipe -- under the two policies
+    # that exploit them: the scales ride in the fp8 MFMA's E8M0 operands / are folded into the exact e4m3 -> bf16 conversions
+    if rank == 0 and world == 1 and not args.no_policies and args.workload == "dense_4096":
+        try:
+            res["ue8m0_scales"] = ue8m0_leg(dga, m, n, k, args)
+        except Exception as e:
+            res["ue8m0_scales"] = {"error": repr(e)}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(m, n, k, a, sfa, b, sfb, gpu_out=out, budget_s=args.cpu_budget,
                                            strict_out=strict_out)
@@ -1009,6 +1038,9 @@ def compact(res: dict) -> dict:
             if isinstance(leg.get("parity_vs_oracle"), dict):
                 o["bit_identical_to_cpu_oracle"] = leg["parity_vs_oracle"].get("bit_identical")
             c[name] = o
+    if isinstance(res.get("ue8m0_scales"), dict):
+        c["ue8m0_scales"] = {kk: (_pick(vv, ("value", "kernel_us", "frac_of_fp8_peak", "frac_gt_2ulp", "max_ulp")) if isinstance(vv, dict) else vv)
+                             for kk, vv in res["ue8m0_scales"].items() if kk != "recipe"}
     if isinstance(res.get("dsv3_prefill"), dict):
         dp = res["dsv3_prefill"]
         o = _pick(dp, ("policy", "value", "unit", "error"))
@@ -1048,7 +1080,7 @@ def compact(res: dict) -> dict:
     if "per_rank_kernel_us" in res and (res.get("n_gpus") or 1) > 1:
         c["per_rank_kernel_us"] = res["per_rank_kernel_us"]
     line = json.dumps(c)
-    for drop in ("shape_list", "dsv3_prefill", "strict", "parity", "cpu_baseline.sample"):   # never expected: a guard, not a plan
+    for drop in ("shape_list", "ue8m0_scales", "dsv3_prefill", "strict", "parity", "cpu_baseline.sample"):   # never expected: a guard, not a plan
         if len(line) < COMPACT_LIMIT:
             break
         if "." in drop:

@@ -118,6 +118,16 @@ __global__ void __launch_bounds__(256) mmad_nn_f32_kernel(const B16DirectParams 
         }
 }
 
+// Development switches that scripts and tests flip INSIDE one process ($DGA_B16_PLAN, _DEEP, _NO_TABLE, _WSK, _WSK_ODD) are looked up
+// per call only when $DGA_B16_DEV is set (read once): a product process never calls getenv on the launch path (a few hundred
+// nanoseconds on a launch of a few microseconds) and never races a setenv from another thread (tests/conftest.py sets it).
+static const char *b16_dev_env(const char *name)
+{
+    static const bool dev = [] { const char *e = std::getenv("DGA_B16_DEV"); return e && *e && *e != '0'; }();
+    return dev ? std::getenv(name) : nullptr;
+}
+
+
 // Tile and split-K of the tiled path (shared by the workspace size and the launch).  The largest tile that still gives
 // every CU a workgroup; when even the shortest tile leaves most CUs idle (the reference's benchmark list,
 // framework/benchmark/benchmark.py:24-44, is mostly M = 8..128 against N, K in the thousands: the y stream is the cost),
@@ -148,7 +158,7 @@ static const B16Swept kB16SweptNN[] = {   // run_mmad_rtc / run_mmad_bench: y [K
 static const B16Swept *b16_swept(int batch, int m, int n, int k, bool nn)
 {
     if (batch != 1 || m > 128) return nullptr;
-    if (const char *e = std::getenv("DGA_B16_NO_TABLE"); e && *e == '1') return nullptr;   // (per call: the sweep flips it)
+    if (const char *e = b16_dev_env("DGA_B16_NO_TABLE"); e && *e == '1') return nullptr;   // (per call: the sweep flips it)
     const int m_hi = m <= 8 ? 8 : (m <= 16 ? 16 : (m <= 32 ? 32 : (m <= 64 ? 64 : 128)));
     for (const B16Swept *r = nn ? kB16SweptNN : kB16Swept; r->m_hi; ++r)
         if (r->m_hi == m_hi && r->n == n && r->k == k) return r;
@@ -163,7 +173,7 @@ static const B16Swept *b16_swept(int batch, int m, int n, int k, bool nn)
 static bool b16_deep(const B16Plan &pl, int batch, int m, int n)
 {
     if (pl.bm > 64) return false;
-    if (const char *e = std::getenv("DGA_B16_DEEP")) return std::atoi(e) != 0;
+    if (const char *e = b16_dev_env("DGA_B16_DEEP")) return std::atoi(e) != 0;
     const int64_t items = static_cast<int64_t>(batch) * ((m + pl.bm - 1) / pl.bm) * ((n + pl.bn - 1) / pl.bn) * pl.splitk;
     return items <= device_cus();
 }
@@ -176,7 +186,7 @@ static B16Plan b16_plan(int batch, int m, int n, int k, bool nn)
     auto split = [&](int s) {
         if (s > 1) { pl.ks_per_split = (ks_n + s - 1) / s; pl.splitk = (ks_n + pl.ks_per_split - 1) / pl.ks_per_split; }
     };
-    if (const char *e = std::getenv("DGA_B16_PLAN")) {   // development: "bm,bn,splitk" (scripts/op16_plan_ab.py)
+    if (const char *e = b16_dev_env("DGA_B16_PLAN")) {   // development: "bm,bn,splitk" (scripts/op16_plan_ab.py)
         int bm = 0, bn = 0, s = 1, tail = 0, w8 = 0;
         if (std::sscanf(e, "%d,%d,%d,%d,%d", &bm, &bn, &s, &tail, &w8) >= 2 && bm > 0 && bn > 0) {
             pl.bm = bm; pl.bn = bn; pl.w8 = (w8 && bm == 128 && bn == 128) ? 1 : 0;
@@ -464,7 +474,7 @@ static int launch_b16_wsk(const B16Params &p_in, hipStream_t stream)
 {
     B16Params p = p_in;
     p.ks_per_split = (p.k / 64 + 7) / 8;
-    if (const char *e = std::getenv("DGA_B16_WSK_ODD"); e && *e == '1' && p.ks_per_split % 2 == 0) ++p.ks_per_split;
+    if (const char *e = b16_dev_env("DGA_B16_WSK_ODD"); e && *e == '1' && p.ks_per_split % 2 == 0) ++p.ks_per_split;
     if (p.m > 32 || p.m <= 0 || p.batch != 1 || (p.k % 64) || !p.z16 || ((p.ldx * 2) & 15) || ((p.ldy * 2) & 15) ||
         (reinterpret_cast<uintptr_t>(p.x) & 15) || (reinterpret_cast<uintptr_t>(p.yt) & 15) ||
         static_cast<int64_t>(p.m) * p.ldx * 2 >= 0x7FFFFFFFll)
@@ -536,7 +546,7 @@ static int launch_b16_nt(const void *a, const void *b, void *out, int m, int n, 
     // decode rows: one launch, the K slices are the waves of a workgroup (gemm_b16_wsk_kernel.hpp).  When it was built the tile path
     // was two-stage tiles by the fill rule and it won on 51 of 57 cold decode shapes by 15-35 % (profiles/r04_op16_wsk_cold.txt);
     // the deep small tiles took most of that back.  $DGA_B16_WSK = 0 / 1 overrides the rule.
-    const char *wsk_e = std::getenv("DGA_B16_WSK");   // (read per call, like $DGA_B16_PLAN: the tests flip it inside one process)
+    const char *wsk_e = b16_dev_env("DGA_B16_WSK");   // (read per call, like $DGA_B16_PLAN: the tests flip it inside one process)
     const int wsk_env = wsk_e ? std::atoi(wsk_e) : -1;
     // The rule, against the best tile plan of the cold sweep (profiles/r04_op16_plan_cold.txt; since the small tiles have their deep
     // builds): at <= 16 rows the one launch is ahead by 5-25 % on streams of N K <= 32 M elements and level (+-5 %) on longer ones

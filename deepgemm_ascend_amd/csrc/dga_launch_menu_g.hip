@@ -71,7 +71,10 @@ static int launch_wsk_dma_math(const GemmParams &p, hipStream_t stream)
 {
     if (p.groups != 1 || p.masked_m || p.m_indices || p.row_index || p.splitk > 1 || p.tail_sub || p.m > 32 || p.m <= 0 || (p.k % 16) ||
         p.k <= 0 || (reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.b) & 15) || (p.lda & 15) || (p.ldb & 15) ||
-        static_cast<int64_t>(p.m) * p.lda >= 0x7FFFFFFFll)
+        static_cast<int64_t>(p.m) * p.lda >= 0x7FFFFFFFll ||
+        // B is addressed through a descriptor rebased at every pass's first row: 32-bit offsets cover the pass's rows (at most 96) as
+        // long as 96 rows fit 2 GB -- whatever N is (a weight matrix of more than 2 GB is fine, a single row of more than 22 MB is not)
+        static_cast<int64_t>(p.ldb) * 96 >= 0x7FFFFFFFll)
         return DGA_E_TILING;
     const int nt = (p.n + 15) / 16;
     const int64_t cus = device_cus();
@@ -112,7 +115,7 @@ int launch_wsk(const GemmParams &p, hipStream_t stream)
 {
     // dense problems of at most 64 rows, 16-byte K chunks; everything else keeps the tile kernels
     if (p.groups != 1 || p.masked_m || p.m_indices || p.row_index || p.splitk > 1 || p.tail_sub || p.m > 64 || p.m <= 0 || (p.k % 16) ||
-        p.k <= 0)
+        p.k <= 0 || static_cast<int64_t>(p.m) * p.lda >= 0x7FFFFFFFll || static_cast<int64_t>(p.ldb) * 96 >= 0x7FFFFFFFll)
         return DGA_E_TILING;
     const int nt = (p.n + 15) / 16, tnmax = wsk_max_ntiles(p.m);
     const int64_t cus = device_cus();

@@ -1,5 +1,7 @@
 """The aclnn operator's 16-bit path: the plan's tile against the alternatives on mid-size shapes ($DGA_B16_PLAN forces a plan;
 one subprocess per plan, device time by graph replay)."""
+import os
+os.environ.setdefault("DGA_B16_DEV", "1")   # the 16-bit operators read their development switches per call only when told so (dga_b16.hip)
 import os, subprocess, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent

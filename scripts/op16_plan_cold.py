@@ -5,6 +5,8 @@ $DGA_B16_WSK / $DGA_B16_NO_TABLE are read per call).  Device time by graph repla
 Usage: python scripts/op16_plan_cold.py [--mmad] [m ...]"""
 import json
 import os
+os.environ.setdefault("DGA_B16_DEV", "1")   # the 16-bit operators read their development switches per call only when told so (dga_b16.hip)
+
 import sys
 from pathlib import Path
 

@@ -4,6 +4,8 @@ Usage: python scripts/op16_plan_mid.py"""
 import json
 import math
 import os
+os.environ.setdefault("DGA_B16_DEV", "1")   # the 16-bit operators read their development switches per call only when told so (dga_b16.hip)
+
 import sys
 from pathlib import Path
 

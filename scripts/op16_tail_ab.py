@@ -3,6 +3,8 @@
 Usage: python scripts/op16_tail_ab.py"""
 import json
 import os
+os.environ.setdefault("DGA_B16_DEV", "1")   # the 16-bit operators read their development switches per call only when told so (dga_b16.hip)
+
 import sys
 from pathlib import Path
 

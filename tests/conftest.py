@@ -4,6 +4,10 @@ from pathlib import Path
 
 import pytest
 
+# the 16-bit operators look their development switches ($DGA_B16_PLAN, ...) up per call only in a process that says so, once, before
+# the library's first launch (csrc/dga_b16.hip b16_dev_env): the tests flip those switches between cases
+os.environ.setdefault("DGA_B16_DEV", "1")
+
 ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
