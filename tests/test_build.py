@@ -11,6 +11,29 @@ ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "deepgemm_ascend_amd" / "csrc"
 
 
+def _ship_flags(unit):
+    """The flags the Makefile compiles this unit with, taken from `make -n` (not a hand-kept copy: a unit's own switches --
+    FLAGS_<unit>, NOFORM_<unit> -- change what ships)."""
+    obj = f"../../build/csrc/{Path(unit).stem}.o"
+    r = subprocess.run(["make", "-n", "-B", "-C", str(CSRC), obj], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr[-1000:]
+    line = [l for l in r.stdout.splitlines() if "hipcc" in l and f" {unit} " in l + " "]
+    assert line, r.stdout[-1000:]
+    words = line[-1].split()
+    keep, skip = [], 0
+    for i, w in enumerate(words[1:], 1):
+        if skip:
+            skip -= 1
+            continue
+        if w in ("-c",) or w == unit:
+            continue
+        if w == "-o":
+            skip = 1
+            continue
+        keep.append(w)
+    return keep
+
+
 @pytest.mark.parametrize("unit,min_kernels,tile_kernel", [
     ("dga_launch.hip", 4, "gemm_fp8_strict_nt_kernel"),          # strict x 2, element-wise, split-K combine
     ("dga_rows.hip", 5, "pad_rows_kernel"),                      # row copies, routing, the odd-K re-layout pass
@@ -24,14 +47,16 @@ CSRC = ROOT / "deepgemm_ascend_amd" / "csrc"
     ("dga_launch_menu_g.hip", 6, "gemm_fp8_wsk_kernel"),         # workgroup split-K (3 row counts x k-tail)
     ("dga_launch_menu_h.hip", 2, "gemm_fp8_bf16x_persistent_kernel"),   # persistent bf16-exact 128x256 build x k-tail
     ("dga_b16.hip", 26, "gemm_b16_"),                            # 16-bit tile builds + the workgroup split-K (3 builds x bf16 / fp16)
-    ("dga_b16_w4.hip", 2, "gemm_b16_w4_kernel")])                # the four-wave 32x32x16 build (bf16 / fp16): accumulators in AGPRs on purpose
+    ("dga_b16_w4.hip", 2, "gemm_b16_w4_kernel"),                 # the four-wave 32x32x16 build (bf16 / fp16): accumulators in AGPRs on purpose
+    ("dga_launch_menu_i.hip", 20, "gemm_fp8_blockscaled_nt_kernel"),   # hardware-scale builds (MATH = 2): 10 tile builds x k-tail
+    ("dga_launch_menu_j.hip", 6, "gemm_fp8_blockscaled_nt_kernel"),    # four-wave builds with AGPR accumulators on purpose (MATH = 2 / 3)
+    ("dga_launch_menu_k.hip", 2, "gemm_fp8_blockscaled_nt_streamk_kernel")])   # one-launch Stream-K (promotion / hardware-scale form)
 def test_no_kernel_spills_or_scratch(unit, min_kernels, tile_kernel):
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT / 'include'}", f"-I{CSRC}",
-           "-fno-slp-vectorize", *([] if unit == "dga_b16_w4.hip" else ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),   # the Makefile's flags: the build that ships
-           *(["-mllvm", "-pragma-unroll-threshold=1000000"] if unit == "dga_launch_menu_f.hip" else []),
-           "-x", "hip", "--cuda-device-only", "-S", "-o", "/dev/null",
+    flags = _ship_flags(unit)
+    assert "--offload-arch=gfx950" in flags and "-O3" in flags
+    cmd = ["/opt/rocm/bin/hipcc", *flags, "--cuda-device-only", "-S", "-o", "/dev/null",
            "-Rpass-analysis=kernel-resource-usage", str(CSRC / unit)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(CSRC))   # (the Makefile's include paths are relative)
     assert r.returncode == 0, r.stderr[-2000:]
     name, seen = None, 0
     for line in r.stderr.splitlines():
@@ -45,7 +70,7 @@ def test_no_kernel_spills_or_scratch(unit, min_kernels, tile_kernel):
             # loader waves and set-up values of the computing waves, none of it inside the MFMA loop, no scratch.
             # Everything else must not spill at all.
             # (the LDS-DMA staged workgroup split-K parks pass-loop scalars of its K-tail builds the same way, outside the k loop)
-            allowed = 32 if (m.group(1) == "SGPRs Spill" and "persistent" in (name or "")) else 0
+            allowed = 40 if (m.group(1) == "SGPRs Spill" and ("persistent" in (name or "") or "streamk" in (name or ""))) else 0
             if m.group(1) == "SGPRs Spill" and "wskd_kernel" in (name or ""):
                 allowed = 16
             assert int(m.group(2)) <= allowed, f"{name}: {m.group(1)} = {m.group(2)}"
@@ -54,6 +79,8 @@ def test_no_kernel_spills_or_scratch(unit, min_kernels, tile_kernel):
             assert int(m.group(1)) <= 256, name
         m = re.search(r"AGPRs: (\d+)", line)
         # (the both-operand image builds read their fragments straight into AGPRs on purpose: MFMA operands, never promoted values)
-        if m and "gemm_" in (name or "") and "bf16x_image_kernel" not in (name or "") and "gemm_b16_w4_kernel" not in (name or ""):
+        # (... and the four-wave builds of dga_launch_menu_j.hip accumulate inside the MFMA: no vector instruction reads an accumulator)
+        if m and "gemm_" in (name or "") and "bf16x_image_kernel" not in (name or "") and "gemm_b16_w4_kernel" not in (name or "") and \
+                unit != "dga_launch_menu_j.hip":
             assert int(m.group(1)) == 0, f"{name}: MFMA results in AGPRs (a v_accvgpr_read per promoted value in the main loop)"
     assert seen >= min_kernels, seen
