@@ -4,6 +4,7 @@
 // stream, synchronous as gemm.hpp:110), plus the fp8 operators of BASELINE.json's north star.  torch types stay on this
 // side of the boundary; everything below it is plain pointers and sizes (include/dga_hip.h).
 // Built in-tree by deepgemm_ascend_amd/build_ext.py (hipcc, host code only -- there is no device code in this file).
+#include <cstdlib>
 #include <torch/extension.h>
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
@@ -39,15 +40,24 @@ at::Tensor scratch(const at::Tensor &like, size_t bytes)   // caller-owned works
 {
     return at::empty({static_cast<int64_t>(bytes ? bytes : 1)}, like.options().dtype(at::kByte));
 }
-// the arithmetic policy of an fp8 call: strict = true or policy = "strict" -> dispatchPolicyTag 3; "bf16_exact" -> 7;
-// "" / "fast" -> whatever schedule the tiling names (api.py ARITHMETIC_POLICIES)
-int policy_tag(bool strict, const std::string &policy)
+// the arithmetic policy of an fp8 call (api.py ARITHMETIC_POLICIES): strict = true or policy = "strict" -> dispatchPolicyTag 3;
+// "bf16_exact" -> 7; "fast" -> whatever schedule the fast tiling names (-1); "fast_ue8m0" -> that schedule | 16 (-2);
+// "bf16_exact_ue8m0" -> 7 | 16; "" -> the operator's default: $DGA_DEFAULT_POLICY, else bf16-exact (inside the 2-ULP contract)
+int policy_tag(bool strict, const std::string &policy_in)
 {
-    TORCH_CHECK(policy.empty() || policy == "fast" || policy == "bf16_exact" || policy == "strict",
-                "policy must be one of 'fast', 'bf16_exact', 'strict'");
+    std::string policy = policy_in;
+    if (policy.empty() && !strict) {
+        const char *e = std::getenv("DGA_DEFAULT_POLICY");
+        policy = (e && *e) ? e : "bf16_exact";
+    }
+    TORCH_CHECK(policy.empty() || policy == "fast" || policy == "bf16_exact" || policy == "strict" || policy == "fast_ue8m0" ||
+                    policy == "bf16_exact_ue8m0",
+                "policy must be one of 'fast', 'bf16_exact', 'strict', 'fast_ue8m0', 'bf16_exact_ue8m0'");
     TORCH_CHECK(!(strict && !policy.empty() && policy != "strict"), "strict=True contradicts policy='", policy, "'");
     if (strict || policy == "strict") return DGA_POLICY_STRICT;
     if (policy == "bf16_exact") return DGA_POLICY_BF16_EXACT;
+    if (policy == "bf16_exact_ue8m0") return DGA_POLICY_BF16_EXACT | DGA_POLICY_UE8M0_SCALES;
+    if (policy == "fast_ue8m0") return -2;
     return -1;
 }
 dga_tiling_t tiling_for(int m, int n, int k, int groups, int expected_m, unsigned flags, int tag)
@@ -57,12 +67,14 @@ dga_tiling_t tiling_for(int m, int n, int k, int groups, int expected_m, unsigne
     p.layoutTagA = DGA_LAYOUT_ROW_MAJOR; p.layoutTagB = DGA_LAYOUT_COLUMN_MAJOR; p.layoutTagC = DGA_LAYOUT_ROW_MAJOR;
     p.dtype = DGA_DT_FP8_E4M3FN; p.flags = flags;
     dga_tiling_t t{};
-    if (tag == DGA_POLICY_BF16_EXACT) {   // that policy's own tile / split-K pick
+    if (tag >= 0 && (tag & 7) == DGA_POLICY_BF16_EXACT) {   // that policy's own tile / split-K pick
         check(dga_tiling_bf16_exact(&p, &t), "tiling_bf16_exact");
+        t.dispatchPolicyTag = static_cast<uint8_t>(tag);
         return t;
     }
     check(dga_tiling(&p, &t), "tiling");
     if (tag >= 0) t.dispatchPolicyTag = static_cast<uint8_t>(tag);
+    if (tag == -2) t.dispatchPolicyTag |= DGA_POLICY_UE8M0_SCALES;
     return t;
 }
 // Operand checks of the fp8 operators -- the same the ctypes mirror makes (api.py _require): full shapes, dtypes, contiguity,
