@@ -13,6 +13,11 @@ echo "bench done"
 # the command the driver runs, under the kernel trace (same steps / warmup as the driver's own call)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o r05 -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-live-traffic --detail-out $O/bench_under_rocprof_detail.json > $O/bench_under_rocprof.json 2> $O/rocprof_stats.err
 echo "stats done"
+# the headline kernel on its own in the trace (the bench's trace mixes it with the grouped launches of the same grid size)
+for pol in bf16_exact fast; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/dense_$pol -o d -- python3 $R/scripts/prof_dense.py 4096 4096 4096 600 --policy $pol > $O/dense_$pol.log 2>&1
+done
+echo "dense traces done"
 for c in FETCH_SIZE WRITE_SIZE; do
   for pol in bf16_exact fast; do
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_dense_${pol}_$c -o p -- python3 $R/scripts/prof_dense.py 4096 4096 4096 420 --policy $pol > $O/pmc_dense_${pol}_$c.log 2>&1
