@@ -42,8 +42,6 @@ int launch_streamk(const GemmParams &p, void *ws, size_t ws_bytes, bool ue8m0, h
     StreamKArgs sk;
     sk.partials = static_cast<float *>(ws);
     sk.flags = reinterpret_cast<unsigned long long *>(sk.partials + static_cast<size_t>(grid) * (256 * 256));
-    static const int debug = [] { const char *d = std::getenv("DGA_SK_DEBUG"); return d ? std::atoi(d) : 0; }();
-    sk.debug = debug;
     // A flag is raised when it holds this launch's epoch: 64 mixed bits no earlier launch used and stale workspace bytes will not
     // hold -- nothing to zero.  A launch that is being CAPTURED into a graph is replayed with the same arguments, so there the flags
     // are zeroed by a memset node in front of the kernel and the epoch is a constant.

@@ -28,7 +28,6 @@ namespace dga {
 struct StreamKArgs {
     float *partials;               // [gridDim.x][256 * 256] fp32, one slot per workgroup
     unsigned long long *flags;     // [gridDim.x]: `epoch` = "this launch's partial is in the slot"
-    int debug;                     // diagnostics ($DGA_SK_DEBUG; results are then wrong): 1 no partial stores, 2 no partial loads, 4 no flag wait
     unsigned long long epoch;      // a value no earlier launch used (and the memory is unlikely to hold: 64 mixed bits); graph replays
                                    // repeat it, which is why a consumer puts the flag back to 0
 };
@@ -367,7 +366,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_streamk_kerne
         //      acquire loop that invalidates the XCD's L2 on every poll took the operand panels of its neighbours with it.
         {
             float *slot = sk.partials + (int64_t)(kpart * R + rt) * SLOT + tid * 4;     // (one running pointer: an asm operand takes no immediate offset)
-            if (!(sk.debug & 1))
+#ifndef DGA_SK_ABLATE_STORES      // (diagnostic builds only -- results are then wrong: the exchange with one cost removed, scripts/ubench)
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
@@ -376,6 +375,7 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_streamk_kerne
                     slot += NT * 4;
                     asm volatile("" : "+v"(slot));
                 }
+#endif
             wait_vmcnt<0>();                                        // this wave's rows have reached the coherent level ...
             barrier();                                              // ... every wave's have
             if (tid == 0) __hip_atomic_store(sk.flags + kpart * R + rt, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -383,11 +383,9 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_streamk_kerne
         // ---- this part's share of the reduction: accumulator tiles [kpart * 32 / sp, +32 / sp) of every lane (pairs of n-tiles: one
         //      16-byte bf16 store each), summed over the sp partials in k order
         const int per = (TM * TN) / sp;                  // 16, 8, 4 or 2
-        if (!(sk.debug & 4))
-            for (int j = 0; j < sp; ++j)
+        for (int j = 0; j < sp; ++j)
                 while (__hip_atomic_load(sk.flags + j * R + rt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) __builtin_amdgcn_s_sleep(8);
         const bool vec_ok = ((p.ldc & 7) == 0) && ((((uintptr_t)p.out) & 15) == 0);
-        if (!(sk.debug & 2))
         for (int pi = 0; pi < per; pi += 2) {
             const int idx = kpart * per + pi, mt = idx / TN, nt = idx % TN;      // (nt is even)
             v4f lo = v4f{0.f, 0.f, 0.f, 0.f}, hi = v4f{0.f, 0.f, 0.f, 0.f};
