@@ -854,6 +854,10 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
         // conversion c (0..15) of a fragment: dword c >> 1 of the 32 raw bytes, half c & 1 -> dword c & 3 of MFMA (c >> 2).
         // (c is a constant after unrolling; the builtin's half selector must be an immediate)
         auto convert = [](const v4i (&raw)[2], v4i (&dst)[4], int c, float scale = 1.0f) {
+#ifdef DGA_ABL_BX_NOCVT   // diagnostic (results are garbage): the MFMAs run on whatever the fragment registers hold
+            asm volatile("" : "+v"(dst[c >> 2][c & 3]));
+            return;
+#endif
             const int w = raw[(c >> 1) >> 2][(c >> 1) & 3];
             dst[c >> 2][c & 3] = (c & 1) ? __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, scale, true))
                                          : __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, scale, false));
@@ -929,7 +933,9 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
                     q == 0 ? v4f{0.f, 0.f, 0.f, 0.f} : part[t % RING], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 // refill DMA of block kb + 2: one piece per gap from the second tile on
+#ifndef DGA_ABL_BX_NODMA  // diagnostic (results are garbage): no refill -- the stages keep the prologue's bytes
                 if (u >= 4 && u < 4 + NL) issue_one(u - 4, fill, kb + 2);
+#endif
                 // B(nt + 1) -> bfx[(nt + 1) & 1]: 16 conversions over the n-tile's G gaps; the raw halves are reloaded with
                 // B(nt + 2) as they are released (from the readable stage once nt + 2 runs past this block)
 #pragma unroll
@@ -938,15 +944,19 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
                     const int nn = nt + 2;
                     const uint8_t *src = nn < TN ? sc : sn;
                     const int off = b_frag_off(nn < TN ? nn : nn - TN);
+#ifndef DGA_ABL_BX_NOLDS  // diagnostic (results are garbage): no fragment reads inside the loop
                     if (g == G / 2 - 1) braw[0] = *(const v4i *)(src + b_off0 + off);
                     if (g == G - 1) braw[1] = *(const v4i *)(src + b_off1 + off);
+#endif
                 }
                 // A fragments of the NEXT block, in place: raw bytes of A[mt] one tile ahead (at the first gap of its last
                 // tile), conversion during the tile after its last one
+#ifndef DGA_ABL_BX_NOLDS
                 if (nt == TN - 1 && q == 0) {
                     araw[mt & 1][0] = *(const v4i *)(sn + a_off0 + mt * 2048);
                     araw[mt & 1][1] = *(const v4i *)(sn + a_off1 + mt * 2048);
                 }
+#endif
                 if (nt == TN - 1 && mt >= 1) {     // the tile behind (mt - 1, TN - 1): A[mt - 1] of the next block
 #pragma unroll
                     for (int c = 0; c < 4; ++c) convert(araw[(mt - 1) & 1], afx[mt - 1], 4 * q + c, UE ? s_nxt[mt - 1] : 1.0f);
@@ -966,7 +976,11 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
                 if constexpr (!UE) {
                     const int j = t >= LAGT ? t - LAGT : TILES + t - LAGT, jn = j / TM, jm = j % TM;
                     const float sv = t >= LAGT ? s_cur[jm] : s_old[jm];
+#ifdef DGA_ABL_BX_NOFMA   // diagnostic (results are garbage): no promotion
+                    asm volatile("" :: "v"(part[j % RING][q]), "v"(sv));
+#else
                     acc[jm][jn][q] = __builtin_fmaf(part[j % RING][q], sv, acc[jm][jn][q]);
+#endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
