@@ -176,6 +176,8 @@ static int check_tiling(const dga_tiling_t &t)
         if (!find_bf16x_variant(t.m1, t.n1)) return DGA_E_TILING;
         const int st = t.stages;
         if (!(st == 0 || st == 2 || st == 3 || (st >= 4 && st <= 8) || (st == 1 && wsk))) return DGA_E_TILING;
+        if (t.kernelSerial == DGA_KERNEL_STREAMK_ONE_LAUNCH) return DGA_E_TILING;           // fast path only
+        if (t.kernelSerial == DGA_KERNEL_STREAMK_TAIL && !(t.m1 >= 128 && t.n1 >= 256)) return DGA_E_TILING;   // the 128 x 256 tile's tail
         return DGA_OK;
     }
     bool tile = false, grid = false;
@@ -517,11 +519,29 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     static const int pp_env = [] { const char *e = std::getenv("DGA_PINGPONG"); return e ? std::atoi(e) : -1; }();
     const int policy = pp_env >= 0 ? pp_env : tiling->dispatchPolicyTag;
     if (vx) {   // bf16-exact: one launch over the whole raster
-        if (bx_ue8m0 && !bx_image && !clock_stamps) {   // power-of-two scales: folded into the conversions, the MFMA accumulates in place
+        if (bx_ue8m0 && !bx_image && !clock_stamps && tiling->kernelSerial != DGA_KERNEL_STREAMK_TAIL) {   // power-of-two scales: folded into the conversions, the MFMA accumulates in place
             const int rc = launch_bf16u(vx->bm, vx->bn, p, stream);
             if (rc != DGA_E_TILING) return rc;
         }
         if (bx_image) return launch_bf16x_image(p, bx_image, stream);
+        // tail in quarter tiles (kernelSerial 5), as on the fast path below: the whole rounds of 128 x 256 tiles run as they are, the
+        // last partial round -- at most half of the CUs' worth of tiles -- is covered by 64 x 128 tiles (four per parent tile, two
+        // workgroups to a CU) in a second launch.  Same arithmetic in the same k order: the bytes are those of one launch.
+        if (tiling->kernelSerial == DGA_KERNEL_STREAMK_TAIL && groups == 1 && !masked_m && !m_indices && !ix && vx->bm == 128 && vx->bn == 256) {
+            const int tiles = p.tiles_m * p.tiles_n, cus = static_cast<int>(device_cus());
+            const int tail = tiles % cus, main_tiles = tiles - tail;
+            const Bf16xVariant *vq = find_bf16x_variant(64, 128);
+            if (tail > 0 && tail * 2 <= cus && main_tiles > 0 && vq && vq->bm == 64 && vq->bn == 128) {
+                GemmParams pm = p;
+                pm.launch_tiles = main_tiles;
+                if (int rc = vx->launch(pm, stream)) return rc;
+                GemmParams pt = p;  // tiles_m / tiles_n / raster_group stay those of the parent raster
+                pt.tail_begin = main_tiles;
+                pt.tail_sub = 2;
+                pt.launch_tiles = tail * 4;
+                return vq->launch(pt, stream);
+            }
+        }
         // the 128 x 256 tile's persistent form (gemm_fp8_bf16x_persistent_kernel.hpp; same bits).  The dispatcher hides most of a tile
         // boundary already, so it pays little -- masked grouped 256 x (128, 7168, 2048): full mask 1010 -> 998 us, random masks
         // 856 -> 835; 4096^3 114.1 -> 113.4; configs[2], 1.75 tiles per CU, 97.3 -> 98.5 (profiles/r04_bf16x_persistent_ab.txt) --

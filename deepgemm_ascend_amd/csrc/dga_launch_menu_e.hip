@@ -26,8 +26,8 @@ static int launch_bf16x_one(const GemmParams &p, hipStream_t stream)
 template <class Cfg>
 int launch_bf16x(const GemmParams &p, hipStream_t stream)
 {
-    // tiles no taller than the contiguous layout's segment alignment (no second pass), no quarter-tile tail
-    if (p.tail_sub || (p.m_indices && Cfg::kBM > DGA_CONTIGUOUS_M_ALIGNMENT)) return DGA_E_TILING;
+    // tiles no taller than the contiguous layout's segment alignment (no second pass)
+    if (p.m_indices && Cfg::kBM > DGA_CONTIGUOUS_M_ALIGNMENT) return DGA_E_TILING;
     return (p.k % 128) ? launch_bf16x_one<Cfg, true>(p, stream) : launch_bf16x_one<Cfg, false>(p, stream);
 }
 

@@ -436,6 +436,12 @@ static double dense_cost_us(const DenseCostModel &mo, uint32_t m, uint32_t n, ui
         const uint64_t tail = tiles % cus;
         if (tail > 0 && tail * 4 <= cus) rounds = static_cast<double>(tiles / cus) + 0.5;
     }
+    if (&mo == &kBf16xModel && c.bm == 128 && c.bn == 256 && s == 1 && tiles > cus) {
+        // the bf16-exact tile's last partial round in 64 x 128 quarter tiles (dga_launch.hip, kernelSerial 5): a quarter tile alone on a CU
+        // takes 0.6 of a parent tile's time, two to a CU 0.9 (scripts/bx_tail_ab.py, profiles/r05_bx_tail_ab.txt)
+        const uint64_t tail = tiles % cus;
+        if (tail > 0 && tail * 2 <= cus) rounds = static_cast<double>(tiles / cus) + (tail * 4 <= cus ? 0.62 : 0.90);
+    }
     const double share = static_cast<double>(std::min<uint64_t>(wpc, (items + cus - 1) / cus));
     double t = mo.launch_us + rounds * (per * c.us_per_kblock * std::pow(share, mo.share_exponent) + mo.prologue_us);
     const double bytes = static_cast<double>(m) * k + static_cast<double>(n) * k * (m <= 256 ? static_cast<double>(tiles_m) : 1.0) +
@@ -1070,6 +1076,12 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out)
     out->stages = 3; out->wavesM = 0; out->wavesN = 0;
     const uint64_t tiles = static_cast<uint64_t>((out->m + bm - 1) / bm) * ((out->n + bn - 1) / bn);
     out->blockDim = static_cast<uint32_t>(tiles * sk);
+    if (bm == 128 && bn == 256 && sk == 1 && tiles > cus && tiles % cus > 0 && (tiles % cus) * 2 <= cus) {
+        // the cost above counted the last partial round in quarter tiles: name that launch pair (1024 x 18432 x 7168, 2.25 rounds:
+        // 276 -> 241 us; 2304 x 4096 x 7168, 1.125 rounds, 168 on 128 x 128 tiles -> 139; same bytes as the single launch)
+        out->kernelSerial = DGA_KERNEL_STREAMK_TAIL;
+        out->blockDim = static_cast<uint32_t>(tiles - tiles % cus + 4 * (tiles % cus));
+    }
     {   // raster group: the XCD's concurrent patch square in operand ROWS (see select_mi355x); 4096^3 on 128 x 256 tiles:
         // 202 -> 169 MB of fabric traffic per launch at the same time (profiles/r05_raster_traffic.txt)
         const uint32_t tiles_m = (out->m + bm - 1) / bm;

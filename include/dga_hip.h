@@ -48,7 +48,9 @@ enum { DGA_PADDING_NONE = 0, DGA_PADDING_ND = 1, DGA_PADDING_BLOCK_ND = 2, DGA_P
  *   0 Common, 1 Small, 2 PaddingCommon (K % 16 != 0 read in place by the loader waves of the 128 x 256 tile: the re-layout fused
  *   with the matmul as in the reference's kernel of that name; without it odd K takes a padding pass), 4 StreamK/split-K. */
 enum { DGA_KERNEL_COMMON = 0, DGA_KERNEL_SMALL = 1, DGA_KERNEL_PADDING_COMMON = 2, DGA_KERNEL_STREAMK = 4,
-       DGA_KERNEL_STREAMK_TAIL = 5 /* whole waves of 256x256 tiles, the last partial wave covered by 128x128 tiles */,
+       DGA_KERNEL_STREAMK_TAIL = 5 /* whole waves of 256x256 tiles, the last partial wave covered by 128x128 tiles in a second launch;
+                                      under DGA_POLICY_BF16_EXACT: whole waves of 128x256 tiles + 64x128 quarter tiles.  Same bytes as
+                                      the single launch; a tail longer than half the CUs runs as the single launch */,
        DGA_KERNEL_SPLITK_WORKGROUP = 6 /* M <= 64: the 8 waves of a workgroup are the 8 K slices of one output tile, partial tiles
                                           combined in LDS -- one launch, no slab (the reference's single-core split-K kernel types,
                                           op_kernel/catlass_dynamic_matmul_tiling_key.h:30-36); the bits of split-K with factor 8.

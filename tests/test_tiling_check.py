@@ -70,8 +70,26 @@ def test_fields_outside_the_menu_are_refused():
     for st, want in ((0, OK), (2, OK), (3, OK), (4, OK), (5, OK), (6, OK), (7, OK), (8, OK), (1, E_TILING), (9, E_TILING), (200, E_TILING)):
         t = _copy(bx); t.stages = st
         assert dga.tiling_check(t) == want, st
+    # ... its quarter-tile tail (kernelSerial 5) exists for the 128 x 256 tile only, the one-launch Stream-K (7) not at all
+    assert (bx.m1, bx.n1) == (128, 256)
+    for ks, m1, n1, want in ((5, 128, 256, OK), (5, 64, 256, E_TILING), (5, 128, 128, E_TILING), (5, 32, 128, E_TILING), (7, 128, 256, E_TILING)):
+        t = _copy(bx); t.kernelSerial, t.m1, t.n1 = ks, m1, n1
+        assert dga.tiling_check(t) == want, (ks, m1, n1)
     t = _copy(base); t.dispatchPolicyTag = 3; t.m1 = 7; t.n1 = 9; t.stages = 77; t.wavesM = 5
     assert dga.tiling_check(t) == OK
+
+
+def test_the_bf16_exact_selector_names_its_quarter_tile_tail():
+    """Rasters of 128 x 256 tiles that leave a last round of at most half the CUs: the policy's own tiling names the launch pair
+    (kernelSerial 5, blockDim = whole rounds + 4 quarter tiles per tail tile); whole rounds and long tails stay single launches."""
+    for (m, n, k), tail in (((1024, 18432, 7168), 64), ((2304, 4096, 7168), 32), ((5120, 5120, 5120), 32), ((2560, 4096, 4096), 64)):
+        t = dga.tiling(m, n, k, policy="bf16_exact")
+        tiles = -(-m // 128) * -(-n // 256)
+        assert (t.m1, t.n1, t.kernelSerial, t.splitkFactor) == (128, 256, 5, 1) and tiles % 256 == tail, (m, n, k, t.as_dict())
+        assert t.blockDim == tiles - tail + 4 * tail and dga.tiling_check(t) == OK
+    for (m, n, k) in ((4096, 4096, 4096), (8192, 8192, 8192), (4096, 2048, 7168), (1279, 5120, 7680)):
+        t = dga.tiling(m, n, k, policy="bf16_exact")
+        assert t.kernelSerial != 5, (m, n, k, t.as_dict())
 
 
 def test_fuzzed_structs_are_either_in_the_menu_or_refused():
