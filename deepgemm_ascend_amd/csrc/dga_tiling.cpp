@@ -438,9 +438,9 @@ static double dense_cost_us(const DenseCostModel &mo, uint32_t m, uint32_t n, ui
     }
     if (&mo == &kBf16xModel && c.bm == 128 && c.bn == 256 && s == 1 && tiles > cus) {
         // the bf16-exact tile's last partial round in 64 x 128 quarter tiles (dga_launch.hip, kernelSerial 5): a quarter tile alone on a CU
-        // takes 0.6 of a parent tile's time, two to a CU 0.9 (scripts/bx_tail_ab.py, profiles/r05_bx_tail_ab.txt)
+        // takes 0.6 of a parent tile's time, two to a CU 0.85 (scripts/bx_tail_ab.py, profiles/r05_bx_tail_ab.txt)
         const uint64_t tail = tiles % cus;
-        if (tail > 0 && tail * 2 <= cus) rounds = static_cast<double>(tiles / cus) + (tail * 4 <= cus ? 0.62 : 0.90);
+        if (tail > 0 && tail * 2 <= cus) rounds = static_cast<double>(tiles / cus) + (tail * 4 <= cus ? 0.62 : 0.85);
     }
     const double share = static_cast<double>(std::min<uint64_t>(wpc, (items + cus - 1) / cus));
     double t = mo.launch_us + rounds * (per * c.us_per_kblock * std::pow(share, mo.share_exponent) + mo.prologue_us);

@@ -8,7 +8,7 @@ import deepgemm_ascend_amd as dga
 import bench
 
 SHAPES = [(1024, 18432, 7168), (1024, 4096, 7168), (2048, 4096, 7168), (4096, 4096, 4096), (4096, 2048, 7168), (1024, 7168, 18432),
-          (2048, 7168, 2048), (1536, 4096, 7168), (3072, 4096, 4096), (1279, 5003, 7681), (3511, 6151, 8191), (512, 7168, 4096), (768, 7168, 2048)]
+          (2048, 7168, 2048), (1536, 4096, 7168), (3072, 4096, 4096), (512, 7168, 4096), (768, 7168, 2048), (2304, 4096, 7168), (5120, 5120, 5120)]
 TILES = [(128, 256), (64, 256), (128, 128), (64, 128)]
 for (m, n, k) in SHAPES:
     a, sfa, b, sfb = bench.make_dense_inputs(m, n, k, seed=3)
@@ -20,11 +20,13 @@ for (m, n, k) in SHAPES:
     us0 = min(bench._prewarmed_us(f0, 30, 100.0) for _ in range(2))
     rows = []
     for (bm, bn) in TILES:
-        for sk in (1, 2, 4):
+        for sk in (1, 2, 4, 0):            # 0: the 128 x 256 tile with its last partial round in quarter tiles (kernelSerial 5)
+            if sk == 0 and (bm, bn) != (128, 256):
+                continue
             t = dga.tiling(m, n, k, policy="bf16_exact")
-            t.m1, t.n1, t.splitkFactor = bm, bn, sk
-            t.kernelSerial = 4 if sk > 1 else 0
-            t.blockDim = ((m + bm - 1) // bm) * ((n + bn - 1) // bn) * sk
+            t.m1, t.n1, t.splitkFactor = bm, bn, max(sk, 1)
+            t.kernelSerial = 4 if sk > 1 else (5 if sk == 0 else 0)
+            t.blockDim = ((m + bm - 1) // bm) * ((n + bn - 1) // bn) * max(sk, 1)
             t.stages = 3
             if dga.tiling_check(t) != 0:
                 continue
