@@ -1,5 +1,5 @@
-"""The bf16-exact 128 x 256 tile on dense rasters that give every CU the same number of tiles: the persistent kernel (tiling.stages = 7) against
-the one-tile build (8), whose loop keeps two blocks of refill in flight (the barrier at the gap from which a block reads the next block's stage)."""
+"""The bf16-exact 128 x 256 tile on dense rasters that give every CU the same number of tiles: the persistent kernel (tiling.stages = 7)
+against the one-tile build (8) -- the dispatcher's rule for when the persistent form pays (dga_launch.hip)."""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
