@@ -534,7 +534,9 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
             if (tail > 0 && tail * 2 <= cus && main_tiles > 0 && vq && vq->bm == 64 && vq->bn == 128) {
                 GemmParams pm = p;
                 pm.launch_tiles = main_tiles;
-                if (int rc = vx->launch(pm, stream)) return rc;
+                int rc = launch_bf16x_persistent(pm, stream);    // (DGA_E_TILING: a launch it does not take -- one k block)
+                if (rc == DGA_E_TILING) rc = vx->launch(pm, stream);
+                if (rc != DGA_OK) return rc;
                 GemmParams pt = p;  // tiles_m / tiles_n / raster_group stay those of the parent raster
                 pt.tail_begin = main_tiles;
                 pt.tail_sub = 2;
@@ -545,11 +547,13 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
         // the 128 x 256 tile's persistent form (gemm_fp8_bf16x_persistent_kernel.hpp; same bits).  The dispatcher hides most of a tile
         // boundary already, so it pays little -- masked grouped 256 x (128, 7168, 2048): full mask 1010 -> 998 us, random masks
         // 856 -> 835; 4096^3 114.1 -> 113.4; configs[2], 1.75 tiles per CU, 97.3 -> 98.5 (profiles/r04_bf16x_persistent_ab.txt) --
-        // and runs on the masked grouped layout and on dense rasters that give every CU the same number of tiles.  tiling.stages = 7
-        // names it, 8 names the one-tile build, $DGA_BF16X_PERSIST = 0 / 1 overrides.
+        // and runs on every masked grouped or dense raster of more than one round: uneven rasters gain most where K is short -- 4096 x 7168 x
+        // 2048 (3.5 rounds) 121.8 -> 111.5 us, 8064 x 4096 x 512 48.3 -> 40.0, 6016 x 4096 x 4096 173.8 -> 167.7; at exactly one round it
+        // loses 1.6 % (profiles/r05_bx_persist_ab.txt).  tiling.stages = 7 names it, 8 names the one-tile build, $DGA_BF16X_PERSIST = 0 / 1
+        // overrides.
         static const int bxp_env = [] { const char *e = std::getenv("DGA_BF16X_PERSIST"); return e ? std::atoi(e) : -1; }();
         const int64_t tiles = static_cast<int64_t>(p.groups) * p.tiles_m * p.tiles_n, cus = static_cast<int64_t>(device_cus());
-        const bool pays = tiles > cus && (masked_m || tiles % cus == 0);
+        const bool pays = tiles > cus;
         if (vx->bm == 128 && vx->bn == 256 && !clock_stamps &&
             (bxp_env >= 0 ? bxp_env != 0 : (tiling->stages == 7 || (tiling->stages != 8 && pays)))) {
             const int rc = launch_bf16x_persistent(p, stream);

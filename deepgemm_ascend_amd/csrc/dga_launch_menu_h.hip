@@ -18,7 +18,7 @@ static int launch_bf16x_persistent_one(const GemmParams &p, hipStream_t stream)
         attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     });
     if (int rc = record_hip(attr_err[dev])) return rc;
-    const int64_t tiles = static_cast<int64_t>(p.groups) * p.tiles_m * p.tiles_n;
+    const int64_t tiles = p.launch_tiles > 0 ? p.launch_tiles : static_cast<int64_t>(p.groups) * p.tiles_m * p.tiles_n;
     if (tiles == 0) return DGA_OK;
     const unsigned grid = static_cast<unsigned>(std::min<int64_t>(tiles, device_cus()));
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p);
@@ -27,9 +27,10 @@ static int launch_bf16x_persistent_one(const GemmParams &p, hipStream_t stream)
 
 int launch_bf16x_persistent(const GemmParams &p, hipStream_t stream)
 {
-    // dense and masked-grouped rasters of at least two k blocks; split-K, the quarter-tile tail, indexed rows and the contiguous
-    // layout keep the one-tile build
-    if (p.tail_sub || p.m_indices || p.row_index || p.launch_tiles > 0 || p.splitk > 1 || p.kb_n < 2) return DGA_E_TILING;
+    // dense and masked-grouped rasters of at least two k blocks (launch_tiles > 0: the first tiles of a dense raster -- the whole
+    // rounds in front of a quarter-tile tail); split-K, the quarter tiles themselves, indexed rows and the contiguous layout keep
+    // the one-tile build
+    if (p.tail_sub || p.m_indices || p.row_index || (p.launch_tiles > 0 && p.groups != 1) || p.splitk > 1 || p.kb_n < 2) return DGA_E_TILING;
     return (p.k % 128) ? launch_bf16x_persistent_one<true>(p, stream) : launch_bf16x_persistent_one<false>(p, stream);
 }
 }

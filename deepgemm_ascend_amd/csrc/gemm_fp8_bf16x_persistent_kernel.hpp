@@ -43,7 +43,7 @@ gemm_fp8_bf16x_persistent_kernel(const GemmParams p)
     // ---- this workgroup's tile list (as gemm_fp8_persistent_kernel.hpp): one contiguous chunk of the raster per XCD, walked
     //      together by the workgroups of that XCD, `step` tiles per round
     const int tiles_per_group = p.tiles_m * p.tiles_n;
-    const int total = p.groups * tiles_per_group;
+    const int total = p.launch_tiles > 0 ? p.launch_tiles : p.groups * tiles_per_group;   // (launch_tiles: the first tiles of a dense raster, the rest follows in another launch)
     int first = 0, count = total, step = gridDim.x, slot = blockIdx.x;
     if (p.xcd_remap) {
         const int xcd = blockIdx.x & 7, q = total >> 3, r = total & 7;
