@@ -8,7 +8,7 @@ import deepgemm_ascend_amd as dga
 import bench
 
 SHAPES = [(1024, 18432, 7168), (1024, 4096, 7168), (2048, 4096, 7168), (4096, 4096, 4096), (4096, 2048, 7168), (1024, 7168, 18432),
-          (2048, 7168, 2048), (1536, 4096, 7168), (3072, 4096, 4096), (512, 7168, 4096), (768, 7168, 2048), (2304, 4096, 7168), (5120, 5120, 5120)]
+          (2048, 7168, 2048), (1536, 4096, 7168), (3072, 4096, 4096), (512, 7168, 4096), (768, 7168, 2048), (2304, 4096, 7168), (5120, 5120, 5120), (4096, 7168, 2048), (8064, 4096, 1024), (4096, 5120, 1536), (3584, 4096, 2048), (2048, 7168, 1024), (1536, 7168, 2048)]
 TILES = [(128, 256), (64, 256), (128, 128), (64, 128)]
 for (m, n, k) in SHAPES:
     a, sfa, b, sfb = bench.make_dense_inputs(m, n, k, seed=3)
