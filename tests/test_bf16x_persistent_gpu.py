@@ -3,7 +3,7 @@ the raster, the LDS ring runs across tile boundaries) against the one-tile build
 so the bar is BIT IDENTITY; against the oracle it is the policy's bar (tests/test_bf16_exact_gpu.py).  Counterpart in the reference:
 its device loop walks the tiles of a core's section with double-buffered L1 across them
 (/root/reference/deep_gemm_ascend/framework/csrc/jit/generate_code.hpp:160-198).  tiling.stages = 7 names the persistent form, 8 the
-one-tile build (3 = the dispatcher's rule: persistent where a CU gets more than one tile)."""
+one-tile build (3 = the dispatcher's rule: persistent on every raster of more than one round)."""
 import numpy as np
 import pytest
 import torch
@@ -32,6 +32,8 @@ def _run(dga, a, sfa, b, sfb, t):
     (2400, 4200, 400),          # the same with every edge cut (rows, columns, K % 128 = 16)
     (129, 257, 2048),           # one row / one column into the second tile: three tiles are almost empty
     (4096, 4096, 256),          # 512 tiles, two per workgroup
+    (4096, 7168, 256),          # 896 tiles = 3.5 rounds: the uneven rasters the dispatcher hands to this kernel since round 5
+    (1000, 9000, 384 + 16),     # 8 x 36 = 288 tiles, every edge cut, uneven
     (100, 70000, 256 + 16),     # a short tile row: the second half of the waves has no rows in any tile
     (64, 256, 128 * 9),
 ])
