@@ -69,6 +69,8 @@ DGA_MENU_BX(DGA_MENU_EXTERN_BX)
 int launch_bf16x_image(const GemmParams &p, int waves, hipStream_t stream);
 // the persistent form of the 128 x 256 in-register build (dense / masked grouped rasters); DGA_E_TILING: not a launch it takes
 int launch_bf16x_persistent(const GemmParams &p, hipStream_t stream);
+// the masked grouped layout's kernel (gemm_fp8_bf16x_grouped_kernel.hpp; dga_launch_menu_l.hip): two k blocks in flight, per-m-tile row skipping
+int launch_bf16x_grouped(const GemmParams &p, hipStream_t stream);
 
 // loader-wave build of the 128 x 256 tile for rows that start at any byte (K % 16 != 0, no padded copy; dga_launch_menu_d.hip)
 int launch_unaligned(const GemmParams &p, hipStream_t stream);

@@ -175,7 +175,7 @@ static int check_tiling(const dga_tiling_t &t)
     if (tag == DGA_POLICY_BF16_EXACT) {
         if (!find_bf16x_variant(t.m1, t.n1)) return DGA_E_TILING;
         const int st = t.stages;
-        if (!(st == 0 || st == 2 || st == 3 || (st >= 4 && st <= 8) || (st == 1 && wsk))) return DGA_E_TILING;
+        if (!(st == 0 || st == 2 || st == 3 || (st >= 4 && st <= 9) || (st == 1 && wsk))) return DGA_E_TILING;
         if (t.kernelSerial == DGA_KERNEL_STREAMK_ONE_LAUNCH) return DGA_E_TILING;           // fast path only
         if (t.kernelSerial == DGA_KERNEL_STREAMK_TAIL && !(t.m1 >= 128 && t.n1 >= 256)) return DGA_E_TILING;   // the 128 x 256 tile's tail
         return DGA_OK;
@@ -553,6 +553,14 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
         // overrides.
         static const int bxp_env = [] { const char *e = std::getenv("DGA_BF16X_PERSIST"); return e ? std::atoi(e) : -1; }();
         const int64_t tiles = static_cast<int64_t>(p.groups) * p.tiles_m * p.tiles_n, cus = static_cast<int64_t>(device_cus());
+        // the masked grouped layout's own kernel (gemm_fp8_bf16x_grouped_kernel.hpp; same bits): two k blocks of the ring in flight and
+        // the loop unrolled for the m-tiles that hold rows.  tiling.stages = 9 names it, $DGA_BX_GROUPED = 0 / 1 overrides.
+        static const int bxg_env = [] { const char *e = std::getenv("DGA_BX_GROUPED"); return e ? std::atoi(e) : -1; }();
+        if (vx->bm == 128 && vx->bn == 256 && !clock_stamps && masked_m && !m_indices && !ix &&
+            (bxg_env >= 0 ? bxg_env != 0 : tiling->stages == 9)) {
+            const int rc = launch_bf16x_grouped(p, stream);
+            if (rc != DGA_E_TILING) return rc;
+        }
         const bool pays = tiles > cus;
         if (vx->bm == 128 && vx->bn == 256 && !clock_stamps &&
             (bxp_env >= 0 ? bxp_env != 0 : (tiling->stages == 7 || (tiling->stages != 8 && pays)))) {

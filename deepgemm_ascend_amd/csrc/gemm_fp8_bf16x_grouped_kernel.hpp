@@ -1,0 +1,342 @@
+// The bf16-exact policy's kernel for the masked grouped layout (dispatchPolicyTag 7, 128 x 256 tile on 2 x 4 waves): a persistent
+// kernel like gemm_fp8_bf16x_persistent_kernel.hpp, rebuilt around the two things that bound the expert weight stream there
+// (profiles/r06_grouped_masks_base.txt: 5.2-5.4 TB/s with few rows per expert against the fast policy's 6.6-7.0; 879 us on random masks).
+//
+//  (1) Rows that do not exist are not multiplied, at the granularity of the matrix instruction: a wave whose 64-row share of an expert
+//      holds L = 0..4 m-tiles (16 rows each) with rows runs the loop that is unrolled for exactly L -- L x 16 MFMAs, L x 16 A
+//      conversions, L x 16 promotions per k block instead of 64 of each.  L is fixed for a whole tile (masked_m[g] is), so the choice
+//      is one scalar branch per tile, outside the k loop.  This is the reference's walk over the blocks that exist
+//      (/root/reference/deep_gemm_ascend/framework/csrc/jit/generate_code.hpp:189-200: the last part multiplies r_m_blocks, not
+//      m_sec_o_blocks).
+//  (2) TWO k blocks of the ring are in flight, not one.  The persistent kernel converts the next block's fragments in place while it
+//      multiplies the current one, which needs the next block LANDED at the top of a block: of three stages one is consumed, one
+//      readable and only one in flight, and a stage's round trip (~2.3 us under load) bounds the stream at ~48 KB per 2.3 us per CU.
+//      Here a block reads its fragments from its own stage only (first fragments converted in a burst behind the barrier; the burst of
+//      one wave overlaps the other wave of its SIMD), so the wait at the top of a block leaves the younger stage's pieces in flight
+//      (counted vmcnt, also across the previous tile's output stores).
+//
+// Same arithmetic in the same k order as every other build of the policy (four chained v_mfma_f32_16x16x32_bf16 per scale block on
+// exactly converted operands, one fp32 promotion per block): bit-identical outputs (tests/test_bf16x_grouped_gpu.py).  Masked grouped
+// rasters of 128-row experts' tiles with K of at least two k blocks; everything else keeps the other builds.
+#pragma once
+#include "gemm_fp8_kernel.hpp"
+
+namespace dga {
+
+template <bool KTAIL, bool BNT>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
+{
+    typedef GemmCfg<128, 256, 2, 4, 3> Cfg;
+    constexpr int BM = Cfg::kBM, BN = Cfg::kBN, WN = Cfg::kWN, TM = Cfg::TM, TN = Cfg::TN, DNT = Cfg::DNT;
+    constexpr int NL = Cfg::LOADS_PER_STAGE, LAGT = 2, RING = 4;
+    static_assert(Cfg::NT == 512 && DNT == 512 && TM == 4 && TN == 4 && Cfg::SC_ITERS == 1 && Cfg::STAGES == 3, "the grouped schedule");
+    typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, kg = lane >> 4;
+    const int KB = p.kb_n;   // >= 2 (host)
+
+    // ---- this workgroup's tile list (gemm_fp8_persistent_kernel.hpp): one contiguous chunk of the raster per XCD
+    const int tiles_per_group = p.tiles_m * p.tiles_n;
+    const int total = p.groups * tiles_per_group;
+    int first = 0, count = total, step = gridDim.x, slot = blockIdx.x;
+    if (p.xcd_remap) {
+        const int xcd = blockIdx.x & 7, q = total >> 3, r = total & 7;
+        first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        count = q + (xcd < r ? 1 : 0);
+        step = ((int)gridDim.x - xcd + 7) >> 3;
+        slot = blockIdx.x >> 3;
+    }
+    struct Tile { int g, M, m0, n0; };
+    typedef const __attribute__((address_space(4))) int32_t *const_i32_ptr;   // scalar loads (see gemm_fp8_persistent_kernel.hpp)
+    const const_i32_ptr masked_m_c = (const_i32_ptr)p.masked_m;
+    auto seek = [&](int &local, Tile &t) -> bool {
+        for (; local < count; local += step) {
+            const int tile = first + local;
+            const int g = tile / tiles_per_group;
+            const int t_in = tile - g * tiles_per_group;
+            const int gm = p.raster_group;
+            const int per = gm * p.tiles_n;
+            const int band = t_in / per;
+            const int row0 = band * gm;
+            const int rows = min(p.tiles_m - row0, gm);
+            const int loc = t_in - band * per;
+            const int tm = row0 + loc % rows, tn = loc / rows;
+            const int M = p.masked_m ? min(masked_m_c[g], p.m) : p.m;
+            const int m0 = tm * BM;
+            if (m0 >= M) continue;              // empty expert / fully masked tile
+            t.g = g; t.M = M; t.m0 = m0; t.n0 = tn * BN;
+            return true;
+        }
+        return false;
+    };
+
+    // ---- the FILL tile: the tile whose k blocks the refill fetches (two blocks ahead of the block being multiplied, so during a
+    //      tile's last two blocks it is the next tile).  Its descriptors and per-lane offsets are the only DMA state there is.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    constexpr uint32_t kOutOfRange = 0x80000000u;
+    const int a_col = ((tid & 7) ^ swz_a(tid >> 3)) * 16;
+    const int b_col = ((tid & 7) ^ swz_b(tid >> 3)) * 16;
+    v4i a_rsrc, b_rsrc;
+    uint32_t a_voff[Cfg::A_ITERS], b_voff[Cfg::B_ITERS];
+    const float *sc_src;
+    int kbf = 0;            // the fill tile's next k block
+    bool fill_valid = true;
+    auto set_fill = [&](const Tile &t) {
+        a_rsrc = make_rsrc(p.a + (int64_t)t.g * p.a_gs + (int64_t)t.m0 * p.lda, (int64_t)(t.M - t.m0) * p.lda);
+        b_rsrc = make_rsrc(p.b + (int64_t)t.g * p.b_gs + (int64_t)t.n0 * p.ldb, (int64_t)(p.n - t.n0) * p.ldb);
+#pragma unroll
+        for (int it = 0; it < Cfg::A_ITERS; ++it) {
+            const int row = (it * DNT + tid) >> 3;
+            a_voff[it] = row < t.M - t.m0 ? (uint32_t)row * (uint32_t)p.lda + a_col : kOutOfRange;   // rows at or beyond M: zero-filled, not fetched
+        }
+#pragma unroll
+        for (int it = 0; it < Cfg::B_ITERS; ++it) {
+            const int row = (it * DNT + tid) >> 3;
+            b_voff[it] = (uint32_t)min(row, p.n - 1 - t.n0) * (uint32_t)p.ldb + b_col;
+        }
+        const float *SFA = p.sfa + (int64_t)t.g * p.sfa_gs, *SFB = p.sfb + (int64_t)t.g * p.sfb_gs;
+        sc_src = tid < BM ? SFA + (int64_t)min(t.m0 + tid, t.M - 1) * p.sfa_ld
+                          : SFB + (int64_t)min(t.n0 / 128 + min(tid - BM, 7), p.nb_n - 1) * p.kb_n;
+    };
+    // piece idx of stage `stage` from the fill tile's k block kbf (no fill tile: every lane out of range -- zeros land, nothing is
+    // fetched; the scale piece re-reads a block of the last tile)
+    auto refill = [&](int idx, int stage) {
+        const uint32_t sa = lds0 + stage * Cfg::STAGE_BYTES + wave * 1024;
+        const int k0 = kbf * 128;
+        if (idx < Cfg::A_ITERS) {
+            uint32_t voff = fill_valid ? a_voff[idx] : kOutOfRange;
+            if constexpr (KTAIL) voff = (k0 + a_col < p.k) ? voff : kOutOfRange;
+            dma16(voff, a_rsrc, (uint32_t)k0, sa + idx * DNT * 16);
+        } else if (idx < Cfg::A_ITERS + Cfg::B_ITERS) {
+            const int it = idx - Cfg::A_ITERS;
+            uint32_t voff = fill_valid ? b_voff[it] : kOutOfRange;
+            if constexpr (KTAIL) voff = (k0 + b_col < p.k) ? voff : kOutOfRange;
+            if constexpr (BNT) dma16_nt(voff, b_rsrc, (uint32_t)k0, sa + Cfg::A_BYTES + it * DNT * 16);
+            else dma16(voff, b_rsrc, (uint32_t)k0, sa + Cfg::A_BYTES + it * DNT * 16);
+        } else {
+            dma4(sc_src + (fill_valid ? kbf : KB - 1), lds0 + stage * Cfg::STAGE_BYTES + Cfg::A_BYTES + Cfg::B_BYTES + wave * 256);
+        }
+    };
+
+    // ---- per-lane fragment read offsets (bytes inside a stage): gemm_fp8_kernel.hpp
+    const int a_row = wm * (BM / Cfg::kWM) + li;
+    const int a_off0 = a_row * 128 + ((kg ^ swz_a(a_row)) * 16);
+    const int a_off1 = a_row * 128 + (((kg + 4) ^ swz_a(a_row)) * 16);
+    const int b_row = wn * (BN / WN) + 8 * (li >> 2) + (li & 3);
+    const int b_off0 = Cfg::A_BYTES + b_row * 128 + ((kg ^ swz_b(b_row)) * 16);
+    const int b_off1 = Cfg::A_BYTES + b_row * 128 + (((kg + 4) ^ swz_b(b_row)) * 16);
+    const int sa_off = Cfg::A_BYTES + Cfg::B_BYTES + (wm * (BM / Cfg::kWM) + li) * 4;
+    const int sb_off = Cfg::A_BYTES + Cfg::B_BYTES + (BM + (wn * (BN / WN)) / 128) * 4;
+
+    v4f acc[TM][TN];
+    v4f part[RING];
+    v4i afx[TM][4], bfx[2][4];      // bf16 fragments: [q] = the 8 bf16 of MFMA q of the chain
+    v4i braw[2], araw[2][2];         // raw e4m3 bytes: [0] = bytes [16 kg, +16), [1] = bytes [64 + 16 kg, +16)
+    float s_cur[TM], s_old[TM];
+    auto convert = [](const v4i (&raw)[2], v4i (&dst)[4], int c) {
+        const int w = raw[(c >> 1) >> 2][(c >> 1) & 3];
+        dst[c >> 2][c & 3] = (c & 1) ? __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true))
+                                     : __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false));
+    };
+    auto b_frag_off = [](int nt) { return (nt >> 1) * 4096 + (nt & 1) * 512; };
+
+    // counted wait at the top of a block: everything but the NL pieces of the younger stage in flight -- and, in a tile's first two
+    // blocks, but the previous tile's output stores, which were issued behind those pieces (never fewer stores than `extra`)
+    auto wait_landed = [&](int extra) {
+        if (extra >= 8) wait_vmcnt<NL + 8>();
+        else if (extra >= 6) wait_vmcnt<NL + 6>();
+        else if (extra >= 4) wait_vmcnt<NL + 4>();
+        else if (extra >= 2) wait_vmcnt<NL + 2>();
+        else wait_vmcnt<NL>();
+    };
+
+    Tile T{}, F{};
+    int local = slot;
+    if (!seek(local, T)) return;
+    F = T;
+    set_fill(F);
+    // ---- prologue: blocks 0 and 1 of the first tile on their way
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+#pragma unroll
+        for (int idx = 0; idx < NL; ++idx) refill(idx, d);
+        ++kbf;
+    }
+    int cur = 0;             // the stage of the block being multiplied; its predecessor's stage, (cur + 2) % 3, is refilled
+    int stores_pending = 0;  // output stores of the previous tile issued by this wave (a lower bound)
+
+    // the fill tile moves on when its last block has been issued
+    auto advance_fill = [&]() {
+        if (kbf == KB) {
+            local += step;
+            fill_valid = seek(local, F);
+            if (fill_valid) set_fill(F);
+            kbf = 0;
+        }
+    };
+
+    // one tile with L m-tiles of this wave's 64 rows present (L = 0: the wave only takes part in the refill and the barriers)
+    auto run_tile = [&](auto Lc) __attribute__((always_inline)) {
+        constexpr int L = decltype(Lc)::value;
+        constexpr int G = 4 * (L > 0 ? L : 1);       // MFMA gaps per n-tile
+        constexpr int TILES = (L > 0 ? L : 1) * TN;
+        if constexpr (L > 0) {
+#pragma unroll
+            for (int i = 0; i < L; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < RING; ++i) part[i] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < L; ++i) s_old[i] = 0.f;    // the first LAGT tiles "promote the previous block": part (= 0) * 0
+        }
+        for (int kb = 0; kb < KB; ++kb) {
+            wait_landed(kb < 2 ? stores_pending : 0);     // this wave's pieces of this block have landed
+            __builtin_amdgcn_s_barrier();                 // ... everyone's have; and everyone has left the block whose stage is refilled now
+            asm volatile("" ::: "memory");
+            advance_fill();
+            const int fill = cur >= 1 ? cur - 1 : 2;
+            if constexpr (L == 0) {
+#pragma unroll
+                for (int idx = 0; idx < NL; ++idx) refill(idx, fill);
+            } else {
+                const uint8_t *sc = smem + cur * Cfg::STAGE_BYTES;
+                // -- the block's first fragments: A(0), B(0) converted in a burst (the refill is issued while their bytes travel)
+                araw[0][0] = *(const v4i *)(sc + a_off0);
+                araw[0][1] = *(const v4i *)(sc + a_off1);
+                braw[0] = *(const v4i *)(sc + b_off0);
+                braw[1] = *(const v4i *)(sc + b_off1);
+                if constexpr (L > 1) {
+                    araw[1][0] = *(const v4i *)(sc + a_off0 + 2048);
+                    araw[1][1] = *(const v4i *)(sc + a_off1 + 2048);
+                }
+                const float sfb0 = *(const float *)(sc + sb_off);
+                float sa[L];
+#pragma unroll
+                for (int i = 0; i < L; ++i) sa[i] = *(const float *)(sc + sa_off + i * 64);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int idx = 0; idx < NL; ++idx) refill(idx, fill);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) convert(braw, bfx[0], c);
+                braw[0] = *(const v4i *)(sc + b_off0 + b_frag_off(1));    // B(1), raw
+#pragma unroll
+                for (int c = 8; c < 16; ++c) convert(braw, bfx[0], c);
+                braw[1] = *(const v4i *)(sc + b_off1 + b_frag_off(1));
+#pragma unroll
+                for (int c = 0; c < 16; ++c) convert(araw[0], afx[0], c);
+                if constexpr (L > 2) {
+                    araw[0][0] = *(const v4i *)(sc + a_off0 + 2 * 2048);
+                    araw[0][1] = *(const v4i *)(sc + a_off1 + 2 * 2048);
+                }
+#pragma unroll
+                for (int i = 0; i < L; ++i) s_cur[i] = sa[i] * sfb0;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4 * TILES; ++u) {
+                    const int t = u >> 2, q = u & 3, nt = t / L, mt = t % L, g = u % G;
+                    part[t % RING] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(v8bf, bfx[nt & 1][q]), __builtin_bit_cast(v8bf, afx[mt][q]),
+                        q == 0 ? v4f{0.f, 0.f, 0.f, 0.f} : part[t % RING], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // A(mt + 1) is converted behind the MFMAs of the first n-tile's m-tile mt; its raw bytes were read a tile earlier
+                    if (nt == 0 && mt + 1 < L) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) convert(araw[(mt + 1) & 1], afx[mt + 1], 4 * q + c);
+                        if (q == 3 && mt + 3 < L) {
+                            araw[(mt + 1) & 1][0] = *(const v4i *)(sc + a_off0 + (mt + 3) * 2048);
+                            araw[(mt + 1) & 1][1] = *(const v4i *)(sc + a_off1 + (mt + 3) * 2048);
+                        }
+                    }
+                    // B(nt + 1) is converted behind the MFMAs of n-tile nt into the other bf16 set; the raw halves are reloaded for
+                    // B(nt + 2) as the conversions release them
+                    if (nt + 1 < TN) {
+#pragma unroll
+                        for (int c = 16 * g / G; c < 16 * (g + 1) / G; ++c) convert(braw, bfx[(nt + 1) & 1], c);
+                        if (nt + 2 < TN) {
+                            if (g == G / 2 - 1) braw[0] = *(const v4i *)(sc + b_off0 + b_frag_off(nt + 2));
+                            if (g == G - 1) braw[1] = *(const v4i *)(sc + b_off1 + b_frag_off(nt + 2));
+                        }
+                    }
+                    {   // the promotion of tile t - LAGT (the previous block's last tiles during this block's first ones)
+                        const int j = t >= LAGT ? t - LAGT : TILES + t - LAGT, jn = j / L, jm = j % L;
+                        const float sv = t >= LAGT ? s_cur[jm] : s_old[jm];
+                        acc[jm][jn][q] = __builtin_fmaf(part[j % RING][q], sv, acc[jm][jn][q]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < L; ++i) s_old[i] = s_cur[i];
+            }
+            ++kbf;
+            cur = cur == 2 ? 0 : cur + 1;
+        }
+        stores_pending = 0;
+        if constexpr (L > 0) {
+            // ---- boundary: the last LAGT tiles of the last block, the stores
+#pragma unroll
+            for (int t = 0; t < LAGT; ++t) {
+                const int j = TILES + t - LAGT, jn = j / L, jm = j % L;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[jm][jn][q] = __builtin_fmaf(part[j % RING][q], s_old[jm], acc[jm][jn][q]);
+            }
+            uint16_t *C = p.out + (int64_t)T.g * p.c_gs;
+            const int m_row = T.m0 + wm * (BM / Cfg::kWM) + li;
+            const int n_base = T.n0 + wn * (BN / WN) + 8 * kg;
+            const bool vec_ok = ((p.ldc & 7) == 0) && ((((uintptr_t)C) & 15) == 0);
+            // every m-tile below L has a row, so each of the 2 L vector stores below is issued (full-width tiles of aligned rows)
+            if (vec_ok && T.n0 + BN <= p.n) stores_pending = 2 * L;
+#pragma unroll
+            for (int mt = 0; mt < L; ++mt) {
+                const int m = m_row + mt * 16;
+                if (m >= T.M) continue;
+                uint16_t *crow = C + (int64_t)m * p.ldc;
+#pragma unroll
+                for (int j = 0; j < TN / 2; ++j) {
+                    const int n = n_base + 32 * j;
+                    const v4f lo = acc[mt][2 * j], hi = acc[mt][2 * j + 1];
+                    const v2bf h0 = __builtin_convertvector(v2f{lo.x, lo.y}, v2bf);
+                    const v2bf h1 = __builtin_convertvector(v2f{lo.z, lo.w}, v2bf);
+                    const v2bf h2 = __builtin_convertvector(v2f{hi.x, hi.y}, v2bf);
+                    const v2bf h3 = __builtin_convertvector(v2f{hi.z, hi.w}, v2bf);
+                    const v4i pk = v4i{__builtin_bit_cast(int, h0), __builtin_bit_cast(int, h1),
+                                       __builtin_bit_cast(int, h2), __builtin_bit_cast(int, h3)};
+                    if (vec_ok && n + 8 <= p.n) {
+                        if (p.out_nt == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(crow + n), "v"(pk) : "memory");
+                        else if (p.out_nt == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(crow + n), "v"(pk) : "memory");
+                        else if (p.out_nt == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(crow + n), "v"(pk) : "memory");
+                        else asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(crow + n), "v"(pk) : "memory");
+                    } else {
+                        const uint16_t *e = (const uint16_t *)&pk;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            if (n + q < p.n) crow[n + q] = e[q];
+                    }
+                }
+            }
+        }
+    };
+
+    for (;;) {
+        // m-tiles of this wave's rows that exist in this tile (wave-uniform, fixed for the tile)
+        const int rows = T.M - T.m0 - wm * (BM / Cfg::kWM);
+        const int L = rows <= 0 ? 0 : (rows >= 64 ? 4 : (rows + 15) >> 4);
+        if (L == 0) run_tile(std::integral_constant<int, 0>{});
+        else if (L == 1) run_tile(std::integral_constant<int, 1>{});
+        else if (L == 2) run_tile(std::integral_constant<int, 2>{});
+        else if (L == 3) run_tile(std::integral_constant<int, 3>{});
+        else run_tile(std::integral_constant<int, 4>{});
+        // the tile after this one is the fill tile (the fill moved on during this tile's last two blocks)
+        if (!fill_valid) break;
+        T = F;
+    }
+    wait_vmcnt<0>();   // the refills past the last tile (zeros) land in LDS nobody reads: drain them before exit
+}
+
+}  // namespace dga

@@ -1,0 +1,122 @@
+"""The bf16-exact policy's masked-grouped kernel (csrc/gemm_fp8_bf16x_grouped_kernel.hpp: persistent, two k blocks of the ring in
+flight, the loop unrolled for the 0..4 m-tiles of a wave's rows that exist) against the one-tile build of the same tile: the same
+arithmetic in the same order, so the bar is BIT IDENTITY; against the oracle it is the policy's bar (tests/test_bf16_exact_gpu.py);
+rows at or beyond masked_m stay untouched.  Counterpart in the reference: its m_parts walk multiplies only the blocks that exist
+(/root/reference/deep_gemm_ascend/framework/csrc/jit/generate_code.hpp:189-200).  tiling.stages = 9 names the kernel, 8 the one-tile
+build."""
+import numpy as np
+import pytest
+import torch
+
+from test_bf16_exact_gpu import _assert_bar, _bits, _dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiling(dga, mmax, n, k, groups, grouped_kernel, raster=1):
+    t = dga.tiling(mmax, n, k, groups=groups, policy="bf16_exact")
+    t.m1, t.n1, t.splitkFactor, t.kernelSerial, t.dispatchPolicyTag = 128, 256, 1, 0, 7
+    t.stages, t.wavesM, t.wavesN, t.swizzleOffset = (9 if grouped_kernel else 8), 2, 4, raster
+    return t
+
+
+def _stack(oracle, g, mmax, n, k, seed):
+    parts = [oracle.make_inputs(mmax, n, k, seed=seed + i) for i in range(4)]
+    return tuple(np.stack([parts[i % 4][j] for i in range(g)]) for j in range(4))
+
+
+def _both(dga, A, SFA, B, SFB, masked, fill=-7.0):
+    g, mmax, _ = A.shape
+    n = B.shape[1]
+    k = A.shape[2]
+    outs = []
+    for grouped_kernel in (True, False):
+        out = torch.full((g, mmax, n), fill, dtype=torch.bfloat16, device="cuda")
+        t = _tiling(dga, mmax, n, k, g, grouped_kernel)
+        dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((_dev(A), _dev(SFA)), (_dev(B), _dev(SFB)), out, _dev(masked),
+                                                  expected_m=mmax, policy="bf16_exact", sync=True, tiling_=t)
+        outs.append(_bits(out))
+    return outs
+
+
+# every count of m-tiles in either half of the tile (0..4 in rows 0..63, 0..4 in rows 64..127), edges of each, empty experts
+ALL_L = np.array([0, 1, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 79, 80, 81, 95, 96, 97, 111, 112, 113, 127, 128, 5, 70, 100,
+                  0, 128, 64, 1], np.int32)
+
+
+@pytest.mark.parametrize("k", [256, 384, 128 * 9, 512 + 16])
+def test_every_row_count_is_bit_identical_to_the_one_tile_build(dga, oracle, k):
+    """32 experts x 8 n-tiles = 256 tiles (one per workgroup) and 48 experts (384 tiles: half the workgroups walk two tiles, so tiles of
+    different m-tile counts follow each other in one workgroup)."""
+    for g in (32, 48):
+        n, mmax = 2048, 128
+        A, SFA, B, SFB = _stack(oracle, g, mmax, n, k, seed=10 + k)
+        masked = np.resize(ALL_L, g).astype(np.int32)
+        if g == 48:
+            masked = masked[::-1].copy()
+        got, ref = _both(dga, A, SFA, B, SFB, masked)
+        assert np.array_equal(got, ref), f"g {g}: {int((got != ref).sum())} of {got.size} outputs differ"
+        init = _bits(torch.tensor([-7.0], dtype=torch.bfloat16))[0]
+        for i in range(g):
+            assert (got[i, int(masked[i]):] == init).all(), "rows >= masked_m were written"
+        for i in (3, 9, 17, 26):
+            mm = int(masked[i])
+            if mm and k <= 384:
+                want = oracle.gemm_fp8_fp8_bf16_nt(A[i, :mm], SFA[i, :mm], B[i], SFB[i], threads=8)
+                _assert_bar(oracle, got[i, :mm], want, A[i, :mm], SFA[i, :mm], B[i], SFB[i])
+
+
+def test_long_walks_and_ragged_n(dga, oracle):
+    """600 experts x 3 n-tiles (N = 640: the last tile is half columns, so the scalar store path and the counted wait's fallback run)
+    on 256 workgroups: every workgroup walks seven tiles."""
+    g, mmax, n, k = 600, 128, 640, 256
+    A, SFA, B, SFB = _stack(oracle, g, mmax, n, k, seed=77)
+    rng = np.random.default_rng(5)
+    masked = rng.integers(0, mmax + 1, size=g).astype(np.int32)
+    got, ref = _both(dga, A, SFA, B, SFB, masked)
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} of {got.size} outputs differ"
+
+
+def test_small_m_max_and_two_tile_rows(dga, oracle):
+    """m_max below and above the tile height: 96 (one tile row, the second half of the waves has at most two m-tiles) and 200 (two tile
+    rows per expert, the second one 72 rows)."""
+    for mmax in (96, 200):
+        g, n, k = 24, 1024, 384
+        A, SFA, B, SFB = _stack(oracle, g, mmax, n, k, seed=5 + mmax)
+        rng = np.random.default_rng(mmax)
+        masked = rng.integers(0, mmax + 1, size=g).astype(np.int32)
+        masked[:3] = (mmax, 0, 129 if mmax > 129 else 1)
+        got, ref = _both(dga, A, SFA, B, SFB, masked)
+        assert np.array_equal(got, ref), f"m_max {mmax}: {int((got != ref).sum())} of {got.size} outputs differ"
+
+
+def test_nan_does_not_cross_tiles(dga, oracle):
+    g, mmax, n, k = 48, 128, 2048, 384
+    A, SFA, B, SFB = _stack(oracle, g, mmax, n, k, seed=31)
+    A = A.copy(); A[0, 3, 200] = 0x7F
+    masked = np.resize(ALL_L, g).astype(np.int32); masked[0] = 40
+    got, ref = _both(dga, A, SFA, B, SFB, masked)
+    nan = (got & 0x7FFF) > 0x7F80
+    assert np.array_equal(nan, (ref & 0x7FFF) > 0x7F80) and nan.sum() == n
+    assert np.array_equal(got[~nan], ref[~nan])
+
+
+def test_config4_full_size_random_masks(dga):
+    """BASELINE configs[3] at full size: 256 experts x (M <= 128, K = 7168, N = 2048), random masks, both kernels byte for byte."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    g, mmax, n, k = 256, 128, 2048, 7168
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    a = torch.randint(0, 120, (g, mmax, k), dtype=torch.uint8, device="cuda", generator=gen)
+    b = torch.randint(0, 120, (g, n, k), dtype=torch.uint8, device="cuda", generator=gen)
+    sfa = torch.rand((g, mmax, k // 128), device="cuda") + 0.5
+    sfb = torch.rand((g, n // 128, k // 128), device="cuda") + 0.5
+    masked = torch.randint(0, mmax + 1, (g,), generator=torch.Generator().manual_seed(3)).to(torch.int32).cuda()
+    outs = []
+    for grouped_kernel in (True, False):
+        out = torch.full((g, mmax, n), -7.0, dtype=torch.bfloat16, device="cuda")
+        dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), out, masked, expected_m=mmax, policy="bf16_exact", sync=True,
+                                                  tiling_=_tiling(dga, mmax, n, k, g, grouped_kernel))
+        outs.append(out)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
