@@ -29,7 +29,7 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
 {
     typedef GemmCfg<128, 256, 2, 4, 3> Cfg;
     constexpr int BM = Cfg::kBM, BN = Cfg::kBN, WN = Cfg::kWN, TM = Cfg::TM, TN = Cfg::TN, DNT = Cfg::DNT;
-    constexpr int NL = Cfg::LOADS_PER_STAGE, LAGT = 2, RING = 4;
+    constexpr int NL = Cfg::LOADS_PER_STAGE, LAGT = 2, RING = 4, NT = Cfg::NT;
     static_assert(Cfg::NT == 512 && DNT == 512 && TM == 4 && TN == 4 && Cfg::SC_ITERS == 1 && Cfg::STAGES == 3, "the grouped schedule");
     typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -168,6 +168,9 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
         ++kbf;
     }
     int cur = 0;             // the stage of the block being multiplied; its predecessor's stage, (cur + 2) % 3, is refilled
+    DGA_STAMP_DECL           // (diagnostic builds only: scripts/ubench/stamp_grouped_bx.hip)
+    DGA_STAMP_CLOCK(6, 7);
+    DGA_STAMP_START();
     int stores_pending = 0;  // output stores of the previous tile issued by this wave (a lower bound)
 
     // the fill tile moves on when its last block has been issued
@@ -185,6 +188,8 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
         constexpr int L = decltype(Lc)::value;
         constexpr int G = 4 * (L > 0 ? L : 1);       // MFMA gaps per n-tile
         constexpr int TILES = (L > 0 ? L : 1) * TN;
+        constexpr int SP = L > 0 ? L : 1;            // gaps between two refill pieces
+        static_assert(1 + (NL - 1) * SP < 4 * TILES, "the refill fits the block");
         if constexpr (L > 0) {
 #pragma unroll
             for (int i = 0; i < L; ++i)
@@ -196,9 +201,12 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
             for (int i = 0; i < L; ++i) s_old[i] = 0.f;    // the first LAGT tiles "promote the previous block": part (= 0) * 0
         }
         for (int kb = 0; kb < KB; ++kb) {
+            DGA_STAMP(0);
             wait_landed(kb < 2 ? stores_pending : 0);     // this wave's pieces of this block have landed
+            DGA_STAMP(1);
             __builtin_amdgcn_s_barrier();                 // ... everyone's have; and everyone has left the block whose stage is refilled now
             asm volatile("" ::: "memory");
+            DGA_STAMP(2);
             advance_fill();
             const int fill = cur >= 1 ? cur - 1 : 2;
             if constexpr (L == 0) {
@@ -221,9 +229,6 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
                 for (int i = 0; i < L; ++i) sa[i] = *(const float *)(sc + sa_off + i * 64);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int idx = 0; idx < NL; ++idx) refill(idx, fill);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
                 for (int c = 0; c < 8; ++c) convert(braw, bfx[0], c);
                 braw[0] = *(const v4i *)(sc + b_off0 + b_frag_off(1));    // B(1), raw
 #pragma unroll
@@ -238,6 +243,7 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
 #pragma unroll
                 for (int i = 0; i < L; ++i) s_cur[i] = sa[i] * sfb0;
                 __builtin_amdgcn_sched_barrier(0);
+                DGA_STAMP(3);
 #pragma unroll
                 for (int u = 0; u < 4 * TILES; ++u) {
                     const int t = u >> 2, q = u & 3, nt = t / L, mt = t % L, g = u % G;
@@ -245,6 +251,10 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
                         __builtin_bit_cast(v8bf, bfx[nt & 1][q]), __builtin_bit_cast(v8bf, afx[mt][q]),
                         q == 0 ? v4f{0.f, 0.f, 0.f, 0.f} : part[t % RING], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
+                    // the refill rides on the MFMA gaps, one piece per SP gaps: issued in a burst behind the barrier the 56 pieces of the
+                    // workgroup queue on the CU's one vector-memory path and every wave's first MFMA waits for the last of them
+                    // (profiles/r06_grouped_stamps.txt: 880 ticks of head per k block against ~270)
+                    if (u >= 1 && (u - 1) % SP == 0 && (u - 1) / SP < NL) refill((u - 1) / SP, fill);
                     // A(mt + 1) is converted behind the MFMAs of the first n-tile's m-tile mt; its raw bytes were read a tile earlier
                     if (nt == 0 && mt + 1 < L) {
 #pragma unroll
@@ -273,6 +283,7 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
                 }
 #pragma unroll
                 for (int i = 0; i < L; ++i) s_old[i] = s_cur[i];
+                DGA_STAMP(4);
             }
             ++kbf;
             cur = cur == 2 ? 0 : cur + 1;
@@ -336,6 +347,9 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
         if (!fill_valid) break;
         T = F;
     }
+    DGA_STAMP(5);
+    DGA_STAMP_CLOCK(6, 7);
+    DGA_STAMP_FLUSH();
     wait_vmcnt<0>();   // the refills past the last tile (zeros) land in LDS nobody reads: drain them before exit
 }
 
