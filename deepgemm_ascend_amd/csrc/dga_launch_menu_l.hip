@@ -1,5 +1,6 @@
 // fp8 tile-kernel menu, part L: the bf16-exact policy's kernel for the masked grouped layout (gemm_fp8_bf16x_grouped_kernel.hpp,
 // dispatchPolicyTag 7): persistent, two k blocks of the ring in flight, the loop unrolled for the m-tiles of a wave that hold rows.
+#include <cstdlib>
 #include "dga_fp8_menu_impl.hpp"
 #include "gemm_fp8_bf16x_grouped_kernel.hpp"
 namespace dga {
@@ -31,7 +32,9 @@ int launch_bf16x_grouped(const GemmParams &p, hipStream_t stream)
     // contiguous layout keep the other builds
     if (p.tail_sub || p.m_indices || p.row_index || p.launch_tiles > 0 || p.splitk > 1 || p.kb_n < 2) return DGA_E_TILING;
     const bool nt = p.b_nt != 0;
-    if (p.k % 128) return nt ? launch_bf16x_grouped_one<true, true>(p, stream) : launch_bf16x_grouped_one<true, false>(p, stream);
-    return nt ? launch_bf16x_grouped_one<false, true>(p, stream) : launch_bf16x_grouped_one<false, false>(p, stream);
+    GemmParams q = p;
+    if (const char *e = std::getenv("DGA_BXG_KNOB")) q.tail_begin = std::atoi(e);   // development knobs (A/B runs in one process)
+    if (p.k % 128) return nt ? launch_bf16x_grouped_one<true, true>(q, stream) : launch_bf16x_grouped_one<true, false>(q, stream);
+    return nt ? launch_bf16x_grouped_one<false, true>(q, stream) : launch_bf16x_grouped_one<false, false>(q, stream);
 }
 }

@@ -81,47 +81,61 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
     constexpr uint32_t kOutOfRange = 0x80000000u;
     const int a_col = ((tid & 7) ^ swz_a(tid >> 3)) * 16;
     const int b_col = ((tid & 7) ^ swz_b(tid >> 3)) * 16;
+    // A wave issues its own pieces (thread slot tid: offsets kept in registers) and -- a wave of the second row that has no rows to
+    // multiply, see `lone` below -- IN ITS PARTNER'S PLACE the pieces of the wave four below it (slot tid - 256: offsets computed
+    // where they are used, by a wave that has nothing else to do; kept, they cost the registers the L = 4 loop needs).
     v4i a_rsrc, b_rsrc;
     uint32_t a_voff[Cfg::A_ITERS], b_voff[Cfg::B_ITERS];
     const float *sc_src;
     int kbf = 0;            // the fill tile's next k block
     bool fill_valid = true;
+    auto a_off_of = [&](const Tile &t, int it, int td) -> uint32_t {
+        const int row = (it * DNT + td) >> 3;
+        return row < t.M - t.m0 ? (uint32_t)row * (uint32_t)p.lda + a_col : kOutOfRange;   // rows at or beyond M: zero-filled, not fetched
+    };
+    auto b_off_of = [&](const Tile &t, int it, int td) -> uint32_t {
+        const int row = (it * DNT + td) >> 3;
+        return (uint32_t)min(row, p.n - 1 - t.n0) * (uint32_t)p.ldb + b_col;
+    };
+    auto sc_of = [&](const Tile &t, int td) -> const float * {   // slot td: [0, BM) sfa rows of the tile, then its sfb blocks
+        const float *SFA = p.sfa + (int64_t)t.g * p.sfa_gs, *SFB = p.sfb + (int64_t)t.g * p.sfb_gs;
+        return td < BM ? SFA + (int64_t)min(t.m0 + td, t.M - 1) * p.sfa_ld
+                       : SFB + (int64_t)min(t.n0 / 128 + min(td - BM, 7), p.nb_n - 1) * p.kb_n;
+    };
+    Tile T{}, F{};
     auto set_fill = [&](const Tile &t) {
         a_rsrc = make_rsrc(p.a + (int64_t)t.g * p.a_gs + (int64_t)t.m0 * p.lda, (int64_t)(t.M - t.m0) * p.lda);
         b_rsrc = make_rsrc(p.b + (int64_t)t.g * p.b_gs + (int64_t)t.n0 * p.ldb, (int64_t)(p.n - t.n0) * p.ldb);
 #pragma unroll
-        for (int it = 0; it < Cfg::A_ITERS; ++it) {
-            const int row = (it * DNT + tid) >> 3;
-            a_voff[it] = row < t.M - t.m0 ? (uint32_t)row * (uint32_t)p.lda + a_col : kOutOfRange;   // rows at or beyond M: zero-filled, not fetched
-        }
+        for (int it = 0; it < Cfg::A_ITERS; ++it) a_voff[it] = a_off_of(t, it, tid);
 #pragma unroll
-        for (int it = 0; it < Cfg::B_ITERS; ++it) {
-            const int row = (it * DNT + tid) >> 3;
-            b_voff[it] = (uint32_t)min(row, p.n - 1 - t.n0) * (uint32_t)p.ldb + b_col;
-        }
-        const float *SFA = p.sfa + (int64_t)t.g * p.sfa_gs, *SFB = p.sfb + (int64_t)t.g * p.sfb_gs;
-        sc_src = tid < BM ? SFA + (int64_t)min(t.m0 + tid, t.M - 1) * p.sfa_ld
-                          : SFB + (int64_t)min(t.n0 / 128 + min(tid - BM, 7), p.nb_n - 1) * p.kb_n;
+        for (int it = 0; it < Cfg::B_ITERS; ++it) b_voff[it] = b_off_of(t, it, tid);
+        sc_src = sc_of(t, tid);
     };
-    // piece idx of stage `stage` from the fill tile's k block kbf (no fill tile: every lane out of range -- zeros land, nothing is
-    // fetched; the scale piece re-reads a block of the last tile)
-    auto refill = [&](int idx, int stage) {
-        const uint32_t sa = lds0 + stage * Cfg::STAGE_BYTES + wave * 1024;
+    // piece idx of stage `stage` from the fill tile's k block kbf, for this wave (S = 0) or in its partner's place (S = 1).  No fill
+    // tile: every lane out of range -- zeros land, nothing is fetched; the scale piece re-reads a block of the last tile
+    auto refill = [&](int idx, int stage, auto sc) {
+        constexpr int S = decltype(sc)::value;
+        const int w = wave - 4 * S, td = tid - S * (DNT / 2);
+        const uint32_t sa = lds0 + stage * Cfg::STAGE_BYTES + w * 1024;
         const int k0 = kbf * 128;
         if (idx < Cfg::A_ITERS) {
-            uint32_t voff = fill_valid ? a_voff[idx] : kOutOfRange;
+            uint32_t voff = fill_valid ? (S ? a_off_of(F, idx, td) : a_voff[idx]) : kOutOfRange;
             if constexpr (KTAIL) voff = (k0 + a_col < p.k) ? voff : kOutOfRange;
             dma16(voff, a_rsrc, (uint32_t)k0, sa + idx * DNT * 16);
         } else if (idx < Cfg::A_ITERS + Cfg::B_ITERS) {
             const int it = idx - Cfg::A_ITERS;
-            uint32_t voff = fill_valid ? b_voff[it] : kOutOfRange;
+            uint32_t voff = fill_valid ? (S ? b_off_of(F, it, td) : b_voff[it]) : kOutOfRange;
             if constexpr (KTAIL) voff = (k0 + b_col < p.k) ? voff : kOutOfRange;
             if constexpr (BNT) dma16_nt(voff, b_rsrc, (uint32_t)k0, sa + Cfg::A_BYTES + it * DNT * 16);
             else dma16(voff, b_rsrc, (uint32_t)k0, sa + Cfg::A_BYTES + it * DNT * 16);
         } else {
-            dma4(sc_src + (fill_valid ? kbf : KB - 1), lds0 + stage * Cfg::STAGE_BYTES + Cfg::A_BYTES + Cfg::B_BYTES + wave * 256);
+            const float *src = S ? sc_of(F, td) : sc_src;
+            dma4(src + (fill_valid ? kbf : KB - 1), lds0 + stage * Cfg::STAGE_BYTES + Cfg::A_BYTES + Cfg::B_BYTES + w * 256);
         }
     };
+    constexpr std::integral_constant<int, 0> kOwn{};
+    constexpr std::integral_constant<int, 1> kPartner{};
 
     // ---- per-lane fragment read offsets (bytes inside a stage): gemm_fp8_kernel.hpp
     const int a_row = wm * (BM / Cfg::kWM) + li;
@@ -147,15 +161,21 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
 
     // counted wait at the top of a block: everything but the NL pieces of the younger stage in flight -- and, in a tile's first two
     // blocks, but the previous tile's output stores, which were issued behind those pieces (never fewer stores than `extra`)
-    auto wait_landed = [&](int extra) {
-        if (extra >= 8) wait_vmcnt<NL + 8>();
-        else if (extra >= 6) wait_vmcnt<NL + 6>();
-        else if (extra >= 4) wait_vmcnt<NL + 4>();
-        else if (extra >= 2) wait_vmcnt<NL + 2>();
-        else wait_vmcnt<NL>();
+    auto wait_all_but = [&](auto base, int extra) {
+        constexpr int B = decltype(base)::value;
+        if (extra >= 8) wait_vmcnt<B + 8>();
+        else if (extra >= 6) wait_vmcnt<B + 6>();
+        else if (extra >= 4) wait_vmcnt<B + 4>();
+        else if (extra >= 2) wait_vmcnt<B + 2>();
+        else wait_vmcnt<B>();
+    };
+    // `younger` = the pieces this wave issued during the previous block (0, NL or 2 NL: see `lone`)
+    auto wait_landed = [&](int younger, int extra) {
+        if (younger >= 2 * NL) wait_all_but(std::integral_constant<int, 2 * NL>{}, extra);
+        else if (younger >= NL) wait_all_but(std::integral_constant<int, NL>{}, extra);
+        else wait_all_but(std::integral_constant<int, 0>{}, extra);
     };
 
-    Tile T{}, F{};
     int local = slot;
     if (!seek(local, T)) return;
     F = T;
@@ -164,7 +184,7 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
 #pragma unroll
-        for (int idx = 0; idx < NL; ++idx) refill(idx, d);
+        for (int idx = 0; idx < NL; ++idx) refill(idx, d, kOwn);
         ++kbf;
     }
     int cur = 0;             // the stage of the block being multiplied; its predecessor's stage, (cur + 2) % 3, is refilled
@@ -172,6 +192,7 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
     DGA_STAMP_CLOCK(6, 7);
     DGA_STAMP_START();
     int stores_pending = 0;  // output stores of the previous tile issued by this wave (a lower bound)
+    int younger = NL;        // pieces this wave issued during the previous block
 
     // the fill tile moves on when its last block has been issued
     auto advance_fill = [&]() {
@@ -184,8 +205,9 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
     };
 
     // one tile with L m-tiles of this wave's 64 rows present (L = 0: the wave only takes part in the refill and the barriers)
-    auto run_tile = [&](auto Lc) __attribute__((always_inline)) {
+    auto run_tile = [&](auto Lc, auto lonec) __attribute__((always_inline)) {
         constexpr int L = decltype(Lc)::value;
+        constexpr bool lone = decltype(lonec)::value;
         constexpr int G = 4 * (L > 0 ? L : 1);       // MFMA gaps per n-tile
         constexpr int TILES = (L > 0 ? L : 1) * TN;
         constexpr int SP = L > 0 ? L : 1;            // gaps between two refill pieces
@@ -202,17 +224,22 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
         }
         for (int kb = 0; kb < KB; ++kb) {
             DGA_STAMP(0);
-            wait_landed(kb < 2 ? stores_pending : 0);     // this wave's pieces of this block have landed
+            wait_landed(younger, kb < 2 ? stores_pending : 0);     // this wave's pieces of this block have landed
             DGA_STAMP(1);
             __builtin_amdgcn_s_barrier();                 // ... everyone's have; and everyone has left the block whose stage is refilled now
             asm volatile("" ::: "memory");
             DGA_STAMP(2);
             advance_fill();
             const int fill = cur >= 1 ? cur - 1 : 2;
-            if constexpr (L == 0) {
+            if constexpr (L == 0) {     // (a wave of the second row, in a lone tile)
 #pragma unroll
-                for (int idx = 0; idx < NL; ++idx) refill(idx, fill);
+                for (int idx = 0; idx < NL; ++idx) {
+                    if (lone) refill(idx, fill, kPartner);
+                    refill(idx, fill, kOwn);
+                }
+                younger = lone ? 2 * NL : NL;
             } else {
+                younger = lone ? 0 : NL;
                 const uint8_t *sc = smem + cur * Cfg::STAGE_BYTES;
                 // -- the block's first fragments: A(0), B(0) converted in a burst (the refill is issued while their bytes travel)
                 araw[0][0] = *(const v4i *)(sc + a_off0);
@@ -254,7 +281,7 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
                     // the refill rides on the MFMA gaps, one piece per SP gaps: issued in a burst behind the barrier the 56 pieces of the
                     // workgroup queue on the CU's one vector-memory path and every wave's first MFMA waits for the last of them
                     // (profiles/r06_grouped_stamps.txt: 880 ticks of head per k block against ~270)
-                    if (u >= 1 && (u - 1) % SP == 0 && (u - 1) / SP < NL) refill((u - 1) / SP, fill);
+                    if (u >= 1 && (u - 1) % SP == 0 && (u - 1) / SP < NL && !lone) refill((u - 1) / SP, fill, kOwn);
                     // A(mt + 1) is converted behind the MFMAs of the first n-tile's m-tile mt; its raw bytes were read a tile earlier
                     if (nt == 0 && mt + 1 < L) {
 #pragma unroll
@@ -338,11 +365,27 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
         // m-tiles of this wave's rows that exist in this tile (wave-uniform, fixed for the tile)
         const int rows = T.M - T.m0 - wm * (BM / Cfg::kWM);
         const int L = rows <= 0 ? 0 : (rows >= 64 ? 4 : (rows + 15) >> 4);
-        if (L == 0) run_tile(std::integral_constant<int, 0>{});
-        else if (L == 1) run_tile(std::integral_constant<int, 1>{});
-        else if (L == 2) run_tile(std::integral_constant<int, 2>{});
-        else if (L == 3) run_tile(std::integral_constant<int, 3>{});
-        else run_tile(std::integral_constant<int, 4>{});
+        // A tile whose rows all lie in the first wave row's half (at most 64 rows: waves 4..7 multiply nothing) has the idle waves
+        // issue the whole refill, their partners' pieces too: a wave alone on its SIMD pays every piece it issues with ~50 cycles of
+        // its own MFMA stream (profiles/r06_grouped_stamps.txt), an idle wave pays nothing.  The role holds for a tile (it is a
+        // compile-time property of the tile's loop: a branch per MFMA gap costs the loop its registers); the counted wait at the top
+        // of a block goes by what THIS wave issued a block ago.
+        const bool lone = T.M - T.m0 <= BM / Cfg::kWM && !(p.tail_begin & 1);   // (tail_begin: development knobs of this kernel, $DGA_BXG_KNOB)
+        constexpr std::true_type yes{};
+        constexpr std::false_type no{};
+        if (lone) {
+            if (L == 0) run_tile(std::integral_constant<int, 0>{}, yes);
+            else if (L == 1) run_tile(std::integral_constant<int, 1>{}, yes);
+            else if (L == 2) run_tile(std::integral_constant<int, 2>{}, yes);
+            else if (L == 3) run_tile(std::integral_constant<int, 3>{}, yes);
+            else run_tile(std::integral_constant<int, 4>{}, yes);
+        } else {
+            if (L == 0) run_tile(std::integral_constant<int, 0>{}, no);
+            else if (L == 1) run_tile(std::integral_constant<int, 1>{}, no);
+            else if (L == 2) run_tile(std::integral_constant<int, 2>{}, no);
+            else if (L == 3) run_tile(std::integral_constant<int, 3>{}, no);
+            else run_tile(std::integral_constant<int, 4>{}, no);
+        }
         // the tile after this one is the fill tile (the fill moved on during this tile's last two blocks)
         if (!fill_valid) break;
         T = F;

@@ -50,7 +50,14 @@ def main():
             legs = legs[1:2]
         for st in [int(x) for x in sys.argv[sys.argv.index("--stages") + 1:] if x.isdigit()] if "--stages" in sys.argv else []:
             legs.insert(0, (f"bf16_exact_stages_{st}", dict(policy="bf16_exact"), MMAX, st))
+        if "--knobs" in sys.argv:   # $DGA_BXG_KNOB values of the grouped kernel, A/B in this process
+            for kn in sys.argv[sys.argv.index("--knobs") + 1].split(","):
+                legs.insert(0, (f"bf16_exact_stages_9_knob_{kn}", dict(policy="bf16_exact", knob=kn), MMAX, 9))
+        import os
         for leg, kw, hint, st in legs:
+            os.environ.pop("DGA_BXG_KNOB", None)
+            if "knob" in kw:
+                os.environ["DGA_BXG_KNOB"] = kw["knob"]
             t = dga.tiling(MMAX, N, K, groups=G, expected_m=hint, policy=kw["policy"])
             if st:
                 t.stages = st
