@@ -42,7 +42,8 @@ class Tiling(ctypes.Structure):
                 ("swizzleOffset", c_uint8), ("swizzleDirection", c_uint8), ("splitkFactor", c_uint16),
                 ("layoutTagA", c_uint8), ("layoutTagB", c_uint8), ("layoutTagC", c_uint8),
                 ("paddingTagA", c_uint8), ("paddingTagB", c_uint8), ("paddingTagC", c_uint8),
-                ("kernelSerial", c_uint8), ("dispatchPolicyTag", c_uint8), ("blockDim", c_uint32),
+                ("kernelSerial", c_uint8), ("dispatchPolicyTag", c_uint8), ("build", c_uint8), ("reserved0", c_uint8),
+                ("blockDim", c_uint32),
                 ("wavesM", c_uint8), ("wavesN", c_uint8), ("stages", c_uint8), ("contiguous", c_uint8),
                 ("ldsBytes", c_uint32), ("groups", c_uint32)]
 
@@ -57,6 +58,9 @@ class Problem(ctypes.Structure):
 
 
 PROBLEM_CONTIGUOUS_M = 1
+# dga_tiling_t.build (include/dga_hip.h DGA_BUILD_*)
+BUILD_DEFAULT, BUILD_WSK_REGISTER, BUILD_BX_AIMAGE, BUILD_BX_IMAGE8, BUILD_BX_IMAGE4 = 0, 1, 4, 5, 6
+BUILD_BX_PERSISTENT, BUILD_BX_ONE_TILE, BUILD_BX_GROUPED = 7, 8, 9
 ROWS_A_ZERO_PADDED, ROWS_B_ZERO_PADDED = 1, 2   # dga_gemm_fp8_fp8_bf16_nt_strided flags
 CAST_UE8M0 = 1                                  # dga_cast_to_fp8_*_ex flag: block scales rounded up to powers of two
 CONTIGUOUS_M_ALIGNMENT = 128
@@ -210,7 +214,7 @@ def lib() -> ctypes.CDLL:
                 raise DGALibraryError(f"{LIB_PATH} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
-        if L.dga_abi_version() != 6:
+        if L.dga_abi_version() != 7:
             raise DGALibraryError("ABI version mismatch")
         _lib = L
     return _lib

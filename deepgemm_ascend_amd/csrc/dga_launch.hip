@@ -154,10 +154,8 @@ static const Variant *find_variant(int bm, int bn, int wm, int wn, int stages)
 // refused BEFORE any launch (dga_tiling_check; run_fp8 calls it first).  A caller's dga_tiling_t is data from outside: the
 // counterpart of CatlassDynamicMatmulTilingFunc returning GRAPH_FAILED on what it cannot tile
 // (/root/reference/aclnn_catlass_dynamic_matmul/op_host/catlass_dynamic_matmul_tiling.cpp:86-100).
-//   tiling.stages also names a BUILD where no tile build has that many stages (the magic values of include/dga_hip.h):
-//     fast path      0 / 2 / 3 = LDS stages (0: the tile's default); 1 only with kernelSerial 6 (the register workgroup split-K)
-//     bf16-exact     0 / 2 / 3 = the in-register build; 4 / 5 / 6 = the A-image / 8-wave image / 4-wave image builds (128 x 256 tile);
-//                    7 / 8 = persistent / one-tile build; 1 only with kernelSerial 6
+//   tiling.build names a compiled build beside the tile and the schedule (include/dga_hip.h DGA_BUILD_*; ABI <= 6 carried these
+//   names in magic values of tiling.stages); tiling.stages is the LDS stage count and nothing else: 0 (the tile's default), 2 or 3
 static int check_tiling(const dga_tiling_t &t)
 {
     if (t.dispatchPolicyTag & ~(DGA_POLICY_UE8M0_SCALES | 7)) return DGA_E_TILING;      // bits nobody defined
@@ -169,13 +167,19 @@ static int check_tiling(const dga_tiling_t &t)
     }
     if (t.k1 != 0 && t.k1 != 128) return DGA_E_TILING;                                  // one scale block per k step
     if (t.splitkFactor > 1024) return DGA_E_RANGE;
+    if (t.reserved0) return DGA_E_TILING;
     if (tag == DGA_POLICY_STRICT) return DGA_OK;                                        // takes every shape as it is
     if (t.m1 == 0 || t.n1 == 0) return DGA_E_TILING;
+    if (!(t.stages == 0 || t.stages == 2 || t.stages == 3)) return DGA_E_TILING;          // LDS stages some build has
     const bool wsk = t.kernelSerial == DGA_KERNEL_SPLITK_WORKGROUP;
+    if (t.build == DGA_BUILD_WSK_REGISTER && !wsk) return DGA_E_TILING;
     if (tag == DGA_POLICY_BF16_EXACT) {
         if (!find_bf16x_variant(t.m1, t.n1)) return DGA_E_TILING;
-        const int st = t.stages;
-        if (!(st == 0 || st == 2 || st == 3 || (st >= 4 && st <= 9) || (st == 1 && wsk))) return DGA_E_TILING;
+        switch (t.build) {
+            case DGA_BUILD_DEFAULT: case DGA_BUILD_WSK_REGISTER: case DGA_BUILD_BX_AIMAGE: case DGA_BUILD_BX_IMAGE8: case DGA_BUILD_BX_IMAGE4:
+            case DGA_BUILD_BX_PERSISTENT: case DGA_BUILD_BX_ONE_TILE: case DGA_BUILD_BX_GROUPED: break;
+            default: return DGA_E_TILING;
+        }
         if (t.kernelSerial == DGA_KERNEL_STREAMK_ONE_LAUNCH) return DGA_E_TILING;           // fast path only
         if (t.kernelSerial == DGA_KERNEL_STREAMK_TAIL && !(t.m1 >= 128 && t.n1 >= 256)) return DGA_E_TILING;   // the 128 x 256 tile's tail
         return DGA_OK;
@@ -192,7 +196,7 @@ static int check_tiling(const dga_tiling_t &t)
         (tag == DGA_POLICY_CONTINUOUS || tag == DGA_POLICY_CONTINUOUS_PERSISTENT))
         grid = true;
     if ((t.wavesM || t.wavesN) && !grid) return DGA_E_TILING;                           // a wave grid no build of this tile has
-    if (!(t.stages == 0 || t.stages == 2 || t.stages == 3 || (t.stages == 1 && wsk))) return DGA_E_TILING;
+    if (t.build != DGA_BUILD_DEFAULT && t.build != DGA_BUILD_WSK_REGISTER) return DGA_E_TILING;   // the bf16-exact policy's names
     if (tag == DGA_POLICY_PINGPONG && !(t.m1 == 256 && t.n1 == 256)) return DGA_E_TILING;
     if ((t.kernelSerial == DGA_KERNEL_STREAMK_TAIL || t.kernelSerial == DGA_KERNEL_STREAMK_ONE_LAUNCH) && !(t.m1 == 256 && t.n1 == 256))
         return DGA_E_TILING;
@@ -435,7 +439,7 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     if (bf16x && (!vx || clock_stamps)) return DGA_E_TILING;
     // the 128 x 256 tile's image builds (bf16 LDS image converted once per workgroup; same bits as the in-register build; dense
     // and masked-grouped layouts).  Both-operand images measured 10 % SLOWER than the in-register build, the A-only image ties it
-    // (profiles/r04_bximg_stamps.txt, r04_aimage.txt), so they run only when NAMED: tiling.stages = 4 (A image), 5 (both operands, 8
+    // (profiles/r04_bximg_stamps.txt, r04_aimage.txt), so they run only when NAMED: tiling.build = DGA_BUILD_BX_AIMAGE (A image), _IMAGE8 (both operands, 8
     // waves), 6 (both operands, 4 waves), or $DGA_BX_IMAGE = 1 / 8 / 4 (0: never).  (Stage counts no tile build has, so that a fast-path
     // tiling that is handed this policy's tag -- 2 x 2 waves, two stages -- cannot name one by accident: it did, for a while, on every
     // grouped call of the policy.)
@@ -443,9 +447,9 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     int bx_image = 0;
     if (vx && vx->bm == 128 && vx->bn == 256 && !m_indices && !ix) {
         if (bx_image_env >= 0) bx_image = bx_image_env == 4 ? 4 : (bx_image_env == 1 ? 1 : (bx_image_env ? 8 : 0));
-        else if (tiling->stages == 4) bx_image = 1;
-        else if (tiling->stages == 5) bx_image = 8;
-        else if (tiling->stages == 6) bx_image = 4;
+        else if (tiling->build == DGA_BUILD_BX_AIMAGE) bx_image = 1;
+        else if (tiling->build == DGA_BUILD_BX_IMAGE8) bx_image = 8;
+        else if (tiling->build == DGA_BUILD_BX_IMAGE4) bx_image = 4;
     }
     const Variant *v = find_variant(tiling->m1, tiling->n1, tiling->wavesM, tiling->wavesN, tiling->stages);
     if (!v && !vx) return DGA_E_TILING;
@@ -479,10 +483,10 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     }
     if (!bf16x && !clock_stamps && groups == 1 && !masked_m && !m_indices && !ix &&
         (wsk_env >= 0 ? wsk_env != 0 : tiling->kernelSerial == DGA_KERNEL_SPLITK_WORKGROUP)) {
-        // M <= 32: the LDS-DMA staged build (whole-line requests, hand-counted vmcnt); a tiling with stages = 1 names the register
+        // M <= 32: the LDS-DMA staged build (whole-line requests, hand-counted vmcnt); a tiling with build = DGA_BUILD_WSK_REGISTER names the register
         // build (fragments global -> registers), which also takes 32 < M <= 64.  $DGA_WSK_DMA = 0 / 1 overrides.
         static const int wsk_dma_env = [] { const char *e = std::getenv("DGA_WSK_DMA"); return e ? std::atoi(e) : -1; }();
-        if (wsk_dma_env >= 0 ? wsk_dma_env != 0 : tiling->stages != 1) {
+        if (wsk_dma_env >= 0 ? wsk_dma_env != 0 : tiling->build != DGA_BUILD_WSK_REGISTER) {
             const int rc = launch_wsk_dma(p, stream);
             if (rc != DGA_E_TILING) return rc;
         }
@@ -549,21 +553,21 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
         // 856 -> 835; 4096^3 114.1 -> 113.4; configs[2], 1.75 tiles per CU, 97.3 -> 98.5 (profiles/r04_bf16x_persistent_ab.txt) --
         // and runs on every masked grouped or dense raster of more than one round: uneven rasters gain most where K is short -- 4096 x 7168 x
         // 2048 (3.5 rounds) 121.8 -> 111.5 us, 8064 x 4096 x 512 48.3 -> 40.0, 6016 x 4096 x 4096 173.8 -> 167.7; at exactly one round it
-        // loses 1.6 % (profiles/r05_bx_persist_ab.txt).  tiling.stages = 7 names it, 8 names the one-tile build, $DGA_BF16X_PERSIST = 0 / 1
+        // loses 1.6 % (profiles/r05_bx_persist_ab.txt).  tiling.build = DGA_BUILD_BX_PERSISTENT names it, _ONE_TILE the one-tile build, $DGA_BF16X_PERSIST = 0 / 1
         // overrides.
         static const int bxp_env = [] { const char *e = std::getenv("DGA_BF16X_PERSIST"); return e ? std::atoi(e) : -1; }();
         const int64_t tiles = static_cast<int64_t>(p.groups) * p.tiles_m * p.tiles_n, cus = static_cast<int64_t>(device_cus());
         // the masked grouped layout's own kernel (gemm_fp8_bf16x_grouped_kernel.hpp; same bits): two k blocks of the ring in flight and
-        // the loop unrolled for the m-tiles that hold rows.  tiling.stages = 9 names it, $DGA_BX_GROUPED = 0 / 1 overrides.
+        // the loop unrolled for the m-tiles that hold rows.  tiling.build = DGA_BUILD_BX_GROUPED names it (dga_tiling_bf16_exact does), $DGA_BX_GROUPED = 0 / 1 overrides.
         static const int bxg_env = [] { const char *e = std::getenv("DGA_BX_GROUPED"); return e ? std::atoi(e) : -1; }();
         if (vx->bm == 128 && vx->bn == 256 && !clock_stamps && masked_m && !m_indices && !ix &&
-            (bxg_env >= 0 ? bxg_env != 0 : tiling->stages == 9)) {
+            (bxg_env >= 0 ? bxg_env != 0 : tiling->build == DGA_BUILD_BX_GROUPED)) {
             const int rc = launch_bf16x_grouped(p, stream);
             if (rc != DGA_E_TILING) return rc;
         }
         const bool pays = tiles > cus;
         if (vx->bm == 128 && vx->bn == 256 && !clock_stamps &&
-            (bxp_env >= 0 ? bxp_env != 0 : (tiling->stages == 7 || (tiling->stages != 8 && pays)))) {
+            (bxp_env >= 0 ? bxp_env != 0 : (tiling->build == DGA_BUILD_BX_PERSISTENT || (tiling->build != DGA_BUILD_BX_ONE_TILE && pays)))) {
             const int rc = launch_bf16x_persistent(p, stream);
             if (rc != DGA_E_TILING) return rc;
         }

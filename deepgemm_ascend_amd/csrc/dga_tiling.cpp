@@ -658,6 +658,9 @@ constexpr int kCsvExtCols = 6;
 // ... and two more that key grouped problems (absent = a dense row): groups (> 1: masked grouped with m = m_max; with
 // contiguous = 1: the number of B matrices of the contiguous-grouped layout)
 static const char *kCsvGrp[] = {"groups", "contiguous"};
+// ... and one that names the compiled build (dga_tiling_t.build, ABI 7; absent = 0).  Files from before it existed carried build names
+// in magic `stages` values (1, 4..8): such a row is read as (build = stages, stages = 3).
+static const char *kCsvBuild = "build";
 
 class Cache {
 public:
@@ -671,7 +674,7 @@ public:
         std::lock_guard<std::mutex> lk(mu_);
         data_.clear();
         path_.clear();
-        ext_ = grp_ = false;
+        ext_ = grp_ = bld_ = false;
         if (!path || !*path) return DGA_OK;
         std::ifstream in(path);
         std::string line;
@@ -687,6 +690,7 @@ public:
             ext_ = true;
             for (const char *h : kCsvExt) ext_ = ext_ && col.count(h);
             grp_ = ext_ && col.count(kCsvGrp[0]) && col.count(kCsvGrp[1]);
+            bld_ = grp_ && col.count(kCsvBuild);
             while (std::getline(in, line)) {
                 if (line.empty()) continue;
                 const auto cells = split(line);
@@ -706,6 +710,11 @@ public:
                 e.splitk = opt("splitkFactor"); e.stages = opt("stages"); e.raster = opt("swizzleOffset");
                 e.waves_m = opt("wavesM"); e.waves_n = opt("wavesN"); e.policy = opt("dispatchPolicyTag");
                 e.has_policy = col.count("dispatchPolicyTag") != 0;
+                e.build = opt(kCsvBuild);
+                if (e.stages == 1 || (e.stages >= 4 && e.stages <= 9)) {   // a build name of ABI <= 6
+                    if (!e.build) e.build = e.stages;
+                    e.stages = 3;
+                }
                 const uint32_t groups = std::max(1u, opt("groups")), contiguous = opt("contiguous") ? 1u : 0u;
                 data_[key_of(get("m"), get("n"), get("k"), groups, contiguous)] = e;
             }
@@ -716,8 +725,8 @@ public:
             if (!out.is_open()) return DGA_E_IO;
             for (int i = 0; i < kCsvCols; ++i) out << (i ? "," : "") << kCsvHead[i];
             for (int i = 0; i < kCsvExtCols; ++i) out << "," << kCsvExt[i];
-            out << "," << kCsvGrp[0] << "," << kCsvGrp[1] << "\n";
-            ext_ = grp_ = true;
+            out << "," << kCsvGrp[0] << "," << kCsvGrp[1] << "," << kCsvBuild << "\n";
+            ext_ = grp_ = bld_ = true;
         }
         path_ = path;
         return DGA_OK;
@@ -758,6 +767,7 @@ public:
         t.splitkFactor = e.splitk ? static_cast<uint16_t>(e.splitk) : 1;
         t.stages = static_cast<uint8_t>(e.stages); t.wavesM = static_cast<uint8_t>(e.waves_m);
         t.wavesN = static_cast<uint8_t>(e.waves_n); t.dispatchPolicyTag = static_cast<uint8_t>(e.policy);
+        t.build = static_cast<uint8_t>(e.build);
         if (e.raster) t.swizzleOffset = static_cast<uint8_t>(e.raster);
         if (bucketed && t.m1 && t.n1)   // the neighbour's grid is not this problem's
             t.blockDim = ((t.m + t.m1 - 1) / t.m1) * ((t.n + t.n1 - 1) / t.n1) * std::max<uint32_t>(1, t.splitkFactor);
@@ -776,7 +786,7 @@ public:
         if (t.contiguous && data_.size() >= kMaxEntries) return;
         Entry e{t.m1, t.n1, t.k1, t.kernelSerial, t.paddingTagA, t.paddingTagB, t.paddingTagC, t.blockDim};
         e.splitk = t.splitkFactor; e.stages = t.stages; e.raster = t.swizzleOffset; e.waves_m = t.wavesM;
-        e.waves_n = t.wavesN; e.policy = t.dispatchPolicyTag;
+        e.waves_n = t.wavesN; e.policy = t.dispatchPolicyTag; e.build = t.build;
         data_[key] = e;
         if (!path_.empty() && (grp_ || (t.groups <= 1 && !t.contiguous))) {  // a file without the group columns: dense rows only
             std::ofstream out(path_, std::ios::app);
@@ -789,13 +799,14 @@ public:
                         << unsigned(t.swizzleOffset) << ',' << unsigned(t.wavesM) << ',' << unsigned(t.wavesN) << ','
                         << unsigned(t.dispatchPolicyTag);
                 if (grp_) out << ',' << t.groups << ',' << unsigned(t.contiguous ? 1 : 0);
+                if (bld_) out << ',' << unsigned(t.build);
                 out << "\n";
             }
         }
     }
 
 private:
-    struct Entry { uint32_t m1, n1, k1, serial, pa, pb, pc, block_dim, splitk = 0, stages = 0, raster = 0, waves_m = 0, waves_n = 0, policy = 0; bool has_policy = false; };
+    struct Entry { uint32_t m1, n1, k1, serial, pa, pb, pc, block_dim, splitk = 0, stages = 0, raster = 0, waves_m = 0, waves_n = 0, policy = 0, build = 0; bool has_policy = false; };
     static constexpr size_t kMaxEntries = 16384;
     // (m, n, k, groups, contiguous); the contiguous layout's m (total rows) is bucketed to 128 x a power of two: what the
     // tiling depends on is the rows per group against the tile heights, not the exact count
@@ -850,6 +861,7 @@ private:
     std::string path_;
     bool ext_ = false;   // the open file's header has the CDNA4 columns
     bool grp_ = false;   // ... and the groups / contiguous columns
+    bool bld_ = false;   // ... and the build column
 };
 
 // TilingParams ctor (tiling_params.h:45-65): strides from the layouts, swizzle defaults.
@@ -985,6 +997,17 @@ int dga_tiling(const dga_problem_t *problem, dga_tiling_t *out)
     init_params(*problem, *out);
     bool swept = false, timed_policy = false;
     if (Cache::instance().get(*out, &swept, &timed_policy)) {
+        // A reference-format file (or one written by hand) may name what this library's menu does not hold: the reference's own
+        // fixture row `512,512,512,128,256,256,0,...` carries k1 = 256, its kernel type 3 (PaddingStreamK) has no build here.  The
+        // kernels step one 128-wide scale block at a time whatever k1 says, so a cached row is normalised onto the menu -- as its
+        // CDNA4-only fields are re-derived below -- instead of coming back as a tiling that dga_tiling_check refuses
+        // (csv_test.cpp:33-35 rows; tests/test_tiling.py, tests/test_tiling_check.py).
+        if (out->k1 != 0 && out->k1 != 128) out->k1 = 128;
+        switch (out->kernelSerial) {
+            case DGA_KERNEL_COMMON: case DGA_KERNEL_SMALL: case DGA_KERNEL_PADDING_COMMON: case DGA_KERNEL_STREAMK:
+            case DGA_KERNEL_STREAMK_TAIL: case DGA_KERNEL_SPLITK_WORKGROUP: case DGA_KERNEL_STREAMK_ONE_LAUNCH: break;
+            default: out->kernelSerial = DGA_KERNEL_COMMON;
+        }
         if (out->contiguous)   // a bucketed key: the workgroup count follows this call's row count
             out->blockDim = static_cast<uint32_t>(static_cast<uint64_t>((out->m + out->m1 - 1) / std::max<uint32_t>(1, out->m1)) *
                                                   ((out->n + out->n1 - 1) / std::max<uint32_t>(1, out->n1)) *
@@ -1032,6 +1055,18 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out)
     // 256 x (128, 7168, 2048) with 32 x 128 tiles, 0..32: 886 -> 628, 0..64: 938 -> 734 with 64 x 256 (scripts/grouped_decode_bf16x.py,
     // profiles/r04_grouped_decode_bf16x.txt).  A hint that is too low costs time only (every further tile row of an expert streams its
     // weights again), never rows: the raster still covers m_max.
+    // Masked grouped layout, experts of more than 64 rows allocated: the layout's own kernel on the 128 x 256 tile (gemm_fp8_bf16x_grouped_kernel.hpp:
+    // rows that do not exist are not multiplied, at 16-row granularity, and two k blocks of the weight stream are in flight) whatever
+    // the hint says -- 256 x (128, 7168, 2048): random masks 865-900 -> 761-796 us, 0..16 rows 674 (617 with the hint's 32 x 128 tiles)
+    // -> 522, 0..64 rows 735 -> 600, full mask level (profiles/r06_grouped_masks.txt).
+    if (std::max<uint32_t>(1, out->groups) > 1 && !out->contiguous && out->m > 64 && out->k >= 256 && (out->k % 16) == 0) {
+        out->m1 = 128; out->n1 = 256;
+        out->stages = 3; out->wavesM = 0; out->wavesN = 0; out->splitkFactor = 1; out->kernelSerial = DGA_KERNEL_COMMON;
+        out->build = DGA_BUILD_BX_GROUPED;
+        out->swizzleOffset = 1;
+        out->blockDim = out->groups * ((out->m + out->m1 - 1) / out->m1) * ((out->n + out->n1 - 1) / out->n1);
+        return DGA_OK;
+    }
     if (std::max<uint32_t>(1, out->groups) > 1 && !out->contiguous && problem->expected_m > 0 && problem->expected_m <= 64 && out->m > 64 &&
         out->k >= 128 && (out->k % 16) == 0) {
         out->m1 = problem->expected_m <= 32 ? 32 : 64;

@@ -103,7 +103,8 @@ def candidates(m, n, k, rasters=None):
                             out.append({"m1": bm, "n1": bn, "raster": rr, "stages": st, "splitk": sk, "policy": pol, "tail": 1})
     # short-M: the one-launch workgroup split-K kernel (csrc/gemm_fp8_wsk_kernel.hpp, kernelSerial 6): 8 waves = 8 K slices
     if m <= 64 and k % 16 == 0 and k > 0:
-        # (stages names the build: 1 = fragments global -> registers, 3 = per-wave LDS-DMA rings, M <= 32)
+        # (wsk names the build: 1 = fragments global -> registers (tiling.build = 1; the candidate record keeps the "stages": 1 it
+        #  had when the name rode on that field), 2 = per-wave LDS-DMA rings, M <= 32)
         out.append({"m1": 16 if m <= 16 else (32 if m <= 32 else 64), "n1": 128, "raster": 1, "stages": 1, "splitk": 1, "policy": 0, "wsk": 1})
         if m <= 32:
             out.append({"m1": 16 if m <= 16 else 32, "n1": 128, "raster": 1, "stages": 3, "splitk": 1, "policy": 0, "wsk": 2})
@@ -287,10 +288,10 @@ def benchmark_shape(shape, out_dir: Path, rank=0, num_processes=1, iters=10, ras
     cands = candidates(m, n, k, rasters)
     if versus_tuned:   # a supplementary sweep of the kernels outside the tile menu against the operator's current pick
         t0 = dga.tiling(m, n, k)
-        pick = {"m1": int(t0.m1), "n1": int(t0.n1), "raster": int(t0.swizzleOffset), "stages": int(t0.stages),
+        pick = {"m1": int(t0.m1), "n1": int(t0.n1), "raster": int(t0.swizzleOffset), "stages": 1 if t0.build == 1 else int(t0.stages),
                 "splitk": int(t0.splitkFactor), "policy": int(t0.dispatchPolicyTag)}
         if t0.kernelSerial == 6:
-            pick["wsk"] = 2 if (t0.stages != 1 and m <= 32) else 1
+            pick["wsk"] = 2 if (t0.build != 1 and m <= 32) else 1
         elif t0.kernelSerial == 5:
             pick["tail"] = 1
         cands = [pick] + [c for c in cands if c.get("wsk") and c != pick]
@@ -337,7 +338,8 @@ def benchmark_shape(shape, out_dir: Path, rank=0, num_processes=1, iters=10, ras
         ck_path.write_text(json.dumps({"last_process_idx": idx}) + "\n")
         t = dga.tiling(m, n, k)
         t.m1, t.n1, t.swizzleOffset = p["m1"], p["n1"], p["raster"]
-        t.stages, t.wavesM, t.wavesN, t.dispatchPolicyTag = p["stages"], 0, 0, p["policy"]
+        t.stages, t.wavesM, t.wavesN, t.dispatchPolicyTag = (3 if p["stages"] == 1 else p["stages"]), 0, 0, p["policy"]
+        t.build = 1 if p.get("wsk") == 1 else 0
         t.splitkFactor = p["splitk"]; t.kernelSerial = 6 if p.get("wsk") else (5 if p.get("tail") else (4 if p["splitk"] > 1 else 0))
         def fn():
             c = sets[turn[0] % len(sets)]

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define DGA_ABI_VERSION 6
+#define DGA_ABI_VERSION 7
 
 /* ---- status codes (reference: DGA_HOST_ASSERT throws DGAException,
  *      deep_gemm_ascend/framework/csrc/utils/exception.hpp:9-33; op hooks return
@@ -102,6 +102,20 @@ enum { DGA_POLICY_PLAIN = 0, DGA_POLICY_PINGPONG = 1, DGA_POLICY_CONTINUOUS = 2,
        DGA_POLICY_LOADER_WAVES = 4, DGA_POLICY_PERSISTENT = 5, DGA_POLICY_CONTINUOUS_PERSISTENT = 6,
        DGA_POLICY_BF16_EXACT = 7, DGA_POLICY_UE8M0_SCALES = 16 };
 
+/* dga_tiling_t.build: the compiled build a caller (a sweep, a test, a tuned CSV row) names beside the tile and the schedule.  0 lets
+ * the dispatcher choose (what every selector of this library writes unless it says otherwise below).  No reference counterpart: the
+ * reference compiles one kernel per tiling key (op_kernel/catlass_dynamic_matmul_tiling_key.h:30-36).
+ *   fast path     DGA_BUILD_WSK_REGISTER with kernelSerial 6 only: fragments global -> registers (M <= 64) instead of the LDS-DMA rings
+ *   bf16-exact    DGA_BUILD_BX_AIMAGE / _IMAGE8 / _IMAGE4: the 128 x 256 tile with A (8 waves) or both operands (8 / 4 waves) converted
+ *                 once per workgroup into a bf16 LDS image;  DGA_BUILD_BX_PERSISTENT / _ONE_TILE: one workgroup per CU walking the raster /
+ *                 one workgroup per tile (0: persistent on rasters of more than one round);  DGA_BUILD_BX_GROUPED: the masked grouped
+ *                 layout's kernel (two k blocks of the ring in flight, the loop unrolled for the m-tiles that hold rows) -- what
+ *                 dga_tiling_bf16_exact names for masked grouped problems;  DGA_BUILD_WSK_REGISTER as above.
+ * The values are the magic `stages` values of ABI <= 6, so a CSV row written then (stages 1, 4..8) maps onto (build = stages,
+ * stages = 3) when it is read. */
+enum { DGA_BUILD_DEFAULT = 0, DGA_BUILD_WSK_REGISTER = 1, DGA_BUILD_BX_AIMAGE = 4, DGA_BUILD_BX_IMAGE8 = 5, DGA_BUILD_BX_IMAGE4 = 6,
+       DGA_BUILD_BX_PERSISTENT = 7, DGA_BUILD_BX_ONE_TILE = 8, DGA_BUILD_BX_GROUPED = 9 };
+
 /* Platform description: the CDNA4 retarget of PlatformInfo
  * (op_tiling/platform_info.h:16-41; Python mirror get_best_config/tiling_calculator.py:25-30).
  * The same struct carries the Ascend numbers when the reference's own arithmetic is
@@ -131,10 +145,14 @@ typedef struct dga_tiling_t {
     uint8_t paddingTagA, paddingTagB, paddingTagC;
     uint8_t kernelSerial;
     uint8_t dispatchPolicyTag;
+    uint8_t build;               /* DGA_BUILD_*: which compiled build of (kernelSerial, dispatchPolicyTag, tile) runs; 0 = the
+                                    dispatcher's rule.  ABI 7: until ABI 6 these names rode on magic values of `stages` */
+    uint8_t reserved0;           /* 0 */
     uint32_t blockDim;           /* workgroups launched (reference: uint8 AI-core count) */
     /* CDNA4 */
     uint8_t wavesM, wavesN;      /* wave grid inside the workgroup */
-    uint8_t stages;              /* LDS stages */
+    uint8_t stages;              /* LDS stages, as in the reference's tiling data (op_kernel/catlass_dynamic_matmul_tiling_data.h:19-33
+                                    has none: the catlass dispatch policy fixes them): 0 = the tile's default, 2 or 3 */
     uint8_t contiguous;          /* 1 = contiguous-grouped layout (groups = number of B matrices) */
     uint32_t ldsBytes;
     uint32_t groups;             /* 1 = dense */
@@ -177,12 +195,13 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out);
  * (they call the same check first): DGA_E_TILING for a (kernelSerial, dispatchPolicyTag, m1 x n1, wavesM x wavesN, stages) no build
  * answers to, DGA_E_RANGE for a split factor beyond 1024.  A caller-written dga_tiling_t is data from outside; the counterpart of
  * CatlassDynamicMatmulTilingFunc returning GRAPH_FAILED (op_host/catlass_dynamic_matmul_tiling.cpp:86-100).  What the fields may
- * hold:  kernelSerial 0, 1, 2, 4, 5, 6, 7;  k1 0 or 128;  dispatchPolicyTag 0..7, optionally | DGA_POLICY_UE8M0_SCALES;
- *   policy 3 (strict): any tile (the kernel picks its own);
- *   policy 7 (bf16-exact): any m1, n1 > 0 (mapped onto that policy's menu); stages 0 / 2 / 3 = the in-register build, 4 = A-image,
- *     5 / 6 = 8- / 4-wave image builds, 7 / 8 = persistent / one-tile build, 1 only with kernelSerial 6;
- *   fast path: m1 x n1 a tile of the menu, wavesM x wavesN either 0 x 0 or a wave grid that tile is built with, stages 0 / 2 / 3
- *     (1 only with kernelSerial 6: the register build of the workgroup split-K); policy 1 and kernelSerial 5 / 7: 256 x 256 only. */
+ * hold:  kernelSerial 0, 1, 2, 4, 5, 6, 7;  k1 0 or 128;  dispatchPolicyTag 0..7, optionally | DGA_POLICY_UE8M0_SCALES;  stages 0, 2 or 3;
+ * reserved0 0;
+ *   policy 3 (strict): any tile, stages and build (the kernel picks its own);
+ *   policy 7 (bf16-exact): any m1, n1 > 0 (mapped onto that policy's menu); build 0 or a DGA_BUILD_BX_* name (DGA_BUILD_WSK_REGISTER only
+ *     with kernelSerial 6);
+ *   fast path: m1 x n1 a tile of the menu, wavesM x wavesN either 0 x 0 or a wave grid that tile is built with; build 0
+ *     (DGA_BUILD_WSK_REGISTER only with kernelSerial 6); policy 1 and kernelSerial 5 / 7: 256 x 256 only. */
 int dga_tiling_check(const dga_tiling_t *tiling);
 
 /* SelectKernel without the cache, on an explicit platform (select_kernel.cpp:333-369).

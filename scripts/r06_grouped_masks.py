@@ -48,11 +48,11 @@ def main():
                 ("fast", dict(policy="fast"), mean, 0)]
         if "--base-only" in sys.argv:
             legs = legs[1:2]
-        for st in [int(x) for x in sys.argv[sys.argv.index("--stages") + 1:] if x.isdigit()] if "--stages" in sys.argv else []:
-            legs.insert(0, (f"bf16_exact_stages_{st}", dict(policy="bf16_exact"), MMAX, st))
+        for st in [int(x) for x in sys.argv[sys.argv.index("--builds") + 1:] if x.isdigit()] if "--builds" in sys.argv else []:
+            legs.insert(0, (f"bf16_exact_build_{st}", dict(policy="bf16_exact"), MMAX, st))
         if "--knobs" in sys.argv:   # $DGA_BXG_KNOB values of the grouped kernel, A/B in this process
             for kn in sys.argv[sys.argv.index("--knobs") + 1].split(","):
-                legs.insert(0, (f"bf16_exact_stages_9_knob_{kn}", dict(policy="bf16_exact", knob=kn), MMAX, 9))
+                legs.insert(0, (f"bf16_exact_build_9_knob_{kn}", dict(policy="bf16_exact", knob=kn), MMAX, 9))
         import os
         for leg, kw, hint, st in legs:
             os.environ.pop("DGA_BXG_KNOB", None)
@@ -60,7 +60,7 @@ def main():
                 os.environ["DGA_BXG_KNOB"] = kw["knob"]
             t = dga.tiling(MMAX, N, K, groups=G, expected_m=hint, policy=kw["policy"])
             if st:
-                t.stages = st
+                t.build = st
             fn = lambda: dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), out, masked, hint, tiling_=t)
             fn(); torch.cuda.synchronize()
             us = min(bench._prewarmed_us(fn, 20 if quick else 40, 60.0 if quick else 150.0) for _ in range(2))

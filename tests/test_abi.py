@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(dga):
 def test_struct_layouts_match_header(dga):
     from deepgemm_ascend_amd import _lib
     assert ctypes.sizeof(_lib.Tiling) == 72 and ctypes.sizeof(_lib.Platform) == 56 and ctypes.sizeof(_lib.Problem) == 28
-    assert _lib.lib().dga_abi_version() == 6
+    assert _lib.lib().dga_abi_version() == 7
 
 
 def test_status_strings_and_null_checks(dga):

@@ -146,20 +146,25 @@ def test_baseline_configs_on_their_own_recipe(dga, oracle, shape):
     assert rep["worst_excess_over_S"] <= EPS * 1.01, rep   # 1.01: S itself is bf16-rounded (2^-9)
 
 
-@pytest.mark.parametrize("expected_m", [16, 64, 128])
-def test_grouped_masked_c4_experts(dga, oracle, expected_m):
-    """BASELINE configs[3] shape per expert (M<=128, K=7168, N=2048), 8 experts with ragged masks; masked rows stay
-    untouched.  The policy's tile height follows the expected_m hint (32 / 64 / 128 rows): a hint below the rows actually present
-    costs time, never rows."""
+@pytest.mark.parametrize("tile", [None, (32, 128), (64, 256), (128, 256)])
+def test_grouped_masked_c4_experts(dga, oracle, tile):
+    """BASELINE configs[3] shape per expert (M<=128, K=7168, N=2048), 8 experts with ragged masks; masked rows stay untouched.
+    tile None: what the policy's selector names whatever the expected_m hint says -- the layout's own kernel on the 128 x 256 tile
+    (DGA_BUILD_BX_GROUPED; until round 5 the tile height followed the hint because the loop multiplied every row of its tile).  The
+    other cases: the tile builds a caller can still name for this layout (a tile lower than the rows present costs time, never rows)."""
     g, mmax, n, k = 8, 128, 2048, 7168
-    t = dga.tiling(mmax, n, k, groups=g, expected_m=expected_m, policy="bf16_exact")
-    assert t.m1 == {16: 32, 64: 64, 128: 128}[expected_m]
+    for hint in (16, 64, 128):
+        t = dga.tiling(mmax, n, k, groups=g, expected_m=hint, policy="bf16_exact")
+        assert (t.m1, t.n1, t.build, t.kernelSerial, t.splitkFactor) == (128, 256, 9, 0, 1), t.as_dict()
+    if tile is not None:
+        t.m1, t.n1, t.build = tile[0], tile[1], (8 if tile == (128, 256) else 0)
+        t.blockDim = g * -(-mmax // t.m1) * -(-n // t.n1)
     parts = [oracle.make_inputs(mmax, n, k, seed=40 + i) for i in range(g)]
     A, SFA, B, SFB = (np.stack([p[j] for p in parts]) for j in range(4))
     masked = np.array([128, 0, 1, 77, 128, 16, 127, 64], np.int32)
     out = torch.full((g, mmax, n), -7.0, dtype=torch.bfloat16, device="cuda")
     dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((_dev(A), _dev(SFA)), (_dev(B), _dev(SFB)), out, _dev(masked),
-                                              expected_m=expected_m, policy="bf16_exact", sync=True)
+                                              expected_m=64, policy="bf16_exact", sync=True, tiling_=None if tile is None else t)
     got = _bits(out)
     init = np.full((g, mmax, n), _bits(torch.tensor([-7.0], dtype=torch.bfloat16))[0], np.uint16)
     want = oracle.m_grouped_gemm_fp8_fp8_bf16_nt_masked(A, SFA, B, SFB, init, masked, threads=8)

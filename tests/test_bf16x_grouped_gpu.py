@@ -2,8 +2,8 @@
 flight, the loop unrolled for the 0..4 m-tiles of a wave's rows that exist) against the one-tile build of the same tile: the same
 arithmetic in the same order, so the bar is BIT IDENTITY; against the oracle it is the policy's bar (tests/test_bf16_exact_gpu.py);
 rows at or beyond masked_m stay untouched.  Counterpart in the reference: its m_parts walk multiplies only the blocks that exist
-(/root/reference/deep_gemm_ascend/framework/csrc/jit/generate_code.hpp:189-200).  tiling.stages = 9 names the kernel, 8 the one-tile
-build."""
+(/root/reference/deep_gemm_ascend/framework/csrc/jit/generate_code.hpp:189-200).  tiling.build = 9 (DGA_BUILD_BX_GROUPED, what
+dga_tiling_bf16_exact names for this layout) is the kernel, 8 the one-tile build."""
 import numpy as np
 import pytest
 import torch
@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def _tiling(dga, mmax, n, k, groups, grouped_kernel, raster=1):
     t = dga.tiling(mmax, n, k, groups=groups, policy="bf16_exact")
     t.m1, t.n1, t.splitkFactor, t.kernelSerial, t.dispatchPolicyTag = 128, 256, 1, 0, 7
-    t.stages, t.wavesM, t.wavesN, t.swizzleOffset = (9 if grouped_kernel else 8), 2, 4, raster
+    t.stages, t.build, t.wavesM, t.wavesN, t.swizzleOffset = 3, (9 if grouped_kernel else 8), 2, 4, raster
     return t
 
 

@@ -33,7 +33,7 @@ def _tiling(dga, m, n, k, image, splitk=1, raster=4, groups=1):
     t = dga.tiling(m, n, k, groups=groups) if groups > 1 else dga.tiling(m, n, k)
     t.m1, t.n1, t.splitkFactor, t.kernelSerial = 128, 256, splitk, (4 if splitk > 1 else 0)
     t.dispatchPolicyTag = 7
-    t.stages = {0: 3, 1: 4, 8: 5, 4: 6}[image]   # (stage counts no tile build has name the image builds)
+    t.stages, t.build = 3, {0: 0, 1: 4, 8: 5, 4: 6}[image]   # (include/dga_hip.h DGA_BUILD_BX_AIMAGE / _IMAGE8 / _IMAGE4)
     t.swizzleOffset = raster
     t.wavesM, t.wavesN = 2, 4
     return t

@@ -2,8 +2,8 @@
 the raster, the LDS ring runs across tile boundaries) against the one-tile build of the same tile: the same arithmetic in the same order,
 so the bar is BIT IDENTITY; against the oracle it is the policy's bar (tests/test_bf16_exact_gpu.py).  Counterpart in the reference:
 its device loop walks the tiles of a core's section with double-buffered L1 across them
-(/root/reference/deep_gemm_ascend/framework/csrc/jit/generate_code.hpp:160-198).  tiling.stages = 7 names the persistent form, 8 the
-one-tile build (3 = the dispatcher's rule: persistent on every raster of more than one round)."""
+(/root/reference/deep_gemm_ascend/framework/csrc/jit/generate_code.hpp:160-198).  tiling.build = 7 (DGA_BUILD_BX_PERSISTENT) names the persistent form, 8 (_ONE_TILE)
+the one-tile build (0 = the dispatcher's rule: persistent on every raster of more than one round)."""
 import numpy as np
 import pytest
 import torch
@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def _tiling(dga, m, n, k, persistent, groups=1, raster=4):
     t = dga.tiling(m, n, k, groups=groups, policy="bf16_exact") if groups > 1 else dga.tiling(m, n, k, policy="bf16_exact")
     t.m1, t.n1, t.splitkFactor, t.kernelSerial, t.dispatchPolicyTag = 128, 256, 1, 0, 7
-    t.stages, t.wavesM, t.wavesN, t.swizzleOffset = (7 if persistent else 8), 2, 4, raster
+    t.stages, t.build, t.wavesM, t.wavesN, t.swizzleOffset = 3, (7 if persistent else 8), 2, 4, raster
     return t
 
 

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 def _tiling(dga, m, n, k, tail):
     t = dga.tiling(m, n, k, policy="bf16_exact")
     t.m1, t.n1, t.splitkFactor, t.dispatchPolicyTag, t.wavesM, t.wavesN = 128, 256, 1, 7, 0, 0
-    t.kernelSerial, t.stages = (5, 3) if tail else (0, 8)
+    t.kernelSerial, t.stages, t.build = (5, 3, 0) if tail else (0, 3, 8)
     return t
 
 

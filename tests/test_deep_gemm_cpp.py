@@ -18,7 +18,7 @@ def test_module_exports_the_reference_names(ext):
                  "gemm_fp8_fp8_bf16_nt", "m_grouped_gemm_fp8_fp8_bf16_nt_masked", "m_grouped_gemm_fp8_fp8_bf16_nt_contiguous",
                  "per_token_cast_to_fp8", "per_block_cast_to_fp8", "get_m_alignment_for_contiguous_layout"):
         assert callable(getattr(ext, name)), name
-    assert ext.abi_version() == 6 and ext.get_m_alignment_for_contiguous_layout() == 128
+    assert ext.abi_version() == 7 and ext.get_m_alignment_for_contiguous_layout() == 128
 
 
 def test_cpu_tensors_are_refused(ext):

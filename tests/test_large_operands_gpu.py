@@ -33,14 +33,15 @@ def test_fp8_beyond_2_and_4_gb(dga, m, n, k):
 @pytest.mark.parametrize("m,stages,policy", [(8, 3, "fast"), (8, 1, "fast"), (24, 3, "fast"), (8, 3, "bf16_exact")])
 def test_fp8_workgroup_split_k_beyond_2_gb_by_name(dga, m, stages, policy):
     """kernelSerial 6 NAMED on a weight matrix past 2^31 bytes (the selector keeps it to N <= 65536): the pass-by-pass and the
-    continuous-ring builds (stages 3; the register build with stages 1) rebase the B descriptor at every pass's first row, so 32-bit
+    continuous-ring builds (the register build with build = 1, DGA_BUILD_WSK_REGISTER) rebase the B descriptor at every pass's first row, so 32-bit
     offsets never leave a pass -- the last rows of the matrix are the ones that would be wrong."""
     from deepgemm_ascend_amd.harness import sweep
     n, k = 140000, 16384
     a, sfa, b, sfb, golden, s_abs = sweep.gen_data(m, n, k)
     assert b.numel() > (1 << 31)
     t = dga.tiling(m, n, k, policy="bf16_exact" if policy == "bf16_exact" else None)
-    t.kernelSerial, t.m1, t.n1, t.splitkFactor, t.stages, t.wavesM, t.wavesN = 6, 16 if m <= 16 else 32, 128, 1, stages, 0, 0
+    t.kernelSerial, t.m1, t.n1, t.splitkFactor, t.stages, t.wavesM, t.wavesN = 6, 16 if m <= 16 else 32, 128, 1, 3, 0, 0
+    t.build = 1 if stages == 1 else 0
     assert dga.tiling_check(t) == 0
     out = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device="cuda")
     dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, tiling_=t, sync=True)

@@ -108,7 +108,10 @@ def test_tiling_cache_csv_roundtrip(dga, tmp_path):
         dga.tiling_cache_open(str(path))
         assert dga.tiling_cache_size() == 2
         t = dga.tiling(512, 512, 512)                       # hit: values come from the file
-        assert (t.m1, t.n1, t.k1, t.kernelSerial, t.blockDim) == (128, 256, 256, 0, 24)
+        # (k1: the reference's L1 k tile; the kernels here step one 128-wide scale block whatever it says -- the cached row is
+        #  normalised onto the menu so that dga_tiling_check accepts what dga_tiling returns)
+        assert (t.m1, t.n1, t.k1, t.kernelSerial, t.blockDim) == (128, 256, 128, 0, 24)
+        assert dga.tiling_check(t) == 0
         t = dga.tiling(1024, 1024, 1024)
         assert (t.m1, t.n1, t.kernelSerial, t.paddingTagA) == (256, 256, 1, 1)
         t3 = dga.tiling(2048, 2048, 2048)                   # miss: computed, appended
@@ -133,7 +136,7 @@ def test_tiling_cache_creates_header_for_new_file(dga, tmp_path):
         dga.tiling_cache_open(str(path))
         # the reference's eleven columns (csv.cpp:23-26) first, the CDNA4 columns behind them
         assert path.read_text() == ("m,n,k,m1,n1,k1,kernelSerial,paddingTagA,paddingTagB,paddingTagC,blockDim,"
-                                    "splitkFactor,stages,swizzleOffset,wavesM,wavesN,dispatchPolicyTag,groups,contiguous\n")
+                                    "splitkFactor,stages,swizzleOffset,wavesM,wavesN,dispatchPolicyTag,groups,contiguous,build\n")
         dga.tiling(256, 256, 256)
         assert len(path.read_text().strip().splitlines()) == 2
     finally:
@@ -350,7 +353,12 @@ def test_bf16_exact_policy_has_its_own_tiling(dga):
     assert dga.tiling(48, 18432, 7168, policy="bf16_exact").m1 in (32, 64) and dga.tiling(32, 18432, 7168, policy="bf16_exact").kernelSerial != 6
     g = dga.tiling(128, 2048, 7168, groups=256, expected_m=128, policy="bf16_exact")
     f = dga.tiling(128, 2048, 7168, groups=256, expected_m=128)
-    assert g.dispatchPolicyTag == dga.api.POLICY_BF16_EXACT and (g.m1, g.n1) == (f.m1, f.n1)
-    assert (g.wavesM, g.wavesN) != (2, 2) and g.stages == 3   # (2 x 2 waves / two stages would name the policy's slower image builds)
+    assert g.dispatchPolicyTag == dga.api.POLICY_BF16_EXACT and (g.m1, g.n1) == (f.m1, f.n1) == (128, 256)
+    assert (g.wavesM, g.wavesN) != (2, 2) and g.stages == 3 and g.build == 9   # the masked grouped layout's own kernel (DGA_BUILD_BX_GROUPED)
+    for hint in (4, 16, 64):   # ... whatever the hint says: the kernel skips the rows that do not exist itself
+        h = dga.tiling(128, 2048, 7168, groups=256, expected_m=hint, policy="bf16_exact")
+        assert (h.m1, h.n1, h.build) == (128, 256, 9)
+    small = dga.tiling(64, 2048, 7168, groups=256, expected_m=16, policy="bf16_exact")   # experts of at most 64 rows keep the fast tiling's tile
+    assert small.build == 0 and small.m1 <= 64
     assert dga.tiling(4096, 4096, 4096).dispatchPolicyTag != dga.api.POLICY_BF16_EXACT      # the cache entry is the fast path's
     assert dga.tiling(4096, 4096, 4096, policy="strict").dispatchPolicyTag == dga.api.POLICY_STRICT

@@ -39,7 +39,8 @@ def test_fields_outside_the_menu_are_refused():
     assert (base.m1, base.n1) == (256, 256) and dga.tiling_check(base) == OK
     for field, bad in (("kernelSerial", 3), ("kernelSerial", 8), ("kernelSerial", 255), ("dispatchPolicyTag", 8), ("dispatchPolicyTag", 32),
                        ("dispatchPolicyTag", 0x80 | 2), ("k1", 64), ("k1", 256), ("m1", 0), ("n1", 0), ("m1", 512), ("m1", 48), ("n1", 64),
-                       ("stages", 1), ("stages", 4), ("stages", 9), ("wavesM", 3), ("wavesN", 7)):
+                       ("stages", 1), ("stages", 4), ("stages", 9), ("wavesM", 3), ("wavesN", 7),
+                       ("build", 1), ("build", 2), ("build", 4), ("build", 7), ("build", 9), ("build", 255), ("reserved0", 1)):
         t = _copy(base)
         setattr(t, field, bad)
         assert dga.tiling_check(t) == E_TILING, (field, bad)
@@ -48,7 +49,7 @@ def test_fields_outside_the_menu_are_refused():
     t = _copy(base); t.splitkFactor = 1024
     assert dga.tiling_check(t) == OK
     # what a field MAY hold beside the selector's pick
-    for field, good in (("stages", 0), ("stages", 3), ("wavesM", 0), ("dispatchPolicyTag", 0), ("dispatchPolicyTag", 1), ("dispatchPolicyTag", 2 | 16),
+    for field, good in (("stages", 0), ("stages", 3), ("build", 0), ("wavesM", 0), ("dispatchPolicyTag", 0), ("dispatchPolicyTag", 1), ("dispatchPolicyTag", 2 | 16),
                         ("dispatchPolicyTag", 6), ("kernelSerial", 5), ("kernelSerial", 7), ("k1", 0)):
         t = _copy(base)
         setattr(t, field, good)
@@ -62,20 +63,27 @@ def test_fields_outside_the_menu_are_refused():
         if (t.m1, t.n1) != (256, 256):
             setattr(t, field, v)
             assert dga.tiling_check(t) == E_TILING
-    # stages = 1 names the register build of the workgroup split-K and nothing else
-    t = _copy(base); t.stages = 1; t.kernelSerial = 6
+    # build = 1 (DGA_BUILD_WSK_REGISTER) names the register build of the workgroup split-K and nothing else; `stages` is a stage count again
+    t = _copy(base); t.build = 1; t.kernelSerial = 6
     assert dga.tiling_check(t) == OK
-    # the bf16-exact policy's build names: 4 .. 8; strict takes anything
+    t = _copy(base); t.stages = 1; t.kernelSerial = 6
+    assert dga.tiling_check(t) == E_TILING
+    # the bf16-exact policy's build names (include/dga_hip.h DGA_BUILD_BX_*): 4 .. 9; strict takes anything
     bx = dga.tiling(4096, 4096, 4096, policy="bf16_exact")
-    for st, want in ((0, OK), (2, OK), (3, OK), (4, OK), (5, OK), (6, OK), (7, OK), (8, OK), (1, E_TILING), (9, E_TILING), (200, E_TILING)):
+    for b, want in ((0, OK), (4, OK), (5, OK), (6, OK), (7, OK), (8, OK), (9, OK), (1, E_TILING), (2, E_TILING), (3, E_TILING), (10, E_TILING), (200, E_TILING)):
+        t = _copy(bx); t.build = b
+        assert dga.tiling_check(t) == want, b
+    for st, want in ((0, OK), (2, OK), (3, OK), (1, E_TILING), (4, E_TILING), (7, E_TILING), (9, E_TILING), (200, E_TILING)):
         t = _copy(bx); t.stages = st
         assert dga.tiling_check(t) == want, st
+    t = _copy(bx); t.build = 1; t.kernelSerial = 6
+    assert dga.tiling_check(t) == OK
     # ... its quarter-tile tail (kernelSerial 5) exists for the 128 x 256 tile only, the one-launch Stream-K (7) not at all
     assert (bx.m1, bx.n1) == (128, 256)
     for ks, m1, n1, want in ((5, 128, 256, OK), (5, 64, 256, E_TILING), (5, 128, 128, E_TILING), (5, 32, 128, E_TILING), (7, 128, 256, E_TILING)):
         t = _copy(bx); t.kernelSerial, t.m1, t.n1 = ks, m1, n1
         assert dga.tiling_check(t) == want, (ks, m1, n1)
-    t = _copy(base); t.dispatchPolicyTag = 3; t.m1 = 7; t.n1 = 9; t.stages = 77; t.wavesM = 5
+    t = _copy(base); t.dispatchPolicyTag = 3; t.m1 = 7; t.n1 = 9; t.stages = 77; t.wavesM = 5; t.build = 33
     assert dga.tiling_check(t) == OK
 
 
@@ -106,7 +114,9 @@ def test_fuzzed_structs_are_either_in_the_menu_or_refused():
         t.n1 = rng.choice([0, 64, 128, 192, 256, 512])
         t.k1 = rng.choice([0, 128, 128, 128, 64, 256])
         t.wavesM = rng.choice([0, 0, 1, 2, 3, 4, 8]); t.wavesN = rng.choice([0, 0, 1, 2, 4, 8])
-        t.stages = rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 255])
+        t.stages = rng.choice([0, 0, 1, 2, 2, 3, 3, 4, 7, 9, 255])
+        t.build = rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 255])
+        t.reserved0 = rng.choice([0, 0, 0, 0, 0, 0, 0, 1, 255])
         t.splitkFactor = rng.choice([0, 1, 2, 4, 8, 56, 1024, 1025, 65535])
         rc = dga.tiling_check(t)
         assert rc in (OK, E_TILING, E_RANGE) and rc == dga.tiling_check(t)
@@ -114,9 +124,43 @@ def test_fuzzed_structs_are_either_in_the_menu_or_refused():
             accepted += 1
             tag = t.dispatchPolicyTag & 7
             assert t.kernelSerial in (0, 1, 2, 4, 5, 6, 7) and t.k1 in (0, 128) and t.splitkFactor <= 1024 and not (t.dispatchPolicyTag & ~23)
+            assert t.reserved0 == 0
+            if tag != 3:
+                assert t.stages in (0, 2, 3) and (t.build != 1 or t.kernelSerial == 6)
             if tag not in (3, 7):
-                assert (t.m1, t.n1) in FAST_TILES and t.stages in (0, 2, 3) or (t.stages == 1 and t.kernelSerial == 6)
+                assert (t.m1, t.n1) in FAST_TILES and t.build in (0, 1)
+            if tag == 7:
+                assert t.build in (0, 1, 4, 5, 6, 7, 8, 9)
     assert 0 < accepted < 20000
+
+
+REFERENCE_ROWS = ("m,n,k,m1,n1,k1,kernelSerial,paddingTagA,paddingTagB,paddingTagC,blockDim\n"
+                  "512,512,512,128,256,256,0,0,0,0,24\n"          # the reference's own fixture rows (csv_test.cpp:33-35): k1 = 256
+                  "1024,1024,1024,256,256,256,1,1,0,0,24\n"
+                  "2048,2048,2048,128,256,512,3,1,1,0,24\n"       # kernel type 3 (PaddingStreamK): no build of that name here
+                  "4096,4096,4096,256,128,1024,4,0,0,0,24\n"
+                  "300,520,1024,128,128,256,0,0,0,0,15\n")
+
+
+def test_tilings_from_a_reference_format_cache_pass_the_check(tmp_path):
+    """With a reference-format CSV open (cache.cpp:22-101), what dga_tiling and dga_tiling_bf16_exact hand back for a cached shape is
+    a tiling the launchers accept: k1 and kernel types the menu lacks are normalised on the way out of the cache, not refused at the
+    launch (they were, for every cached shape)."""
+    path = tmp_path / "ref.csv"
+    path.write_text(REFERENCE_ROWS)
+    try:
+        dga.tiling_cache_open(str(path))
+        assert dga.tiling_cache_size() == 5
+        for m, n, k in ((512, 512, 512), (1024, 1024, 1024), (2048, 2048, 2048), (4096, 4096, 4096), (300, 520, 1024)):
+            for pol in (None, "bf16_exact", "strict"):
+                t = dga.tiling(m, n, k, policy=pol)
+                assert dga.tiling_check(t) == OK, (m, n, k, pol, t.as_dict())
+                assert t.k1 in (0, 128) and t.kernelSerial in (0, 1, 2, 4, 5, 6, 7)
+        t = dga.tiling(512, 512, 512)
+        assert (t.m1, t.n1, t.blockDim) == (128, 256, 24)      # the tile is still the file's
+    finally:
+        dga.tiling_cache_open(None)
+        dga.tiling_cache_clear()
 
 
 def test_null_is_an_error_not_a_crash():

@@ -1,6 +1,6 @@
 """The one-launch workgroup split-K kernel for short-M problems (csrc/gemm_fp8_wsk_kernel.hpp, kernelSerial 6): the 8 waves of a
 workgroup are the 8 K slices of one output tile, partial tiles combined in LDS.  Two builds: fragments streamed global ->
-registers (M <= 64; a tiling with stages = 1 names it), and -- M <= 32, the default there -- operands staged through per-wave
+registers (M <= 64; a tiling with build = 1, DGA_BUILD_WSK_REGISTER, names it), and -- M <= 32, the default there -- operands staged through per-wave
 LDS-DMA rings (whole-line requests, hand-counted vmcnt).
 
 Reference counterparts: the Stream-K kernel's fused reduce
@@ -33,7 +33,7 @@ def _run(dga, a, sfa, b, sfb, wsk, split=8, policy=None):
     t = dga.tiling(m, n, k)
     if wsk:
         t.kernelSerial, t.splitkFactor = 6, 1
-        t.stages = 1 if wsk == "reg" else 3
+        t.stages, t.build = 3, (1 if wsk == "reg" else 0)
     else:
         t.kernelSerial, t.splitkFactor = 4, split
         t.m1, t.n1, t.stages, t.wavesM, t.wavesN, t.dispatchPolicyTag = 64, 128, 3, 1, 4, 0
