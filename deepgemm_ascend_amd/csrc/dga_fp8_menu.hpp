@@ -96,6 +96,12 @@ int launch_bf16u(int bm, int bn, const GemmParams &p, hipStream_t stream);
 // full tiles, fp32 partial tiles through the caller's workspace.  DGA_E_TILING: not a problem it takes
 int launch_streamk(const GemmParams &p, void *ws, size_t ws_bytes, bool ue8m0, hipStream_t stream);
 size_t streamk_workspace_bytes();
+// ... and of the bf16-exact policy's persistent 128 x 256 kernel (gemm_fp8_bf16x_streamk_kernel.hpp; dga_launch_menu_m.hip): any dense
+// raster with a partial last round.  DGA_E_TILING: not a launch it takes (nothing to cut, no workspace, co-residency not guaranteed)
+int launch_bf16x_streamk(const GemmParams &p, void *ws, size_t ws_bytes, hipStream_t stream);
+size_t bx_streamk_workspace_bytes();
+// workgroups a launch on this stream can count on being resident together, one per CU; 0 when a CU mask narrows the queue
+int coresident_workgroups(hipStream_t stream);
 
 // persistent continuous-pipeline build of the 256x256 tile (gemm_fp8_cont_persistent_kernel.hpp, dispatchPolicyTag 6): dense
 // rasters of full tiles only -- launch_cont_persistent returns DGA_E_TILING for anything else

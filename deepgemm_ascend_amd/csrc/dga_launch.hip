@@ -180,8 +180,8 @@ static int check_tiling(const dga_tiling_t &t)
             case DGA_BUILD_BX_PERSISTENT: case DGA_BUILD_BX_ONE_TILE: case DGA_BUILD_BX_GROUPED: break;
             default: return DGA_E_TILING;
         }
-        if (t.kernelSerial == DGA_KERNEL_STREAMK_ONE_LAUNCH) return DGA_E_TILING;           // fast path only
-        if (t.kernelSerial == DGA_KERNEL_STREAMK_TAIL && !(t.m1 >= 128 && t.n1 >= 256)) return DGA_E_TILING;   // the 128 x 256 tile's tail
+        // the quarter-tile tail and the one-launch Stream-K are builds of the 128 x 256 tile
+        if ((t.kernelSerial == DGA_KERNEL_STREAMK_TAIL || t.kernelSerial == DGA_KERNEL_STREAMK_ONE_LAUNCH) && !(t.m1 >= 128 && t.n1 >= 256)) return DGA_E_TILING;
         return DGA_OK;
     }
     bool tile = false, grid = false;
@@ -557,11 +557,23 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
         // overrides.
         static const int bxp_env = [] { const char *e = std::getenv("DGA_BF16X_PERSIST"); return e ? std::atoi(e) : -1; }();
         const int64_t tiles = static_cast<int64_t>(p.groups) * p.tiles_m * p.tiles_n, cus = static_cast<int64_t>(device_cus());
+        // Stream-K in one launch (kernelSerial 7 under this policy; gemm_fp8_bf16x_streamk_kernel.hpp): whole rounds as the persistent kernel
+        // runs them, the last partial round cut along K with fp32 partial tiles through the workspace.  What it does not take (no partial
+        // round, no workspace, a CU mask) runs the builds below.
+        if (tiling->kernelSerial == DGA_KERNEL_STREAMK_ONE_LAUNCH && vx->bm == 128 && vx->bn == 256 && !clock_stamps && groups == 1 &&
+            !masked_m && !m_indices && !ix) {
+            const size_t need = bx_streamk_workspace_bytes();
+            if (uint8_t *sk_ws = carve(need)) {
+                const int rc = launch_bf16x_streamk(p, sk_ws, need, stream);
+                if (rc != DGA_E_TILING) return rc;
+            }
+        }
         // the masked grouped layout's own kernel (gemm_fp8_bf16x_grouped_kernel.hpp; same bits): two k blocks of the ring in flight and
         // the loop unrolled for the m-tiles that hold rows.  tiling.build = DGA_BUILD_BX_GROUPED names it (dga_tiling_bf16_exact does), $DGA_BX_GROUPED = 0 / 1 overrides.
         static const int bxg_env = [] { const char *e = std::getenv("DGA_BX_GROUPED"); return e ? std::atoi(e) : -1; }();
-        if (vx->bm == 128 && vx->bn == 256 && !clock_stamps && masked_m && !m_indices && !ix &&
-            (bxg_env >= 0 ? bxg_env != 0 : tiling->build == DGA_BUILD_BX_GROUPED)) {
+        // (a dense raster runs it too when the tiling names it: the loop is the same, every tile has all its rows)
+        if (vx->bm == 128 && vx->bn == 256 && !clock_stamps && !m_indices && !ix &&
+            (bxg_env >= 0 ? (bxg_env != 0 && masked_m) : tiling->build == DGA_BUILD_BX_GROUPED)) {
             const int rc = launch_bf16x_grouped(p, stream);
             if (rc != DGA_E_TILING) return rc;
         }

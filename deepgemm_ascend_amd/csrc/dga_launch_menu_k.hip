@@ -7,7 +7,7 @@
 #include "gemm_fp8_streamk_kernel.hpp"
 namespace dga {
 
-size_t streamk_workspace_bytes() { return static_cast<size_t>(device_cus()) * (256 * 256 * 4) + 4096; }
+size_t streamk_workspace_bytes() { return static_cast<size_t>(device_cus()) * (256 * 256 * 4 + 8) + 256; }
 
 template <int MATH>
 static int launch_streamk_one(const GemmParams &p, const StreamKArgs &sk, unsigned grid, hipStream_t stream)
@@ -34,11 +34,13 @@ int launch_streamk(const GemmParams &p, void *ws, size_t ws_bytes, bool ue8m0, h
 {
     if (p.groups != 1 || p.masked_m || p.m_indices || p.row_index || p.splitk > 1 || p.tail_sub || p.stamps || p.launch_tiles) return DGA_E_TILING;
     if ((p.m % 256) || (p.n % 256) || (p.k % 128) || p.kb_n < 2) return DGA_E_TILING;
-    const int64_t cus = device_cus();
-    // one workgroup per CU (they wait for one another's partial tiles: all of them must fit the device at once)
-    const int64_t grid = cus;
-    if (!ws || ws_bytes < static_cast<size_t>(grid) * (256 * 256 * 4) + static_cast<size_t>(grid) * 8) return DGA_E_WORKSPACE;
-    if (reinterpret_cast<uintptr_t>(ws) & 15) return DGA_E_ALIGN;
+    // one workgroup per CU (they wait for one another's partial tiles: all of them must be resident at once -- where a CU mask narrows
+    // the queue that cannot be promised, and the caller runs the tile kernel: dga_launch_menu_m.hip coresident_workgroups)
+    const int64_t grid = coresident_workgroups(stream);
+    if (grid <= 0) return DGA_E_TILING;
+    // (a workspace that is missing, short or misaligned: the tile kernel too -- the documented fall-back, not an error)
+    if (!ws || ws_bytes < static_cast<size_t>(grid) * (256 * 256 * 4) + static_cast<size_t>(grid) * 8) return DGA_E_TILING;
+    if (reinterpret_cast<uintptr_t>(ws) & 15) return DGA_E_TILING;
     StreamKArgs sk;
     sk.partials = static_cast<float *>(ws);
     sk.flags = reinterpret_cast<unsigned long long *>(sk.partials + static_cast<size_t>(grid) * (256 * 256));

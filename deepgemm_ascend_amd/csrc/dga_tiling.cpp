@@ -1113,6 +1113,17 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out)
     out->stages = 3; out->wavesM = 0; out->wavesN = 0;
     const uint64_t tiles = static_cast<uint64_t>((out->m + bm - 1) / bm) * ((out->n + bn - 1) / bn);
     out->blockDim = static_cast<uint32_t>(tiles * sk);
+    if (bm == 128 && bn == 256 && sk == 1 && tiles >= 2 * static_cast<uint64_t>(cus) && tiles % cus > 0 && kb >= 4) {
+        // Rasters of at least two rounds with a partial last one: Stream-K in one launch (kernelSerial 7, gemm_fp8_bf16x_streamk_kernel.hpp)
+        // -- the whole rounds as the persistent kernel runs them, the last round cut along K.  3511 x 6151 x 8191 (2.73 rounds) 380 ->
+        // 368 us, 1024 x 18432 x 7168 (2.25 rounds) 233 (the launch pair below) -> 227; below two rounds the cut does not pay: at 1.125
+        // rounds it ties the pair, at 1.75 and at 0.78 it LOSES 2-6 % (with every CU busy on two k fronts a k block takes 2.0 us
+        // instead of 1.8, and 200 adding workgroups read their partials in one burst at the end: profiles/r06_bx_streamk.txt), at
+        // half a round the 128 x 128 tiles are 4 % ahead.  The reference's rule: more blocks than cores with a remainder below 0.8 of
+        // the cores and k > 3072 (op_host/op_tiling/select_kernel.cpp:303-331).
+        out->kernelSerial = DGA_KERNEL_STREAMK_ONE_LAUNCH;
+        out->blockDim = cus;
+    } else
     if (bm == 128 && bn == 256 && sk == 1 && tiles > cus && tiles % cus > 0 && (tiles % cus) * 2 <= cus) {
         // the cost above counted the last partial round in quarter tiles: name that launch pair (1024 x 18432 x 7168, 2.25 rounds:
         // 276 -> 241 us; 2304 x 4096 x 7168, 1.125 rounds, 168 on 128 x 128 tiles -> 139; same bytes as the single launch)
@@ -1159,7 +1170,8 @@ size_t dga_workspace_bytes(const dga_tiling_t *tiling)
     }
     if (tiling->splitkFactor > 1) add(static_cast<size_t>(tiling->splitkFactor) * tiling->m * tiling->n * 4);
     // Stream-K proper: one fp32 partial tile (256 x 256) per CU + the flags
-    if (tiling->kernelSerial == DGA_KERNEL_STREAMK_ONE_LAUNCH) add(static_cast<size_t>(dga::device_cus()) * (256 * 256 * 4) + 4096);
+    // (one slot per CU: 256 x 256 floats on the fast path, 128 x 256 under the bf16-exact policy; + the flags)
+    if (tiling->kernelSerial == DGA_KERNEL_STREAMK_ONE_LAUNCH) add(static_cast<size_t>(dga::device_cus()) * (256 * 256 * 4 + 8) + 256);
     return bytes ? bytes + 256 : 0;
 }
 

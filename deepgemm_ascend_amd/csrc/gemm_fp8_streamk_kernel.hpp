@@ -15,7 +15,8 @@
 // partials (/root/reference/aclnn_catlass_dynamic_matmul/op_kernel/kernel/padding_streamk_matmul_kernel.h:94-98; selection rule
 // op_host/op_tiling/select_kernel.cpp:303-331: more blocks than cores, a remainder below 0.8 of the cores, k > 3072).
 //
-// Waiting is safe whatever subset of the workgroups is resident: a flag is raised before its workgroup waits for anything.
+// A flag is raised before its workgroup waits for anything, but the wait itself holds a CU: every workgroup must be RESIDENT at
+// once (one per CU; where a CU mask narrows the queue the launcher does not launch this kernel: dga_launch_menu_m.hip).
 // A flag is "raised" when it holds this launch's 64-bit epoch value, so nothing has to be zeroed in front of an ordinary launch; a
 // launch that is being captured into a graph (replays repeat the epoch) has its flags zeroed by a memset node instead (launcher).
 // Restrictions (launcher): dense, M and N multiples of 256, K of 128, at least 2 k blocks per part.

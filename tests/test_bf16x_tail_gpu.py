@@ -62,5 +62,7 @@ def test_tail_on_another_tile_is_refused(dga):
     t.m1, t.n1 = 64, 128
     assert dga.tiling_check(t) != 0
     t = _tiling(dga, 2304, 4096, 256, True)
-    t.kernelSerial = 7
+    t.kernelSerial = 7          # (the one-launch Stream-K is a build of the 128 x 256 tile too since round 6: tests/test_bf16x_streamk_gpu.py)
+    assert dga.tiling_check(t) == 0
+    t.m1, t.n1 = 128, 128
     assert dga.tiling_check(t) != 0

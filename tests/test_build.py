@@ -84,3 +84,25 @@ def test_no_kernel_spills_or_scratch(unit, min_kernels, tile_kernel):
                 unit != "dga_launch_menu_j.hip":
             assert int(m.group(1)) == 0, f"{name}: MFMA results in AGPRs (a v_accvgpr_read per promoted value in the main loop)"
     assert seen >= min_kernels, seen
+
+
+def test_the_rccl_host_compiles_and_links():
+    """tests/host/sharded_host_rccl.cpp -- INTEGRATION.md section 6 with its RCCL callback (ncclGroupStart / ncclSend / ncclRecv per peer /
+    ncclGroupEnd on the stream the executor names, ncclCommInitRank per process) -- compiles against rccl.h and links against
+    librccl.so and the in-tree libdga_hip.so on this box; running it needs two GPUs (tests/test_sharded_host_rccl_gpu.py)."""
+    lib = ROOT / "deepgemm_ascend_amd" / "libdga_hip.so"
+    ora = ROOT / "oracle" / "libdga_oracle.so"
+    if not lib.exists() or not ora.exists():
+        pytest.skip("libdga_hip.so / libdga_oracle.so not built")
+    out = ROOT / "build" / "host" / "sharded_host_rccl"
+    out.parent.mkdir(parents=True, exist_ok=True)
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-x", "hip", f"-I{ROOT / 'include'}", "-I/opt/rocm/include",
+           str(ROOT / "tests" / "host" / "sharded_host_rccl.cpp"), "-o", str(out), f"-L{lib.parent}", "-ldga_hip", f"-L{ora.parent}", "-ldga_oracle",
+           "-L/opt/rocm/lib", "-lrccl", "-lpthread", f"-Wl,-rpath,{lib.parent}", f"-Wl,-rpath,{ora.parent}", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    syms = subprocess.run(["nm", "-D", "--undefined-only", str(out)], capture_output=True, text=True, timeout=60).stdout
+    for name in ("ncclCommInitRank", "ncclGetUniqueId", "ncclGroupStart", "ncclSend", "ncclRecv", "ncclGroupEnd", "dga_sharded_forward", "dga_sharded_layout"):
+        assert re.search(rf"\bU {name}\b", syms), f"{name} is not a dynamic import of the host program"
+    needed = subprocess.run(["readelf", "-d", str(out)], capture_output=True, text=True, timeout=60).stdout
+    assert "librccl.so" in needed and "libdga_hip.so" in needed

@@ -21,7 +21,8 @@ def _build(oracle):
     ora = ROOT / "oracle" / "libdga_oracle.so"
     assert lib.exists(), "libdga_hip.so is not built (python -c 'import __graft_entry__ as g; g.build()')"
     oracle.build()
-    if OUT.exists() and OUT.stat().st_mtime >= max(SRC.stat().st_mtime, lib.stat().st_mtime):
+    hdr = SRC.with_name("sharded_host_common.hpp")
+    if OUT.exists() and OUT.stat().st_mtime >= max(SRC.stat().st_mtime, hdr.stat().st_mtime, lib.stat().st_mtime):
         return
     OUT.parent.mkdir(parents=True, exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-x", "hip", f"-I{ROOT / 'include'}", str(SRC),

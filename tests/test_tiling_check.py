@@ -78,9 +78,10 @@ def test_fields_outside_the_menu_are_refused():
         assert dga.tiling_check(t) == want, st
     t = _copy(bx); t.build = 1; t.kernelSerial = 6
     assert dga.tiling_check(t) == OK
-    # ... its quarter-tile tail (kernelSerial 5) exists for the 128 x 256 tile only, the one-launch Stream-K (7) not at all
+    # ... its quarter-tile tail (kernelSerial 5) and its one-launch Stream-K (7) exist for the 128 x 256 tile only
     assert (bx.m1, bx.n1) == (128, 256)
-    for ks, m1, n1, want in ((5, 128, 256, OK), (5, 64, 256, E_TILING), (5, 128, 128, E_TILING), (5, 32, 128, E_TILING), (7, 128, 256, E_TILING)):
+    for ks, m1, n1, want in ((5, 128, 256, OK), (5, 64, 256, E_TILING), (5, 128, 128, E_TILING), (5, 32, 128, E_TILING), (7, 128, 256, OK),
+                             (7, 128, 128, E_TILING), (7, 64, 256, E_TILING)):
         t = _copy(bx); t.kernelSerial, t.m1, t.n1 = ks, m1, n1
         assert dga.tiling_check(t) == want, (ks, m1, n1)
     t = _copy(base); t.dispatchPolicyTag = 3; t.m1 = 7; t.n1 = 9; t.stages = 77; t.wavesM = 5; t.build = 33
@@ -88,16 +89,21 @@ def test_fields_outside_the_menu_are_refused():
 
 
 def test_the_bf16_exact_selector_names_its_quarter_tile_tail():
-    """Rasters of 128 x 256 tiles that leave a last round of at most half the CUs: the policy's own tiling names the launch pair
-    (kernelSerial 5, blockDim = whole rounds + 4 quarter tiles per tail tile); whole rounds and long tails stay single launches."""
-    for (m, n, k), tail in (((1024, 18432, 7168), 64), ((2304, 4096, 7168), 32), ((5120, 5120, 5120), 32), ((2560, 4096, 4096), 64)):
+    """Rasters of 128 x 256 tiles between one and two rounds that leave a last round of at most half the CUs: the policy's own tiling
+    names the launch pair (kernelSerial 5, blockDim = whole rounds + 4 quarter tiles per tail tile); from two rounds on a partial last
+    round is cut by the one-launch Stream-K (kernelSerial 7, one workgroup per CU); whole rounds stay single launches."""
+    for (m, n, k), tail in (((2304, 4096, 7168), 32), ((2560, 4096, 4096), 64)):
         t = dga.tiling(m, n, k, policy="bf16_exact")
         tiles = -(-m // 128) * -(-n // 256)
         assert (t.m1, t.n1, t.kernelSerial, t.splitkFactor) == (128, 256, 5, 1) and tiles % 256 == tail, (m, n, k, t.as_dict())
         assert t.blockDim == tiles - tail + 4 * tail and dga.tiling_check(t) == OK
+    for (m, n, k) in ((1024, 18432, 7168), (5120, 5120, 5120), (3511, 6151, 8191)):
+        t = dga.tiling(m, n, k, policy="bf16_exact")
+        assert (t.m1, t.n1, t.kernelSerial, t.splitkFactor, t.blockDim) == (128, 256, 7, 1, 256), (m, n, k, t.as_dict())
+        assert dga.tiling_check(t) == OK
     for (m, n, k) in ((4096, 4096, 4096), (8192, 8192, 8192), (4096, 2048, 7168), (1279, 5120, 7680)):
         t = dga.tiling(m, n, k, policy="bf16_exact")
-        assert t.kernelSerial != 5, (m, n, k, t.as_dict())
+        assert t.kernelSerial not in (5, 7), (m, n, k, t.as_dict())
 
 
 def test_fuzzed_structs_are_either_in_the_menu_or_refused():
