@@ -178,6 +178,7 @@ SIGNATURES = {
     "dga_sharded_events_destroy": (c_int, [c_int, POINTER(c_void_p)]),
     "dga_mfma_ceiling": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, POINTER(c_float)]),
     "dga_tiling_check": (c_int, [POINTER(Tiling)]),
+    "dga_default_policy": (c_int, [ctypes.c_char_p, c_int]),
     "dga_status_string": (c_char_p, [c_int]),
     "dga_last_hip_error": (c_int, []),
     "dga_abi_version": (c_int, []),

@@ -145,7 +145,31 @@ POLICY_BF16_EXACT = 7
 ARITHMETIC_POLICIES = {"fast": None, "bf16_exact": POLICY_BF16_EXACT, "strict": POLICY_STRICT, "auto": None, "fast_ue8m0": None,
                        "bf16_exact_ue8m0": POLICY_BF16_EXACT | 16}
 POLICY_UE8M0_SCALES = 16      # DGA_POLICY_UE8M0_SCALES: a flag beside the fast-path schedules
-_DEFAULT_POLICY = os.environ.get("DGA_DEFAULT_POLICY") or "bf16_exact"
+
+
+def default_policy() -> str:
+    """$DGA_DEFAULT_POLICY as the C library parsed and validated it (dga_default_policy: once per process, the same answer for every
+    front end); a value that names no policy raises instead of silently changing the arithmetic."""
+    buf = ctypes.create_string_buffer(32)
+    rc = _lib.lib().dga_default_policy(buf, 32)
+    if rc:
+        _fail(f"$DGA_DEFAULT_POLICY={os.environ.get('DGA_DEFAULT_POLICY')!r} names no arithmetic policy (one of {sorted(ARITHMETIC_POLICIES)})")
+    return buf.value.decode()
+
+
+class _DefaultPolicy:
+    """Lazy `_DEFAULT_POLICY` (the library need not be loaded at import time): str(...) / == compare against the parsed name."""
+    def __str__(self):
+        return default_policy()
+
+    def __eq__(self, other):
+        return default_policy() == other
+
+    def __hash__(self):
+        return hash(default_policy())
+
+
+_DEFAULT_POLICY = _DefaultPolicy()
 
 
 def _with_policy(t: Tiling, strict: bool, policy: Optional[str] = None) -> Tiling:
@@ -198,7 +222,7 @@ def _planned(index: int, m: int, n: int, k: int, groups: int, expected_m: int, c
     """tiling(...) + the arithmetic policy's tag, remembered per problem: the C side's (m,n,k) cache answers the same question, but
     through two ctypes calls and a struct copy per GEMM.  Dropped whenever the cache file, the cache or the predictor changes."""
     if policy is None and not strict:
-        policy = _DEFAULT_POLICY
+        policy = default_policy()
     key = (index, m, n, k, groups, expected_m, contiguous, strict, policy)
     t = _PLANS.get(key)
     if t is None:
@@ -646,7 +670,7 @@ def m_grouped_gemm_fp8_fp8_bf16_nt_contiguous(lhs, rhs, out: torch.Tensor, m_ind
     with _device_guard(a, b, sfa, sfb, out, m_indices):
         if tiling_ is None:   # (the C side buckets Msum in its cache key and re-derives the workgroup count per call: not memoised here)
             if policy is None and not strict:
-                policy = _DEFAULT_POLICY       # no tiling, no policy: the operator's default arithmetic, as in the other entries
+                policy = default_policy()      # no tiling, no policy: the operator's default arithmetic, as in the other entries
             _require(policy != "auto" or not strict, "strict=True contradicts policy='auto'")
             policy = "fast" if policy == "auto" else policy
             tiling_ = tiling(msum, n, k, groups=g, contiguous=True, policy="bf16_exact" if policy in ("bf16_exact", "bf16_exact_ue8m0") else None)

@@ -119,13 +119,17 @@ static const Bf16xVariant *find_bf16x_variant(int m1, int n1)
     return nullptr;
 }
 
+// $DGA_DEFAULT_POLICY, parsed once: 0 fast, 1 bf16_exact, 2 strict, 3 fast_ue8m0, 4 bf16_exact_ue8m0, 5 auto; -1 = a value that is none
+// of these (every front end refuses it: dga_default_policy)
+static const char *const kPolicyNames[] = {"fast", "bf16_exact", "strict", "fast_ue8m0", "bf16_exact_ue8m0", "auto"};
 int default_policy()
 {
     static const int v = [] {
         const char *e = std::getenv("DGA_DEFAULT_POLICY");
-        if (e && !std::strcmp(e, "fast")) return 0;
-        if (e && !std::strcmp(e, "strict")) return 2;
-        return 1;
+        if (!e || !*e) return 1;
+        for (int i = 0; i < 6; ++i)
+            if (!std::strcmp(e, kPolicyNames[i])) return i;
+        return -1;
     }();
     return v;
 }
@@ -239,9 +243,15 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
         // instruction: twice the rate, product bits ~13 below each octet's largest dropped) or "strict".  $DGA_BF16_EXACT=1
         // (older switch) still forces the bf16-exact pick.
         const int default_policy = dga::default_policy();
+        if (default_policy < 0) return DGA_E_RANGE;      // $DGA_DEFAULT_POLICY names no policy: refused, not guessed
         static const int bf16x_auto = [] { const char *e = std::getenv("DGA_BF16_EXACT"); return e ? std::atoi(e) : 0; }();
-        int rc = (bf16x_auto || default_policy == 1) ? dga_tiling_bf16_exact(&pr, &local) : dga_tiling(&pr, &local);
+        int rc = (bf16x_auto || default_policy == 1 || default_policy == 4) ? dga_tiling_bf16_exact(&pr, &local) : dga_tiling(&pr, &local);
+        if (rc == DGA_OK && default_policy == 5 && groups == 1 && !m_indices) {   // "auto": bf16-exact where the decode kernel carries it
+            dga_tiling_t tb;
+            if (dga_tiling_bf16_exact(&pr, &tb) == DGA_OK && tb.kernelSerial == DGA_KERNEL_SPLITK_WORKGROUP) local = tb;
+        }
         if (rc == DGA_OK && default_policy == 2) local.dispatchPolicyTag = DGA_POLICY_STRICT;
+        if (rc == DGA_OK && (default_policy == 3 || default_policy == 4)) local.dispatchPolicyTag |= DGA_POLICY_UE8M0_SCALES;
         if (rc != DGA_OK) return rc;
         tiling = &local;
     }
@@ -663,6 +673,17 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
 }  // namespace dga
 
 extern "C" {
+
+int dga_default_policy(char *name_out, int cap)
+{
+    const int v = dga::default_policy();
+    if (v < 0) return DGA_E_RANGE;
+    if (name_out && cap > 0) {
+        std::strncpy(name_out, dga::kPolicyNames[v], static_cast<size_t>(cap) - 1);
+        name_out[cap - 1] = 0;
+    }
+    return DGA_OK;
+}
 
 int dga_tiling_check(const dga_tiling_t *tiling)
 {

@@ -229,10 +229,19 @@ int dga_sharded_forward(const dga_sharded_shape_t *shape, const dga_sharded_buff
         pr.dtype = DGA_DT_FP8_E4M3FN;
         // policy -1 = the library's default arithmetic ($DGA_DEFAULT_POLICY: bf16-exact unless told otherwise), -2 = the fast
         // policy's own tiling as it is; the bf16-exact policy picks its own tile (height from expected_m)
+        // (-3 = the fast policy's tiling with DGA_POLICY_UE8M0_SCALES: the caller's promise of power-of-two scales)
         const int dp = dga::default_policy();
-        const int pol = shape->policy == -1 ? (dp == 1 ? DGA_POLICY_BF16_EXACT : (dp == 2 ? DGA_POLICY_STRICT : -2)) : shape->policy;
-        if (int rc = pol == DGA_POLICY_BF16_EXACT ? dga_tiling_bf16_exact(&pr, &tiling) : dga_tiling(&pr, &tiling)) return rc;
+        if (shape->policy == -1 && dp < 0) return DGA_E_RANGE;     // $DGA_DEFAULT_POLICY names no policy
+        int pol = shape->policy;
+        if (pol == -1) {
+            static const int of_default[] = {-2, DGA_POLICY_BF16_EXACT, DGA_POLICY_STRICT, -3, DGA_POLICY_BF16_EXACT | DGA_POLICY_UE8M0_SCALES, -2 /* auto: no decode kernel on this layout */};
+            pol = of_default[dp];
+        }
+        if (pol < -3) return DGA_E_RANGE;
+        const bool bx = pol >= 0 && (pol & 15) == DGA_POLICY_BF16_EXACT;
+        if (int rc = bx ? dga_tiling_bf16_exact(&pr, &tiling) : dga_tiling(&pr, &tiling)) return rc;
         if (pol >= 0) tiling.dispatchPolicyTag = static_cast<uint8_t>(pol);
+        else if (pol == -3) tiling.dispatchPolicyTag |= DGA_POLICY_UE8M0_SCALES;
     }
     uint8_t *send = static_cast<uint8_t *>(buf->send), *recv = static_cast<uint8_t *>(buf->recv);
     uint8_t *osend = static_cast<uint8_t *>(buf->osend), *oback = static_cast<uint8_t *>(buf->oback);

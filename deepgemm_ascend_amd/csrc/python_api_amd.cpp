@@ -46,9 +46,11 @@ at::Tensor scratch(const at::Tensor &like, size_t bytes)   // caller-owned works
 int policy_tag(bool strict, const std::string &policy_in)
 {
     std::string policy = policy_in;
-    if (policy.empty() && !strict) {
-        const char *e = std::getenv("DGA_DEFAULT_POLICY");
-        policy = (e && *e) ? e : "bf16_exact";
+    if (policy.empty() && !strict) {   // the library's default, parsed and validated once in the C library (dga_default_policy)
+        char name[32] = {0};
+        TORCH_CHECK(dga_default_policy(name, sizeof name) == DGA_OK, "$DGA_DEFAULT_POLICY names no arithmetic policy");
+        policy = name;
+        TORCH_CHECK(policy != "auto", "$DGA_DEFAULT_POLICY=auto is a policy of the Python API (deepgemm_ascend_amd.api); name one here");
     }
     TORCH_CHECK(policy.empty() || policy == "fast" || policy == "bf16_exact" || policy == "strict" || policy == "fast_ue8m0" ||
                     policy == "bf16_exact_ue8m0",

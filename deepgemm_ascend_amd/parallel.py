@@ -137,7 +137,14 @@ class ExpertShardedGroupedGemm:
         if indexed is None:
             indexed = compute is None and self.device.type == "cuda" and world == 1
         assert not (indexed and compute is not None), "an injected compute takes the packed layout"
-        tag = -2 if self.policy == "fast" else (api.ARITHMETIC_POLICIES.get(self.policy) if self.policy else None)
+        # the C executor's policy word: -1 = the library's default (dga_default_policy), -2 / -3 = the fast policy's own tiling (as it is /
+        # with the power-of-two-scales flag), >= 0 = a dispatchPolicyTag.  "auto" picks per SHAPE between two arithmetics and this layout
+        # has one shape: name the arithmetic.
+        if self.policy is not None and self.policy not in api.ARITHMETIC_POLICIES:
+            raise ValueError(f"policy must be one of {sorted(api.ARITHMETIC_POLICIES)}")
+        if self.policy == "auto":
+            raise ValueError("policy='auto' has no meaning for the expert-sharded forward: name 'bf16_exact', 'fast', ...")
+        tag = {"fast": -2, "fast_ue8m0": -3}.get(self.policy, api.ARITHMETIC_POLICIES.get(self.policy) if self.policy else None)
         self.shape = _lib.ShardedShape(world, rank, groups_total, m_max, n, k, int(chunks or 0), int(max_tokens or 0),
                                        float(capacity_factor) if capacity_factor is not None else 0.0, 1 if indexed else 0,
                                        -1 if tag is None else int(tag))
@@ -451,7 +458,7 @@ def _kernel_of(eng) -> dict:
     kernel under this name)."""
     try:
         from . import api
-        pol = eng.policy or api._DEFAULT_POLICY
+        pol = eng.policy or api.default_policy()
         t = api.tiling(eng.m_max, eng.n, eng.k, groups=eng.Gl, expected_m=eng.m_max, policy=pol if pol == "bf16_exact" else None)
         name = ("gemm_fp8_bf16x_persistent_kernel / gemm_fp8_blockscaled_nt_kernel<MATH = 1>" if pol == "bf16_exact" else
                 "gemm_fp8_blockscaled_nt_persistent_kernel" if t.dispatchPolicyTag == api.POLICY_PERSISTENT

@@ -204,6 +204,15 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out);
  *     (DGA_BUILD_WSK_REGISTER only with kernelSerial 6); policy 1 and kernelSerial 5 / 7: 256 x 256 only. */
 int dga_tiling_check(const dga_tiling_t *tiling);
 
+/* The arithmetic of an fp8 call that names neither a policy nor a tiling: $DGA_DEFAULT_POLICY, parsed and validated ONCE per process,
+ * here, for every front end (the C entry points with tiling == NULL, deepgemm_ascend_amd/api.py, the deep_gemm_cpp extension).
+ * Names: "bf16_exact" (the default: inside the operator's 2-ULP contract), "fast", "strict", "fast_ue8m0", "bf16_exact_ue8m0" (the
+ * caller's promise of power-of-two scales for every call), "auto" (bf16-exact where the decode kernel carries it, fast elsewhere).
+ * Writes the NUL-terminated name to name_out[cap] (nullable) and returns DGA_OK -- or DGA_E_RANGE for a value that is none of these
+ * (an unset or empty variable is "bf16_exact"): a typo must not silently change the arithmetic; every fp8 entry that needs the default
+ * returns the same error.  No reference counterpart (its one kernel has one arithmetic). */
+int dga_default_policy(char *name_out, int cap);
+
 /* SelectKernel without the cache, on an explicit platform (select_kernel.cpp:333-369).
  * platform == NULL -> MI355X.  With dga_platform_ascend910b() it replays the reference's
  * DoTilingLayout01 + handler chain for parity tests. */
@@ -433,7 +442,7 @@ typedef struct dga_sharded_shape_t {
     int32_t indexed;          /* 1: the GEMM gathers its rows from the receive buffer and scatters results into the buffer that
                                  travels back (no unpack / gather copy); 0: packed masked layout */
     int32_t policy;           /* dispatchPolicyTag of the GEMM (DGA_POLICY_STRICT, DGA_POLICY_BF16_EXACT, ...); -1 = the library's default
-                                 arithmetic ($DGA_DEFAULT_POLICY: bf16-exact unless it says "fast" / "strict"); -2 = the fast policy's
+                                 arithmetic (dga_default_policy); -3 = the fast policy's tiling | DGA_POLICY_UE8M0_SCALES; -2 = the fast policy's
                                  own tiling, schedule included */
 } dga_sharded_shape_t;
 
