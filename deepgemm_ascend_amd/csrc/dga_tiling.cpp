@@ -716,7 +716,10 @@ public:
                     e.stages = 3;
                 }
                 const uint32_t groups = std::max(1u, opt("groups")), contiguous = opt("contiguous") ? 1u : 0u;
-                data_[key_of(get("m"), get("n"), get("k"), groups, contiguous)] = e;
+                // rows timed under the bf16-exact policy (dispatchPolicyTag 7, with or without the power-of-two-scales flag) are a class of
+                // their own: the policy has its own menu, so a shape may hold one row per class and neither shadows the other
+                const uint32_t bx = (e.policy & 15u) == DGA_POLICY_BF16_EXACT ? kBxClass : 0u;
+                data_[key_of(get("m"), get("n"), get("k"), groups, contiguous | bx)] = e;
             }
         }
         in.close();
@@ -743,19 +746,21 @@ public:
     }
     // *swept = the entry carries the CDNA4 columns of a sweep (complete as it stands); *timed_policy = its file also named the
     // dispatchPolicyTag, i.e. the schedule is the one the sweep timed
-    bool get(dga_tiling_t &t, bool *swept, bool *timed_policy)
+    bool get(dga_tiling_t &t, bool *swept, bool *timed_policy, bool bf16_exact_class = false)
     {
         std::lock_guard<std::mutex> lk(mu_);
-        auto it = data_.find(key_of(t.m, t.n, t.k, t.groups, t.contiguous ? 1u : 0u));
+        const uint32_t bx = bf16_exact_class ? kBxClass : 0u;
+        auto it = data_.find(key_of(t.m, t.n, t.k, t.groups, (t.contiguous ? 1u : 0u) | bx));
         bool bucketed = false;
-        if (it == data_.end() && t.groups <= 1 && !t.contiguous && t.m >= 1 && t.m <= 128) {
+        // (fast class only: the bf16-exact policy's rows are exact-shape hits -- its decode rows go to the workgroup split-K by rule)
+        if (it == data_.end() && !bf16_exact_class && t.groups <= 1 && !t.contiguous && t.m >= 1 && t.m <= 128) {
             // a decode batch is any M <= 128 on a handful of (N, K): what a short-M tiling depends on is the tile height that covers M
             // and the (N, K) stream, so a miss falls back to the swept row of the same (N, K) at the next row count of the decode
             // grid (harness/sweep.py --cold over M in {1, 4, 8, 16, 32, 48, 64, 96, 128}: profiles/r04_sweep_decode)
             static constexpr uint32_t kDecodeRows[] = {1, 4, 8, 16, 32, 48, 64, 96, 128};
             for (uint32_t mb : kDecodeRows) {
                 if (mb < t.m) continue;
-                it = data_.find(key_of(mb, t.n, t.k, 1u, 0u));
+                it = data_.find(key_of(mb, t.n, t.k, 1u, bx));
                 if (it != data_.end() && it->second.stages != 0) { bucketed = true; break; }
                 it = data_.end();
             }
@@ -778,7 +783,7 @@ public:
     void put(const dga_tiling_t &t)
     {
         std::lock_guard<std::mutex> lk(mu_);
-        const auto key = key_of(t.m, t.n, t.k, t.groups, t.contiguous ? 1u : 0u);
+        const auto key = key_of(t.m, t.n, t.k, t.groups, (t.contiguous ? 1u : 0u) | ((t.dispatchPolicyTag & 15u) == DGA_POLICY_BF16_EXACT ? kBxClass : 0u));
         if (data_.count(key)) return;
         // the contiguous layout's row count changes from call to call in prefill serving: its tilings are keyed -- in memory
         // and in the file -- by the BUCKETED row count (key_of: a handful of rows per (n, k, groups)), and the map stops
@@ -810,10 +815,11 @@ private:
     static constexpr size_t kMaxEntries = 16384;
     // (m, n, k, groups, contiguous); the contiguous layout's m (total rows) is bucketed to 128 x a power of two: what the
     // tiling depends on is the rows per group against the tile heights, not the exact count
+    static constexpr uint32_t kBxClass = 2u;   // bit 1 of the key's layout word: a row of the bf16-exact policy's menu
     static std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t> key_of(uint32_t m, uint32_t n, uint32_t k, uint32_t groups,
                                                                                uint32_t contiguous)
     {
-        if (contiguous) {
+        if (contiguous & 1u) {
             uint32_t blocks = (m + DGA_CONTIGUOUS_M_ALIGNMENT - 1) / DGA_CONTIGUOUS_M_ALIGNMENT, b = 1;
             while (b < blocks && b < (1u << 24)) b <<= 1;
             m = b * DGA_CONTIGUOUS_M_ALIGNMENT;
@@ -1047,6 +1053,21 @@ int dga_tiling(const dga_problem_t *problem, dga_tiling_t *out)
 // Grouped layouts keep the fast tiling's tile (its height is dictated by the layout).
 int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out)
 {
+    if (!problem || !out) return DGA_E_NULL;
+    {   // The cache first, as the reference's op does on every call (select_kernel.cpp:371-378, cache.cpp:69-100): a row the sweep timed
+        // under THIS policy (dispatchPolicyTag 7 in tuned/mi355x.csv or in the caller's $DGA_CACHE_FILE_PATH; harness/sweep.py --arith
+        // bf16_exact) is what a default call runs, before any cost model
+        init_params(*problem, *out);
+        bool swept = false, timed_policy = false;
+        if (out->m && out->n && Cache::instance().get(*out, &swept, &timed_policy, /*bf16_exact_class*/ true) && out->m1 && out->n1) {
+            if (out->k1 != 0 && out->k1 != 128) out->k1 = 128;
+            if (!out->stages) out->stages = 3;
+            if (!out->splitkFactor) out->splitkFactor = 1;
+            out->wavesM = out->wavesN = 0;      // (this policy's builds are named by tile and `build`)
+            if (!out->blockDim) out->blockDim = std::max<uint32_t>(1, out->groups) * ((out->m + out->m1 - 1) / out->m1) * ((out->n + out->n1 - 1) / out->n1) * out->splitkFactor;
+            return DGA_OK;
+        }
+    }
     int rc = dga_tiling(problem, out);
     if (rc != DGA_OK) return rc;
     out->dispatchPolicyTag = DGA_POLICY_BF16_EXACT;
@@ -1113,14 +1134,18 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out)
     out->stages = 3; out->wavesM = 0; out->wavesN = 0;
     const uint64_t tiles = static_cast<uint64_t>((out->m + bm - 1) / bm) * ((out->n + bn - 1) / bn);
     out->blockDim = static_cast<uint32_t>(tiles * sk);
-    if (bm == 128 && bn == 256 && sk == 1 && tiles >= 2 * static_cast<uint64_t>(cus) && tiles % cus > 0 && kb >= 4) {
+    // (tails per spare workgroup of the cut's second form, as gemm_fp8_bf16x_streamk_kernel.hpp bx_streamk_plan computes it)
+    const uint64_t rem = tiles % cus, spare_t = (rem * 2 > cus) ? (rem + (cus - rem) - 1) / (cus - rem) : 1;
+    if (bm == 128 && bn == 256 && sk == 1 && tiles >= 2 * static_cast<uint64_t>(cus) && rem > 0 && kb >= 48 && spare_t <= 4) {
         // Rasters of at least two rounds with a partial last one: Stream-K in one launch (kernelSerial 7, gemm_fp8_bf16x_streamk_kernel.hpp)
         // -- the whole rounds as the persistent kernel runs them, the last round cut along K.  3511 x 6151 x 8191 (2.73 rounds) 380 ->
         // 368 us, 1024 x 18432 x 7168 (2.25 rounds) 233 (the launch pair below) -> 227; below two rounds the cut does not pay: at 1.125
         // rounds it ties the pair, at 1.75 and at 0.78 it LOSES 2-6 % (with every CU busy on two k fronts a k block takes 2.0 us
         // instead of 1.8, and 200 adding workgroups read their partials in one burst at the end: profiles/r06_bx_streamk.txt), at
-        // half a round the 128 x 128 tiles are 4 % ahead.  The reference's rule: more blocks than cores with a remainder below 0.8 of
-        // the cores and k > 3072 (op_host/op_tiling/select_kernel.cpp:303-331).
+        // half a round the 128 x 128 tiles are 4 % ahead; and the adding pass at the end is a fixed cost, so K has to be deep: at K = 2048 /
+        // 4096 / 5120 the cut LOSES 10 / 8 / 3 % (4096 x 7168 x 2048, 6016 x 4096 x 4096, 5120^3: profiles/r06_bx_regret.txt) -- from
+        // K = 6144 on, and with at most four tails per spare workgroup.  The reference's rule: more blocks than cores with a remainder
+        // below 0.8 of the cores and k > 3072 (op_host/op_tiling/select_kernel.cpp:303-331).
         out->kernelSerial = DGA_KERNEL_STREAMK_ONE_LAUNCH;
         out->blockDim = cus;
     } else

@@ -111,6 +111,52 @@ def candidates(m, n, k, rasters=None):
     return out
 
 
+BX_TILES = [(128, 256), (128, 128), (64, 256), (64, 128), (32, 128)]    # the bf16-exact policy's menu (csrc/dga_launch_menu_e.hip)
+
+
+def bx_raster(m, n, bm, bn, cus=256):
+    """The raster group dga_tiling_bf16_exact gives a tile: the XCD's concurrent patch square in operand rows."""
+    tiles_m = -(-m // bm)
+    tiles = tiles_m * -(-n // bn)
+    wpc = 2 if bm * bn <= 64 * 128 else 1
+    conc = min(max(1, tiles // 8), (cus // 8) * wpc)
+    gm = 1
+    while (gm * 2) * (gm * 2) * bm <= conc * bn and gm * 2 <= tiles_m:
+        gm *= 2
+    return gm
+
+
+def candidates_bx(m, n, k, cus=256):
+    """Candidates of the bf16-exact policy (dispatchPolicyTag 7) for a dense problem: its five tiles x split-K, and for the 128 x 256
+    tile the quarter-tile tail (kernelSerial 5), the one-launch Stream-K (7) and the one-tile build beside the persistent one; the
+    workgroup split-K (6) for decode rows.  The reference's grid under the policy's own constraints
+    (/root/reference/get_best_config/catlass_parameter.py:68-126; driver benchmark.py:47-193)."""
+    kb = -(-k // 128)
+    out = []
+    for bm, bn in BX_TILES:
+        if bm > 32 and bm >= 4 * max(m, 16):      # a tile four times the rows there are
+            continue
+        tiles = -(-m // bm) * -(-n // bn)
+        rr = bx_raster(m, n, bm, bn, cus)
+        splits = [1] + [sk for sk in (2, 3, 4, 6, 8, 16) if kb // sk >= 4 and tiles * sk <= 4 * cus and tiles < cus and sk * m * n * 4 <= (512 << 20)]
+        for sk in splits:
+            out.append({"m1": bm, "n1": bn, "raster": rr, "stages": 3, "splitk": sk, "policy": 7})
+        if (bm, bn) == (128, 256):
+            if tiles > cus:
+                out.append({"m1": bm, "n1": bn, "raster": rr, "stages": 3, "splitk": 1, "policy": 7, "build": 8})     # one tile per workgroup
+                if 0 < tiles % cus <= cus // 2:
+                    out.append({"m1": bm, "n1": bn, "raster": rr, "stages": 3, "splitk": 1, "policy": 7, "tail": 1})
+            if tiles % cus and kb >= 4:
+                out.append({"m1": bm, "n1": bn, "raster": rr, "stages": 3, "splitk": 1, "policy": 7, "streamk": 1})
+    if m <= 32 and k % 16 == 0 and kb >= 8:
+        out.append({"m1": 16 if m <= 16 else 32, "n1": 128, "raster": 1, "stages": 3, "splitk": 1, "policy": 7, "wsk": 2})
+    return out
+
+
+def bx_serial(p):
+    return 6 if p.get("wsk") else (7 if p.get("streamk") else (5 if p.get("tail") else (4 if p["splitk"] > 1 else 0)))
+
+
 # ---- the compiled menu (csrc/dga_launch.hip kVariants) and its constraints -------------------------------------------
 # (bm, bn, wavesM, wavesN, stages, dispatch policies the build exists in)
 MENU = [(256, 256, 4, 2, 2, (0, 1, 2, 6)), (128, 256, 2, 2, 2, (0, 2)), (256, 128, 4, 1, 2, (0, 2)), (128, 128, 2, 2, 2, (0, 2)),
@@ -278,15 +324,16 @@ INFINITY_CACHE = 256 << 20
 
 
 def benchmark_shape(shape, out_dir: Path, rank=0, num_processes=1, iters=10, rasters=None, prewarm_s=0.15, only_policy=None,
-                    cold=False, versus_tuned=False):
+                    cold=False, versus_tuned=False, arith="fast"):
     """cold: time the candidates of a short-M shape on operand sets rotated past the Infinity Cache (SURVEY.md 8(d)'s
     protocol).  Re-launching on one set keeps a decode shape's 20-140 MB of weights in the 256 MiB cache, which favours
     tilings that leave CUs idle (fewer, longer streams): 64x4096x7168 picks 16x128 without split-K warm (16.2 us) and pays
     26.9 us for it cold, where a 4-way split takes 17.6 us either way (scripts/decode_cold_sweep.py)."""
     import deepgemm_ascend_amd as dga
     m, n, k = shape
-    cands = candidates(m, n, k, rasters)
-    if versus_tuned:   # a supplementary sweep of the kernels outside the tile menu against the operator's current pick
+    bx = arith == "bf16_exact"     # the in-contract policy's own menu (candidates_bx), gated on ITS bar, same checkpoint / jsonl protocol
+    cands = candidates_bx(m, n, k) if bx else candidates(m, n, k, rasters)
+    if versus_tuned and not bx:   # a supplementary sweep of the kernels outside the tile menu against the operator's current pick
         t0 = dga.tiling(m, n, k)
         pick = {"m1": int(t0.m1), "n1": int(t0.n1), "raster": int(t0.swizzleOffset), "stages": 1 if t0.build == 1 else int(t0.stages),
                 "splitk": int(t0.splitkFactor), "policy": int(t0.dispatchPolicyTag)}
@@ -301,8 +348,9 @@ def benchmark_shape(shape, out_dir: Path, rank=0, num_processes=1, iters=10, ras
             return None
     per = -(-len(cands) // num_processes)
     lo, hi = rank * per, min(len(cands), (rank + 1) * per)
-    res_path = out_dir / f"shape_{m}_{n}_{k}_rank_{rank}.jsonl"
-    ck_path = out_dir / f"shape_{m}_{n}_{k}_rank_{rank}_checkpoint.jsonl"
+    tagx = "bx_" if bx else ""
+    res_path = out_dir / f"shape_{tagx}{m}_{n}_{k}_rank_{rank}.jsonl"
+    ck_path = out_dir / f"shape_{tagx}{m}_{n}_{k}_rank_{rank}_checkpoint.jsonl"
     last = -1
     if ck_path.exists():
         try:
@@ -314,11 +362,11 @@ def benchmark_shape(shape, out_dir: Path, rank=0, num_processes=1, iters=10, ras
     # clock pre-warm: after the idle gap of the data generation the GPU needs ~100 ms of work to reach its sustained
     # clocks; without it the first candidates of every shape (the 256x256 builds) are timed 10-15 % slow
     import time as _time
-    t_warm = dga.tiling(m, n, k)
+    t_warm = dga.tiling(m, n, k, policy="bf16_exact" if bx else None)
     t0 = _time.perf_counter()
     while _time.perf_counter() - t0 < prewarm_s:
         for _ in range(20):
-            dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, tiling_=t_warm)
+            dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, tiling_=t_warm, policy="bf16_exact" if bx else "fast")
         torch.cuda.synchronize()
     opbytes = m * k + n * k + 2 * m * n
     sets = [(a, sfa, b, sfb, out)]
@@ -336,21 +384,32 @@ def benchmark_shape(shape, out_dir: Path, rank=0, num_processes=1, iters=10, ras
                 f.write(json.dumps(asdict(Result(idx, m, n, k, -1, -1, True, p))) + "\n")
             continue
         ck_path.write_text(json.dumps({"last_process_idx": idx}) + "\n")
-        t = dga.tiling(m, n, k)
+        t = dga.tiling(m, n, k, policy="bf16_exact" if bx else None)
         t.m1, t.n1, t.swizzleOffset = p["m1"], p["n1"], p["raster"]
         t.stages, t.wavesM, t.wavesN, t.dispatchPolicyTag = (3 if p["stages"] == 1 else p["stages"]), 0, 0, p["policy"]
-        t.build = 1 if p.get("wsk") == 1 else 0
-        t.splitkFactor = p["splitk"]; t.kernelSerial = 6 if p.get("wsk") else (5 if p.get("tail") else (4 if p["splitk"] > 1 else 0))
+        t.build = p.get("build", 0) if bx else (1 if p.get("wsk") == 1 else 0)
+        t.splitkFactor = p["splitk"]
+        t.kernelSerial = bx_serial(p) if bx else (6 if p.get("wsk") else (5 if p.get("tail") else (4 if p["splitk"] > 1 else 0)))
+        if dga.tiling_check(t) != 0:     # (a candidate the compiled menu does not hold: recorded, not run)
+            with open(res_path, "a") as f:
+                f.write(json.dumps(asdict(Result(idx, m, n, k, -1, -1, True, dict(p, refused=1)))) + "\n")
+            continue
         def fn():
             c = sets[turn[0] % len(sets)]
             turn[0] += 1
-            dga.gemm_fp8_fp8_bf16_nt((c[0], c[1]), (c[2], c[3]), c[4], tiling_=t)
+            dga.gemm_fp8_fp8_bf16_nt((c[0], c[1]), (c[2], c[3]), c[4], tiling_=t, policy="bf16_exact" if bx else None)
         turn[0] = 0
         fn(); torch.cuda.synchronize()
-        ok, diff = is_correct(golden, out, s_abs, short_k=k < 128)
+        ok, diff = is_correct(golden, out, s_abs, policy="bf16_exact" if bx else "fast", short_k=k < 128)
         n_it = -(-max(iters, 2 * len(sets)) // len(sets)) * len(sets)   # whole turns of the operand sets (a graph replays them in order)
         turn[0] = 0
-        us = time_us(fn, warm=max(3, len(sets)), iters=n_it, device_time=True) if ok else 999999999
+        if ok and bx:   # (behind a clock pre-warm, five replays: the policy's candidates differ by a few per cent)
+            for _ in range(max(3, len(sets))):
+                fn()
+            torch.cuda.synchronize()
+            us = graph_us(fn, n_it, replays=5, prewarm_ms=25.0) or time_us(fn, warm=3, iters=n_it)
+        else:
+            us = time_us(fn, warm=max(3, len(sets)), iters=n_it, device_time=True) if ok else 999999999
         if len(sets) > 1:
             p = dict(p, cold_sets=len(sets))
         with open(res_path, "a") as f:
@@ -431,6 +490,40 @@ def benchmark_grouped(shape, out_dir: Path, iters=10, prewarm_s=0.15):
 
 GROUPED_CSV_HEAD = ("m,n,k,m1,n1,k1,kernelSerial,paddingTagA,paddingTagB,paddingTagC,blockDim,"
                     "splitkFactor,stages,swizzleOffset,wavesM,wavesN,dispatchPolicyTag,groups,contiguous\n")
+FULL_CSV_HEAD = GROUPED_CSV_HEAD.strip() + ",build\n"      # + dga_tiling_t.build (ABI 7)
+
+
+def bx_row(m, n, k, p, cus=256):
+    """The cache row of a bf16-exact winner: dispatchPolicyTag 7 keys it into that policy's class (csrc/dga_tiling.cpp Cache)."""
+    tiles = -(-m // p["m1"]) * -(-n // p["n1"])
+    serial = bx_serial(p)
+    block_dim = tiles * p["splitk"]
+    if serial == 5:
+        block_dim = tiles - tiles % cus + 4 * (tiles % cus)
+    elif serial == 7:
+        block_dim = cus
+    elif serial == 6:
+        block_dim = min(-(-n // 16), cus)
+    return (f"{m},{n},{k},{p['m1']},{p['n1']},128,{serial},0,0,0,{block_dim},{p['splitk']},3,{p['raster']},0,0,7,1,0,{p.get('build', 0)}\n")
+
+
+def write_bx_rows(path, winners):
+    """Append tag-7 rows to a cache CSV that has (or gets) the full header; rows of the same shape and class already there are replaced."""
+    path = Path(path)
+    lines = path.read_text().splitlines(keepends=True) if path.exists() else []
+    if not lines:
+        lines = [FULL_CSV_HEAD]
+    head = lines[0].strip().split(",")
+    if "build" not in head:      # an older file: give every row the column
+        assert head == GROUPED_CSV_HEAD.strip().split(","), "the cache file must carry the CDNA4 and group columns"
+        lines = [FULL_CSV_HEAD] + [ln.rstrip("\n") + ",0\n" for ln in lines[1:] if ln.strip()]
+    keys = {(m, n, k) for (m, n, k), _ in winners}
+    def is_old_bx(ln):
+        c = ln.strip().split(",")
+        return len(c) >= 19 and (int(c[0]), int(c[1]), int(c[2])) in keys and (int(c[16]) & 15) == 7 and int(c[17]) <= 1 and int(c[18]) == 0
+    lines = [lines[0]] + [ln for ln in lines[1:] if ln.strip() and not is_old_bx(ln)]
+    lines += [bx_row(m, n, k, p) for (m, n, k), p in winners]
+    path.write_text("".join(lines))
 
 
 def main(argv=None):
@@ -451,6 +544,9 @@ def main(argv=None):
                     help="time only the operator's current pick and the workgroup split-K builds (a supplementary sweep)")
     ap.add_argument("--cold", action="store_true",
                     help=f"shapes with M <= {COLD_MAX_M}: rotate operand sets past the Infinity Cache (decode weights are never warm)")
+    ap.add_argument("--arith", default="fast", choices=["fast", "bf16_exact"],
+                    help="the arithmetic policy whose menu is swept: the fast path's (dispatchPolicyTag 0-6) or the in-contract "
+                         "bf16-exact policy's (7: the operator's default; winners become tag-7 rows of the cache CSV)")
     ap.add_argument("--grouped", action="store_true",
                     help="sweep the masked / contiguous grouped shapes (GROUPED_SHAPES) instead of the dense list")
     ap.add_argument("--grouped-shapes", nargs="*", default=None,
@@ -486,13 +582,15 @@ def main(argv=None):
     winners = []
     for shape in shapes:
         best = benchmark_shape(shape, out_dir, a.rank, a.num_processes, a.iters, [0] if a.heuristic_raster else None,
-                               a.prewarm_ms / 1e3, a.only_policy, a.cold, a.versus_tuned)
+                               a.prewarm_ms / 1e3, a.only_policy, a.cold, a.versus_tuned, a.arith)
         if best:
             us, p = best
             m, n, k = shape
             print(json.dumps({"shape": shape, "best_us": round(us, 2), "tflops": round(2.0 * m * n * k / us / 1e6, 1), **p}), flush=True)
             winners.append((shape, p))
-    if a.cache_csv and winners:
+    if a.cache_csv and winners and a.arith == "bf16_exact":
+        write_bx_rows(a.cache_csv, winners)
+    elif a.cache_csv and winners:
         new = not Path(a.cache_csv).exists()
         with open(a.cache_csv, "a") as f:
             if new:   # the reference's 11 columns (csv.cpp:23-26) + the CDNA4 columns the cache reads when present

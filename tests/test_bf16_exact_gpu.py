@@ -203,3 +203,27 @@ def test_policy_argument_is_checked(dga):
         dga.gemm_fp8_fp8_bf16_nt((t, sf), (t, sfb), out, policy="exactish")
     with pytest.raises(dga.DGAError):
         dga.gemm_fp8_fp8_bf16_nt((t, sf), (t, sfb), out, strict=True, policy="bf16_exact")
+
+
+def test_a_default_call_runs_the_tag_7_row_of_the_cache(dga, oracle, tmp_path):
+    """A cache row written under this policy (dispatchPolicyTag 7: harness/sweep.py --arith bf16_exact) is the tiling of a call that names
+    neither policy nor tiling -- the reference's op consults its cache first (select_kernel.cpp:371-378) -- and the result holds the bar."""
+    m, n, k = 300, 520, 1024
+    path = tmp_path / "bx.csv"
+    path.write_text("m,n,k,m1,n1,k1,kernelSerial,paddingTagA,paddingTagB,paddingTagC,blockDim,splitkFactor,stages,swizzleOffset,wavesM,wavesN,"
+                    "dispatchPolicyTag,groups,contiguous,build\n"
+                    f"{m},{n},{k},64,256,128,4,0,0,0,30,2,3,1,0,0,7,1,0,0\n")
+    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=21)
+    want = oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, threads=8)
+    try:
+        dga.tiling_cache_open(str(path))
+        dga.api._PLANS.clear()
+        t = dga.api._planned(0, m, n, k, 1, 0, False, False, None)
+        assert (t.m1, t.n1, t.splitkFactor, t.kernelSerial, t.dispatchPolicyTag) == (64, 256, 2, 4, 7)
+        out = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device="cuda")
+        dga.gemm_fp8_fp8_bf16_nt((_dev(a), _dev(sfa)), (_dev(b), _dev(sfb)), out, sync=True)
+        _assert_bar(oracle, _bits(out), want, a, sfa, b, sfb)
+    finally:
+        dga.tiling_cache_open(None)
+        dga.tiling_cache_clear()
+        dga.api._PLANS.clear()

@@ -33,11 +33,15 @@ def test_table_is_well_formed(dga):
     assert len(rows) >= 100
     seen = set()
     for r in rows:
-        key = (r["m"], r["n"], r["k"], r["groups"], r["contiguous"])
+        bx = (int(r["dispatchPolicyTag"]) & 15) == 7    # a row of the bf16-exact policy's menu: a class of its own (one row per shape and class)
+        key = (r["m"], r["n"], r["k"], r["groups"], r["contiguous"], bx)
         assert key not in seen, f"duplicate row {key}"
         seen.add(key)
         assert int(r["m1"]) in (16, 32, 64, 128, 256) and int(r["n1"]) in (128, 256) and int(r["stages"]) in (2, 3)
-        assert int(r["kernelSerial"]) in (0, 1, 4, 5, 6) and int(r["splitkFactor"]) >= 1   # (2, odd K in place, is never tabled)
+        assert int(r["kernelSerial"]) in ((0, 4, 5, 6, 7) if bx else (0, 1, 4, 5, 6)) and int(r["splitkFactor"]) >= 1   # (2, odd K in place, is never tabled)
+        assert int(r["build"]) in ((0, 7, 8) if bx else (0,))
+        if bx:
+            assert (int(r["m1"]), int(r["n1"])) in ((128, 256), (128, 128), (64, 256), (64, 128), (32, 128), (16, 128))
         if int(r["kernelSerial"]) == 6:   # the workgroup split-K on LDS-DMA rings: decode rows only (profiles/r04_sweep_wskd)
             assert int(r["m"]) <= 32 and int(r["stages"]) == 3 and int(r["splitkFactor"]) == 1 and r["groups"] == "1"
 
@@ -59,3 +63,37 @@ def test_no_fallback_beyond_the_grid_or_off_its_shapes(table):
     assert t_sel.m1 in (16, 32, 64) and t_sel.n1 in (128, 256)
     t_big = dga.tiling(129, 18432, 7168)      # M > 128: not a decode row
     assert t_big.m1 >= 128
+
+
+def test_a_row_of_the_bf16_exact_class_is_what_a_default_call_runs(dga, tmp_path):
+    """The operator's default arithmetic consults the cache first (select_kernel.cpp:371-378, cache.cpp:69-100): a row written with
+    dispatchPolicyTag 7 (harness/sweep.py --arith bf16_exact) is the tiling of a default call, before the policy's cost model; the fast
+    class of the same shape keeps its own row; the shipped table carries such rows (profiles/r06_bx_regret.txt)."""
+    from deepgemm_ascend_amd import api
+    path = tmp_path / "bx.csv"
+    path.write_text("m,n,k,m1,n1,k1,kernelSerial,paddingTagA,paddingTagB,paddingTagC,blockDim,splitkFactor,stages,swizzleOffset,wavesM,wavesN,"
+                    "dispatchPolicyTag,groups,contiguous,build\n"
+                    "640,4096,7168,64,256,128,4,0,0,0,320,2,3,2,0,0,7,1,0,0\n"          # a tile + split the cost model does not pick
+                    "640,4096,7168,128,128,128,0,0,0,0,160,1,3,2,2,2,4,1,0,0\n"         # the fast class's row of the same shape
+                    "4096,4096,4096,128,256,128,0,0,0,0,512,1,3,8,0,0,7,1,0,8\n")        # names a build (the one-tile build)
+    try:
+        dga.tiling_cache_open(str(path))
+        assert dga.tiling_cache_size() == 3
+        t = dga.tiling(640, 4096, 7168, policy="bf16_exact")
+        assert (t.m1, t.n1, t.kernelSerial, t.splitkFactor, t.swizzleOffset, t.dispatchPolicyTag, t.build) == (64, 256, 4, 2, 2, 7, 0)
+        assert dga.tiling_check(t) == 0 and t.blockDim == 320
+        f = dga.tiling(640, 4096, 7168)
+        assert (f.m1, f.n1, f.dispatchPolicyTag) == (128, 128, 4)
+        t = dga.tiling(4096, 4096, 4096, policy="bf16_exact")
+        assert (t.m1, t.n1, t.build, t.dispatchPolicyTag) == (128, 256, 8, 7)
+        # what a call without policy and tiling plans (the operator's default = bf16_exact) is the row
+        p = api._planned(0, 640, 4096, 7168, 1, 0, False, False, None)
+        assert (p.m1, p.n1, p.splitkFactor, p.dispatchPolicyTag) == (64, 256, 2, 7)
+        # a shape without a row: the selector, as before
+        s = dga.tiling(768, 4096, 7168, policy="bf16_exact")
+        assert s.dispatchPolicyTag == 7 and dga.tiling_check(s) == 0
+    finally:
+        dga.tiling_cache_open(None)
+        dga.tiling_cache_clear()
+    shipped = [r for r in _rows() if (int(r["dispatchPolicyTag"]) & 15) == 7]
+    assert len(shipped) >= 4
