@@ -5,11 +5,11 @@
 #include "gemm_fp8_bf16x_grouped_kernel.hpp"
 namespace dga {
 
-template <bool KTAIL, bool BNT>
+template <bool KTAIL, bool BNT, bool STAG>
 static int launch_bf16x_grouped_one(const GemmParams &p, hipStream_t stream)
 {
     typedef GemmCfg<128, 256, 2, 4, 3> Cfg;
-    auto kfn = gemm_fp8_bf16x_grouped_kernel<KTAIL, BNT>;
+    auto kfn = gemm_fp8_bf16x_grouped_kernel<KTAIL, BNT, STAG>;
     static std::once_flag once[64];
     static hipError_t attr_err[64];
     int dev = 0;
@@ -34,7 +34,12 @@ int launch_bf16x_grouped(const GemmParams &p, hipStream_t stream)
     const bool nt = p.b_nt != 0;
     GemmParams q = p;
     if (const char *e = std::getenv("DGA_BXG_KNOB")) q.tail_begin = std::atoi(e);   // development knobs (A/B runs in one process)
-    if (p.k % 128) return nt ? launch_bf16x_grouped_one<true, true>(q, stream) : launch_bf16x_grouped_one<true, false>(q, stream);
-    return nt ? launch_bf16x_grouped_one<false, true>(q, stream) : launch_bf16x_grouped_one<false, false>(q, stream);
+    const bool stag = !(q.tail_begin & 2);      // (development knob bit 1: the build without the stagger)
+    if (p.k % 128) {
+        if (stag) return nt ? launch_bf16x_grouped_one<true, true, true>(q, stream) : launch_bf16x_grouped_one<true, false, true>(q, stream);
+        return nt ? launch_bf16x_grouped_one<true, true, false>(q, stream) : launch_bf16x_grouped_one<true, false, false>(q, stream);
+    }
+    if (stag) return nt ? launch_bf16x_grouped_one<false, true, true>(q, stream) : launch_bf16x_grouped_one<false, false, true>(q, stream);
+    return nt ? launch_bf16x_grouped_one<false, true, false>(q, stream) : launch_bf16x_grouped_one<false, false, false>(q, stream);
 }
 }

@@ -23,7 +23,7 @@
 
 namespace dga {
 
-template <bool KTAIL, bool BNT>
+template <bool KTAIL, bool BNT, bool STAGGER = true>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
 {
@@ -204,14 +204,21 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
         }
     };
 
-    // one tile with L m-tiles of this wave's 64 rows present (L = 0: the wave only takes part in the refill and the barriers)
-    auto run_tile = [&](auto Lc, auto lonec) __attribute__((always_inline)) {
+    // one tile with L m-tiles of this wave's 64 rows present (L = 0: the wave only takes part in the refill and the barriers).
+    // STAG: the wave runs HALF A BLOCK behind the barrier -- between two barriers it finishes the previous block (n-tiles 2 and 3:
+    // registers only, no LDS read) and then reads and starts the block the barrier announced.  The two waves of a SIMD then do not
+    // stand in their first-fragment bursts at the same time (the port idles there: profiles/r06_grouped_stamps.txt, head 880 / 2400
+    // ticks), one converts while the other multiplies (MI355X_MICROARCH.md "Two waves per SIMD" item 9: stagger waves 4..7).
+    auto run_tile = [&](auto Lc, auto lonec, auto stagc) __attribute__((always_inline)) {
         constexpr int L = decltype(Lc)::value;
         constexpr bool lone = decltype(lonec)::value;
+        constexpr bool STAG = decltype(stagc)::value;
         constexpr int G = 4 * (L > 0 ? L : 1);       // MFMA gaps per n-tile
         constexpr int TILES = (L > 0 ? L : 1) * TN;
         constexpr int SP = L > 0 ? L : 1;            // gaps between two refill pieces
-        static_assert(1 + (NL - 1) * SP < 4 * TILES, "the refill fits the block");
+        constexpr int HALF = 2 * TILES;              // gaps of n-tiles 0 and 1
+        static_assert(1 + (NL - 1) * SP < HALF, "the refill fits half a block");
+        static_assert(!(STAG && (lone || L == 0)), "a staggered wave multiplies and issues its own pieces");
         if constexpr (L > 0) {
 #pragma unroll
             for (int i = 0; i < L; ++i)
@@ -222,98 +229,148 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
 #pragma unroll
             for (int i = 0; i < L; ++i) s_old[i] = 0.f;    // the first LAGT tiles "promote the previous block": part (= 0) * 0
         }
-        for (int kb = 0; kb < KB; ++kb) {
+        // the block's first fragments out of its stage: A(0), B(0) converted in a burst
+        auto head = [&](const uint8_t *sc) __attribute__((always_inline)) {
+            araw[0][0] = *(const v4i *)(sc + a_off0);
+            araw[0][1] = *(const v4i *)(sc + a_off1);
+            braw[0] = *(const v4i *)(sc + b_off0);
+            braw[1] = *(const v4i *)(sc + b_off1);
+            if constexpr (L > 1) {
+                araw[1][0] = *(const v4i *)(sc + a_off0 + 2048);
+                araw[1][1] = *(const v4i *)(sc + a_off1 + 2048);
+            }
+            const float sfb0 = *(const float *)(sc + sb_off);
+            float sa[L > 0 ? L : 1];
+#pragma unroll
+            for (int i = 0; i < L; ++i) sa[i] = *(const float *)(sc + sa_off + i * 64);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) convert(braw, bfx[0], c);
+            braw[0] = *(const v4i *)(sc + b_off0 + b_frag_off(1));    // B(1), raw
+#pragma unroll
+            for (int c = 8; c < 16; ++c) convert(braw, bfx[0], c);
+            braw[1] = *(const v4i *)(sc + b_off1 + b_frag_off(1));
+#pragma unroll
+            for (int c = 0; c < 16; ++c) convert(araw[0], afx[0], c);
+            if constexpr (L > 2) {
+                araw[0][0] = *(const v4i *)(sc + a_off0 + 2 * 2048);
+                araw[0][1] = *(const v4i *)(sc + a_off1 + 2 * 2048);
+            }
+#pragma unroll
+            for (int i = 0; i < L; ++i) s_cur[i] = sa[i] * sfb0;
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // MFMA gaps [U0, U1) of a block; REFILL: the refill rides on them, one piece per SP gaps from the second gap on.  (Issued in a
+        // burst behind the barrier the 56 pieces of the workgroup queue on the CU's one vector-memory path and every wave's first MFMA
+        // waits for the last of them.)  Gaps of n-tiles 2 and 3 read no LDS.
+        auto gaps = [&](auto u0c, auto u1c, auto refillc, const uint8_t *sc, int fill) __attribute__((always_inline)) {
+            constexpr int U0 = decltype(u0c)::value, U1 = decltype(u1c)::value;
+            constexpr bool REFILL = decltype(refillc)::value;
+#pragma unroll
+            for (int u = U0; u < U1; ++u) {
+                const int t = u >> 2, q = u & 3, nt = t / L, mt = t % L, g = u % G;
+                part[t % RING] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(v8bf, bfx[nt & 1][q]), __builtin_bit_cast(v8bf, afx[mt][q]),
+                    q == 0 ? v4f{0.f, 0.f, 0.f, 0.f} : part[t % RING], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (REFILL && u - U0 >= 1 && (u - U0 - 1) % SP == 0 && (u - U0 - 1) / SP < NL) refill((u - U0 - 1) / SP, fill, kOwn);
+                // A(mt + 1) is converted behind the MFMAs of the first n-tile's m-tile mt; its raw bytes were read a tile earlier
+                if (nt == 0 && mt + 1 < L) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) convert(araw[(mt + 1) & 1], afx[mt + 1], 4 * q + c);
+                    if (q == 3 && mt + 3 < L) {
+                        araw[(mt + 1) & 1][0] = *(const v4i *)(sc + a_off0 + (mt + 3) * 2048);
+                        araw[(mt + 1) & 1][1] = *(const v4i *)(sc + a_off1 + (mt + 3) * 2048);
+                    }
+                }
+                // B(nt + 1) is converted behind the MFMAs of n-tile nt into the other bf16 set; the raw halves are reloaded for
+                // B(nt + 2) as the conversions release them
+                if (nt + 1 < TN) {
+#pragma unroll
+                    for (int c = 16 * g / G; c < 16 * (g + 1) / G; ++c) convert(braw, bfx[(nt + 1) & 1], c);
+                    if (nt + 2 < TN) {
+                        if (g == G / 2 - 1) braw[0] = *(const v4i *)(sc + b_off0 + b_frag_off(nt + 2));
+                        if (g == G - 1) braw[1] = *(const v4i *)(sc + b_off1 + b_frag_off(nt + 2));
+                    }
+                }
+                {   // the promotion of tile t - LAGT (the previous block's last tiles during this block's first ones)
+                    const int j = t >= LAGT ? t - LAGT : TILES + t - LAGT, jn = j / L, jm = j % L;
+                    const float sv = t >= LAGT ? s_cur[jm] : s_old[jm];
+                    acc[jm][jn][q] = __builtin_fmaf(part[j % RING][q], sv, acc[jm][jn][q]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        constexpr std::integral_constant<int, 0> kU0{};
+        constexpr std::integral_constant<int, HALF> kUh{};
+        constexpr std::integral_constant<int, 4 * TILES> kU1{};
+        auto end_of_block = [&]() {
+#pragma unroll
+            for (int i = 0; i < L; ++i) s_old[i] = s_cur[i];
+        };
+        // the top of a block: this wave's pieces of it have landed; everyone's have; and everyone has left the block whose stage is
+        // refilled now.  Returns that stage.
+        auto top = [&](int kb) __attribute__((always_inline)) -> int {
             DGA_STAMP(0);
-            wait_landed(younger, kb < 2 ? stores_pending : 0);     // this wave's pieces of this block have landed
+            wait_landed(younger, kb < 2 ? stores_pending : 0);
             DGA_STAMP(1);
-            __builtin_amdgcn_s_barrier();                 // ... everyone's have; and everyone has left the block whose stage is refilled now
+            __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             DGA_STAMP(2);
             advance_fill();
-            const int fill = cur >= 1 ? cur - 1 : 2;
-            if constexpr (L == 0) {     // (a wave of the second row, in a lone tile)
-#pragma unroll
-                for (int idx = 0; idx < NL; ++idx) {
-                    if (lone) refill(idx, fill, kPartner);
-                    refill(idx, fill, kOwn);
-                }
-                younger = lone ? 2 * NL : NL;
-            } else {
-                younger = lone ? 0 : NL;
-                const uint8_t *sc = smem + cur * Cfg::STAGE_BYTES;
-                // -- the block's first fragments: A(0), B(0) converted in a burst (the refill is issued while their bytes travel)
-                araw[0][0] = *(const v4i *)(sc + a_off0);
-                araw[0][1] = *(const v4i *)(sc + a_off1);
-                braw[0] = *(const v4i *)(sc + b_off0);
-                braw[1] = *(const v4i *)(sc + b_off1);
-                if constexpr (L > 1) {
-                    araw[1][0] = *(const v4i *)(sc + a_off0 + 2048);
-                    araw[1][1] = *(const v4i *)(sc + a_off1 + 2048);
-                }
-                const float sfb0 = *(const float *)(sc + sb_off);
-                float sa[L];
-#pragma unroll
-                for (int i = 0; i < L; ++i) sa[i] = *(const float *)(sc + sa_off + i * 64);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) convert(braw, bfx[0], c);
-                braw[0] = *(const v4i *)(sc + b_off0 + b_frag_off(1));    // B(1), raw
-#pragma unroll
-                for (int c = 8; c < 16; ++c) convert(braw, bfx[0], c);
-                braw[1] = *(const v4i *)(sc + b_off1 + b_frag_off(1));
-#pragma unroll
-                for (int c = 0; c < 16; ++c) convert(araw[0], afx[0], c);
-                if constexpr (L > 2) {
-                    araw[0][0] = *(const v4i *)(sc + a_off0 + 2 * 2048);
-                    araw[0][1] = *(const v4i *)(sc + a_off1 + 2 * 2048);
-                }
-#pragma unroll
-                for (int i = 0; i < L; ++i) s_cur[i] = sa[i] * sfb0;
-                __builtin_amdgcn_sched_barrier(0);
-                DGA_STAMP(3);
-#pragma unroll
-                for (int u = 0; u < 4 * TILES; ++u) {
-                    const int t = u >> 2, q = u & 3, nt = t / L, mt = t % L, g = u % G;
-                    part[t % RING] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(v8bf, bfx[nt & 1][q]), __builtin_bit_cast(v8bf, afx[mt][q]),
-                        q == 0 ? v4f{0.f, 0.f, 0.f, 0.f} : part[t % RING], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    // the refill rides on the MFMA gaps, one piece per SP gaps: issued in a burst behind the barrier the 56 pieces of the
-                    // workgroup queue on the CU's one vector-memory path and every wave's first MFMA waits for the last of them
-                    // (profiles/r06_grouped_stamps.txt: 880 ticks of head per k block against ~270)
-                    if (u >= 1 && (u - 1) % SP == 0 && (u - 1) / SP < NL && !lone) refill((u - 1) / SP, fill, kOwn);
-                    // A(mt + 1) is converted behind the MFMAs of the first n-tile's m-tile mt; its raw bytes were read a tile earlier
-                    if (nt == 0 && mt + 1 < L) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) convert(araw[(mt + 1) & 1], afx[mt + 1], 4 * q + c);
-                        if (q == 3 && mt + 3 < L) {
-                            araw[(mt + 1) & 1][0] = *(const v4i *)(sc + a_off0 + (mt + 3) * 2048);
-                            araw[(mt + 1) & 1][1] = *(const v4i *)(sc + a_off1 + (mt + 3) * 2048);
-                        }
-                    }
-                    // B(nt + 1) is converted behind the MFMAs of n-tile nt into the other bf16 set; the raw halves are reloaded for
-                    // B(nt + 2) as the conversions release them
-                    if (nt + 1 < TN) {
-#pragma unroll
-                        for (int c = 16 * g / G; c < 16 * (g + 1) / G; ++c) convert(braw, bfx[(nt + 1) & 1], c);
-                        if (nt + 2 < TN) {
-                            if (g == G / 2 - 1) braw[0] = *(const v4i *)(sc + b_off0 + b_frag_off(nt + 2));
-                            if (g == G - 1) braw[1] = *(const v4i *)(sc + b_off1 + b_frag_off(nt + 2));
-                        }
-                    }
-                    {   // the promotion of tile t - LAGT (the previous block's last tiles during this block's first ones)
-                        const int j = t >= LAGT ? t - LAGT : TILES + t - LAGT, jn = j / L, jm = j % L;
-                        const float sv = t >= LAGT ? s_cur[jm] : s_old[jm];
-                        acc[jm][jn][q] = __builtin_fmaf(part[j % RING][q], sv, acc[jm][jn][q]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int i = 0; i < L; ++i) s_old[i] = s_cur[i];
-                DGA_STAMP(4);
-            }
+            return cur >= 1 ? cur - 1 : 2;
+        };
+        auto next_block = [&]() {
             ++kbf;
             cur = cur == 2 ? 0 : cur + 1;
+        };
+        if constexpr (STAG) {
+            // block 0: nothing to finish -- the refill in a burst, the head, n-tiles 0 and 1
+            {
+                const int fill = top(0);
+                younger = NL;
+#pragma unroll
+                for (int idx = 0; idx < NL; ++idx) refill(idx, fill, kOwn);
+                const uint8_t *sc = smem + cur * Cfg::STAGE_BYTES;
+                head(sc);
+                gaps(kU0, kUh, std::false_type{}, sc, fill);
+                next_block();
+            }
+            for (int kb = 1; kb < KB; ++kb) {
+                const int fill = top(kb);
+                const uint8_t *sc = smem + cur * Cfg::STAGE_BYTES;
+                gaps(kUh, kU1, std::true_type{}, sc, fill);     // the previous block's n-tiles 2 and 3 (no LDS read), the refill on them
+                end_of_block();
+                head(sc);
+                DGA_STAMP(3);
+                gaps(kU0, kUh, std::false_type{}, sc, fill);
+                DGA_STAMP(4);
+                next_block();
+            }
+            gaps(kUh, kU1, std::false_type{}, smem, 0);         // the last block's second half
+            end_of_block();
+        } else {
+            for (int kb = 0; kb < KB; ++kb) {
+                const int fill = top(kb);
+                if constexpr (L == 0) {     // (a wave of the second row, in a lone tile)
+#pragma unroll
+                    for (int idx = 0; idx < NL; ++idx) {
+                        if (lone) refill(idx, fill, kPartner);
+                        refill(idx, fill, kOwn);
+                    }
+                    younger = lone ? 2 * NL : NL;
+                } else {
+                    younger = lone ? 0 : NL;
+                    const uint8_t *sc = smem + cur * Cfg::STAGE_BYTES;
+                    head(sc);
+                    DGA_STAMP(3);
+                    if constexpr (lone) gaps(kU0, kU1, std::false_type{}, sc, fill);
+                    else gaps(kU0, kU1, std::true_type{}, sc, fill);
+                    end_of_block();
+                    DGA_STAMP(4);
+                }
+                next_block();
+            }
         }
         stores_pending = 0;
         if constexpr (L > 0) {
@@ -374,17 +431,19 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
         constexpr std::true_type yes{};
         constexpr std::false_type no{};
         if (lone) {
-            if (L == 0) run_tile(std::integral_constant<int, 0>{}, yes);
-            else if (L == 1) run_tile(std::integral_constant<int, 1>{}, yes);
-            else if (L == 2) run_tile(std::integral_constant<int, 2>{}, yes);
-            else if (L == 3) run_tile(std::integral_constant<int, 3>{}, yes);
-            else run_tile(std::integral_constant<int, 4>{}, yes);
-        } else {
-            if (L == 0) run_tile(std::integral_constant<int, 0>{}, no);
-            else if (L == 1) run_tile(std::integral_constant<int, 1>{}, no);
-            else if (L == 2) run_tile(std::integral_constant<int, 2>{}, no);
-            else if (L == 3) run_tile(std::integral_constant<int, 3>{}, no);
-            else run_tile(std::integral_constant<int, 4>{}, no);
+            if (L == 0) run_tile(std::integral_constant<int, 0>{}, yes, no);
+            else if (L == 1) run_tile(std::integral_constant<int, 1>{}, yes, no);
+            else if (L == 2) run_tile(std::integral_constant<int, 2>{}, yes, no);
+            else if (L == 3) run_tile(std::integral_constant<int, 3>{}, yes, no);
+            else run_tile(std::integral_constant<int, 4>{}, yes, no);
+        } else if (wm == 0) {                       // both wave rows multiply: the first one has all four m-tiles ...
+            run_tile(std::integral_constant<int, 4>{}, no, no);
+        } else {                                    // ... the second one runs half a block behind it
+            constexpr std::integral_constant<bool, STAGGER> st{};
+            if (L == 1) run_tile(std::integral_constant<int, 1>{}, no, st);
+            else if (L == 2) run_tile(std::integral_constant<int, 2>{}, no, st);
+            else if (L == 3) run_tile(std::integral_constant<int, 3>{}, no, st);
+            else run_tile(std::integral_constant<int, 4>{}, no, st);
         }
         // the tile after this one is the fill tile (the fill moved on during this tile's last two blocks)
         if (!fill_valid) break;
