@@ -32,14 +32,13 @@ int launch_bf16x_grouped(const GemmParams &p, hipStream_t stream)
     // contiguous layout keep the other builds
     if (p.tail_sub || p.m_indices || p.row_index || p.launch_tiles > 0 || p.splitk > 1 || p.kb_n < 2) return DGA_E_TILING;
     const bool nt = p.b_nt != 0;
-    GemmParams q = p;
-    if (const char *e = std::getenv("DGA_BXG_KNOB")) q.tail_begin = std::atoi(e);   // development knobs (A/B runs in one process)
-    const bool stag = !(q.tail_begin & 2);      // (development knob bit 1: the build without the stagger)
-    if (p.k % 128) {
-        if (stag) return nt ? launch_bf16x_grouped_one<true, true, true>(q, stream) : launch_bf16x_grouped_one<true, false, true>(q, stream);
-        return nt ? launch_bf16x_grouped_one<true, true, false>(q, stream) : launch_bf16x_grouped_one<true, false, false>(q, stream);
+#ifdef DGA_BXG_KNOBS      // development builds: $DGA_BXG_KNOB & 2 = the build without the stagger (A/B runs in one process)
+    if (const char *e = std::getenv("DGA_BXG_KNOB"); e && (std::atoi(e) & 2)) {
+        if (p.k % 128) return nt ? launch_bf16x_grouped_one<true, true, false>(p, stream) : launch_bf16x_grouped_one<true, false, false>(p, stream);
+        return nt ? launch_bf16x_grouped_one<false, true, false>(p, stream) : launch_bf16x_grouped_one<false, false, false>(p, stream);
     }
-    if (stag) return nt ? launch_bf16x_grouped_one<false, true, true>(q, stream) : launch_bf16x_grouped_one<false, false, true>(q, stream);
-    return nt ? launch_bf16x_grouped_one<false, true, false>(q, stream) : launch_bf16x_grouped_one<false, false, false>(q, stream);
+#endif
+    if (p.k % 128) return nt ? launch_bf16x_grouped_one<true, true, true>(p, stream) : launch_bf16x_grouped_one<true, false, true>(p, stream);
+    return nt ? launch_bf16x_grouped_one<false, true, true>(p, stream) : launch_bf16x_grouped_one<false, false, true>(p, stream);
 }
 }

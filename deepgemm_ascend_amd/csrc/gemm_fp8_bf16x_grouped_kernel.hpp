@@ -325,6 +325,7 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
             cur = cur == 2 ? 0 : cur + 1;
         };
         if constexpr (STAG) {
+            // (a static priority for this half -- s_setprio 1 around its tile -- measured 2-3 % SLOWER at 80 / 96 rows: not done)
             // block 0: nothing to finish -- the refill in a burst, the head, n-tiles 0 and 1
             {
                 const int fill = top(0);
@@ -427,7 +428,7 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
         // its own MFMA stream (profiles/r06_grouped_stamps.txt), an idle wave pays nothing.  The role holds for a tile (it is a
         // compile-time property of the tile's loop: a branch per MFMA gap costs the loop its registers); the counted wait at the top
         // of a block goes by what THIS wave issued a block ago.
-        const bool lone = T.M - T.m0 <= BM / Cfg::kWM && !(p.tail_begin & 1);   // (tail_begin: development knobs of this kernel, $DGA_BXG_KNOB)
+        const bool lone = T.M - T.m0 <= BM / Cfg::kWM;
         constexpr std::true_type yes{};
         constexpr std::false_type no{};
         if (lone) {
