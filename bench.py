@@ -141,7 +141,7 @@ def make_dense_inputs(m, n, k, seed, ue8m0=False):
     return qa.contiguous(), sa.contiguous().float(), qb.contiguous(), sb.contiguous().float()
 
 
-TRAFFIC_FILES = ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")   # newest first
+TRAFFIC_FILES = ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")   # newest first
 
 
 def pmc_traffic_source():

@@ -44,10 +44,14 @@ def main():
         mean = max(1, rows // G)
         byt = int((masked > 0).sum()) * N * K + rows * (K + 4 * (K // 128) + 2 * N) + G * (N // 128) * (K // 128) * 4
         row = {"rows": rows, "bytes": byt}
-        legs = [("bf16_exact_hint_mean", dict(policy="bf16_exact"), mean, 0), ("bf16_exact_hint_max", dict(policy="bf16_exact"), MMAX, 0),
+        # the default call (the selector names the layout's own kernel, build 9), the persistent kernel it replaced (build 7) and the
+        # tile the round-5 selector took from the hint (32 x 128 / 64 x 256 below 64 expected rows), the fast policy beside them
+        legs = [("bf16_exact", dict(policy="bf16_exact"), mean, 0), ("bf16_exact_build_7_persistent", dict(policy="bf16_exact"), MMAX, 7),
                 ("fast", dict(policy="fast"), mean, 0)]
+        if mean <= 64:
+            legs.insert(2, ("bf16_exact_r05_hint_tile", dict(policy="bf16_exact", tile=(32, 128) if mean <= 32 else (64, 256)), mean, 0))
         if "--base-only" in sys.argv:
-            legs = legs[1:2]
+            legs = legs[:2]
         for st in [int(x) for x in sys.argv[sys.argv.index("--builds") + 1:] if x.isdigit()] if "--builds" in sys.argv else []:
             legs.insert(0, (f"bf16_exact_build_{st}", dict(policy="bf16_exact"), MMAX, st))
         if "--knobs" in sys.argv:   # $DGA_BXG_KNOB values of the grouped kernel, A/B in this process
@@ -61,11 +65,14 @@ def main():
             t = dga.tiling(MMAX, N, K, groups=G, expected_m=hint, policy=kw["policy"])
             if st:
                 t.build = st
+            if "tile" in kw:
+                t.m1, t.n1 = kw["tile"]; t.build = 0
+                t.blockDim = G * -(-MMAX // t.m1) * -(-N // t.n1)
             fn = lambda: dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((a, sfa), (b, sfb), out, masked, hint, tiling_=t)
             fn(); torch.cuda.synchronize()
             us = min(bench._prewarmed_us(fn, 20 if quick else 40, 60.0 if quick else 150.0) for _ in range(2))
-            row[leg] = {"us": round(us, 1), "TBps": round(byt / us / 1e6, 3), "tile": f"{t.m1}x{t.n1}", "stages": int(t.stages),
-                        "serial": int(t.kernelSerial)}
+            row[leg] = {"us": round(us, 1), "TBps": round(byt / us / 1e6, 3), "tile": f"{t.m1}x{t.n1}", "build": int(t.build),
+                        "tok_per_s": round(rows / us * 1e6)}
             print(name, leg, row[leg], flush=True)
         res[name] = row
     print(json.dumps(res))
