@@ -346,7 +346,11 @@ def kernel_name(t, policy):
     if policy == "bf16_exact":
         if int(t.kernelSerial) == 6:
             return "gemm_fp8_wsk_dma_kernel (MATH = 1)"
-        return "gemm_fp8_blockscaled_nt_kernel<..., MATH = 1> (bf16-exact build; persistent form where every CU gets the same tile count)"
+        if int(t.kernelSerial) == 7:
+            return "gemm_fp8_bf16x_streamk_kernel"
+        if int(t.m1) == 128 and int(t.n1) == 256:
+            return "gemm_fp8_bf16x_persistent_kernel (rasters of more than one round; gemm_fp8_blockscaled_nt_kernel<..., MATH = 1> otherwise)"
+        return "gemm_fp8_blockscaled_nt_kernel<..., MATH = 1> (bf16-exact build)"
     if policy == "strict":
         return "gemm_fp8_strict_nt_kernel"
     tag = int(t.dispatchPolicyTag)

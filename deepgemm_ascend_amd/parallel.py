@@ -460,10 +460,11 @@ def _kernel_of(eng) -> dict:
         from . import api
         pol = eng.policy or api.default_policy()
         t = api.tiling(eng.m_max, eng.n, eng.k, groups=eng.Gl, expected_m=eng.m_max, policy=pol if pol == "bf16_exact" else None)
-        name = ("gemm_fp8_bf16x_persistent_kernel / gemm_fp8_blockscaled_nt_kernel<MATH = 1>" if pol == "bf16_exact" else
+        name = (("gemm_fp8_bf16x_grouped_kernel" if int(t.build) == 9 else
+                 "gemm_fp8_bf16x_persistent_kernel / gemm_fp8_blockscaled_nt_kernel<MATH = 1>") if pol == "bf16_exact" else
                 "gemm_fp8_blockscaled_nt_persistent_kernel" if t.dispatchPolicyTag == api.POLICY_PERSISTENT
                 else "gemm_fp8_blockscaled_nt_kernel")
-        return {"kernel": name, "tile": f"{t.m1}x{t.n1}x{t.k1}", "dispatchPolicyTag": int(t.dispatchPolicyTag)}
+        return {"kernel": name, "tile": f"{t.m1}x{t.n1}x{t.k1}", "dispatchPolicyTag": int(t.dispatchPolicyTag), "build": int(t.build)}
     except Exception:
         return {}
 
