@@ -92,12 +92,12 @@ def test_the_bf16_exact_selector_names_its_quarter_tile_tail():
     """Rasters of 128 x 256 tiles between one and two rounds that leave a last round of at most half the CUs: the policy's own tiling
     names the launch pair (kernelSerial 5, blockDim = whole rounds + 4 quarter tiles per tail tile); from two rounds on a partial last
     round is cut by the one-launch Stream-K (kernelSerial 7, one workgroup per CU); whole rounds stay single launches."""
-    for (m, n, k), tail in (((2304, 4096, 7168), 32), ((2560, 4096, 4096), 64)):
+    for (m, n, k), tail in (((2304, 4096, 7168), 32), ((2560, 4096, 4096), 64), ((5120, 5120, 5120), 32)):
         t = dga.tiling(m, n, k, policy="bf16_exact")
         tiles = -(-m // 128) * -(-n // 256)
         assert (t.m1, t.n1, t.kernelSerial, t.splitkFactor) == (128, 256, 5, 1) and tiles % 256 == tail, (m, n, k, t.as_dict())
         assert t.blockDim == tiles - tail + 4 * tail and dga.tiling_check(t) == OK
-    for (m, n, k) in ((1024, 18432, 7168), (5120, 5120, 5120), (3511, 6151, 8191)):
+    for (m, n, k) in ((1024, 18432, 7168), (5119, 6997, 9901), (3511, 6151, 8191)):
         t = dga.tiling(m, n, k, policy="bf16_exact")
         assert (t.m1, t.n1, t.kernelSerial, t.splitkFactor, t.blockDim) == (128, 256, 7, 1, 256), (m, n, k, t.as_dict())
         assert dga.tiling_check(t) == OK
