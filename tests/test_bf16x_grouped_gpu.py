@@ -120,3 +120,36 @@ def test_config4_full_size_random_masks(dga):
                                                   tiling_=_tiling(dga, mmax, n, k, g, grouped_kernel))
         outs.append(out)
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
+def test_fuzzed_layouts_are_bit_identical_to_the_one_tile_build(dga, oracle):
+    """Seeded fuzz over the layout's parameters -- experts 1..300 (rasters below, at and above the CU count), m_max 65..256, N with ragged
+    last tiles, K of 2..12 k blocks with and without a tail, masks of every kind (uniform, mostly empty, mostly full, all zero) -- both
+    kernels byte for byte, rows at or beyond masked_m untouched."""
+    rng = np.random.default_rng(2024)
+    init = _bits(torch.tensor([-7.0], dtype=torch.bfloat16))[0]
+    for case in range(14):
+        g = int(rng.choice([1, 2, 7, 31, 33, 64, 100, 300]))
+        mmax = int(rng.choice([65, 96, 128, 128, 128, 200, 256]))
+        n = int(rng.choice([256, 384, 512, 1024, 1280, 2048]))
+        k = int(rng.choice([256, 384, 512, 640, 1024, 1536])) + int(rng.choice([0, 0, 16, 64]))
+        kind = case % 5
+        if kind == 0:
+            masked = rng.integers(0, mmax + 1, size=g)
+        elif kind == 1:
+            masked = np.where(rng.random(g) < 0.7, 0, rng.integers(0, mmax + 1, size=g))
+        elif kind == 2:
+            masked = np.where(rng.random(g) < 0.7, mmax, rng.integers(0, mmax + 1, size=g))
+        elif kind == 3:
+            masked = rng.integers(0, 20, size=g)
+        else:
+            masked = np.zeros(g, dtype=np.int64) if case % 2 else rng.integers(60, 70, size=g)
+        masked = masked.astype(np.int32)
+        A, SFA, B, SFB = _stack(oracle, min(g, 6), mmax, n, k, seed=1000 + case)
+        reps = -(-g // A.shape[0])
+        A, SFA, B, SFB = (np.concatenate([x] * reps)[:g] for x in (A, SFA, B, SFB))
+        got, ref = _both(dga, A, SFA, B, SFB, masked)
+        what = f"case {case}: g {g} m_max {mmax} n {n} k {k} mask kind {kind}"
+        assert np.array_equal(got, ref), f"{what}: {int((got != ref).sum())} of {got.size} outputs differ"
+        for i in range(g):
+            assert (got[i, int(masked[i]):] == init).all(), f"{what}: rows >= masked_m were written (expert {i})"

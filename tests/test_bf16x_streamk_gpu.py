@@ -122,3 +122,31 @@ def test_the_selector_names_it(dga):
     for m, n, k in ((4096, 4096, 4096), (8192, 8192, 8192), (1024, 4096, 7168), (1279, 5003, 7681), (2304, 4096, 7168), (5120, 5120, 5120),
                     (4096, 7168, 2048)):
         assert dga.tiling(m, n, k, policy="bf16_exact").kernelSerial != 7
+
+
+def test_fuzzed_rasters(dga, oracle):
+    """Seeded fuzz over dense shapes whose rasters fall into every form of the cut (none, s ranges, mains + tails with 1..many tails per
+    spare) with ragged edges and K tails: the policy's bar on sampled rows, every element against the persistent kernel, determinism."""
+    rng = np.random.default_rng(77)
+    for case in range(12):
+        tm, tn = int(rng.integers(1, 30)), int(rng.integers(1, 30))
+        k = 128 * int(rng.integers(2, 14)) + int(rng.choice([0, 0, 16, 80]))
+        m = 128 * tm - int(rng.integers(0, 100)) if tm > 1 else 128 - int(rng.integers(0, 100))
+        n = 256 * tn - int(rng.integers(0, 200)) if tn > 1 else 256 - int(rng.integers(0, 200))
+        a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=500 + case)
+        ta, tsa, tb, tsb = (_dev(x) for x in (a, sfa, b, sfb))
+        t = _tiling(dga, m, n, k)
+        out = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device="cuda")
+        dga.gemm_fp8_fp8_bf16_nt((ta, tsa), (tb, tsb), out, tiling_=t, sync=True)
+        what = f"case {case}: {m} x {n} x {k} ({tm * tn} tiles)"
+        assert not bool(torch.isnan(out.float()).any()), what + ": an output element was never written"
+        ref = torch.empty_like(out)
+        dga.gemm_fp8_fp8_bf16_nt((ta, tsa), (tb, tsb), ref, tiling_=_tiling(dga, m, n, k, streamk=False), sync=True)
+        d = oracle.bf16_ulp_diff(_bits(out), _bits(ref))
+        assert float((d > 0).mean()) < 3e-3 and float((d > 1).mean()) < 3e-4, (what, int(d.max(initial=0)), float((d > 0).mean()))
+        rows = sorted(set(list(range(0, min(m, 24))) + list(range(max(0, m - 24), m))))
+        want = oracle.gemm_fp8_fp8_bf16_nt(a[rows], sfa[rows], b, sfb, threads=8)
+        _assert_bar(oracle, _bits(out)[rows], want, a[rows], sfa[rows], b, sfb)
+        out2 = torch.empty_like(out)
+        dga.gemm_fp8_fp8_bf16_nt((ta, tsa), (tb, tsb), out2, tiling_=t, sync=True)
+        assert torch.equal(out.view(torch.int16), out2.view(torch.int16)), what + ": two launches differ"
