@@ -376,7 +376,9 @@ int dga_select_kernel_with_predictor_ex(const dga_problem_t *problem, dga_tiling
     // outside the candidate space the model was trained on: the quarter-tile tail and the one-launch workgroup split-K (a model that
     // sees the latter as "16 x 128, no split" replaces it with a two-launch split-K: 8 x 1024 x 4096 5.7 -> 8.6 us, 8 x 3072 x 8192
     // 9.6 -> 12.5 cold -- what happened to every decode shape off the tuned table until round 4's third decode sweep showed it)
-    if (out->kernelSerial == DGA_KERNEL_STREAMK_TAIL || out->kernelSerial == DGA_KERNEL_SPLITK_WORKGROUP) return DGA_OK;
+    // (kernels the model has no feature for: the quarter-tile tail, the workgroup split-K, the one-launch Stream-K)
+    if (out->kernelSerial == DGA_KERNEL_STREAMK_TAIL || out->kernelSerial == DGA_KERNEL_SPLITK_WORKGROUP ||
+        out->kernelSerial == DGA_KERNEL_STREAMK_ONE_LAUNCH) return DGA_OK;
     float f[kFeatures];
     const Cand native{out->m1, out->n1, out->stages == 3 ? 3 : 2, std::max<int>(1, out->splitkFactor), out->dispatchPolicyTag};
     feature_row(problem->m, problem->n, problem->k, native, f);

@@ -644,6 +644,19 @@ void select_mi355x(dga_tiling_t &t, const dga_platform_t &pf, uint32_t groups, u
         t.blockDim = std::min<uint32_t>(ceil_div(t.n, 16), pf.coreNum);
         t.ldsBytes = menu_lds_bytes(t);   // (of the 16 x 128 tile a shape the kernel does not take falls back to: what a cache file gives back)
     }
+    // Very deep K on a raster of at most 64 tiles of 256 x 256 (a quarter of the CUs): Stream-K in ONE launch (kernelSerial 7,
+    // gemm_fp8_streamk_kernel.hpp) -- every tile cut into 4..16 k ranges, partials added in k order inside the launch -- instead of the
+    // split-K pair with its fp32 slabs and combine launch: 256 x 4096 x 32768 69.6 -> 54.7 us, 512 x 7168 x 32768 153.9 -> 141.8,
+    // 768 x 4096 x 32768 108.6 -> 105.5, 1024 x 4096 x 32768 131.1 -> 125.4; at K = 16384 / 18432 it is between -8 and +8 % and keeps
+    // the pair (profiles/r05_streamk_class_sweep.txt).  The reference's rule for its Stream-K: select_kernel.cpp:303-331 (k > 3072
+    // and a raster that leaves cores idle).
+    if (groups == 1 && !contiguous && t.k >= 32768 && (t.k % 128) == 0 && (t.m % 256) == 0 && (t.n % 256) == 0 &&
+        static_cast<uint64_t>(t.m / 256) * (t.n / 256) <= 64) {
+        t.m1 = 256; t.n1 = 256; t.k1 = 128; t.wavesM = 4; t.wavesN = 2; t.stages = 2; t.splitkFactor = 1;
+        t.dispatchPolicyTag = DGA_POLICY_CONTINUOUS; t.kernelSerial = DGA_KERNEL_STREAMK_ONE_LAUNCH;
+        t.blockDim = pf.coreNum; t.swizzleOffset = 1;
+        t.ldsBytes = menu_lds_bytes(t);
+    }
 }
 
 // ---- CSV-backed (m,n,k)-keyed cache ---------------------------------------------------------

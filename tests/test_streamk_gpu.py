@@ -101,3 +101,22 @@ def test_shapes_it_does_not_take_run_the_tile_kernel(dga, oracle):
     dga.gemm_fp8_fp8_bf16_nt(tuple(torch.from_numpy(x).cuda() for x in (a, sfa)), tuple(torch.from_numpy(x).cuda() for x in (b, sfb)), out,
                              tiling_=t, sync=True)
     oracle.assert_parity(_bits(out), oracle.gemm_fp8_fp8_bf16_nt(a, sfa, b, sfb, threads=8), a, sfa, b, sfb)
+
+
+def test_the_selector_names_it_for_very_deep_k(dga, oracle):
+    """dga_tiling (fast policy) names the one-launch Stream-K for rasters of at most 64 tiles of 256 x 256 with K >= 32768
+    (profiles/r05_streamk_class_sweep.txt: -2..-21 % there; select_kernel.cpp:303-331 is the reference's rule for its kernel type 4),
+    the learned predictor leaves the pick alone, and a default fast call on such a shape runs it and is right."""
+    for m, n, k in ((256, 4096, 32768), (512, 7168, 32768), (1024, 4096, 32768)):
+        t = dga.tiling(m, n, k, policy="fast")
+        assert (t.m1, t.n1, t.kernelSerial, t.splitkFactor, t.blockDim) == (256, 256, 7, 1, _cus()), (m, n, k, t.as_dict())
+        assert dga.tiling_check(t) == 0
+    for m, n, k in ((256, 4096, 16384), (1024, 7168, 32768), (4096, 4096, 4096), (300, 4096, 32768)):   # shallower K, more tiles, whole rounds, ragged M
+        assert dga.tiling(m, n, k, policy="fast").kernelSerial != 7
+    m, n, k = 256, 1024, 32768
+    a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=11)
+    out = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dga.gemm_fp8_fp8_bf16_nt(tuple(torch.from_numpy(x).cuda() for x in (a, sfa)), tuple(torch.from_numpy(x).cuda() for x in (b, sfb)), out,
+                             policy="fast", sync=True)
+    rows = list(range(0, 32)) + list(range(m - 32, m))
+    oracle.assert_parity(_bits(out)[rows], oracle.gemm_fp8_fp8_bf16_nt(a[rows], sfa[rows], b, sfb, threads=8), a[rows], sfa[rows], b, sfb)
