@@ -1066,6 +1066,10 @@ def compact(res: dict) -> dict:
                 o[side] = _pick(g[side], ("policy", "tok_per_s_gemm_only", "ms_gemm", "frac_of_8TBps"))
         if isinstance(g.get("parity"), dict):
             o["parity"] = {kk: _pick(vv, ("max_ulp", "frac_gt_2ulp")) for kk, vv in g["parity"].items() if isinstance(vv, dict)}
+        # the GEMM alone under SURVEY 8(d)'s second mask, randint(0, m_max + 1): where the rows that do not exist are skipped
+        if isinstance(g.get("random_mask"), dict) and isinstance(g["random_mask"].get("roofline"), dict):
+            o["random_mask"] = {"tok_per_s_gemm_only": g["random_mask"].get("tok_per_s_gemm_only"),
+                                **_pick(g["random_mask"]["roofline"], ("kernel_us", "frac"))}
         if isinstance(g.get("dropped_tokens"), dict):
             o["dropped_tokens"] = g["dropped_tokens"].get("timed_steps")
         c["grouped"] = o
