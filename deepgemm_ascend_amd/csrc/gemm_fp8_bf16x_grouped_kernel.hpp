@@ -15,6 +15,11 @@
 //      one wave overlaps the other wave of its SIMD), so the wait at the top of a block leaves the younger stage's pieces in flight
 //      (counted vmcnt, also across the previous tile's output stores).
 //
+// (Tried on top of (2), not kept: the XCD's L2 as further stages of the ring -- one dword of every 64 bytes of the weight block two or
+//  four blocks ahead of the refill, "loaded" by LDS-DMA into a dump slot, so that the refill would hit the L2.  0..16 rows per expert
+//  544 -> 692 us two blocks ahead, 897 four: 64 separate lines per wave-instruction cost the memory path more than the refill's round
+//  trip did.  profiles/r06_grouped_masks.txt, "L2 prefetch" rows.)
+//
 // Same arithmetic in the same k order as every other build of the policy (four chained v_mfma_f32_16x16x32_bf16 per scale block on
 // exactly converted operands, one fp32 promotion per block): bit-identical outputs (tests/test_bf16x_grouped_gpu.py).  Masked grouped
 // rasters of 128-row experts' tiles with K of at least two k blocks; everything else keeps the other builds.
