@@ -582,7 +582,7 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
         // the loop unrolled for the m-tiles that hold rows.  tiling.build = DGA_BUILD_BX_GROUPED names it (dga_tiling_bf16_exact does), $DGA_BX_GROUPED = 0 / 1 overrides.
         static const int bxg_env = [] { const char *e = std::getenv("DGA_BX_GROUPED"); return e ? std::atoi(e) : -1; }();
         // (a dense raster runs it too when the tiling names it: the loop is the same, every tile has all its rows)
-        if (vx->bm == 128 && vx->bn == 256 && !clock_stamps && !m_indices && !ix &&
+        if (vx->bm == 128 && vx->bn == 256 && !clock_stamps && !m_indices &&
             (bxg_env >= 0 ? (bxg_env != 0 && masked_m) : tiling->build == DGA_BUILD_BX_GROUPED)) {
             const int rc = launch_bf16x_grouped(p, stream);
             if (rc != DGA_E_TILING) return rc;

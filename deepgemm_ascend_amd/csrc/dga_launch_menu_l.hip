@@ -5,11 +5,11 @@
 #include "gemm_fp8_bf16x_grouped_kernel.hpp"
 namespace dga {
 
-template <bool KTAIL, bool BNT, bool STAG>
+template <bool KTAIL, bool BNT, bool STAG, bool IDX = false>
 static int launch_bf16x_grouped_one(const GemmParams &p, hipStream_t stream)
 {
     typedef GemmCfg<128, 256, 2, 4, 3> Cfg;
-    auto kfn = gemm_fp8_bf16x_grouped_kernel<KTAIL, BNT, STAG>;
+    auto kfn = gemm_fp8_bf16x_grouped_kernel<KTAIL, BNT, STAG, IDX>;
     static std::once_flag once[64];
     static hipError_t attr_err[64];
     int dev = 0;
@@ -28,9 +28,9 @@ static int launch_bf16x_grouped_one(const GemmParams &p, hipStream_t stream)
 
 int launch_bf16x_grouped(const GemmParams &p, hipStream_t stream)
 {
-    // whole masked-grouped (or dense) rasters of at least two k blocks; split-K, quarter tiles, part launches, indexed rows and the
-    // contiguous layout keep the other builds
-    if (p.tail_sub || p.m_indices || p.row_index || p.launch_tiles > 0 || p.splitk > 1 || p.kb_n < 2) return DGA_E_TILING;
+    // whole masked-grouped (or dense) rasters of at least two k blocks, packed or indexed rows; split-K, quarter tiles, part launches and
+    // the contiguous layout keep the other builds
+    if (p.tail_sub || p.m_indices || p.launch_tiles > 0 || p.splitk > 1 || p.kb_n < 2) return DGA_E_TILING;
     const bool nt = p.b_nt != 0;
 #ifdef DGA_BXG_KNOBS      // development builds: $DGA_BXG_KNOB & 2 = the build without the stagger (A/B runs in one process)
     if (const char *e = std::getenv("DGA_BXG_KNOB"); e && (std::atoi(e) & 2)) {
@@ -38,6 +38,10 @@ int launch_bf16x_grouped(const GemmParams &p, hipStream_t stream)
         return nt ? launch_bf16x_grouped_one<false, true, false>(p, stream) : launch_bf16x_grouped_one<false, false, false>(p, stream);
     }
 #endif
+    if (p.row_index) {     // indexed rows: the build that finds every row, its scales and its result row through the slot table
+        if (p.k % 128) return nt ? launch_bf16x_grouped_one<true, true, true, true>(p, stream) : launch_bf16x_grouped_one<true, false, true, true>(p, stream);
+        return nt ? launch_bf16x_grouped_one<false, true, true, true>(p, stream) : launch_bf16x_grouped_one<false, false, true, true>(p, stream);
+    }
     if (p.k % 128) return nt ? launch_bf16x_grouped_one<true, true, true>(p, stream) : launch_bf16x_grouped_one<true, false, true>(p, stream);
     return nt ? launch_bf16x_grouped_one<false, true, true>(p, stream) : launch_bf16x_grouped_one<false, false, true>(p, stream);
 }

@@ -22,13 +22,13 @@
 //
 // Same arithmetic in the same k order as every other build of the policy (four chained v_mfma_f32_16x16x32_bf16 per scale block on
 // exactly converted operands, one fp32 promotion per block): bit-identical outputs (tests/test_bf16x_grouped_gpu.py).  Masked grouped
-// rasters of 128-row experts' tiles with K of at least two k blocks; everything else keeps the other builds.
+// rasters, packed or indexed rows, with K of at least two k blocks; everything else keeps the other builds.
 #pragma once
 #include "gemm_fp8_kernel.hpp"
 
 namespace dga {
 
-template <bool KTAIL, bool BNT, bool STAGGER = true>
+template <bool KTAIL, bool BNT, bool STAGGER = true, bool INDEXED = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
 {
@@ -94,9 +94,16 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
     const float *sc_src;
     int kbf = 0;            // the fill tile's next k block
     bool fill_valid = true;
+    // Indexed form (GemmParams::row_index; dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed): row r of expert g is row
+    // row_index[g * m + r] of ONE flat source (group strides 0); its scales and its result row are found the same way.  The index
+    // entries are plain loads where a tile becomes the fill tile / is stored -- the compiler drains the wave's refills in front of
+    // their first use, once per tile, which is why a lone tile's idle waves do not take over their partners' pieces in this form.
+    constexpr bool indexed = INDEXED;     // (a build of its own: as a runtime flag it takes the packed build from 245 to 256 registers)
     auto a_off_of = [&](const Tile &t, int it, int td) -> uint32_t {
         const int row = (it * DNT + td) >> 3;
-        return row < t.M - t.m0 ? (uint32_t)row * (uint32_t)p.lda + a_col : kOutOfRange;   // rows at or beyond M: zero-filled, not fetched
+        if (row >= t.M - t.m0) return kOutOfRange;                                          // rows at or beyond M: zero-filled, not fetched
+        const uint32_t r = indexed ? (uint32_t)p.row_index[(int64_t)t.g * p.m + t.m0 + row] : (uint32_t)row;
+        return r * (uint32_t)p.lda + a_col;
     };
     auto b_off_of = [&](const Tile &t, int it, int td) -> uint32_t {
         const int row = (it * DNT + td) >> 3;
@@ -104,12 +111,14 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
     };
     auto sc_of = [&](const Tile &t, int td) -> const float * {   // slot td: [0, BM) sfa rows of the tile, then its sfb blocks
         const float *SFA = p.sfa + (int64_t)t.g * p.sfa_gs, *SFB = p.sfb + (int64_t)t.g * p.sfb_gs;
-        return td < BM ? SFA + (int64_t)min(t.m0 + td, t.M - 1) * p.sfa_ld
-                       : SFB + (int64_t)min(t.n0 / 128 + min(td - BM, 7), p.nb_n - 1) * p.kb_n;
+        if (td >= BM) return SFB + (int64_t)min(t.n0 / 128 + min(td - BM, 7), p.nb_n - 1) * p.kb_n;
+        const int mr = min(t.m0 + td, t.M - 1);
+        return SFA + (indexed ? p.row_index[(int64_t)t.g * p.m + mr] : (int64_t)mr) * p.sfa_ld;
     };
     Tile T{}, F{};
     auto set_fill = [&](const Tile &t) {
-        a_rsrc = make_rsrc(p.a + (int64_t)t.g * p.a_gs + (int64_t)t.m0 * p.lda, (int64_t)(t.M - t.m0) * p.lda);
+        a_rsrc = indexed ? make_rsrc(p.a, p.a_bytes)
+                         : make_rsrc(p.a + (int64_t)t.g * p.a_gs + (int64_t)t.m0 * p.lda, (int64_t)(t.M - t.m0) * p.lda);
         b_rsrc = make_rsrc(p.b + (int64_t)t.g * p.b_gs + (int64_t)t.n0 * p.ldb, (int64_t)(p.n - t.n0) * p.ldb);
 #pragma unroll
         for (int it = 0; it < Cfg::A_ITERS; ++it) a_voff[it] = a_off_of(t, it, tid);
@@ -397,7 +406,7 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
             for (int mt = 0; mt < L; ++mt) {
                 const int m = m_row + mt * 16;
                 if (m >= T.M) continue;
-                uint16_t *crow = C + (int64_t)m * p.ldc;
+                uint16_t *crow = C + (indexed ? p.row_index[(int64_t)T.g * p.m + m] : (int64_t)m) * p.ldc;
 #pragma unroll
                 for (int j = 0; j < TN / 2; ++j) {
                     const int n = n_base + 32 * j;
@@ -433,7 +442,7 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
         // its own MFMA stream (profiles/r06_grouped_stamps.txt), an idle wave pays nothing.  The role holds for a tile (it is a
         // compile-time property of the tile's loop: a branch per MFMA gap costs the loop its registers); the counted wait at the top
         // of a block goes by what THIS wave issued a block ago.
-        const bool lone = T.M - T.m0 <= BM / Cfg::kWM;
+        const bool lone = T.M - T.m0 <= BM / Cfg::kWM && !indexed;
         constexpr std::true_type yes{};
         constexpr std::false_type no{};
         if (lone) {

@@ -153,3 +153,49 @@ def test_fuzzed_layouts_are_bit_identical_to_the_one_tile_build(dga, oracle):
         assert np.array_equal(got, ref), f"{what}: {int((got != ref).sum())} of {got.size} outputs differ"
         for i in range(g):
             assert (got[i, int(masked[i]):] == init).all(), f"{what}: rows >= masked_m were written (expert {i})"
+
+
+@pytest.mark.parametrize("k", [256, 640 + 16, 7168])
+def test_indexed_rows_equal_the_packed_one_tile_build(dga, oracle, k):
+    """The indexed form (rows, their scales and their result rows found through the slot table, where they lie in one flat payload buffer:
+    dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed) on this kernel against the PACKED call of the one-tile build on the same rows
+    copied into the [G, m_max, K] layout: bit for bit; rows nobody owns stay untouched.  40 experts (320 tiles: workgroups walk two),
+    every m-tile count, scrambled row order."""
+    g, m_max, n = 40, 128, 2048
+    kb = -(-k // 128)
+    row_bytes = -(-(k + 4 * kb + 4) // 16) * 16
+    rng = np.random.default_rng(k)
+    masked = np.resize(ALL_L, g).astype(np.int32)
+    rows = int(masked.sum()) + 7
+    payload = rng.integers(0, 120, size=(rows, row_bytes), dtype=np.uint8)
+    sf = rng.uniform(0.5, 1.5, size=(rows, kb)).astype(np.float32)
+    sf_off = -(-k // 4) * 4
+    payload[:, sf_off:sf_off + 4 * kb] = sf.view(np.uint8)
+    b = rng.integers(0, 120, size=(g, n, k), dtype=np.uint8)
+    sfb = rng.uniform(0.5, 1.5, size=(g, n // 128, kb)).astype(np.float32)
+    perm = rng.permutation(rows)
+    row_index = np.full((g, m_max), -1, np.int64)
+    at = 0
+    for i in range(g):
+        row_index[i, :masked[i]] = perm[at:at + masked[i]]
+        at += masked[i]
+    a_packed = np.zeros((g, m_max, k), np.uint8); sfa_packed = np.ones((g, m_max, kb), np.float32)
+    for i in range(g):
+        a_packed[i, :masked[i]] = payload[row_index[i, :masked[i]], :k]
+        sfa_packed[i, :masked[i]] = sf[row_index[i, :masked[i]]]
+    tb, tsfb, tm = _dev(b), _dev(sfb), _dev(masked)
+    out_packed = torch.zeros((g, m_max, n), dtype=torch.bfloat16, device="cuda")
+    dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked((_dev(a_packed), _dev(sfa_packed)), (tb, tsfb), out_packed, tm, m_max, policy="bf16_exact",
+                                              tiling_=_tiling(dga, m_max, n, k, g, False), sync=True)
+    tp = _dev(payload)
+    out_rows = torch.full((rows, n), -5.0, dtype=torch.bfloat16, device="cuda")
+    t = _tiling(dga, m_max, n, k, g, True)
+    dga.m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed(tp, tp, sf_off, row_bytes // 4, (tb, tsfb), out_rows, _dev(row_index.reshape(-1)),
+                                                      tm, m_max, m_max, policy="bf16_exact", tiling_=t, sync=True)
+    got, want = _bits(out_rows), _bits(out_packed)
+    owned = np.zeros(rows, bool)
+    for i in range(g):
+        idx = row_index[i, :masked[i]]
+        owned[idx] = True
+        assert np.array_equal(got[idx], want[i, :masked[i]]), f"group {i} (masked_m {masked[i]})"
+    assert (got[~owned] == _bits(torch.tensor([-5.0], dtype=torch.bfloat16))[0]).all()
