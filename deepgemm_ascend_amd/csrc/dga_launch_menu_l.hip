@@ -10,19 +10,20 @@ static int launch_bf16x_grouped_one(const GemmParams &p, hipStream_t stream)
 {
     typedef GemmCfg<128, 256, 2, 4, 3> Cfg;
     auto kfn = gemm_fp8_bf16x_grouped_kernel<KTAIL, BNT, STAG, IDX>;
+    constexpr int kLds = Cfg::LDS_BYTES + (IDX ? 256 * 16 : 0);      // the indexed build keeps 16 bytes per thread of waves 4..7 behind the ring
     static std::once_flag once[64];
     static hipError_t attr_err[64];
     int dev = 0;
     if (int rc = record_hip(hipGetDevice(&dev))) return rc;
     if (dev < 0 || dev >= 64) return DGA_E_HIP;
     std::call_once(once[dev], [&] {
-        attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     });
     if (int rc = record_hip(attr_err[dev])) return rc;
     const int64_t tiles = static_cast<int64_t>(p.groups) * p.tiles_m * p.tiles_n;
     if (tiles == 0) return DGA_OK;
     const unsigned grid = static_cast<unsigned>(std::min<int64_t>(tiles, device_cus()));
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(Cfg::NT), kLds, stream, p);
     return record_hip(hipGetLastError());
 }
 

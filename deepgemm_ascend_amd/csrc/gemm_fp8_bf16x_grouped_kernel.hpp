@@ -97,8 +97,12 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
     // Indexed form (GemmParams::row_index; dga_m_grouped_gemm_fp8_fp8_bf16_nt_masked_indexed): row r of expert g is row
     // row_index[g * m + r] of ONE flat source (group strides 0); its scales and its result row are found the same way.  The index
     // entries are plain loads where a tile becomes the fill tile / is stored -- the compiler drains the wave's refills in front of
-    // their first use, once per tile, which is why a lone tile's idle waves do not take over their partners' pieces in this form.
+    // their first use, once per tile; a lone tile's idle waves therefore KEEP their partners' offsets in this form instead of computing
+    // them per piece (that would drain the refill in every block): 16 bytes per thread of waves 4..7 behind the ring in LDS, written
+    // with the fill tile and read back where a piece is issued (in registers they spill the L = 4 loop: 256 + 9).
     constexpr bool indexed = INDEXED;     // (a build of its own: as a runtime flag it takes the packed build from 245 to 256 registers)
+    static_assert(Cfg::A_ITERS == 2, "partner slot: two A offsets and the scale pointer");
+    uint32_t *const pslot = reinterpret_cast<uint32_t *>(smem + Cfg::LDS_BYTES) + (tid & (DNT / 2 - 1)) * 4;
     auto a_off_of = [&](const Tile &t, int it, int td) -> uint32_t {
         const int row = (it * DNT + td) >> 3;
         if (row >= t.M - t.m0) return kOutOfRange;                                          // rows at or beyond M: zero-filled, not fetched
@@ -125,6 +129,12 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
 #pragma unroll
         for (int it = 0; it < Cfg::B_ITERS; ++it) b_voff[it] = b_off_of(t, it, tid);
         sc_src = sc_of(t, tid);
+        if constexpr (INDEXED) {
+            if (wm == 1) {     // (needed while the tile being multiplied is lone, whatever the fill tile is)
+                const uint64_t ps = (uint64_t)(uintptr_t)sc_of(t, tid - DNT / 2);
+                *reinterpret_cast<v4i *>(pslot) = v4i{(int)a_off_of(t, 0, tid - DNT / 2), (int)a_off_of(t, 1, tid - DNT / 2), (int)(uint32_t)ps, (int)(uint32_t)(ps >> 32)};
+            }
+        }
     };
     // piece idx of stage `stage` from the fill tile's k block kbf, for this wave (S = 0) or in its partner's place (S = 1).  No fill
     // tile: every lane out of range -- zeros land, nothing is fetched; the scale piece re-reads a block of the last tile
@@ -134,7 +144,7 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
         const uint32_t sa = lds0 + stage * Cfg::STAGE_BYTES + w * 1024;
         const int k0 = kbf * 128;
         if (idx < Cfg::A_ITERS) {
-            uint32_t voff = fill_valid ? (S ? a_off_of(F, idx, td) : a_voff[idx]) : kOutOfRange;
+            uint32_t voff = fill_valid ? (S ? (INDEXED ? pslot[idx] : a_off_of(F, idx, td)) : a_voff[idx]) : kOutOfRange;
             if constexpr (KTAIL) voff = (k0 + a_col < p.k) ? voff : kOutOfRange;
             dma16(voff, a_rsrc, (uint32_t)k0, sa + idx * DNT * 16);
         } else if (idx < Cfg::A_ITERS + Cfg::B_ITERS) {
@@ -144,7 +154,7 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
             if constexpr (BNT) dma16_nt(voff, b_rsrc, (uint32_t)k0, sa + Cfg::A_BYTES + it * DNT * 16);
             else dma16(voff, b_rsrc, (uint32_t)k0, sa + Cfg::A_BYTES + it * DNT * 16);
         } else {
-            const float *src = S ? sc_of(F, td) : sc_src;
+            const float *src = S ? (INDEXED ? reinterpret_cast<const float *>((uintptr_t)*reinterpret_cast<const uint64_t *>(pslot + 2)) : sc_of(F, td)) : sc_src;
             dma4(src + (fill_valid ? kbf : KB - 1), lds0 + stage * Cfg::STAGE_BYTES + Cfg::A_BYTES + Cfg::B_BYTES + w * 256);
         }
     };
@@ -442,7 +452,7 @@ gemm_fp8_bf16x_grouped_kernel(const GemmParams p)
         // its own MFMA stream (profiles/r06_grouped_stamps.txt), an idle wave pays nothing.  The role holds for a tile (it is a
         // compile-time property of the tile's loop: a branch per MFMA gap costs the loop its registers); the counted wait at the top
         // of a block goes by what THIS wave issued a block ago.
-        const bool lone = T.M - T.m0 <= BM / Cfg::kWM && !indexed;
+        const bool lone = T.M - T.m0 <= BM / Cfg::kWM;
         constexpr std::true_type yes{};
         constexpr std::false_type no{};
         if (lone) {
