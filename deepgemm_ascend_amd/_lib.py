@@ -60,7 +60,7 @@ class Problem(ctypes.Structure):
 PROBLEM_CONTIGUOUS_M = 1
 # dga_tiling_t.build (include/dga_hip.h DGA_BUILD_*)
 BUILD_DEFAULT, BUILD_WSK_REGISTER, BUILD_BX_AIMAGE, BUILD_BX_IMAGE8, BUILD_BX_IMAGE4 = 0, 1, 4, 5, 6
-BUILD_BX_PERSISTENT, BUILD_BX_ONE_TILE, BUILD_BX_GROUPED = 7, 8, 9
+BUILD_BX_PERSISTENT, BUILD_BX_ONE_TILE, BUILD_BX_GROUPED, BUILD_BX_DECODE = 7, 8, 9, 10
 ROWS_A_ZERO_PADDED, ROWS_B_ZERO_PADDED = 1, 2   # dga_gemm_fp8_fp8_bf16_nt_strided flags
 CAST_UE8M0 = 1                                  # dga_cast_to_fp8_*_ex flag: block scales rounded up to powers of two
 CONTIGUOUS_M_ALIGNMENT = 128

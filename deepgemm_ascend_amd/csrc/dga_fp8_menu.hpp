@@ -102,6 +102,11 @@ int launch_bf16x_streamk(const GemmParams &p, void *ws, size_t ws_bytes, hipStre
 size_t bx_streamk_workspace_bytes();
 // workgroups a launch on this stream can count on being resident together, one per CU; 0 when a CU mask narrows the queue
 int coresident_workgroups(hipStream_t stream);
+// one-launch split-K for decode rows under the bf16-exact policy (gemm_fp8_bf16x_dsk_kernel.hpp; dga_launch_menu_n.hip): dense problems of
+// at most as many 64 x 128 tiles as CUs; `splits` = the tiling's splitkFactor.  DGA_E_TILING: not a launch it takes
+int launch_bf16x_dsk(const GemmParams &p, int splits, void *ws, size_t ws_bytes, hipStream_t stream);
+int bx_dsk_splits(int64_t tiles, int kb, int want, int cus);
+size_t bx_dsk_workspace_bytes(int64_t tiles, int splits);
 
 // persistent continuous-pipeline build of the 256x256 tile (gemm_fp8_cont_persistent_kernel.hpp, dispatchPolicyTag 6): dense
 // rasters of full tiles only -- launch_cont_persistent returns DGA_E_TILING for anything else

@@ -182,6 +182,9 @@ static int check_tiling(const dga_tiling_t &t)
         switch (t.build) {
             case DGA_BUILD_DEFAULT: case DGA_BUILD_WSK_REGISTER: case DGA_BUILD_BX_AIMAGE: case DGA_BUILD_BX_IMAGE8: case DGA_BUILD_BX_IMAGE4:
             case DGA_BUILD_BX_PERSISTENT: case DGA_BUILD_BX_ONE_TILE: case DGA_BUILD_BX_GROUPED: break;
+            case DGA_BUILD_BX_DECODE:       // the one-launch split-K of the 64 x 128 tile: a name of kernelSerial 6
+                if (!wsk || t.m1 != 64 || t.n1 != 128) return DGA_E_TILING;
+                break;
             default: return DGA_E_TILING;
         }
         // the quarter-tile tail and the one-launch Stream-K are builds of the 128 x 256 tile
@@ -486,7 +489,21 @@ int run_fp8(const void *a, const float *sfa, const void *b, const float *sfb, vo
     // ---- workgroup split-K (kernelSerial 6): one launch, the K slices are the waves of a workgroup; dense, M <= 64.  fp8 matrix
     //      instruction only; a shape it does not take (DGA_E_TILING) falls through to the tiling's tile kernel
     static const int wsk_env = [] { const char *e = std::getenv("DGA_WSK"); return e ? std::atoi(e) : -1; }();
-    if (bf16x && !clock_stamps && groups == 1 && !masked_m && !m_indices && !ix &&
+    // ... and, under the bf16-exact policy, its form for up to a few 64-row tiles (tiling.build = DGA_BUILD_BX_DECODE;
+    // gemm_fp8_bf16x_dsk_kernel.hpp): two k groups per workgroup, splitkFactor workgroups per tile through the workspace.  What it does
+    // not take runs the two-launch split-K of the same tiling below.
+    if (bf16x && !bx_ue8m0 && !clock_stamps && groups == 1 && !masked_m && !m_indices && !ix && tiling->kernelSerial == DGA_KERNEL_SPLITK_WORKGROUP &&
+        tiling->build == DGA_BUILD_BX_DECODE) {
+        const int64_t dsk_tiles = static_cast<int64_t>((m + 63) / 64) * ((n + 127) / 128);
+        const int s = bx_dsk_splits(dsk_tiles, p.kb_n, tiling->splitkFactor, static_cast<int>(device_cus()));
+        const size_t need = s > 0 ? bx_dsk_workspace_bytes(dsk_tiles, s) : 0;
+        uint8_t *dsk_ws = need ? carve(need) : nullptr;
+        if (s > 0 && (need == 0 || dsk_ws)) {
+            const int rc = launch_bf16x_dsk(p, s, dsk_ws, need, stream);
+            if (rc != DGA_E_TILING) return rc;
+        }
+    }
+    if (bf16x && !clock_stamps && groups == 1 && !masked_m && !m_indices && !ix && tiling->build != DGA_BUILD_BX_DECODE &&
         (wsk_env >= 0 ? wsk_env != 0 : tiling->kernelSerial == DGA_KERNEL_SPLITK_WORKGROUP)) {
         const int rc = launch_wsk_dma(p, stream, 1);   // the bf16-exact policy has the LDS-DMA build only (M <= 32)
         if (rc != DGA_E_TILING) return rc;

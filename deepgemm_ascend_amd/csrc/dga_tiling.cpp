@@ -1177,6 +1177,31 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out)
         while (static_cast<uint64_t>(gm * 2) * (gm * 2) * bm <= static_cast<uint64_t>(conc) * bn && gm * 2 <= tiles_m) gm *= 2;
         out->swizzleOffset = static_cast<uint8_t>(gm);
     }
+    // A few 64-row tiles on a mid-width matrix: the one-launch split-K of the 64 x 128 tile (kernelSerial 6 with build
+    // DGA_BUILD_BX_DECODE, gemm_fp8_bf16x_dsk_kernel.hpp: two k groups per workgroup, splitkFactor workgroups per tile meeting in the
+    // workspace, no combine launch), S = min(8, CUs / tiles, k blocks / 4).  Against the picks above, graph replay, one process
+    // (scripts/r06_decode_grid.py, profiles/r06_decode_grid.txt): 96..128 rows on 32..128 tiles with at most eight k blocks per k group
+    // 0.70-1.04 of the pick's time (128 x 4096 x 7168 20.6 -> 18.3 us, 128 x 2112 x 7168 19.2 -> 15.4, 128 x 4096 x 4096 18.8 -> 13.2,
+    // 128 x 7168 x 2048 15.3 -> 12.3); 49..64 rows only at K = 4096..5120 (64 x 4096 x 4096 14.4 -> 12.4, 64 x 7168 x 4096 16.4 -> 15.0).
+    // It LOSES where the hand-over between workgroups (~4 us: partial rows written through, flag, read back) is not bought back: fewer
+    // than 32 tiles, K below 2048, long k groups (64 x 18432 x 7168 +38 %, 128 x 7168 x 18432 +27 %), and 64 x 4096 x 7168 ties (15.2).
+    static const bool no_dsk = [] { const char *e = std::getenv("DGA_NO_DSK_PICK"); return e && std::atoi(e) != 0; }();
+    if (!no_dsk && (out->k % 16) == 0 && kb >= 16) {
+        const uint64_t dt = static_cast<uint64_t>((out->m + 63) / 64) * ((out->n + 127) / 128);
+        if (dt >= 32 && dt <= 128) {
+            const uint32_t smax = static_cast<uint32_t>(std::min<uint64_t>(std::min<uint64_t>(8, cus / dt), kb / 4));
+            const bool tall = out->m >= 96 && out->m <= 128 && kb <= 16 * smax;
+            const bool one_tile_row = out->m >= 49 && out->m <= 64 && kb >= 32 && kb <= 40;
+            if (smax >= 1 && (tall || one_tile_row)) {
+                out->kernelSerial = DGA_KERNEL_SPLITK_WORKGROUP;
+                out->build = DGA_BUILD_BX_DECODE;
+                out->m1 = 64; out->n1 = 128;
+                out->splitkFactor = static_cast<uint16_t>(smax); out->stages = 3; out->swizzleOffset = 1;
+                out->blockDim = static_cast<uint32_t>(dt * smax);
+                return DGA_OK;
+            }
+        }
+    }
     // Decode rows: the workgroup split-K on LDS-DMA rings runs this policy's arithmetic too (gemm_fp8_wskd_kernel<..., MATH = 1>), and
     // since the stream pays for neither the conversions nor the bf16 matrix rate it takes the fast policy's time: cold, 20-44 % ahead
     // of this policy's tile kernels on 103 of 120 decode shapes (profiles/r04_wskd_cold_bf16x.txt) -- up to 16 rows wherever a wave
@@ -1210,6 +1235,11 @@ size_t dga_workspace_bytes(const dga_tiling_t *tiling)
     // Stream-K proper: one fp32 partial tile (256 x 256) per CU + the flags
     // (one slot per CU: 256 x 256 floats on the fast path, 128 x 256 under the bf16-exact policy; + the flags)
     if (tiling->kernelSerial == DGA_KERNEL_STREAMK_ONE_LAUNCH) add(static_cast<size_t>(dga::device_cus()) * (256 * 256 * 4 + 8) + 256);
+    // the decode build of the workgroup split-K: one fp32 partial tile (64 x 128) per tile and split but the first + the flags
+    if (tiling->build == DGA_BUILD_BX_DECODE && tiling->splitkFactor > 1) {
+        const size_t tiles = (static_cast<size_t>(tiling->m) + 63) / 64 * ((static_cast<size_t>(tiling->n) + 127) / 128);
+        add(tiles * (tiling->splitkFactor - 1) * (64 * 128 * 4 + 8) + 256);
+    }
     return bytes ? bytes + 256 : 0;
 }
 

@@ -150,6 +150,12 @@ def candidates_bx(m, n, k, cus=256):
                 out.append({"m1": bm, "n1": bn, "raster": rr, "stages": 3, "splitk": 1, "policy": 7, "streamk": 1})
     if m <= 32 and k % 16 == 0 and kb >= 8:
         out.append({"m1": 16 if m <= 16 else 32, "n1": 128, "raster": 1, "stages": 3, "splitk": 1, "policy": 7, "wsk": 2})
+    # the one-launch split-K of the 64 x 128 tile (build 10, csrc/gemm_fp8_bf16x_dsk_kernel.hpp): every workgroup resident at once
+    dt = -(-m // 64) * -(-n // 128)
+    if 16 < m <= 256 and k % 16 == 0 and kb >= 4 and dt <= cus:
+        smax = max(1, min(8, cus // dt, kb // 4))
+        for sk in sorted({smax, max(1, (3 * smax) // 4), max(1, smax // 2)}):
+            out.append({"m1": 64, "n1": 128, "raster": 1, "stages": 3, "splitk": sk, "policy": 7, "wsk": 2, "build": 10})
     return out
 
 
@@ -502,7 +508,7 @@ def bx_row(m, n, k, p, cus=256):
         block_dim = tiles - tiles % cus + 4 * (tiles % cus)
     elif serial == 7:
         block_dim = cus
-    elif serial == 6:
+    elif serial == 6 and p.get("build") != 10:
         block_dim = min(-(-n // 16), cus)
     return (f"{m},{n},{k},{p['m1']},{p['n1']},128,{serial},0,0,0,{block_dim},{p['splitk']},3,{p['raster']},0,0,7,1,0,{p.get('build', 0)}\n")
 

@@ -114,7 +114,7 @@ enum { DGA_POLICY_PLAIN = 0, DGA_POLICY_PINGPONG = 1, DGA_POLICY_CONTINUOUS = 2,
  * The values are the magic `stages` values of ABI <= 6, so a CSV row written then (stages 1, 4..8) maps onto (build = stages,
  * stages = 3) when it is read. */
 enum { DGA_BUILD_DEFAULT = 0, DGA_BUILD_WSK_REGISTER = 1, DGA_BUILD_BX_AIMAGE = 4, DGA_BUILD_BX_IMAGE8 = 5, DGA_BUILD_BX_IMAGE4 = 6,
-       DGA_BUILD_BX_PERSISTENT = 7, DGA_BUILD_BX_ONE_TILE = 8, DGA_BUILD_BX_GROUPED = 9 };
+       DGA_BUILD_BX_PERSISTENT = 7, DGA_BUILD_BX_ONE_TILE = 8, DGA_BUILD_BX_GROUPED = 9, DGA_BUILD_BX_DECODE = 10 };
 
 /* Platform description: the CDNA4 retarget of PlatformInfo
  * (op_tiling/platform_info.h:16-41; Python mirror get_best_config/tiling_calculator.py:25-30).

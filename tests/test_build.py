@@ -52,7 +52,8 @@ def _ship_flags(unit):
     ("dga_launch_menu_j.hip", 6, "gemm_fp8_blockscaled_nt_kernel"),    # four-wave builds with AGPR accumulators on purpose (MATH = 2 / 3)
     ("dga_launch_menu_k.hip", 2, "gemm_fp8_blockscaled_nt_streamk_kernel"),   # one-launch Stream-K (promotion / hardware-scale form)
     ("dga_launch_menu_l.hip", 4, "gemm_fp8_bf16x_grouped_kernel"),      # the masked-grouped layout's bf16-exact kernel (k-tail x nt weights)
-    ("dga_launch_menu_m.hip", 2, "gemm_fp8_bf16x_streamk_kernel")])     # one-launch Stream-K of the bf16-exact persistent kernel x k-tail
+    ("dga_launch_menu_m.hip", 2, "gemm_fp8_bf16x_streamk_kernel"),      # one-launch Stream-K of the bf16-exact persistent kernel x k-tail
+    ("dga_launch_menu_n.hip", 2, "gemm_fp8_bf16x_dsk_kernel")])         # one-launch split-K of the 64 x 128 tile for decode rows x k-tail
 def test_no_kernel_spills_or_scratch(unit, min_kernels, tile_kernel):
     flags = _ship_flags(unit)
     assert "--offload-arch=gfx950" in flags and "-O3" in flags

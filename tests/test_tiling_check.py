@@ -78,6 +78,12 @@ def test_fields_outside_the_menu_are_refused():
         assert dga.tiling_check(t) == want, st
     t = _copy(bx); t.build = 1; t.kernelSerial = 6
     assert dga.tiling_check(t) == OK
+    # build 10 (DGA_BUILD_BX_DECODE): the one-launch split-K of the 64 x 128 tile -- a name of kernelSerial 6 on that tile and no other
+    for ks, m1, n1, want in ((6, 64, 128, OK), (4, 64, 128, E_TILING), (0, 64, 128, E_TILING), (6, 128, 256, E_TILING), (6, 32, 128, E_TILING), (6, 64, 256, E_TILING)):
+        t = _copy(bx); t.build, t.kernelSerial, t.m1, t.n1 = 10, ks, m1, n1
+        assert dga.tiling_check(t) == want, (ks, m1, n1)
+    t = _copy(base); t.build, t.kernelSerial = 10, 6          # (the fast path has no such build)
+    assert dga.tiling_check(t) == E_TILING
     # ... its quarter-tile tail (kernelSerial 5) and its one-launch Stream-K (7) exist for the 128 x 256 tile only
     assert (bx.m1, bx.n1) == (128, 256)
     for ks, m1, n1, want in ((5, 128, 256, OK), (5, 64, 256, E_TILING), (5, 128, 128, E_TILING), (5, 32, 128, E_TILING), (7, 128, 256, OK),
@@ -136,7 +142,7 @@ def test_fuzzed_structs_are_either_in_the_menu_or_refused():
             if tag not in (3, 7):
                 assert (t.m1, t.n1) in FAST_TILES and t.build in (0, 1)
             if tag == 7:
-                assert t.build in (0, 1, 4, 5, 6, 7, 8, 9)
+                assert t.build in (0, 1, 4, 5, 6, 7, 8, 9, 10) and (t.build != 10 or (t.kernelSerial, t.m1, t.n1) == (6, 64, 128))
     assert 0 < accepted < 20000
 
 
