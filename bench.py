@@ -344,10 +344,14 @@ def _time_us(fn, iters, warm):
 def kernel_name(t, policy):
     """Name under which the rocprofv3 kernel trace lists the launch a tiling resolves to (csrc/dga_launch.hip)."""
     if policy == "bf16_exact":
+        if int(t.kernelSerial) == 6 and int(t.build) == 10:
+            return "gemm_fp8_bf16x_dsk_kernel"
         if int(t.kernelSerial) == 6:
             return "gemm_fp8_wsk_dma_kernel (MATH = 1)"
         if int(t.kernelSerial) == 7:
             return "gemm_fp8_bf16x_streamk_kernel"
+        if int(t.build) == 9:
+            return "gemm_fp8_bf16x_grouped_kernel"
         if int(t.m1) == 128 and int(t.n1) == 256:
             return "gemm_fp8_bf16x_persistent_kernel (rasters of more than one round; gemm_fp8_blockscaled_nt_kernel<..., MATH = 1> otherwise)"
         return "gemm_fp8_blockscaled_nt_kernel<..., MATH = 1> (bf16-exact build)"

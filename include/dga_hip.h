@@ -110,7 +110,10 @@ enum { DGA_POLICY_PLAIN = 0, DGA_POLICY_PINGPONG = 1, DGA_POLICY_CONTINUOUS = 2,
  *                 once per workgroup into a bf16 LDS image;  DGA_BUILD_BX_PERSISTENT / _ONE_TILE: one workgroup per CU walking the raster /
  *                 one workgroup per tile (0: persistent on rasters of more than one round);  DGA_BUILD_BX_GROUPED: the masked grouped
  *                 layout's kernel (two k blocks of the ring in flight, the loop unrolled for the m-tiles that hold rows) -- what
- *                 dga_tiling_bf16_exact names for masked grouped problems;  DGA_BUILD_WSK_REGISTER as above.
+ *                 dga_tiling_bf16_exact names for masked grouped problems;  DGA_BUILD_BX_DECODE with kernelSerial 6 and the 64 x 128 tile
+ *                 only: the one-launch split-K for a few 64-row tiles (two k groups per workgroup, splitkFactor <= 8 workgroups per tile
+ *                 whose fp32 partial tiles meet in the workspace -- dga_workspace_bytes counts them; a launch it does not take, e.g. no
+ *                 workspace or more tiles than CUs, runs the two-launch split-K of the same tiling);  DGA_BUILD_WSK_REGISTER as above.
  * The values are the magic `stages` values of ABI <= 6, so a CSV row written then (stages 1, 4..8) maps onto (build = stages,
  * stages = 3) when it is read. */
 enum { DGA_BUILD_DEFAULT = 0, DGA_BUILD_WSK_REGISTER = 1, DGA_BUILD_BX_AIMAGE = 4, DGA_BUILD_BX_IMAGE8 = 5, DGA_BUILD_BX_IMAGE4 = 6,
@@ -199,7 +202,7 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out);
  * reserved0 0;
  *   policy 3 (strict): any tile, stages and build (the kernel picks its own);
  *   policy 7 (bf16-exact): any m1, n1 > 0 (mapped onto that policy's menu); build 0 or a DGA_BUILD_BX_* name (DGA_BUILD_WSK_REGISTER only
- *     with kernelSerial 6);
+ *     with kernelSerial 6; DGA_BUILD_BX_DECODE only with kernelSerial 6 on m1 x n1 = 64 x 128);
  *   fast path: m1 x n1 a tile of the menu, wavesM x wavesN either 0 x 0 or a wave grid that tile is built with; build 0
  *     (DGA_BUILD_WSK_REGISTER only with kernelSerial 6); policy 1 and kernelSerial 5 / 7: 256 x 256 only. */
 int dga_tiling_check(const dga_tiling_t *tiling);
