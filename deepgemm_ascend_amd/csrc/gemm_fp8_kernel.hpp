@@ -387,6 +387,9 @@ __global__ void __launch_bounds__(Cfg::NT) gemm_fp8_blockscaled_nt_kernel(const 
                 for (int nt = 0; nt < TN; ++nt) {
                     const int n = n_base + 32 * (nt >> 1) + 4 * (nt & 1);
                     if (v_ok && n + 4 <= p.n) {
+                        // (plain stores: written through -- as the bf16 rows of a short raster are, below -- the slabs leave the XCD's L2
+                        //  and the combine launch reads them from the fabric: 128 x 4096 x 7168 19.7 -> 21.0 us, 128 x 7168 x 18432
+                        //  42.8 -> 47.2; only slabs of a few MB gain, 64 x 2112 x 7168 13.9 -> 13.1.  scripts/r06_splitk_slab_ab.py)
                         *(v4f *)(prow + n) = acc[mt][nt];
                     } else {
 #pragma unroll
