@@ -1177,27 +1177,31 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out)
         while (static_cast<uint64_t>(gm * 2) * (gm * 2) * bm <= static_cast<uint64_t>(conc) * bn && gm * 2 <= tiles_m) gm *= 2;
         out->swizzleOffset = static_cast<uint8_t>(gm);
     }
-    // A few 64-row tiles on a mid-width matrix: the one-launch split-K of the 64 x 128 tile (kernelSerial 6 with build
+    // 33..256 rows on a matrix that gives at most one 64 x 128 tile per CU: the one-launch split-K of that tile (kernelSerial 6 with build
     // DGA_BUILD_BX_DECODE, gemm_fp8_bf16x_dsk_kernel.hpp: two k groups per workgroup, splitkFactor workgroups per tile meeting in the
-    // workspace, no combine launch), S = min(8, CUs / tiles, k blocks / 4).  Against the picks above, graph replay, one process
-    // (scripts/r06_decode_grid.py, profiles/r06_decode_grid.txt): 96..128 rows on 32..128 tiles with at most eight k blocks per k group
-    // 0.70-1.04 of the pick's time (128 x 4096 x 7168 20.6 -> 18.3 us, 128 x 2112 x 7168 19.2 -> 15.4, 128 x 4096 x 4096 18.8 -> 13.2,
-    // 128 x 7168 x 2048 15.3 -> 12.3); 49..64 rows only at K = 4096..5120 (64 x 4096 x 4096 14.4 -> 12.4, 64 x 7168 x 4096 16.4 -> 15.0).
-    // It LOSES where the hand-over between workgroups (~4 us: partial rows written through, flag, read back) is not bought back: fewer
-    // than 32 tiles, K below 2048, long k groups (64 x 18432 x 7168 +38 %, 128 x 7168 x 18432 +27 %), and 64 x 4096 x 7168 ties (15.2).
+    // workspace, no combine launch), S = min(8, CUs / tiles, k blocks / 4), 6 where that is 8.  Timed as decode rows are (SURVEY 8(d):
+    // operand sets rotated past the Infinity Cache) against EVERY other candidate of this policy's menu, 61 shapes
+    // (scripts/r06_bx_regret.py, profiles/r06_decode_cold_table.txt): 0.76-0.98 of the best other candidate inside the rule below --
+    // 128 x 4096 x 7168 21.6 -> 19.0 us, 128 x 7168 x 2048 16.5 -> 13.1, 256 x 7168 x 2048 19.6 -> 14.8, 192 x 2112 x 7168 21.0 -> 16.7,
+    // 64 x 16384 x 7168 36.8 -> 30.7, 64 x 4096 x 7168 17.3 -> 16.8 -- and behind it outside: fewer than 24 tiles (64 x 2112 x 7168 +3 %:
+    // the ~4 us hand-over between workgroups is not bought back), K below 1536, short K on few tiles (64 x 4096 x 2048 +4 %), more than
+    // 30 k blocks per k group (128 x 7168 x 18432 +4 %; 16 above 128 rows: 256 x 5120 x 5120 +7 %).  Warm (the weights in the Infinity
+    // Cache, profiles/r06_decode_grid.txt) the 49..64-row picks are level to 10 % behind the tile kernels; decode weights are not warm.
     static const bool no_dsk = [] { const char *e = std::getenv("DGA_NO_DSK_PICK"); return e && std::atoi(e) != 0; }();
-    if (!no_dsk && (out->k % 16) == 0 && kb >= 16) {
+    if (!no_dsk && (out->k % 16) == 0 && kb >= 12 && out->m >= 33 && out->m <= 256) {
         const uint64_t dt = static_cast<uint64_t>((out->m + 63) / 64) * ((out->n + 127) / 128);
-        if (dt >= 32 && dt <= 128) {
+        if (dt >= 24 && dt <= cus && !(kb < 32 && dt < 48)) {
             const uint32_t smax = static_cast<uint32_t>(std::min<uint64_t>(std::min<uint64_t>(8, cus / dt), kb / 4));
-            const bool tall = out->m >= 96 && out->m <= 128 && kb <= 16 * smax;
-            const bool one_tile_row = out->m >= 49 && out->m <= 64 && kb >= 32 && kb <= 40;
-            if (smax >= 1 && (tall || one_tile_row)) {
+            // (a grid on fewer than 3/4 of the CUs with long k groups: 64 x 18432 x 7168, 144 workgroups of 28 k blocks per group, is 5 %
+            //  behind the tile kernel's 432 workgroups, 48 x 18432 x 7168 10 %)
+            const bool thin = dt * smax * 4 < 3ull * cus && kb > 32u * smax;
+            if (smax >= 1 && !thin && kb <= (out->m > 128 ? 32u : 60u) * smax) {
+                const uint32_t s = smax == 8 ? 6 : smax;
                 out->kernelSerial = DGA_KERNEL_SPLITK_WORKGROUP;
                 out->build = DGA_BUILD_BX_DECODE;
                 out->m1 = 64; out->n1 = 128;
-                out->splitkFactor = static_cast<uint16_t>(smax); out->stages = 3; out->swizzleOffset = 1;
-                out->blockDim = static_cast<uint32_t>(dt * smax);
+                out->splitkFactor = static_cast<uint16_t>(s); out->stages = 3; out->swizzleOffset = 1;
+                out->blockDim = static_cast<uint32_t>(dt * s);
                 return DGA_OK;
             }
         }

@@ -45,7 +45,7 @@ def main():
             continue
         recs = [json.loads(ln) for ln in (out_dir / f"shape_bx_{m}_{n}_{k}_rank_0.jsonl").read_text().splitlines()]
         pick = dga.tiling(m, n, k, policy="bf16_exact")
-        key = (int(pick.m1), int(pick.n1), int(pick.kernelSerial), int(pick.splitkFactor), int(pick.build) if pick.build == 8 else 0)
+        key = (int(pick.m1), int(pick.n1), int(pick.kernelSerial), int(pick.splitkFactor), int(pick.build) if pick.build in (8, 10) else 0)
         def key_of(p):
             return (p["m1"], p["n1"], sweep.bx_serial(p), p["splitk"], p.get("build", 0))
         mine = [r for r in recs if not r["negative"] and key_of(r["parameters"]) == key]
