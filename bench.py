@@ -561,6 +561,28 @@ def shape_list_leg(dga, iters=20):
                                  "in_contract_frac": round(max(t_mfma, t_hbm) / usb, 4)})
             except Exception as e:
                 rows[-1]["in_contract_error"] = repr(e)
+            if bound == "hbm" and k % 16 == 0:
+                # SURVEY 8(d)'s protocol for the HBM-bound rows: the operand sets rotated past the 256 MB Infinity Cache (a decode GEMM's
+                # weights are never warm), the same calls by graph replay -- what harness/sweep.py --cold and the selector's rules go by
+                try:
+                    opb = m * k + n * k + 2 * m * n
+                    sets = [(a, sfa, b, sfb, out)] + [(a.clone(), sfa.clone(), b.clone(), sfb.clone(), torch.empty_like(out))
+                                                      for _ in range(min(16, max(3, -(-(320 << 20) // opb))) - 1)]
+                    turn = [0]
+                    def rot(tt, pol):
+                        c = sets[turn[0] % len(sets)]
+                        turn[0] += 1
+                        dga.gemm_fp8_fp8_bf16_nt((c[0], c[1]), (c[2], c[3]), c[4], tiling_=tt, **({"policy": pol} if pol else {}))
+                    for key, tt, pol in (("us_cold", t, None), ("us_in_contract_cold", dga.tiling(m, n, k, policy="bf16_exact"), "bf16_exact")):
+                        for _ in range(len(sets)):
+                            rot(tt, pol)
+                        torch.cuda.synchronize()
+                        rows[-1][key] = round(_graph_us(lambda: rot(tt, pol), max(n_it, len(sets))), 2)
+                    rows[-1]["frac_cold"] = round(t_hbm / rows[-1]["us_cold"], 4)
+                    rows[-1]["in_contract_frac_cold"] = round(t_hbm / rows[-1]["us_in_contract_cold"], 4)
+                    del sets
+                except Exception as e:
+                    rows[-1]["cold_error"] = repr(e)
             if k % 16:
                 # the same bytes in rows round_up(K, 16) apart with zero tails (what the quantisers' aligned_rows forms write):
                 # read in place, no padding pass -- both operands, and the weights alone (padded once at load time)
@@ -589,7 +611,8 @@ def shape_list_leg(dga, iters=20):
                         "us_eager = launch interval of the same calls issued one by one from Python (host-bound below ~6 us); M <= 128 rows: us_in_contract = the "
                         "bf16-exact policy with its own tiling (in_contract_kernel 6 = the one-launch workgroup split-K); K % 16 != 0 rows: "
                         "us = contiguous operands (padding pass + tile kernel), us_rows_aligned = both operands in 16-byte aligned zero-tailed rows "
-                        "(read in place), us_weights_aligned = only the weights",
+                        "(read in place), us_weights_aligned = only the weights; HBM-bound rows also COLD (SURVEY 8(d): operand sets rotated past the 256 MB "
+                        "Infinity Cache, graph replay): us_cold / frac_cold, us_in_contract_cold / in_contract_frac_cold",
             "shapes": rows}
 
 
@@ -1087,6 +1110,9 @@ def compact(res: dict) -> dict:
                                                "frac_of_bound_median": fi[len(fi) // 2], "frac_of_bound_max": fi[-1]},
                                "fast": {"parity_ok": sum(1 for r in rows if r.get("parity_ok")), "frac_of_bound_min": fr[0],
                                         "frac_of_bound_median": fr[len(fr) // 2], "frac_of_bound_max": fr[-1]}}
+            cold = sorted(r["in_contract_frac_cold"] for r in rows if "in_contract_frac_cold" in r)
+            if cold:     # the HBM-bound rows by SURVEY 8(d)'s protocol (operands rotated past the Infinity Cache)
+                c["shape_list"]["in_contract"]["hbm_rows_cold"] = {"rows": len(cold), "frac_of_bound_min": cold[0], "frac_of_bound_median": cold[len(cold) // 2]}
     if "detail" in res:
         c["detail"] = res["detail"]
     if "per_rank_kernel_us" in res and (res.get("n_gpus") or 1) > 1:
