@@ -17,6 +17,11 @@
 // per block, k ascending inside a slice); the slices are summed as ((g0 + g1) + (g2 + g3)) + ... -- a fixed order: the result does
 // not depend on timing, and differs from the sequential builds' by fp32 rounding of the partial sums only (tests/test_bf16x_dsk_gpu.py).
 //
+// (Measured, not kept: every workgroup of a tile adding its 1 / S of the tile over all S partial tiles -- the reads of the partials spread
+//  over S CUs, flags per workgroup with a generation word -- instead of one adding workgroup: +0.7 ... +1.2 us at S = 2..6, level at 7 and
+//  8 (same box, two passes each: the adder's own partial write and S - 1 flags to watch per workgroup cost more than its read burst); the
+//  refill in a burst behind the barrier: +2 ... +8 %.)
+//
 // Reference counterparts: the split-K kernel types the reference declares (op_kernel/catlass_dynamic_matmul_tiling_key.h:30-36), the
 // fused reduce of its Stream-K kernel (op_kernel/kernel/padding_streamk_matmul_kernel.h:92-107) and the Small handler that serves
 // these shapes there (op_host/op_tiling/select_kernel.cpp:270-291).
