@@ -27,20 +27,21 @@ size_t bx_dsk_workspace_bytes(int64_t tiles, int splits)
     return static_cast<size_t>(tiles) * (splits - 1) * (DskCfg::SLOT_FLOATS * 4 + 8) + 256;
 }
 
-template <bool KTAIL>
+template <bool KTAIL, bool IMG = true>
 static int launch_bx_dsk_one(const GemmParams &p, const StreamKArgs &sk, unsigned grid, hipStream_t stream)
 {
-    auto kfn = gemm_fp8_bf16x_dsk_kernel<KTAIL>;
+    auto kfn = gemm_fp8_bf16x_dsk_kernel<KTAIL, IMG>;
+    constexpr int kLds = IMG ? DskCfg::IMG_LDS_BYTES : DskCfg::LDS_BYTES;
     static std::once_flag once[64];
     static hipError_t attr_err[64];
     int dev = 0;
     if (int rc = record_hip(hipGetDevice(&dev))) return rc;
     if (dev < 0 || dev >= 64) return DGA_E_HIP;
     std::call_once(once[dev], [&] {
-        attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, DskCfg::LDS_BYTES);
+        attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     });
     if (int rc = record_hip(attr_err[dev])) return rc;
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(DskCfg::NT), DskCfg::LDS_BYTES, stream, p, sk);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(DskCfg::NT), kLds, stream, p, sk);
     return record_hip(hipGetLastError());
 }
 
@@ -94,6 +95,10 @@ int launch_bf16x_dsk(const GemmParams &p, int splits, void *ws, size_t ws_bytes,
     if (const char *e = std::getenv("DGA_DSK_KNOB")) q.tail_begin = std::atoi(e);
 #endif
     const unsigned grid = static_cast<unsigned>(tiles * s);
+#ifdef DGA_DSK_KNOBS      // ($DGA_DSK_KNOB & 64: the build that converts A in every wave)
+    if (q.tail_begin & 64)
+        return (p.k % 128) ? launch_bx_dsk_one<true, false>(q, sk, grid, stream) : launch_bx_dsk_one<false, false>(q, sk, grid, stream);
+#endif
     return (p.k % 128) ? launch_bx_dsk_one<true>(q, sk, grid, stream) : launch_bx_dsk_one<false>(q, sk, grid, stream);
 }
 

@@ -35,12 +35,17 @@ struct DskCfg {
     static constexpr int BM = 64, BN = 128, GT = 256, NT = 512, TN = 2;
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SC_BYTES = GT * 4;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES + SC_BYTES, RING_BYTES = 3 * STAGE_BYTES, LDS_BYTES = 2 * RING_BYTES;
+    // the A-image build: two stages + the bf16 image of one k block's A tile (m-tile, chain step, lane: 16 bytes each) per k group
+    static constexpr int IMG_BYTES = BM * 128 * 2, IMG_GROUP_BYTES = 2 * STAGE_BYTES + IMG_BYTES, IMG_LDS_BYTES = 2 * IMG_GROUP_BYTES;
     static constexpr int A_ITERS = 2, B_ITERS = 4, NL = A_ITERS + B_ITERS + 1;
     static constexpr int SLOT_FLOATS = BM * BN;     // one workgroup's partial tile
     static constexpr int MAX_S = 8;
 };
 
-template <bool KTAIL>
+// IMG: the A tile of a k block is converted ONCE per k group -- wave w its m-tile w, into a bf16 image in LDS behind a second barrier --
+// instead of once per wave: 16 + 32 conversions per wave and k block instead of 64 + 32 (the loop is bound by the vector port: two waves
+// per SIMD take twice one wave's time), and the raw stage is dead at that barrier, so two stages carry the refill as far ahead as three.
+template <bool KTAIL, bool IMG = true>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 gemm_fp8_bf16x_dsk_kernel(const GemmParams p, const StreamKArgs sk)
 {
@@ -76,7 +81,7 @@ gemm_fp8_bf16x_dsk_kernel(const GemmParams p, const StreamKArgs sk)
     const int nmax = max(nblk, nblk_o);           // barriers are the workgroup's: both groups walk the longer slice's count
 
     // ---- LDS-DMA sources of this group's ring (gemm_fp8_kernel.hpp: chunk c = it * GT + gtid lands at byte 16 c of the image)
-    uint8_t *const ring = smem + h * C::RING_BYTES;
+    uint8_t *const ring = smem + h * (IMG ? C::IMG_GROUP_BYTES : C::RING_BYTES);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)ring;
     constexpr uint32_t kOutOfRange = 0x80000000u;
     const int a_col = ((gtid & 7) ^ swz_a(gtid >> 3)) * 16;
@@ -146,7 +151,7 @@ gemm_fp8_bf16x_dsk_kernel(const GemmParams p, const StreamKArgs sk)
     // ---- prologue: the slice's first THREE blocks on their way (every stage of the ring: a slice is a handful of blocks, and the
     //      first round trip from a cold HBM is the longest) -- block 0 then issues no refill, its predecessor's stage being block 2's
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
+    for (int d = 0; d < (IMG ? 2 : 3); ++d)       // (the image build has two stages)
 #pragma unroll
         for (int idx = 0; idx < NL; ++idx) refill(idx, d, kb0 + d);
 
@@ -244,8 +249,99 @@ gemm_fp8_bf16x_dsk_kernel(const GemmParams p, const StreamKArgs sk)
             for (int q = 0; q < 4; ++q) acc[jm][jn][q] = __builtin_fmaf(part[j % RING][q], s_old[jm], acc[jm][jn][q]);
         }
     };
-    if (M - m0 <= 32) run(std::integral_constant<int, 2>{});
-    else run(std::integral_constant<int, 4>{});
+    // the same slice on the A-image build: per k block  [barrier: the block has landed]  convert: A m-tile `gw` -> image, both B tiles ->
+    // registers  [barrier: the image is whole; the raw stage is dead]  multiply, the refill of block it + 2 -- into the stage just
+    // consumed -- on the MFMA gaps.  (The second k group one interval behind the first -- one wave of a SIMD converting while the other
+    // multiplies -- measured 11 % SLOWER: a lone wave does not fill the matrix pipe, and the pair waits for the longer interval.)
+    auto run_img = [&](auto Lc) __attribute__((always_inline)) {
+        constexpr int L = decltype(Lc)::value;
+        constexpr int TILES = L * TN, GAPS = 4 * TILES, SP = L;
+        static_assert(TILES % RING == 0 && 1 + (NL - 1) * SP < GAPS, "the ring of partial tiles; the refill fits a block");
+        uint8_t *const img = ring + 2 * C::STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < RING; ++i) part[i] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < L; ++i) s_old[i] = 0.f;
+        int cur = 0;
+        for (int it = 0; it < nmax; ++it) {
+            wait_vmcnt<NL>();                // this wave's pieces of block `it` have landed (the younger block's may be in flight)
+            __builtin_amdgcn_s_barrier();    // everyone's have; and everyone has left block it - 1: its image may be overwritten
+            asm volatile("" ::: "memory");
+            const bool live = it < nblk;
+            const uint8_t *sc = ring + cur * C::STAGE_BYTES;
+            if (live) {
+                if (gw < L) {
+                    araw[0][0] = *(const v4i *)(sc + a_off0 + gw * 2048);
+                    araw[0][1] = *(const v4i *)(sc + a_off1 + gw * 2048);
+                }
+                braw[0][0] = *(const v4i *)(sc + b_off0);
+                braw[0][1] = *(const v4i *)(sc + b_off1);
+                braw[1][0] = *(const v4i *)(sc + b_off0 + 512);
+                braw[1][1] = *(const v4i *)(sc + b_off1 + 512);
+                const float sfb0 = *(const float *)(sc + sb_off);
+                float sa[L];
+#pragma unroll
+                for (int i = 0; i < L; ++i) sa[i] = *(const float *)(sc + sa_off + i * 64);
+                if (gw < L) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) convert(araw[0], afx[0], c);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *(v4i *)(img + ((gw * 4 + q) * 64 + lane) * 16) = afx[0][q];
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c) convert(braw[0], bfx[0], c);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) convert(braw[1], bfx[1], c);
+#pragma unroll
+                for (int i = 0; i < L; ++i) s_cur[i] = sa[i] * sfb0;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();    // the image is whole -- and nobody reads the raw stage any more
+            asm volatile("" ::: "memory");
+            if (live) {
+                const int kbf = kb0 + it + 2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) afx[0][q] = *(const v4i *)(img + (q * 64 + lane) * 16);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < GAPS; ++u) {
+                    const int t = u >> 2, q = u & 3, mt = t / TN, nt = t % TN;
+                    part[t % RING] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(v8bf, bfx[nt][q]), __builtin_bit_cast(v8bf, afx[mt & 1][q]),
+                        q == 0 ? v4f{0.f, 0.f, 0.f, 0.f} : part[t % RING], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (u >= 1 && (u - 1) % SP == 0 && (u - 1) / SP < NL) refill((u - 1) / SP, cur, kbf);
+                    // A(mt + 1) out of the image behind the first MFMA of m-tile mt (its registers were A(mt - 1)'s)
+                    if (nt == 0 && q == 0 && mt + 1 < L) {
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) afx[(mt + 1) & 1][qq] = *(const v4i *)(img + (((mt + 1) * 4 + qq) * 64 + lane) * 16);
+                    }
+                    {   // the promotion of tile t - LAGT (the previous block's last tiles during this block's first ones)
+                        const int j = t >= LAGT ? t - LAGT : TILES + t - LAGT, jm = j / TN, jn = j % TN;
+                        const float sv = t >= LAGT ? s_cur[jm] : s_old[jm];
+                        acc[jm][jn][q] = __builtin_fmaf(part[j % RING][q], sv, acc[jm][jn][q]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < L; ++i) s_old[i] = s_cur[i];
+            }
+            cur ^= 1;
+        }
+#pragma unroll
+        for (int t = 0; t < LAGT; ++t) {
+            const int j = TILES + t - LAGT, jm = j / TN, jn = j % TN;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[jm][jn][q] = __builtin_fmaf(part[j % RING][q], s_old[jm], acc[jm][jn][q]);
+        }
+    };
+    if constexpr (IMG) {
+        if (M - m0 <= 32) run_img(std::integral_constant<int, 2>{});
+        else run_img(std::integral_constant<int, 4>{});
+    } else {
+        if (M - m0 <= 32) run(std::integral_constant<int, 2>{});
+        else run(std::integral_constant<int, 4>{});
+    }
 
     // ---- the two groups' accumulators meet in LDS (lane-linear: tile ti of wave gw at float4 (gw * 8 + ti) * 64 + lane)
     wait_vmcnt<0>();                 // the refills past the slice (zeros) have landed: the ring is dead from here on
