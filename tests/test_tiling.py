@@ -335,9 +335,14 @@ def test_bf16_exact_policy_has_its_own_tiling(dga):
     tiling's tile; nothing is written to the tiling cache under the policy's name."""
     menu = {(128, 256), (128, 128), (64, 256), (64, 128), (32, 128)}
     for (m, n, k) in [(4096, 4096, 4096), (4096, 2048, 7168), (1024, 4096, 7168), (512, 4096, 7168), (128, 4096, 7168),
-                      (64, 7168, 18432), (8, 18432, 7168), (300, 200, 256), (1279, 5003, 7681)]:
+                      (64, 7168, 18432), (8, 18432, 7168), (300, 200, 256), (1279, 5003, 7681), (128, 7168, 18432), (64, 2112, 7168)]:
         t = dga.tiling(m, n, k, policy="bf16_exact")
         assert t.dispatchPolicyTag == dga.api.POLICY_BF16_EXACT and (t.m, t.n, t.k) == (m, n, k)
+        if t.kernelSerial == 6 and t.build == 10:   # a few 64-row tiles: the one-launch split-K of the 64 x 128 tile (DGA_BUILD_BX_DECODE)
+            assert 17 <= m <= 256 and (t.m1, t.n1, t.stages) == (64, 128, 3) and 1 <= t.splitkFactor <= 8
+            assert t.blockDim == -(-m // 64) * -(-n // 128) * t.splitkFactor <= 256
+            assert dga.workspace_bytes(t) >= (-(-m // 64) * -(-n // 128) * (t.splitkFactor - 1) * (64 * 128 * 4 + 8) if t.splitkFactor > 1 else 0)
+            continue
         if t.kernelSerial == 6:   # decode rows: the workgroup split-K with this policy's arithmetic
             assert m <= 32 and (t.m1, t.n1, t.splitkFactor, t.stages) == (16 if m <= 16 else 32, 128, 1, 3)
             assert t.blockDim == min(-(-n // 16), 256)
@@ -350,6 +355,7 @@ def test_bf16_exact_policy_has_its_own_tiling(dga):
     mid = dga.tiling(1024, 4096, 7168, policy="bf16_exact")   # 256 tiles of 128x128, one per CU: 57 us against 85 for 128x256 (r03_vgpr_form.txt)
     assert (mid.m1, mid.n1) == (128, 128) and mid.splitkFactor == 1
     assert dga.tiling(8, 18432, 7168, policy="bf16_exact").kernelSerial == 6 and dga.tiling(32, 4096, 7168, policy="bf16_exact").kernelSerial == 6
+    assert dga.tiling(128, 4096, 7168, policy="bf16_exact").build == 10 and dga.tiling(128, 7168, 18432, policy="bf16_exact").build == 0
     assert dga.tiling(48, 18432, 7168, policy="bf16_exact").m1 in (32, 64) and dga.tiling(32, 18432, 7168, policy="bf16_exact").kernelSerial != 6
     g = dga.tiling(128, 2048, 7168, groups=256, expected_m=128, policy="bf16_exact")
     f = dga.tiling(128, 2048, 7168, groups=256, expected_m=128)
