@@ -1190,7 +1190,8 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out)
     static const bool no_dsk = [] { const char *e = std::getenv("DGA_NO_DSK_PICK"); return e && std::atoi(e) != 0; }();
     // (17..32 rows: where the matrix is too tall for the per-wave split-K below -- 32 x 24576 x 1536 15.9 -> 13.0 us, 24 x 12288 x 5120
     //  21.8 -> 20.1; on matrices of at most 8192 rows that kernel stays 7-30 % ahead)
-    if (!no_dsk && (out->k % 16) == 0 && kb >= 12 && out->m <= 256 && (out->m >= 33 || (out->m >= 17 && out->n > 8192))) {
+    //  (... and where K is long: 24 x 4096 x 18432 26.6 -> 23.4, 32 x 7168 x 18432 33.2 -> 31.5)
+    if (!no_dsk && (out->k % 16) == 0 && kb >= 12 && out->m <= 256 && (out->m >= 33 || (out->m >= 17 && (out->n > 8192 || kb >= 96)))) {
         const uint64_t dt = static_cast<uint64_t>((out->m + 63) / 64) * ((out->n + 127) / 128);
         if (dt >= 24 && dt <= cus && !(kb < 32 && dt < 48)) {
             const uint32_t smax = static_cast<uint32_t>(std::min<uint64_t>(std::min<uint64_t>(8, cus / dt), kb / 4));
@@ -1198,7 +1199,9 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out)
             //  behind the tile kernel's 432 workgroups, 48 x 18432 x 7168 10 %)
             const bool thin = dt * smax * 4 < 3ull * cus && kb > 32u * smax;
             if (smax >= 1 && !thin && kb <= (out->m > 128 ? 32u : 60u) * smax) {
-                const uint32_t s = smax == 8 ? 6 : smax;
+                // (eight workgroups per tile on every CU: six measured 2-4 % ahead -- 64 x 4096 x 7168 17.1 / 17.6 us, 64 x 4096 x 4096
+                //  14.0 / 14.7; on a grid that leaves CUs free eight stay ahead -- 48 x 3072 x 18432 23.1 / 25.4)
+                const uint32_t s = (smax == 8 && dt * 8 > 7ull * cus / 8) ? 6 : smax;
                 out->kernelSerial = DGA_KERNEL_SPLITK_WORKGROUP;
                 out->build = DGA_BUILD_BX_DECODE;
                 out->m1 = 64; out->n1 = 128;
