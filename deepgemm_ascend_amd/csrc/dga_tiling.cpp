@@ -1177,7 +1177,7 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out)
         while (static_cast<uint64_t>(gm * 2) * (gm * 2) * bm <= static_cast<uint64_t>(conc) * bn && gm * 2 <= tiles_m) gm *= 2;
         out->swizzleOffset = static_cast<uint8_t>(gm);
     }
-    // 17..256 rows on a matrix that gives at most one 64 x 128 tile per CU: the one-launch split-K of that tile (kernelSerial 6 with build
+    // 17..512 rows on a matrix that gives at most one 64 x 128 tile per CU: the one-launch split-K of that tile (kernelSerial 6 with build
     // DGA_BUILD_BX_DECODE, gemm_fp8_bf16x_dsk_kernel.hpp: two k groups per workgroup, splitkFactor workgroups per tile meeting in the
     // workspace, no combine launch), S = min(8, CUs / tiles, k blocks / 4), 6 where that is 8.  Timed as decode rows are (SURVEY 8(d):
     // operand sets rotated past the Infinity Cache) against EVERY other candidate of this policy's menu, 61 shapes
@@ -1187,11 +1187,12 @@ int dga_tiling_bf16_exact(const dga_problem_t *problem, dga_tiling_t *out)
     // the ~4 us hand-over between workgroups is not bought back), K below 1536, short K on few tiles (64 x 4096 x 2048 +4 %), more than
     // 30 k blocks per k group (128 x 7168 x 18432 +4 %; 16 above 128 rows: 256 x 5120 x 5120 +7 %).  Warm (the weights in the Infinity
     // Cache, profiles/r06_decode_grid.txt) the 49..64-row picks are level to 10 % behind the tile kernels; decode weights are not warm.
+    // 257..512 rows (timed warm, nine shapes): 0.86-1.01 of the best other candidate (320 x 2112 x 7168 22.0 -> 18.8 us, 512 x 2048 x 7168 26.4 -> 24.0).
     static const bool no_dsk = [] { const char *e = std::getenv("DGA_NO_DSK_PICK"); return e && std::atoi(e) != 0; }();
     // (17..32 rows: where the matrix is too tall for the per-wave split-K below -- 32 x 24576 x 1536 15.9 -> 13.0 us, 24 x 12288 x 5120
     //  21.8 -> 20.1; on matrices of at most 8192 rows that kernel stays 7-30 % ahead)
     //  (... and where K is long: 24 x 4096 x 18432 26.6 -> 23.4, 32 x 7168 x 18432 33.2 -> 31.5)
-    if (!no_dsk && (out->k % 16) == 0 && kb >= 12 && out->m <= 256 && (out->m >= 33 || (out->m >= 17 && (out->n > 8192 || kb >= 96)))) {
+    if (!no_dsk && (out->k % 16) == 0 && kb >= 12 && out->m <= 512 && (out->m >= 33 || (out->m >= 17 && (out->n > 8192 || kb >= 96)))) {
         const uint64_t dt = static_cast<uint64_t>((out->m + 63) / 64) * ((out->n + 127) / 128);
         if (dt >= 24 && dt <= cus && !(kb < 32 && dt < 48)) {
             const uint32_t smax = static_cast<uint32_t>(std::min<uint64_t>(std::min<uint64_t>(8, cus / dt), kb / 4));

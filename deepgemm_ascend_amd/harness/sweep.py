@@ -152,7 +152,7 @@ def candidates_bx(m, n, k, cus=256):
         out.append({"m1": 16 if m <= 16 else 32, "n1": 128, "raster": 1, "stages": 3, "splitk": 1, "policy": 7, "wsk": 2})
     # the one-launch split-K of the 64 x 128 tile (build 10, csrc/gemm_fp8_bf16x_dsk_kernel.hpp): every workgroup resident at once
     dt = -(-m // 64) * -(-n // 128)
-    if 16 < m <= 256 and k % 16 == 0 and kb >= 4 and dt <= cus:
+    if 16 < m <= 512 and k % 16 == 0 and kb >= 4 and dt <= cus:
         smax = max(1, min(8, cus // dt, kb // 4))
         for sk in sorted({smax, max(1, (3 * smax) // 4), max(1, smax // 2)}):
             out.append({"m1": 64, "n1": 128, "raster": 1, "stages": 3, "splitk": sk, "policy": 7, "wsk": 2, "build": 10})

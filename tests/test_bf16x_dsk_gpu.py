@@ -124,13 +124,13 @@ def test_graph_replay_needs_no_memset(dga, oracle):
 
 def test_the_selector_names_it_and_a_default_call_runs_it(dga, oracle):
     """dga_tiling_bf16_exact names the build where it measured ahead of every other candidate under the decode protocol
-    (profiles/r06_decode_cold_table.txt): 33..256 rows (17..32 on matrices of more than 8192 rows), 24 tiles to one per CU, at most 30 k
+    (profiles/r06_decode_cold_table.txt): 33..512 rows (17..32 on matrices of more than 8192 rows or with K of at least 12288), 24 tiles to one per CU, at most 30 k
     blocks per k group (16 above 128 rows), no thin grid with long k groups;
     the neighbours keep their picks."""
     from deepgemm_ascend_amd import _lib
     for m, n, k, s in ((128, 4096, 7168, 4), (128, 2112, 7168, 7), (96, 7168, 2048, 2), (128, 4096, 4096, 4), (64, 4096, 4096, 6), (64, 4096, 7168, 6),
                        (256, 4096, 7168, 2), (40, 7168, 4096, 4), (64, 24576, 1536, 1), (192, 2112, 7168, 5), (64, 7168, 16384, 4), (32, 24576, 1536, 1),
-                       (24, 12288, 5120, 2), (24, 4096, 18432, 6), (48, 3072, 18432, 8)):
+                       (24, 12288, 5120, 2), (24, 4096, 18432, 6), (48, 3072, 18432, 8), (512, 2048, 7168, 2), (320, 2112, 7168, 3)):
         t = dga.tiling(m, n, k, policy="bf16_exact")
         assert (t.m1, t.n1, t.kernelSerial, t.build, t.splitkFactor) == (64, 128, 6, _lib.BUILD_BX_DECODE, s), (m, n, k, t.as_dict())
         assert dga.tiling_check(t) == 0

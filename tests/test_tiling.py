@@ -339,7 +339,7 @@ def test_bf16_exact_policy_has_its_own_tiling(dga):
         t = dga.tiling(m, n, k, policy="bf16_exact")
         assert t.dispatchPolicyTag == dga.api.POLICY_BF16_EXACT and (t.m, t.n, t.k) == (m, n, k)
         if t.kernelSerial == 6 and t.build == 10:   # a few 64-row tiles: the one-launch split-K of the 64 x 128 tile (DGA_BUILD_BX_DECODE)
-            assert 17 <= m <= 256 and (t.m1, t.n1, t.stages) == (64, 128, 3) and 1 <= t.splitkFactor <= 8
+            assert 17 <= m <= 512 and (t.m1, t.n1, t.stages) == (64, 128, 3) and 1 <= t.splitkFactor <= 8
             assert t.blockDim == -(-m // 64) * -(-n // 128) * t.splitkFactor <= 256
             assert dga.workspace_bytes(t) >= (-(-m // 64) * -(-n // 128) * (t.splitkFactor - 1) * (64 * 128 * 4 + 8) if t.splitkFactor > 1 else 0)
             continue
