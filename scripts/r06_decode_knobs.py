@@ -1,5 +1,7 @@
-"""Development build only (make FLAGS_dga_launch_menu_n=-DDGA_DSK_KNOBS): where the one-launch decode split-K spends its time.
-$DGA_DSK_KNOB 1 = partials neither written nor awaited (loop + fixed cost), 2 = written, not awaited; $DGA_DSK_SKEW = wa | wo << 8."""
+"""Development build only (make -C deepgemm_ascend_amd/csrc FLAGS_dga_launch_menu_n=-DDGA_DSK_KNOBS): where the one-launch decode split-K
+spends its time.  $DGA_DSK_KNOB bits: 1 = partials neither written nor awaited, 2 = written, not awaited, 4 = nothing multiplied (the refill alone),
+8 = nothing fetched, 32 = the refill in a burst behind the barrier, 64 = the build that converts A in every wave (4, 8, 32 act on that build
+only).  Graph replay, one process.  Numbers of record: DESIGN.md 2.6."""
 import os, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -25,9 +27,9 @@ for (m, n, k) in shapes:
         t.m1, t.n1, t.kernelSerial, t.build, t.splitkFactor, t.stages = 64, 128, 6, _lib.BUILD_BX_DECODE, s, 0
         f = lambda: dga.gemm_fp8_fp8_bf16_nt((a, sfa), (b, sfb), out, policy="bf16_exact", tiling_=t)
         row = {}
-        for knob in (0, 32, 0, 32, 1, 33):
+        for knob in (0, 64, 65, 66, 69, 73, 77, 96):
             os.environ["DGA_DSK_KNOB"] = str(knob)
             f(); torch.cuda.synchronize()
-            row[f"k{knob}" + ("b" if f"k{knob}" in row else "")] = round(bench._graph_us(f, 20), 2)
+            row[f"k{knob}"] = round(bench._graph_us(f, 20), 2)
         os.environ["DGA_DSK_KNOB"] = "0"
         print(f"{m}x{n}x{k} S={s}", row, flush=True)
