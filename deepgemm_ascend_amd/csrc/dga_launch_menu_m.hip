@@ -70,19 +70,11 @@ int launch_bf16x_streamk(const GemmParams &p, void *ws, size_t ws_bytes, hipStre
     sk.partials = static_cast<float *>(ws);
     sk.flags = reinterpret_cast<unsigned long long *>(sk.partials + static_cast<size_t>(grid) * (128 * 256));
     // A flag is raised when it holds this launch's epoch: 64 mixed bits no earlier launch used and stale workspace bytes will not
-    // hold -- nothing to zero.  A launch that is being CAPTURED into a graph is replayed with the same arguments, so there the flags
-    // are zeroed by a memset node in front of the kernel and the epoch is a constant.
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
-    if (cap != hipStreamCaptureStatusNone) {
-        if (int rc = record_hip(hipMemsetAsync(sk.flags, 0, static_cast<size_t>(grid) * 8, stream))) return rc;
-        sk.epoch = 1ull;
-    } else {
-        static std::atomic<unsigned long long> launches{0};
-        const unsigned long long e = launches.fetch_add(1) + 1;
-        sk.epoch = (e * 0x9E3779B97F4A7C15ull) | 1ull;
-        if (sk.epoch == 1ull) sk.epoch = 3ull;
-    }
+    // hold -- nothing to zero.  Its reader puts it back to 0, so a launch that is being CAPTURED into a graph (replayed with the same
+    // arguments) needs no memset node either: every replay finds zeros.
+    static std::atomic<unsigned long long> launches{0};
+    const unsigned long long e = launches.fetch_add(1) + 1;
+    sk.epoch = (e * 0x9E3779B97F4A7C15ull) | 1ull;
 #ifdef DGA_BXSK_KNOBS
     GemmParams q = p;
     if (const char *e = std::getenv("DGA_BXSK_KNOB")) q.tail_begin = std::atoi(e);

@@ -18,8 +18,8 @@
 // Counterpart in the reference: kernel type 4, PaddingStreamkMatmulKernel -- Stream-K split of the k loop over all cores +
 // StreamkReduceAdd over fp32 partials (/root/reference/aclnn_catlass_dynamic_matmul/op_kernel/kernel/padding_streamk_matmul_kernel.h:94-98;
 // selection rule op_host/op_tiling/select_kernel.cpp:303-331).
-// A flag is "raised" when it holds this launch's 64-bit epoch (nothing to zero in front of an ordinary launch; a captured launch has
-// its flags zeroed by a memset node: launcher).  Every workgroup must be resident at once (the launcher sizes the grid for that).
+// A flag is "raised" when it holds this launch's 64-bit epoch; its one reader puts it back to 0 (nothing to zero in front of a launch,
+// captured or not: a replay repeats the epoch and finds zeros).  Every workgroup must be resident at once (the launcher sizes the grid for that).
 #pragma once
 #include "gemm_fp8_kernel.hpp"
 #include "gemm_fp8_streamk_kernel.hpp"   // StreamKArgs
@@ -457,10 +457,17 @@ gemm_fp8_bf16x_streamk_kernel(const GemmParams p, const StreamKArgs sk)
         //      then this piece's own accumulators (two pieces: the order of one addition does not matter; more: the others' sum is a
         //      k-ordered chain and this piece is the last range of form 1).  Read with sc1 loads (cdna_hip_programming.md Guideline 16).
         const int n_other = pl.form == 1 ? pl.s - 1 : 1;
-        for (int j = 0; j < n_other; ++j) {
-            const int slot = pl.form == 1 ? j * pl.R + T.r : T.r;
-            while (__hip_atomic_load(sk.flags + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) __builtin_amdgcn_s_sleep(8);
-        }
+        // (one thread watches the flags -- each has this ONE reader -- and puts them back to 0 behind the barrier: a launch replayed from
+        //  a graph repeats its epoch and finds the flags as an ordinary launch does, no memset node in front of the kernel)
+        if (tid == 0)
+            for (int j = 0; j < n_other; ++j) {
+                const int slot = pl.form == 1 ? j * pl.R + T.r : T.r;
+                while (__hip_atomic_load(sk.flags + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) __builtin_amdgcn_s_sleep(8);
+            }
+        __syncthreads();
+        if (tid == 0)
+            for (int j = 0; j < n_other; ++j)
+                __hip_atomic_store(sk.flags + (pl.form == 1 ? j * pl.R + T.r : T.r), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (active) {
             constexpr int CH = TILES / 2;      // accumulator tiles per round trip: eight 16-byte loads in flight per lane
 #pragma unroll

@@ -87,7 +87,8 @@ def test_exact_rounds_and_missing_workspace_fall_back_to_the_tile_kernels(dga, o
 
 
 def test_graph_replay(dga, oracle):
-    """A captured launch zeroes its flags by a memset node: three replays give the direct launch's bytes."""
+    """The reader of a flag puts it back to 0, so a captured launch (replayed with its epoch) needs no memset node: three replays give
+    the direct launch's bytes."""
     m, n, k = 128 * 10, 256 * 20, 1280
     a, sfa, b, sfb = oracle.make_inputs(m, n, k, seed=9)
     ta, tsa, tb, tsb = (_dev(x) for x in (a, sfa, b, sfb))
