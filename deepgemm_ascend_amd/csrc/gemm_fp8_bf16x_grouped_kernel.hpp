@@ -20,6 +20,12 @@
 //  544 -> 692 us two blocks ahead, 897 four: 64 separate lines per wave-instruction cost the memory path more than the refill's round
 //  trip did.  profiles/r06_grouped_masks.txt, "L2 prefetch" rows.)
 //
+// (Tried on the lone tiles, not kept: the idle waves 4..7 converting the tile's A rows once per k block into a bf16 image -- in the upper
+//  half of the block's own A stage, which a lone tile never reads, and 8 KB behind the ring -- handed over by a second barrier, so that
+//  the multiplying waves convert B only.  Same bits; 64 rows per expert 664 -> 716 us, 0..64 rows 576 -> 612, random masks level: a
+//  multiplying wave alone on its SIMD waits out the image's round trip at that barrier in every block, where its own A conversions were
+//  hidden in the MFMA gaps.  The decode kernel's image pays because there BOTH waves of a SIMD convert the same rows.)
+//
 // Same arithmetic in the same k order as every other build of the policy (four chained v_mfma_f32_16x16x32_bf16 per scale block on
 // exactly converted operands, one fp32 promotion per block): bit-identical outputs (tests/test_bf16x_grouped_gpu.py).  Masked grouped
 // rasters, packed or indexed rows, with K of at least two k blocks; everything else keeps the other builds.
