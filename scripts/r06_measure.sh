@@ -45,3 +45,26 @@ python3 $R/scripts/r06_grouped_masks.py > $O/grouped_masks.txt 2>&1
 echo "grouped tables done"
 python3 $R/scripts/r06_collect.py $O $O/summary
 ls $O/summary
+# the decode build on its own in the trace (eager launches: the durations are the kernel's, the launch gaps are not in them)
+for shp in "128 4096 7168" "64 4096 7168" "64 7168 18432" "256 4096 7168"; do
+  tag=$(echo $shp | tr ' ' 'x')
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/decode_$tag -o d -- python3 $R/scripts/prof_dense.py $shp 300 --policy bf16_exact > $O/decode_$tag.log 2>&1
+done
+python3 - <<PY
+import collections, csv, glob
+rows = []
+for d in sorted(glob.glob("$O/decode_*/")):
+    for f in glob.glob(d + "**/*_kernel_trace.csv", recursive=True):
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "dga::" in r["Kernel_Name"]:
+                per[(r["Kernel_Name"], int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        for (name, grid, wg), v in per.items():
+            v = v[100:] if len(v) > 150 else v
+            rows.append([d.rstrip("/").split("decode_")[-1], name, grid, wg, len(v), round(sum(v) / len(v), 1), min(v), max(v)])
+with open("$O/summary/r06_decode_kernel_stats.csv", "w", newline="") as f:
+    w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+    w.writerow(["Shape", "Name", "Grid_Size_X", "Workgroup_Size_X", "Calls(after 100 warm)", "AverageNs", "MinNs", "MaxNs"])
+    w.writerows(rows)
+PY
+echo "decode traces done"
