@@ -97,3 +97,29 @@ def test_a_row_of_the_bf16_exact_class_is_what_a_default_call_runs(dga, tmp_path
         dga.tiling_cache_clear()
     shipped = [r for r in _rows() if (int(r["dispatchPolicyTag"]) & 15) == 7]
     assert len(shipped) >= 4
+
+
+def test_the_sweep_writes_decode_build_rows_the_cache_serves(dga, tmp_path):
+    """harness/sweep.py --arith bf16_exact: the one-launch decode split-K (kernelSerial 6, build 10) is among the candidates of a short-M
+    shape; a winner of that kind becomes a tag-7 row with its build, its split count and tiles x splits as blockDim, and the cache hands
+    exactly that to a default call -- also where the selector's own rule would not name the build."""
+    from deepgemm_ascend_amd.harness import sweep
+    m, n, k = 64, 2112, 7168                         # 17 tiles: below the rule's 24
+    assert dga.tiling(m, n, k, policy="bf16_exact").build == 0
+    cands = [c for c in sweep.candidates_bx(m, n, k) if c.get("build") == 10]
+    assert cands and all(c["m1"] == 64 and c["n1"] == 128 and c.get("wsk") and 1 <= c["splitk"] <= 8 for c in cands)
+    assert {sweep.bx_serial(c) for c in cands} == {6}
+    assert not [c for c in sweep.candidates_bx(1024, 4096, 7168) if c.get("build") == 10]      # more tiles than CUs: no such candidate
+    win = max(cands, key=lambda c: c["splitk"])
+    path = tmp_path / "bx_decode.csv"
+    sweep.write_bx_rows(path, [((m, n, k), win)])
+    row = path.read_text().strip().splitlines()[1].split(",")
+    assert row[:5] == [str(m), str(n), str(k), "64", "128"] and row[6] == "6" and row[-1] == "10" and int(row[10]) == 17 * win["splitk"]
+    try:
+        dga.tiling_cache_open(str(path))
+        t = dga.tiling(m, n, k, policy="bf16_exact")
+        assert (t.m1, t.n1, t.kernelSerial, t.build, t.splitkFactor, t.blockDim) == (64, 128, 6, 10, win["splitk"], 17 * win["splitk"])
+        assert dga.tiling_check(t) == 0 and dga.workspace_bytes(t) >= 17 * (win["splitk"] - 1) * (64 * 128 * 4 + 8)
+    finally:
+        dga.tiling_cache_open(None)
+        dga.tiling_cache_clear()
