@@ -415,31 +415,52 @@ gemm_fp8_bf16x_dsk_kernel(const GemmParams p, const StreamKArgs sk)
 #pragma unroll
         for (int ti = 0; ti < 8; ++ti) X[(gw * 8 + ti) * 64 + lane] = acc[ti >> 1][ti & 1];
     }
-    // one thread watches the flags; behind the barrier it puts them back to 0 -- a launch replayed from a graph repeats its epoch, and
-    // finds the flags as an ordinary launch does: not holding it (no memset node in front of the kernel)
-#ifdef DGA_DSK_KNOBS
-    if (!(knob & 3))
-#endif
-    if (tid == 0)
-        for (int j = 0; j < S - 1; ++j)
-            while (__hip_atomic_load(sk.flags + tile * (S - 1) + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) __builtin_amdgcn_s_sleep(2);
-    __syncthreads();
-    if (tid == 0)
-        for (int j = 0; j < S - 1; ++j) __hip_atomic_store(sk.flags + tile * (S - 1) + j, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // one thread watches the flags, one partial at a time: the reads of a partial are on their way while the next one's flag is still
+    // awaited (the partners do not finish together: after the last flag only the last partial's 32 KB are left to come, not all of them).
+    // Behind the last barrier the flags are put back to 0 -- a launch replayed from a graph repeats its epoch, and finds the flags as an
+    // ordinary launch does: not holding it (no memset node in front of the kernel).
     const int e0 = (gw * 8 + 4 * h) * 64 + lane;      // float4 index of (m-tile 2 h, n-tile 0); + 64 per following tile
     v4f w[C::MAX_S - 1][4];
+    __syncthreads();                                  // (the adding workgroup's own sum is in X)
 #pragma unroll
     for (int j = 0; j < C::MAX_S - 1; ++j) {
         if (j < S - 1) {
-            const float *src = sk.partials + (int64_t)(tile * (S - 1) + j) * C::SLOT_FLOATS + e0 * 4;
+#ifdef DGA_DSK_KNOBS
+            if (!(knob & 3))
+#endif
+            if (tid == 0)
+                while (__hip_atomic_load(sk.flags + tile * (S - 1) + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // (the watching wave reads its own share of the partials behind the last flag: a load of its own in flight would stand in
+            //  front of its next look at a flag)
+            if (wave != 0) {
+                const float *src = sk.partials + (int64_t)(tile * (S - 1) + j) * C::SLOT_FLOATS + e0 * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(w[j][e]) : "v"(src) : "memory");
-                src += 64 * 4;
-                asm volatile("" : "+v"(src));
+                for (int e = 0; e < 4; ++e) {
+                    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(w[j][e]) : "v"(src) : "memory");
+                    src += 64 * 4;
+                    asm volatile("" : "+v"(src));
+                }
             }
         }
     }
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < C::MAX_S - 1; ++j) {
+            if (j < S - 1) {
+                const float *src = sk.partials + (int64_t)(tile * (S - 1) + j) * C::SLOT_FLOATS + e0 * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(w[j][e]) : "v"(src) : "memory");
+                    src += 64 * 4;
+                    asm volatile("" : "+v"(src));
+                }
+            }
+        }
+    }
+    if (tid == 0)
+        for (int j = 0; j < S - 1; ++j) __hip_atomic_store(sk.flags + tile * (S - 1) + j, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     v4f sum[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) sum[e] = X[e0 + 64 * e];
